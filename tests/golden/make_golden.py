@@ -1,0 +1,187 @@
+"""
+Generates tests/golden/*.npz by importing the REAL reference functions from /root/reference/src
+(read-only; nothing is written there, bytecode writing is disabled) with sys.modules stubs for the
+third-party packages this image lacks (pytorch3d, lpips, torchvision, toolz, cv2, ...).
+
+Run here (the container that has /root/reference):   python tests/golden/make_golden.py
+The fixtures are data only (inputs + expected outputs); no reference source travels.
+
+Reference functions exercised (the only ones on the hot path that are the reference's OWN torch code,
+SURVEY.md 8c):
+  model/renderer.py:241-273   layered_rgb_blend
+  utils/superquadric.py:10-14 parametric_sq          utils/superquadric.py:17-38 implicit_sq(as_sdf=2)
+  utils/pytorch.py:31-36      signed_pow / safe_pow
+  model/loss.py:43-47         tv_norm_funcs['l2sq']
+  model/tools.py:173-207      elev/azim/roll_to_rotation_matrix (R_world, dbw.py:59)
+  utils/mesh.py:78-89,127-169 point_to_uv_sphericalmap, get_icosphere_uvs post-processing
+                              (fed an icosphere restated per SURVEY A.9 -- PyTorch3D's ico_sphere is absent)
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = '/root/reference/src'
+HERE = os.path.dirname(os.path.abspath(__file__))
+STUB_ROOTS = ['pytorch3d', 'lpips', 'torchvision', 'toolz', 'cv2', 'trimesh', 'open3d', 'seaborn', 'imageio',
+              'iopath', 'fvcore', 'visdom', 'nerfstudio', 'matplotlib', 'sklearn', 'pandas', 'scipy', 'tqdm', 'PIL']
+
+
+class _AnyAttr(type):
+    def __getattr__(cls, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return None
+
+
+class _Stub(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        cls = _AnyAttr(name, (), {'__init__': lambda self, *a, **k: None, '__call__': lambda self, *a, **k: None})
+        setattr(self, name, cls)
+        return cls
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _Stub(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    for k in list(sys.modules):
+        if k.split('.')[0] in STUB_ROOTS:
+            del sys.modules[k]
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, REF)
+    mods = {}
+    for name in ['utils.pytorch', 'utils.superquadric', 'utils.mesh', 'model.renderer', 'model.loss', 'model.tools']:
+        mods[name] = importlib.import_module(name)
+    return mods
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    sys.path.insert(0, os.path.join(HERE, '..', '..', 'oracle'))
+    import oracle as O     # only for the restated icosphere fed to the reference's uv post-processing
+    m = import_reference()
+    ren, sq, pt, mesh, loss, tools = (m['model.renderer'], m['utils.superquadric'], m['utils.pytorch'],
+                                      m['utils.mesh'], m['model.loss'], m['model.tools'])
+    g = torch.Generator().manual_seed(227391)
+
+    # ---- 1. layered_rgb_blend: sigma in {1e-4, 5e-6, 0}, faces_alpha on/off, with grads ------------------
+    class Frag:
+        pass
+
+    class BP:
+        pass
+    N, H, W, K, Ff = 2, 6, 7, 5, 12
+    out = {}
+    for tag, sigma, use_alpha in [('s1e-4_a', 1e-4, True), ('s1e-4', 1e-4, False), ('s5e-6_a', 5e-6, True),
+                                  ('s0', 0.0, False), ('s0_a', 0.0, True)]:
+        p2f = torch.randint(-1, N * Ff, (N, H, W, K), generator=g)
+        p2f[torch.rand(N, H, W, K, generator=g) < 0.3] = -1
+        scale = max(sigma, 1e-5) * 3
+        dists = (torch.randn(N, H, W, K, generator=g) * scale).requires_grad_(True)
+        colors = torch.rand(N, H, W, K, 3, generator=g).requires_grad_(True)
+        fa = torch.rand(N * Ff, generator=g).requires_grad_(True) if use_alpha else None
+        fr = Frag()
+        fr.pix_to_face, fr.dists = p2f, dists
+        bp = BP()
+        bp.sigma, bp.background_color = sigma, (0.2, 0.3, 0.4) if 'a' in tag else (0, 0, 0)
+        res = ren.layered_rgb_blend(colors, fr, bp, clip_inside=True, faces_alpha=fa)
+        w = torch.rand(res.shape, generator=g)
+        (res * w).sum().backward()
+        out.update({f'{tag}/p2f': _np(p2f), f'{tag}/dists': _np(dists), f'{tag}/colors': _np(colors),
+                    f'{tag}/sigma': np.float64(sigma), f'{tag}/bg': np.array(bp.background_color, dtype=np.float32),
+                    f'{tag}/out': _np(res), f'{tag}/w': _np(w), f'{tag}/g_colors': _np(colors.grad)})
+        if sigma > 0:
+            out[f'{tag}/g_dists'] = _np(dists.grad)
+        if use_alpha:
+            out[f'{tag}/faces_alpha'] = _np(fa)
+            out[f'{tag}/g_faces_alpha'] = _np(fa.grad)
+    np.savez_compressed(os.path.join(HERE, 'blend.npz'), **out)
+
+    # ---- 2. parametric_sq on icosphere-1 angles, eps grid incl. grads ----------------------------------
+    v1, _ = O.get_icosphere(1)
+    eta, omega = torch.asin(v1[:, 1]), torch.atan2(v1[:, 0], v1[:, 2])
+    out = {'eta': _np(eta), 'omega': _np(omega)}
+    for i, e1 in enumerate([0.1, 0.5, 1.0, 1.9]):
+        for j, e2 in enumerate([0.1, 0.5, 1.0, 1.9]):
+            eps1 = torch.tensor([[e1]], requires_grad=True)
+            eps2 = torch.tensor([[e2]], requires_grad=True)
+            pts = sq.parametric_sq(eta[None], omega[None], eps1, eps2)
+            w = torch.rand(pts.shape, generator=g)
+            (pts * w).sum().backward()
+            out.update({f'{i}{j}/eps': np.array([e1, e2], dtype=np.float32), f'{i}{j}/pts': _np(pts), f'{i}{j}/w': _np(w),
+                        f'{i}{j}/g_eps1': _np(eps1.grad), f'{i}{j}/g_eps2': _np(eps2.grad)})
+    np.savez_compressed(os.path.join(HERE, 'parametric_sq.npz'), **out)
+
+    # ---- 3. implicit_sq(as_sdf=2), safe_pow, signed_pow, tv l2sq -----------------------------------------
+    Nb, Np = 3, 64
+    pts = (torch.randn(Nb, Np, 3, generator=g) * 2)
+    pts[0, :4] = torch.tensor([[6., -7., 0.], [0., 0., 0.], [1e-4, 0., 5.], [-5., 5., -5.]])
+    pts.requires_grad_(True)
+    eps1 = torch.tensor([[0.1], [1.0], [1.9]], requires_grad=True)
+    eps2 = torch.tensor([[1.9], [0.7], [0.1]], requires_grad=True)
+    sdf = sq.implicit_sq(pts, eps1, eps2, as_sdf=2)
+    w = torch.rand(sdf.shape, generator=g)
+    (sdf * w).sum().backward()
+    a = torch.rand(16, generator=g)
+    a[:3] = torch.tensor([0., 1e-7, 1.])
+    a.requires_grad_(True)
+    sp = pt.safe_pow(a, 0.5)
+    sp.sum().backward()
+    t = torch.randn(32, generator=g)
+    maps = torch.rand(2, 8, 9, 3, generator=g).requires_grad_(True)
+    dx = loss.tv_norm_funcs['l2sq'](torch.diff(maps, dim=2, append=maps[:, :, 0:1]))
+    dy = loss.tv_norm_funcs['l2sq'](torch.diff(maps, dim=1))
+    tv = dx.sum(0).mean() + dy.sum(0).mean()
+    tv.backward()
+    np.savez_compressed(os.path.join(HERE, 'implicit_misc.npz'), pts=_np(pts), eps1=_np(eps1), eps2=_np(eps2),
+                        sdf=_np(sdf), w=_np(w), g_pts=_np(pts.grad), g_eps1=_np(eps1.grad), g_eps2=_np(eps2.grad),
+                        sp_in=_np(a), sp_out=_np(sp), sp_grad=_np(a.grad),
+                        spow_in=_np(t), spow_out=_np(pt.signed_pow(t, torch.tensor(0.37))),
+                        tv_maps=_np(maps), tv=_np(tv), tv_grad=_np(maps.grad))
+
+    # ---- 4. Euler -> R_world (dbw.py:59) for DTU [115,0,0] and BMVS [130,50,0] ----------------------------
+    out = {}
+    for tag, (e, a_, r) in {'dtu': (115, 0, 0), 'bmvs': (130, 50, 0), 'mix': (20, -35, 70)}.items():
+        Rw = tools.elev_to_rotation_matrix(e) @ tools.azim_to_rotation_matrix(a_) @ tools.roll_to_rotation_matrix(r)
+        out[tag] = _np(Rw)
+        out[tag + '_angles'] = np.array([e, a_, r], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, 'world_rotation.npz'), **out)
+
+    # ---- 5. get_icosphere_uvs post-processing (mesh.py:127-169) on the restated icosphere ---------------
+    out = {}
+    for level in [1, 2]:
+        mesh.get_icosphere = lambda level, **k: types.SimpleNamespace(
+            get_mesh_verts_faces=lambda i, _l=level: O.get_icosphere(_l))
+        f_uv, v_uv = mesh.get_icosphere_uvs(level=level, fix_continuity=True, fix_poles=True)
+        f_raw, v_raw = mesh.get_icosphere_uvs(level=level)
+        out.update({f'l{level}/faces_uvs': _np(f_uv), f'l{level}/verts_uvs': _np(v_uv), f'l{level}/verts_uvs_raw': _np(v_raw)})
+    np.savez_compressed(os.path.join(HERE, 'icosphere_uvs.npz'), **out)
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()
