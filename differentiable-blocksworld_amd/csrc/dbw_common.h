@@ -1,0 +1,233 @@
+// Shared device helpers for libdbw_hip.so (gfx950 only).
+//
+// The per-(pixel, face) arithmetic below is held BIT-EXACT to oracle/raster_ref.c (the canonical restatement of the
+// PyTorch3D 0.7.1 CPU rasteriser): same operations, same order, one rounding per operation.
+// That is why this library is built with -ffp-contract=off and IEEE fp32 division/sqrt (hipcc default), and why the
+// helpers are written with explicit ternaries instead of fmaxf/fminf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define DBW_EPS 1e-8f
+#define DBW_WAVE 64
+
+namespace dbw {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+
+// SURVEY A.1 NonSquarePixToNdc
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
+    float range = 2.0f;
+    if (S1 > S2) range = ((float)S1 * range) / (float)S2;
+    const float offset = range / 2.0f;
+    return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+__device__ __forceinline__ float edge_fn(f2 p, f2 a, f2 b) {
+    return (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
+}
+
+__device__ __forceinline__ void edge_fn_bwd(f2 p, f2 a, f2 b, float g, f2 &gp, f2 &ga, f2 &gb) {
+    gp.x = g * (b.y - a.y); gp.y = g * (a.x - b.x);
+    ga.x = g * (p.y - b.y); ga.y = g * (b.x - p.x);
+    gb.x = g * (a.y - p.y); gb.y = g * (p.x - a.x);
+}
+
+__device__ __forceinline__ f3 bary_fwd(f2 p, f2 v0, f2 v1, f2 v2) {
+    const float area = edge_fn(v2, v0, v1) + DBW_EPS;
+    f3 w;
+    w.x = edge_fn(p, v1, v2) / area;
+    w.y = edge_fn(p, v2, v0) / area;
+    w.z = edge_fn(p, v0, v1) / area;
+    return w;
+}
+
+__device__ __forceinline__ void bary_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g, f2 &g0, f2 &g1, f2 &g2) {
+    const float area = edge_fn(v2, v0, v1) + DBW_EPS;
+    const float area2 = area * area;
+    const float area_inv = 1.0f / area;
+    const float e0 = edge_fn(p, v1, v2);
+    const float e1 = edge_fn(p, v2, v0);
+    const float e2 = edge_fn(p, v0, v1);
+    f2 gp, ga, gb, hp, ha, hb;
+    g0.x = g0.y = g1.x = g1.y = g2.x = g2.y = 0.f;
+    edge_fn_bwd(p, v1, v2, g.x * area_inv, gp, ga, gb);
+    edge_fn_bwd(v2, v0, v1, g.x * (-e0 / area2), hp, ha, hb);
+    g0.x += ha.x;        g0.y += ha.y;
+    g1.x += ga.x + hb.x; g1.y += ga.y + hb.y;
+    g2.x += gb.x + hp.x; g2.y += gb.y + hp.y;
+    edge_fn_bwd(p, v2, v0, g.y * area_inv, gp, ga, gb);
+    edge_fn_bwd(v2, v0, v1, g.y * (-e1 / area2), hp, ha, hb);
+    g0.x += gb.x + ha.x; g0.y += gb.y + ha.y;
+    g1.x += hb.x;        g1.y += hb.y;
+    g2.x += ga.x + hp.x; g2.y += ga.y + hp.y;
+    edge_fn_bwd(p, v0, v1, g.z * area_inv, gp, ga, gb);
+    edge_fn_bwd(v2, v0, v1, g.z * (-e2 / area2), hp, ha, hb);
+    g0.x += ga.x + ha.x; g0.y += ga.y + ha.y;
+    g1.x += gb.x + hb.x; g1.y += gb.y + hb.y;
+    g2.x += hp.x;        g2.y += hp.y;
+}
+
+__device__ __forceinline__ f3 persp_fwd(f3 b, float z0, float z1, float z2) {
+    const float t0 = b.x * z1 * z2;
+    const float t1 = z0 * b.y * z2;
+    const float t2 = z0 * z1 * b.z;
+    float denom = t0 + t1 + t2;
+    if (!(denom > DBW_EPS)) denom = DBW_EPS;
+    f3 w; w.x = t0 / denom; w.y = t1 / denom; w.z = t2 / denom;
+    return w;
+}
+
+__device__ __forceinline__ f3 persp_bwd(f3 b, float z0, float z1, float z2, f3 g, float &gz0, float &gz1, float &gz2) {
+    const float t0 = b.x * z1 * z2;
+    const float t1 = z0 * b.y * z2;
+    const float t2 = z0 * z1 * b.z;
+    float denom = t0 + t1 + t2;
+    if (!(denom > DBW_EPS)) denom = DBW_EPS;
+    const float g_denom_top = -t0 * g.x - t1 * g.y - t2 * g.z;
+    const float g_denom = g_denom_top / (denom * denom);
+    const float gt0 = g_denom + g.x / denom;
+    const float gt1 = g_denom + g.y / denom;
+    const float gt2 = g_denom + g.z / denom;
+    f3 gb; gb.x = gt0 * z1 * z2; gb.y = gt1 * z0 * z2; gb.z = gt2 * z0 * z1;
+    gz0 = gt1 * b.y * z2 + gt2 * b.z * z1;
+    gz1 = gt0 * b.x * z2 + gt2 * b.z * z0;
+    gz2 = gt0 * b.x * z1 + gt1 * b.y * z0;
+    return gb;
+}
+
+__device__ __forceinline__ f3 clip_fwd(f3 b) {
+    f3 w;
+    w.x = b.x > 0.f ? b.x : 0.f; w.y = b.y > 0.f ? b.y : 0.f; w.z = b.z > 0.f ? b.z : 0.f;
+    float s = w.x + w.y + w.z;
+    if (!(s > 1e-5f)) s = 1e-5f;
+    w.x /= s; w.y /= s; w.z /= s;
+    return w;
+}
+
+__device__ __forceinline__ f3 clip_bwd(f3 b, f3 g) {
+    f3 w;
+    w.x = b.x > 0.f ? b.x : 0.f; w.y = b.y > 0.f ? b.y : 0.f; w.z = b.z > 0.f ? b.z : 0.f;
+    float s = w.x + w.y + w.z;
+    float gsc = 1.f;
+    if (s < 1e-5f) { gsc = 0.f; s = 1e-5f; }
+    const float cx = b.x < 0.f ? 0.f : 1.f, cy = b.y < 0.f ? 0.f : 1.f, cz = b.z < 0.f ? 0.f : 1.f;
+    const float s2 = s * s;
+    const float gsx = -w.x / s2 * gsc, gsy = -w.y / s2 * gsc, gsz = -w.z / s2 * gsc;
+    const float common = g.x * gsx + g.y * gsy + g.z * gsz;
+    f3 o;
+    o.x = cx * (g.x / s + common);
+    o.y = cy * (g.y / s + common);
+    o.z = cz * (g.z / s + common);
+    return o;
+}
+
+__device__ __forceinline__ float point_line_dist(f2 p, f2 a, f2 b) {
+    const float dx = b.x - a.x, dy = b.y - a.y;
+    const float l2 = dx * dx + dy * dy;
+    if (l2 <= DBW_EPS) return (p.x - b.x) * (p.x - b.x) + (p.y - b.y) * (p.y - b.y);
+    const float t = (dx * (p.x - a.x) + dy * (p.y - a.y)) / l2;
+    const float tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = a.x + tt * dx, qy = a.y + tt * dy;
+    return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
+}
+
+__device__ __forceinline__ void point_line_dist_bwd(f2 p, f2 a, f2 b, float g, f2 &ga, f2 &gb) {
+    const float dx = b.x - a.x, dy = b.y - a.y;
+    const float t_bot = dx * dx + dy * dy;
+    const float t_top = dx * (p.x - a.x) + dy * (p.y - a.y);
+    const float t = t_top / t_bot;
+    const float tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = (1.f - tt) * a.x + tt * b.x, qy = (1.f - tt) * a.y + tt * b.y;
+    ga.x = g * (1.f - tt) * 2.f * (qx - p.x); ga.y = g * (1.f - tt) * 2.f * (qy - p.y);
+    gb.x = g * tt * 2.f * (qx - p.x);         gb.y = g * tt * 2.f * (qy - p.y);
+}
+
+__device__ __forceinline__ float point_tri_dist(f2 p, f2 v0, f2 v1, f2 v2) {
+    const float e01 = point_line_dist(p, v0, v1);
+    const float e02 = point_line_dist(p, v0, v2);
+    const float e12 = point_line_dist(p, v1, v2);
+    const float m = e01 < e02 ? e01 : e02;
+    return m < e12 ? m : e12;
+}
+
+__device__ __forceinline__ void point_tri_dist_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g, f2 &g0, f2 &g1, f2 &g2) {
+    const float e01 = point_line_dist(p, v0, v1);
+    const float e02 = point_line_dist(p, v0, v2);
+    const float e12 = point_line_dist(p, v1, v2);
+    g0.x = g0.y = g1.x = g1.y = g2.x = g2.y = 0.f;
+    if (e01 <= e02 && e01 <= e12) point_line_dist_bwd(p, v0, v1, g, g0, g1);
+    else if (e02 <= e01 && e02 <= e12) point_line_dist_bwd(p, v0, v2, g, g0, g2);
+    else if (e12 <= e01 && e12 <= e02) point_line_dist_bwd(p, v1, v2, g, g1, g2);
+}
+
+// ---- wave-level helpers (wave64) ---------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Wave-aggregated atomic accumulation into base[idx*NC + c]: lanes of a wave that target the same index (neighbouring
+// pixels usually hit the same face / texel) are summed with a butterfly first, so memory sees ~1 atomic per
+// (wave, index) instead of one per lane.  Must be called by ALL lanes of the wave (inactive lanes pass active=false).
+// Bounded: after 8 distinct indices the remaining lanes fall back to plain atomics.
+template <int NC>
+__device__ __forceinline__ void wave_agg_atomic(float *__restrict__ base, long long idx, bool active,
+                                                const float (&g)[NC], int lane) {
+    unsigned long long rem = __ballot(active);
+    int iter = 0;
+    while (rem) {
+        if (iter >= 8) {
+            if (active && ((rem >> lane) & 1ull)) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (g[c] != 0.f) unsafeAtomicAdd(base + idx * NC + c, g[c]);
+            }
+            break;
+        }
+        const int leader = __ffsll((long long)rem) - 1;
+        const long long i0 = __shfl(idx, leader, 64);
+        const bool match = active && (idx == i0);
+        const unsigned long long mm = __ballot(match);
+        if (__popcll(mm) > 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float s = wave_sum(match ? g[c] : 0.f);
+                if (lane == leader && s != 0.f) unsafeAtomicAdd(base + i0 * NC + c, s);
+            }
+        } else if (match) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (g[c] != 0.f) unsafeAtomicAdd(base + idx * NC + c, g[c]);
+        }
+        rem &= ~mm;
+        ++iter;
+    }
+}
+
+// XCD-aware block remap (cdna_hip_programming.md T1): hardware places block b on XCD b % 8; we want consecutive
+// LOGICAL blocks (tiles of one view: same face list, same texture footprint, adjacent output rows) on one XCD/L2.
+// Grid must be launched with 8*ceil(total/8) blocks; returns -1 for padding blocks.
+__device__ __forceinline__ long long xcd_remap(long long b, long long total) {
+    const long long per = (total + 7) / 8;
+    const long long logical = (b % 8) * per + (b / 8);
+    return logical < total ? logical : -1;
+}
+
+}  // namespace dbw
+
+// ---- host-side helpers ------------------------------------------------------------------------------------------
+void dbw_set_error(const char *fmt, ...);
+int dbw_check_launch(const char *what);
+#define DBW_REQUIRE(cond, msg)                          \
+    do {                                                \
+        if (!(cond)) {                                  \
+            dbw_set_error("%s: %s", __func__, msg);     \
+            return DBW_ERR_INVALID;                     \
+        }                                               \
+    } while (0)
+static inline unsigned dbw_xcd_grid(long long total) { return (unsigned)(8 * ((total + 7) / 8)); }

@@ -1,0 +1,257 @@
+// Camera transform + near-plane clipping of one scene seen from B cameras, fully on device (no host sync).
+//
+// Replaces pytorch3d 0.7.1 MeshRasterizer.transform + clip_faces (+ the bookkeeping that
+// convert_clipped_rasterization_to_original_faces needs), reached by the reference through
+// src/model/renderer.py:92-94 (R,T,eps kwargs) with z_clip from renderer.py:35,46.  SURVEY.md A.2, A.4.
+// The clipped face_verts are bit-exact to oracle/oracle.py::transform_to_ndc + clip_faces (same fp32 op order).
+//
+// One workgroup per view: faces are classified, an ordered block-wide scan (two ballots per wave: a face emits 0, 1
+// or 2 triangles) assigns output slots in original face order, and each thread writes its own triangles.
+#include "dbw_common.h"
+#include "../../include/dbw_hip.h"
+
+using namespace dbw;
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Cam {
+    float R[9], T[3], K[16];
+};
+
+__device__ __forceinline__ void load_cam(const float *R, const float *T, const float *Kmat, int b, Cam &c) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = R[b * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.T[i] = T[b * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.K[i] = Kmat[i];
+}
+
+struct Proj {
+    float vx, vy, vz;   // view space
+    float px, py, pw;   // before the perspective divide
+    float denom;
+    f3 ndc;             // x,y NDC, z = view depth
+};
+
+__device__ __forceinline__ Proj project(const float *X, const Cam &c, float eps) {
+    Proj o;
+    const float x = X[0], y = X[1], z = X[2];
+    o.vx = x * c.R[0] + y * c.R[3] + z * c.R[6] + c.T[0];
+    o.vy = x * c.R[1] + y * c.R[4] + z * c.R[7] + c.T[1];
+    o.vz = x * c.R[2] + y * c.R[5] + z * c.R[8] + c.T[2];
+    o.px = o.vx * c.K[0] + o.vy * c.K[1] + o.vz * c.K[2] + c.K[3];
+    o.py = o.vx * c.K[4] + o.vy * c.K[5] + o.vz * c.K[6] + c.K[7];
+    o.pw = o.vx * c.K[12] + o.vy * c.K[13] + o.vz * c.K[14] + c.K[15];
+    const float sgn = o.pw > 0.f ? 1.f : (o.pw < 0.f ? -1.f : 1.f);
+    const float ab = o.pw < 0.f ? -o.pw : o.pw;
+    o.denom = sgn * (ab < eps ? eps : ab);
+    o.ndc.x = o.px / o.denom;
+    o.ndc.y = o.py / o.denom;
+    o.ndc.z = o.vz;
+    return o;
+}
+
+// intersection of segment pa->pb with z = c; w returned
+__device__ __forceinline__ f3 clip_point(f3 pa, f3 pb, float c, int persp, float &w) {
+    w = (pa.z - c) / (pa.z - pb.z);
+    const float omw = 1.f - w;
+    f3 q;
+    q.z = pa.z * omw + pb.z * w;
+    if (persp) {
+        q.x = ((pa.x * pa.z) * omw + (pb.x * pb.z) * w) / c;
+        q.y = ((pa.y * pa.z) * omw + (pb.y * pb.z) * w) / c;
+    } else {
+        q.x = pa.x * omw + pb.x * w;
+        q.y = pa.y * omw + pb.y * w;
+    }
+    return q;
+}
+
+__device__ __forceinline__ void store_tri(float *dst, f3 a, f3 b, f3 c) {
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z;
+    dst[3] = b.x; dst[4] = b.y; dst[5] = b.z;
+    dst[6] = c.x; dst[7] = c.y; dst[8] = c.z;
+}
+
+__global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
+    const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
+    const float *__restrict__ T, const float *__restrict__ Kmat, int V, int F, float eps, int zc_on, float zc,
+    int persp, float *__restrict__ fvc, int *__restrict__ first_idx, int *__restrict__ num_faces,
+    int *__restrict__ c2o, int *__restrict__ neighbor, int *__restrict__ code, float *__restrict__ cw) {
+    __shared__ int s_wcnt[NT / DBW_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    Cam cam;
+    load_cam(R, T, Kmat, b, cam);
+    const long long base_out = (long long)b * 2 * F;
+    int running = 0;
+    for (int f0 = 0; f0 < F; f0 += NT) {
+        const int f = f0 + tid;
+        f3 p[3];
+        int nbh = 0, behind_mask = 0;
+        if (f < F) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int vi = faces[f * 3 + i];
+                p[i] = project(verts + (long long)vi * 3, cam, eps).ndc;
+                if (zc_on && p[i].z < zc) { ++nbh; behind_mask |= 1 << i; }
+            }
+        }
+        const int emit = f < F ? (nbh == 0 ? 1 : (nbh == 3 ? 0 : (nbh == 2 ? 1 : 2))) : 0;
+        const unsigned long long m1 = __ballot(emit >= 1), m2 = __ballot(emit == 2);
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const int prefix = __popcll(m1 & lower) + __popcll(m2 & lower);
+        if (lane == 0) s_wcnt[wv] = __popcll(m1) + __popcll(m2);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / DBW_WAVE; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+        const int slot = running + woff + prefix;
+        if (emit == 1 && nbh == 0) {
+            const long long o = base_out + slot;
+            store_tri(fvc + o * 9, p[0], p[1], p[2]);
+            c2o[o] = f; neighbor[o] = -1; code[o] = -1; cw[o * 2] = 0.f; cw[o * 2 + 1] = 0.f;
+        } else if (emit == 1) {   // case 3: two behind, p1 = the vertex in front -> (p4, p5, p1)
+            const int i1 = (behind_mask == 6) ? 0 : (behind_mask == 5 ? 1 : 2);
+            const f3 p1 = p[i1], p2 = p[(i1 + 1) % 3], p3 = p[(i1 + 2) % 3];
+            float w2, w3;
+            const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
+            const long long o = base_out + slot;
+            store_tri(fvc + o * 9, p4, p5, p1);
+            c2o[o] = f; neighbor[o] = -1; code[o] = i1 | (0 << 2); cw[o * 2] = w2; cw[o * 2 + 1] = w3;
+        } else if (emit == 2) {   // case 4: one behind, p1 = the vertex behind -> t1 (p4,p2,p5), t2 (p5,p2,p3)
+            const int i1 = (behind_mask == 1) ? 0 : (behind_mask == 2 ? 1 : 2);
+            const f3 p1 = p[i1], p2 = p[(i1 + 1) % 3], p3 = p[(i1 + 2) % 3];
+            float w2, w3;
+            const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
+            const long long o = base_out + slot;
+            store_tri(fvc + o * 9, p4, p2, p5);
+            store_tri(fvc + (o + 1) * 9, p5, p2, p3);
+            c2o[o] = f; c2o[o + 1] = f;
+            neighbor[o] = (int)(o + 1); neighbor[o + 1] = (int)o;
+            code[o] = i1 | (1 << 2); code[o + 1] = i1 | (2 << 2);
+            cw[o * 2] = w2; cw[o * 2 + 1] = w3; cw[(o + 1) * 2] = w2; cw[(o + 1) * 2 + 1] = w3;
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { first_idx[b] = (int)base_out; num_faces[b] = running; }
+}
+
+// d(ndc vertex)/d(world vertex), accumulated atomically
+__device__ __forceinline__ void vertex_bwd(const float *verts, int vi, const Cam &c, float eps, f3 g, float *gverts) {
+    const Proj pr = project(verts + (long long)vi * 3, c, eps);
+    const float gpx = g.x / pr.denom, gpy = g.y / pr.denom;
+    const float gden = -(g.x * pr.px + g.y * pr.py) / (pr.denom * pr.denom);
+    const float ab = pr.pw < 0.f ? -pr.pw : pr.pw;
+    const float gpw = ab >= eps ? gden : 0.f;
+    const float gvx = gpx * c.K[0] + gpy * c.K[4] + gpw * c.K[12];
+    const float gvy = gpx * c.K[1] + gpy * c.K[5] + gpw * c.K[13];
+    const float gvz = gpx * c.K[2] + gpy * c.K[6] + gpw * c.K[14] + g.z;
+    const float gx = gvx * c.R[0] + gvy * c.R[1] + gvz * c.R[2];
+    const float gy = gvx * c.R[3] + gvy * c.R[4] + gvz * c.R[5];
+    const float gz = gvx * c.R[6] + gvy * c.R[7] + gvz * c.R[8];
+    if (gx != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 0, gx);
+    if (gy != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 1, gy);
+    if (gz != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 2, gz);
+}
+
+// grads of q = clip_point(pa, pb) (w detached) pushed to ga, gb
+__device__ __forceinline__ void clip_point_bwd(f3 pa, f3 pb, float c, int persp, float w, f3 gq, f3 &ga, f3 &gb) {
+    const float omw = 1.f - w;
+    ga.z += gq.z * omw; gb.z += gq.z * w;
+    if (persp) {
+        ga.x += gq.x * pa.z * omw / c; ga.y += gq.y * pa.z * omw / c;
+        ga.z += (gq.x * pa.x + gq.y * pa.y) * omw / c;
+        gb.x += gq.x * pb.z * w / c; gb.y += gq.y * pb.z * w / c;
+        gb.z += (gq.x * pb.x + gq.y * pb.y) * w / c;
+    } else {
+        ga.x += gq.x * omw; ga.y += gq.y * omw;
+        gb.x += gq.x * w; gb.y += gq.y * w;
+    }
+}
+
+__global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
+    const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
+    const float *__restrict__ T, const float *__restrict__ Kmat, int B, int V, int F, float eps, float zc, int persp,
+    const int *__restrict__ num_faces, const int *__restrict__ c2o, const int *__restrict__ code,
+    const float *__restrict__ cw, const float *__restrict__ gfvc, float *__restrict__ gverts) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j >= num_faces[b]) return;
+    const long long o = (long long)b * 2 * F + j;
+    const float *g = gfvc + o * 9;
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) any |= (g[i] != 0.f);
+    if (!any) return;
+    Cam cam;
+    load_cam(R, T, Kmat, b, cam);
+    const int f = c2o[o], cd = code[o];
+    const int vi[3] = {faces[f * 3], faces[f * 3 + 1], faces[f * 3 + 2]};
+    f3 gv[3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const f3 ga{g[0], g[1], g[2]}, gb{g[3], g[4], g[5]}, gc{g[6], g[7], g[8]};
+    if (cd < 0) {
+        gv[0] = ga; gv[1] = gb; gv[2] = gc;
+    } else {
+        const int i1 = cd & 3, kind = cd >> 2, i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        f3 p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = project(verts + (long long)vi[i] * 3, cam, eps).ndc;
+        const float w2 = cw[o * 2], w3 = cw[o * 2 + 1];
+        f3 g1{0.f, 0.f, 0.f}, g2{0.f, 0.f, 0.f}, g3{0.f, 0.f, 0.f};
+        if (kind == 0) {          // (p4, p5, p1)
+            clip_point_bwd(p[i1], p[i2], zc, persp, w2, ga, g1, g2);
+            clip_point_bwd(p[i1], p[i3], zc, persp, w3, gb, g1, g3);
+            g1.x += gc.x; g1.y += gc.y; g1.z += gc.z;
+        } else if (kind == 1) {   // (p4, p2, p5)
+            clip_point_bwd(p[i1], p[i2], zc, persp, w2, ga, g1, g2);
+            g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
+            clip_point_bwd(p[i1], p[i3], zc, persp, w3, gc, g1, g3);
+        } else {                  // (p5, p2, p3)
+            clip_point_bwd(p[i1], p[i3], zc, persp, w3, ga, g1, g3);
+            g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
+            g3.x += gc.x; g3.y += gc.y; g3.z += gc.z;
+        }
+        gv[i1] = g1; gv[i2] = g2; gv[i3] = g3;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (gv[i].x != 0.f || gv[i].y != 0.f || gv[i].z != 0.f) vertex_bwd(verts, vi[i], cam, eps, gv[i], gverts);
+}
+
+}  // namespace
+
+extern "C" int dbw_project_clip_fwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,
+                                    const float *Kmat, int B, int V, int F, float eps, int z_clip_enabled,
+                                    float z_clip, int perspective_correct, float *face_verts_c, int32_t *first_idx,
+                                    int32_t *num_faces, int32_t *c2o, int32_t *neighbor, int32_t *clip_code,
+                                    float *clip_w, dbw_stream_t stream) {
+    DBW_REQUIRE(verts_world && faces && R && T && Kmat && face_verts_c && first_idx && num_faces && c2o && neighbor &&
+                    clip_code && clip_w, "null pointer");
+    DBW_REQUIRE(B >= 0 && V > 0 && F > 0, "bad size");
+    DBW_REQUIRE((long long)B * 2 * F < 0x7fffffffLL, "B*2F overflows int32 face indices");
+    DBW_REQUIRE(!z_clip_enabled || z_clip > 0.f, "z_clip must be > 0");
+    if (B == 0) return DBW_OK;
+    hipLaunchKernelGGL(project_clip_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, verts_world, faces, R, T,
+                       Kmat, V, F, eps, z_clip_enabled, z_clip, perspective_correct, face_verts_c, first_idx,
+                       num_faces, c2o, neighbor, clip_code, clip_w);
+    return dbw_check_launch("project_clip_fwd_kernel");
+}
+
+extern "C" int dbw_project_clip_bwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,
+                                    const float *Kmat, int B, int V, int F, float eps, float z_clip,
+                                    int perspective_correct, const int32_t *num_faces, const int32_t *c2o,
+                                    const int32_t *clip_code, const float *clip_w, const float *grad_face_verts_c,
+                                    float *grad_verts_world, dbw_stream_t stream) {
+    DBW_REQUIRE(verts_world && faces && R && T && Kmat && num_faces && c2o && clip_code && clip_w &&
+                    grad_face_verts_c && grad_verts_world, "null pointer");
+    DBW_REQUIRE(B >= 0 && V > 0 && F > 0, "bad size");
+    if (B == 0) return DBW_OK;
+    hipLaunchKernelGGL(project_clip_bwd_kernel, dim3((2 * F + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream,
+                       verts_world, faces, R, T, Kmat, B, V, F, eps, z_clip, perspective_correct, num_faces, c2o,
+                       clip_code, clip_w, grad_face_verts_c, grad_verts_world);
+    return dbw_check_launch("project_clip_bwd_kernel");
+}

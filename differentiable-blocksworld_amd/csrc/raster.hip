@@ -1,0 +1,326 @@
+// Tiled screen-space rasteriser for gfx950 (MI355X): forward (per-pixel top-K nearest faces) and backward.
+//
+// Replaces pytorch3d 0.7.1 `_C.rasterize_meshes` / `_C.rasterize_meshes_backward`, reached by the reference through
+// src/model/renderer.py:53-54,92-94 (MeshRasterizer).  Semantics: SURVEY.md A.5 / A.6, canonical = CPU naive path
+// (list kept sorted by (z, face id); split-quad siblings de-duplicated).  Results are bit-exact to
+// oracle/raster_ref.c given the same fp32 face_verts.
+//
+// Design (MI355X-first, not a translation of PyTorch3D's coarse/fine CUDA pair):
+//  * one 256-thread workgroup = one 16x16 pixel tile of one view; a wave64 owns a 16x4 pixel strip;
+//  * the workgroup bins the view's faces against the tile with a wave-ballot ORDERED compaction (face order must
+//    be preserved: the sibling de-duplication rule is order dependent) and stages the surviving faces
+//    (9 coords + margin-expanded bbox + sibling id = 64 B) in LDS; the per-pixel loop then reads them with
+//    wave-uniform (broadcast, conflict-free) ds_read_b128;
+//  * each lane keeps its top-K list entirely in VGPRs (template on K, fully unrolled bubble insert);
+//  * blockIdx -> tile mapping is XCD-aware: all tiles of a view run on one XCD so its face table and its output
+//    rows stay in that XCD's L2;
+//  * the kernel is HBM-write bound: 24*K bytes of fragments per pixel, compute is ~1% of the time.
+#include "dbw_common.h"
+#include "../../include/dbw_hip.h"
+
+#include <math.h>
+
+using namespace dbw;
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int NT = 256;
+constexpr int LIST_CAP = 512;
+
+struct __attribute__((aligned(16))) FaceRec {
+    float v[9];
+    float xlo, xhi, ylo, yhi;
+    int nb;
+    int id;
+    int pad;
+};
+static_assert(sizeof(FaceRec) == 64, "FaceRec must be 64 B");
+
+// Per-face screen bbox expanded by sqrt(blur_radius); faces that can never be hit (touching/behind the camera plane,
+// zero area, culled) get an empty box.  One rounding per value, same as the oracle's per-pixel expression.
+__global__ void face_setup_kernel(const float *__restrict__ fv, long long F, float margin, int cull,
+                                  float4 *__restrict__ bbox) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const float *p = fv + i * 9;
+    f2 a{p[0], p[1]}, b{p[3], p[4]}, c{p[6], p[7]};
+    const float z0 = p[2], z1 = p[5], z2 = p[8];
+    float xmin = a.x < b.x ? a.x : b.x; xmin = xmin < c.x ? xmin : c.x;
+    float xmax = a.x > b.x ? a.x : b.x; xmax = xmax > c.x ? xmax : c.x;
+    float ymin = a.y < b.y ? a.y : b.y; ymin = ymin < c.y ? ymin : c.y;
+    float ymax = a.y > b.y ? a.y : b.y; ymax = ymax > c.y ? ymax : c.y;
+    float zmin = z0 < z1 ? z0 : z1; zmin = zmin < z2 ? zmin : z2;
+    const float area = edge_fn(a, b, c);
+    const bool dead = (zmin < DBW_EPS) || (area <= DBW_EPS && area >= -DBW_EPS) || (cull && area < 0.f);
+    float4 o;
+    if (dead) { o.x = INFINITY; o.y = -INFINITY; o.z = INFINITY; o.w = -INFINITY; }
+    else { o.x = xmin - margin; o.y = xmax + margin; o.z = ymin - margin; o.w = ymax + margin; }
+    bbox[i] = o;
+}
+
+template <int KMAX>
+struct TopK {
+    float pz[KMAX], ds[KMAX], b0[KMAX], b1[KMAX], b2[KMAX];
+    int fi[KMAX];
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) { pz[i] = INFINITY; fi[i] = 0x7fffffff; ds[i] = b0[i] = b1[i] = b2[i] = -1.f; }
+    }
+    __device__ __forceinline__ static bool less(float pa, int fa, float pb, int fb) {
+        return (pa < pb) || (!(pb < pa) && fa < fb);
+    }
+    __device__ __forceinline__ void swap_with(int i, float &cp, int &cf, float &cd, float &c0, float &c1, float &c2) {
+        float t;
+        int ti;
+        t = pz[i]; pz[i] = cp; cp = t;
+        ti = fi[i]; fi[i] = cf; cf = ti;
+        t = ds[i]; ds[i] = cd; cd = t;
+        t = b0[i]; b0[i] = c0; c0 = t;
+        t = b1[i]; b1[i] = c1; c1 = t;
+        t = b2[i]; b2[i] = c2; c2 = t;
+    }
+    // sorted insert; the displaced largest entry falls off the end (== emplace_back, sort, pop_back if size > K)
+    __device__ __forceinline__ void insert(int K, float cp, int cf, float cd, float c0, float c1, float c2) {
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K && less(cp, cf, pz[i], fi[i])) swap_with(i, cp, cf, cd, c0, c1, c2);
+    }
+    __device__ __forceinline__ void cswap(int i) {  // order entries i, i+1
+        if (less(pz[i + 1], fi[i + 1], pz[i], fi[i])) swap_with(i, pz[i + 1], fi[i + 1], ds[i + 1], b0[i + 1], b1[i + 1], b2[i + 1]);
+    }
+    // sibling rule: returns true if `nb` was found (entry possibly replaced, list re-sorted)
+    __device__ __forceinline__ bool sibling(int K, int nb, float dist, float cp, int cf, float cd, float c0, float c1, float c2) {
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            if (i < K && !found && fi[i] == nb) {
+                found = true;
+                const float nd = ds[i] < 0.f ? -ds[i] : ds[i];
+                if (dist < nd) { pz[i] = cp; fi[i] = cf; ds[i] = cd; b0[i] = c0; b1[i] = c1; b2[i] = c2; }
+            }
+        }
+        if (found) {  // one entry may be out of place: one forward + one backward adjacent pass restores the order
+#pragma unroll
+            for (int i = 0; i < KMAX - 1; ++i) if (i + 1 < K) cswap(i);
+#pragma unroll
+            for (int i = KMAX - 2; i >= 0; --i) if (i + 1 < K) cswap(i);
+        }
+        return found;
+    }
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(NT) void raster_fwd_kernel(
+    const float *__restrict__ fv, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
+    const int *__restrict__ num_faces, const int *__restrict__ neighbor, int N, int H, int W, int K, float blur,
+    int persp, int clipb, long long total_blocks, int *__restrict__ p2f, float *__restrict__ zbuf,
+    float *__restrict__ bary, float *__restrict__ dists) {
+    __shared__ FaceRec s_face[LIST_CAP];
+    __shared__ int s_wcnt[NT / DBW_WAVE];
+
+    const long long logical = xcd_remap(blockIdx.x, total_blocks);
+    if (logical < 0) return;
+    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+    const int n = (int)(logical / (tiles_x * tiles_y));
+    const int t = (int)(logical % (tiles_x * tiles_y));
+    const int ty = t / tiles_x, tx = t % tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int xi = tx * TILE + (tid & (TILE - 1)), yi = ty * TILE + (tid >> 4);
+    const bool in_img = xi < W && yi < H;
+    f2 p;
+    p.x = pix_to_ndc(W - 1 - xi, W, H);
+    p.y = pix_to_ndc(H - 1 - yi, H, W);
+    const int x0 = tx * TILE, y0 = ty * TILE;
+    const int x1 = min(x0 + TILE - 1, W - 1), y1 = min(y0 + TILE - 1, H - 1);
+    const float txmax = pix_to_ndc(W - 1 - x0, W, H), txmin = pix_to_ndc(W - 1 - x1, W, H);
+    const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
+
+    TopK<KMAX> q;
+    q.init();
+
+    const int f_begin = first_idx[n], nf = num_faces[n];
+    int cnt = 0;
+    for (int base = 0; base < nf; base += NT) {
+        const int j = base + tid;
+        bool hit = false;
+        float4 bb;
+        if (j < nf) {
+            bb = bbox[f_begin + j];
+            hit = !(txmax < bb.x || txmin > bb.y || tymax < bb.z || tymin > bb.w);
+        }
+        const unsigned long long m = __ballot(hit);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / DBW_WAVE; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+        if (hit) {
+            FaceRec &r = s_face[cnt + woff + prefix];
+            const float *src = fv + (long long)(f_begin + j) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.v[i] = src[i];
+            r.xlo = bb.x; r.xhi = bb.y; r.ylo = bb.z; r.yhi = bb.w;
+            r.nb = neighbor ? neighbor[f_begin + j] : -1;
+            r.id = f_begin + j;
+        }
+        cnt += tot;
+        __syncthreads();
+        if (cnt > LIST_CAP - NT || base + NT >= nf) {
+            for (int i = 0; i < cnt; ++i) {
+                const FaceRec &r = s_face[i];
+                if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
+                    const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
+                    const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
+                    const f3 bary0 = bary_fwd(p, a, b, c);
+                    const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
+                    const f3 bc = clipb ? clip_fwd(bp) : bp;
+                    const float pzv = bc.x * z0 + bc.y * z1 + bc.z * z2;
+                    if (!(pzv < 0.f)) {
+                        const float dist = point_tri_dist(p, a, b, c);
+                        const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
+                        if (inside || !(dist >= blur)) {
+                            const float sd = inside ? -dist : dist;
+                            bool done = false;
+                            if (r.nb != -1) done = q.sibling(K, r.nb, dist, pzv, r.id, sd, bc.x, bc.y, bc.z);
+                            if (!done) q.insert(K, pzv, r.id, sd, bc.x, bc.y, bc.z);
+                        }
+                    }
+                }
+            }
+            cnt = 0;
+            __syncthreads();
+        }
+    }
+    if (!in_img) return;
+    const long long o = (((long long)n * H + yi) * W + xi) * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            const bool valid = q.fi[k] != 0x7fffffff;
+            p2f[o + k] = valid ? q.fi[k] : -1;
+            if (zbuf) zbuf[o + k] = valid ? q.pz[k] : -1.f;
+            dists[o + k] = q.ds[k];
+            bary[(o + k) * 3 + 0] = q.b0[k];
+            bary[(o + k) * 3 + 1] = q.b1[k];
+            bary[(o + k) * 3 + 2] = q.b2[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void raster_bwd_kernel(
+    const float *__restrict__ fv, const int *__restrict__ p2f, const float *__restrict__ gzb,
+    const float *__restrict__ gbary, const float *__restrict__ gdist, int N, int H, int W, int K, int persp,
+    int clipb, long long total_blocks, float *__restrict__ gfv) {
+    const long long logical = xcd_remap(blockIdx.x, total_blocks);
+    if (logical < 0) return;
+    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+    const int n = (int)(logical / (tiles_x * tiles_y));
+    const int t = (int)(logical % (tiles_x * tiles_y));
+    const int ty = t / tiles_x, tx = t % tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int xi = tx * TILE + (tid & (TILE - 1)), yi = ty * TILE + (tid >> 4);
+    const bool in_img = xi < W && yi < H;
+    f2 p;
+    p.x = pix_to_ndc(W - 1 - xi, W, H);
+    p.y = pix_to_ndc(H - 1 - yi, H, W);
+    const long long o = (((long long)n * H + yi) * W + xi) * K;
+    for (int k = 0; k < K; ++k) {
+        int f = -1;
+        if (in_img) f = p2f[o + k];
+        const bool active = f >= 0;
+        if (__ballot(active) == 0ull) continue;
+        float g[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = 0.f;
+        if (active) {
+            const float *q = fv + (long long)f * 9;
+            const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
+            const float z0 = q[2], z1 = q[5], z2 = q[8];
+            const float gd = gdist ? gdist[o + k] : 0.f;
+            const float gz = gzb ? gzb[o + k] : 0.f;
+            f3 gb{0.f, 0.f, 0.f};
+            if (gbary) { gb.x = gbary[(o + k) * 3]; gb.y = gbary[(o + k) * 3 + 1]; gb.z = gbary[(o + k) * 3 + 2]; }
+            const f3 bary0 = bary_fwd(p, a, b, c);
+            const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
+            const f3 bc = clipb ? clip_fwd(bp) : bp;
+            const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
+            const float sign = inside ? -1.f : 1.f;
+            f2 d0, d1, d2;
+            point_tri_dist_bwd(p, a, b, c, sign * gd, d0, d1, d2);
+            f3 gg{gb.x + gz * z0, gb.y + gz * z1, gb.z + gz * z2};
+            if (clipb) gg = clip_bwd(bp, gg);
+            float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
+            if (persp) gg = persp_bwd(bary0, z0, z1, z2, gg, pz0, pz1, pz2);
+            f2 e0, e1, e2;
+            bary_bwd(p, a, b, c, gg, e0, e1, e2);
+            g[0] = e0.x + d0.x; g[1] = e0.y + d0.y; g[2] = gz * bc.x + pz0;
+            g[3] = e1.x + d1.x; g[4] = e1.y + d1.y; g[5] = gz * bc.y + pz1;
+            g[6] = e2.x + d2.x; g[7] = e2.y + d2.y; g[8] = gz * bc.z + pz2;
+        }
+        wave_agg_atomic<9>(gfv, (long long)f, active, g, lane);
+    }
+}
+
+template <int KMAX>
+int launch_fwd(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
+               int N, int H, int W, int K, float blur, int persp, int clipb, int *p2f, float *zbuf, float *bary,
+               float *dists, hipStream_t s) {
+    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    hipLaunchKernelGGL(raster_fwd_kernel<KMAX>, dim3(dbw_xcd_grid(total)), dim3(NT), 0, s, fv, bbox, first_idx,
+                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, p2f, zbuf, bary, dists);
+    return dbw_check_launch("raster_fwd_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) { return (size_t)(F_total > 0 ? F_total : 1) * sizeof(float4); }
+
+extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_idx, const int32_t *num_faces,
+                                 const int32_t *neighbor, int N, int64_t F_total, int H, int W, int K,
+                                 float blur_radius, int perspective_correct, int clip_barycentric_coords,
+                                 int cull_backfaces, int32_t *pix_to_face, float *zbuf, float *bary, float *dists,
+                                 void *workspace, size_t workspace_bytes, dbw_stream_t stream) {
+    DBW_REQUIRE(face_verts && first_idx && num_faces && pix_to_face && bary && dists && workspace, "null pointer");
+    DBW_REQUIRE(N >= 0 && H > 0 && W > 0 && K > 0 && F_total >= 0, "bad size");
+    DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
+    DBW_REQUIRE(blur_radius >= 0.f, "blur_radius < 0");
+    if (K > DBW_MAX_FACES_PER_PIXEL) {
+        dbw_set_error("dbw_rasterize_fwd: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
+        return DBW_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return DBW_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float margin = (float)sqrt((double)blur_radius);
+    float4 *bbox = (float4 *)workspace;
+    if (F_total > 0) {
+        hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts,
+                           (long long)F_total, margin, cull_backfaces, bbox);
+        int rc = dbw_check_launch("face_setup_kernel");
+        if (rc) return rc;
+    }
+#define DBW_FWD(KM) launch_fwd<KM>(face_verts, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur_radius, \
+                                   perspective_correct, clip_barycentric_coords, pix_to_face, zbuf, bary, dists, s)
+    if (K == 1) return DBW_FWD(1);
+    if (K <= 4) return DBW_FWD(4);
+    if (K <= 10) return DBW_FWD(10);
+    if (K <= 16) return DBW_FWD(16);
+    return DBW_FWD(25);
+#undef DBW_FWD
+}
+
+extern "C" int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const float *grad_zbuf,
+                                 const float *grad_bary, const float *grad_dists, int N, int64_t F_total, int H, int W,
+                                 int K, int perspective_correct, int clip_barycentric_coords, float *grad_face_verts,
+                                 dbw_stream_t stream) {
+    DBW_REQUIRE(face_verts && pix_to_face && grad_face_verts, "null pointer");
+    DBW_REQUIRE(N >= 0 && H > 0 && W > 0 && K > 0 && F_total >= 0, "bad size");
+    if (N == 0 || (!grad_zbuf && !grad_bary && !grad_dists)) return DBW_OK;
+    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    hipLaunchKernelGGL(raster_bwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), 0, (hipStream_t)stream, face_verts,
+                       pix_to_face, grad_zbuf, grad_bary, grad_dists, N, H, W, K, perspective_correct,
+                       clip_barycentric_coords, total, grad_face_verts);
+    return dbw_check_launch("raster_bwd_kernel");
+}

@@ -1,0 +1,367 @@
+// Fused shading + layered alpha compositing for gfx950, forward and hand-derived backward.
+//
+// One kernel replaces, per fragment, what the reference spreads over PyTorch3D + ~15 torch kernels:
+//   convert_clipped_rasterization_to_original_faces (barycentric back-conversion),
+//   TexturesUV.sample_textures = interpolate_face_attributes + flip + F.grid_sample(bilinear, align_corners=True,
+//   border) (renderer.py:226), the circular u-padding of dbw.py:339-341 (resolved here by index
+//   arithmetic on the UNPADDED map, so no padded / flipped / per-view texture copy ever exists), and
+//   layered_rgb_blend (renderer.py:241-273, clip_inside=True) with the per-face learned opacity gather.
+// HBM traffic is the fragment stream (20 B per fragment slot in, 16 B per pixel out); texels come from L2/MALL.
+//
+// Backward (reference: torch autograd through the same ops): one pass recomputes alpha/colour per layer, a reverse
+// pass accumulates the "colour behind" U_k and "transmittance behind" V_k so that
+//   d rgb / d a_k = T_k (c_k - U_k),  d A / d a_k = T_k V_k        (no division by (1 - a_k))
+// and scatters: texel gradients (wave-aggregated atomics: under magnification -- sky dome, ground -- most lanes of a
+// wave share one bilinear footprint), per-face opacity gradients, d/d dists, and optionally d/d barycentrics.
+#include "dbw_common.h"
+#include "../../include/dbw_hip.h"
+
+using namespace dbw;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int TILE = 16;
+
+struct ShadeArgs {
+    const int *p2f; const float *bary; const float *dists;
+    const int *c2o; const int *code; const float *cw; int Fc_stride;
+    const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
+    const float *faces_alpha; int alpha_len;
+    int N, H, W, K, F; float sigma; float bg[3];
+};
+
+struct Sample {   // bilinear footprint of one fragment
+    long long a00, a01, a10, a11;   // float offsets of the 4 texels (RGB triplets) in `maps`
+    float w00, w01, w10, w11;
+    float dudx, dvdy;               // d(ix)/du, d(iy)/dv (0 when clamped at the border)
+    float wx0, wx1, wy0, wy1;
+};
+
+struct Frag {
+    int j;            // local original face id
+    int cd;           // clip code
+    float w2, w3;
+    float bo[3];      // barycentrics w.r.t. the original face
+    float e;          // geometric alpha exp(-max(d,0)/sigma) or hard indicator
+    float fa;         // learned face opacity (1 if none)
+    long long aidx;   // index into faces_alpha
+    float d;
+};
+
+__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+__device__ __forceinline__ void convert_bary(int cd, float w2, float w3, const float b[3], float bo[3]) {
+    if (cd < 0) { bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2]; return; }
+    const int i1 = cd & 3, kind = cd >> 2;
+    float o1, o2, o3;
+    if (kind == 0) { o1 = b[0] * (1.f - w2) + b[1] * (1.f - w3) + b[2]; o2 = b[0] * w2; o3 = b[1] * w3; }
+    else if (kind == 1) { o1 = b[0] * (1.f - w2) + b[2] * (1.f - w3); o2 = b[0] * w2 + b[1]; o3 = b[2] * w3; }
+    else { o1 = b[0] * (1.f - w3); o2 = b[1]; o3 = b[0] * w3 + b[2]; }
+    // slot i1 <- o1, slot i1+1 <- o2, slot i1+2 <- o3 (mod 3)
+    bo[0] = sel3(i1, o1, o3, o2);
+    bo[1] = sel3(i1, o2, o1, o3);
+    bo[2] = sel3(i1, o3, o2, o1);
+}
+
+__device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, const float go[3], float gb[3]) {
+    if (cd < 0) { gb[0] = go[0]; gb[1] = go[1]; gb[2] = go[2]; return; }
+    const int i1 = cd & 3, kind = cd >> 2;
+    const float g1 = sel3(i1, go[0], go[1], go[2]), g2 = sel3(i1, go[1], go[2], go[0]), g3 = sel3(i1, go[2], go[0], go[1]);
+    if (kind == 0) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g1 * (1.f - w3) + g3 * w3; gb[2] = g1; }
+    else if (kind == 1) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g2; gb[2] = g1 * (1.f - w3) + g3 * w3; }
+    else { gb[0] = g1 * (1.f - w3) + g3 * w3; gb[1] = g2; gb[2] = g3; }
+}
+
+// fetch + decode one fragment slot; returns false for empty slots
+__device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, long long o, Frag &fr) {
+    const int fc = A.p2f[o];
+    if (fc < 0) return false;
+    float b[3] = {A.bary[o * 3], A.bary[o * 3 + 1], A.bary[o * 3 + 2]};
+    if (A.c2o) {
+        fr.j = A.c2o[fc];
+        fr.cd = A.code[fc];
+        fr.w2 = A.cw[(long long)fc * 2];
+        fr.w3 = A.cw[(long long)fc * 2 + 1];
+    } else {
+        fr.j = fc - n * A.F;
+        fr.cd = -1;
+        fr.w2 = fr.w3 = 0.f;
+    }
+    convert_bary(fr.cd, fr.w2, fr.w3, b, fr.bo);
+    fr.d = A.dists[o];
+    if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
+    fr.fa = 1.f;
+    fr.aidx = 0;
+    if (A.faces_alpha) {
+        fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
+        fr.fa = A.faces_alpha[fr.aidx];
+    }
+    return true;
+}
+
+// grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
+__device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
+    const float *uv = A.face_uvs + (long long)fr.j * 6;
+    const float u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
+    const float v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
+    const int *md = A.map_desc + A.face_map[fr.j] * 4;
+    const long long off = md[0];
+    const int h = md[1], w = md[2], pl = md[3] & 0xffff, pr = (md[3] >> 16) & 0xffff;
+    const int wp = w + pl + pr;
+    float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
+    float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
+    s.dudx = (float)(wp - 1); s.dvdy = (float)(h - 1);
+    // clip_coordinates_set_grad of torch's grid_sampler: no gradient at or beyond the border
+    if (!(ix > 0.f)) { ix = 0.f; s.dudx = 0.f; } else if (ix >= (float)(wp - 1)) { ix = (float)(wp - 1); s.dudx = 0.f; }
+    if (!(iy > 0.f)) { iy = 0.f; s.dvdy = 0.f; } else if (iy >= (float)(h - 1)) { iy = (float)(h - 1); s.dvdy = 0.f; }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const int x1 = min(x0 + 1, wp - 1), y1 = min(y0 + 1, h - 1);
+    s.wx1 = ix - fx; s.wx0 = 1.f - s.wx1;
+    s.wy1 = iy - fy; s.wy0 = 1.f - s.wy1;
+    // padded column -> source column (circular pad), flipped row -> source row
+    int c0 = (x0 - pl) % w; if (c0 < 0) c0 += w;
+    int c1 = (x1 - pl) % w; if (c1 < 0) c1 += w;
+    const int r0 = h - 1 - y0, r1 = h - 1 - y1;
+    s.a00 = off + ((long long)r0 * w + c0) * 3; s.a01 = off + ((long long)r0 * w + c1) * 3;
+    s.a10 = off + ((long long)r1 * w + c0) * 3; s.a11 = off + ((long long)r1 * w + c1) * 3;
+    s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
+}
+
+__device__ __forceinline__ void fetch(const float *maps, const Sample &s, float c[3]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        c[ch] = maps[s.a00 + ch] * s.w00 + maps[s.a01 + ch] * s.w01 + maps[s.a10 + ch] * s.w10 + maps[s.a11 + ch] * s.w11;
+}
+
+__device__ __forceinline__ bool pixel_of_block(const ShadeArgs &A, long long total_blocks, int &n, int &xi, int &yi) {
+    const long long logical = xcd_remap(blockIdx.x, total_blocks);
+    if (logical < 0) return false;
+    const int tiles_x = (A.W + TILE - 1) / TILE, tiles_y = (A.H + TILE - 1) / TILE;
+    n = (int)(logical / (tiles_x * tiles_y));
+    const int t = (int)(logical % (tiles_x * tiles_y));
+    xi = (t % tiles_x) * TILE + (threadIdx.x & (TILE - 1));
+    yi = (t / tiles_x) * TILE + (threadIdx.x >> 4);
+    return true;
+}
+
+__global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long long total_blocks, float *__restrict__ image) {
+    int n, xi, yi;
+    if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    if (xi >= A.W || yi >= A.H) return;
+    const long long pix = ((long long)n * A.H + yi) * A.W + xi;
+    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    for (int k = 0; k < A.K; ++k) {
+        Frag fr;
+        if (!load_frag(A, n, pix * A.K + k, fr)) continue;
+        const float a = fr.e * fr.fa;
+        if (a != 0.f) {
+            Sample s;
+            footprint(A, fr, s);
+            float c[3];
+            fetch(A.maps, s, c);
+            const float wgt = T * a;
+            r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+        }
+        T *= (1.f - a);
+    }
+    const long long plane = (long long)A.H * A.W;
+    float *o = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+    o[0] = r + T * A.bg[0];
+    o[plane] = g + T * A.bg[1];
+    o[2 * plane] = b + T * A.bg[2];
+    o[3 * plane] = 1.f - T;
+}
+
+__global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
+                                                             const float *__restrict__ gimg, float *__restrict__ gmaps,
+                                                             float *__restrict__ galpha, float *__restrict__ gdists,
+                                                             float *__restrict__ gbary) {
+    extern __shared__ float s_layers[];           // [2][K][NT]: alpha_k and T_k of every pixel of the tile
+    float *s_a = s_layers + threadIdx.x, *s_T = s_layers + (long long)A.K * NT + threadIdx.x;
+    int n, xi, yi;
+    if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    const bool in_img = xi < A.W && yi < A.H;
+    const int lane = threadIdx.x & 63;
+    const long long pix = ((long long)n * A.H + yi) * A.W + xi;
+    const long long plane = (long long)A.H * A.W;
+    float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
+    if (in_img) {
+        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        gr = gi[0]; gg = gi[plane]; gbl = gi[2 * plane]; gA = gi[3 * plane];
+    }
+    // pass 1 (front to back): alpha and transmittance per layer; no texture access
+    {
+        float T = 1.f;
+        for (int k = 0; k < A.K; ++k) {
+            float ak = 0.f;
+            Frag fr;
+            if (in_img && load_frag(A, n, pix * A.K + k, fr)) ak = fr.e * fr.fa;
+            s_a[k * NT] = ak;
+            s_T[k * NT] = T;
+            T *= (1.f - ak);
+        }
+    }
+    // pass 2 (back to front)
+    float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
+    for (int k = A.K - 1; k >= 0; --k) {
+        Frag fr;
+        bool valid = false;
+        if (in_img) valid = load_frag(A, n, pix * A.K + k, fr);
+        const float ak = s_a[k * NT], Tk = s_T[k * NT];
+        Sample s;
+        s.a00 = s.a01 = s.a10 = s.a11 = 0;
+        float c[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            footprint(A, fr, s);
+            if (ak != 0.f) fetch(A.maps, s, c);
+        }
+        const float ga = valid ? Tk * (gr * (c[0] - U0) + gg * (c[1] - U1) + gbl * (c[2] - U2) + gA * Vb) : 0.f;
+        const float wgt = valid ? Tk * ak : 0.f;
+        U0 = ak * c[0] + (1.f - ak) * U0;
+        U1 = ak * c[1] + (1.f - ak) * U1;
+        U2 = ak * c[2] + (1.f - ak) * U2;
+        Vb = (1.f - ak) * Vb;
+        // geometric alpha -> dists ; learned opacity
+        float gd = 0.f;
+        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (-1.f / A.sigma);
+        if (gdists && in_img) gdists[pix * A.K + k] = gd;
+        if (galpha) {
+            const float gfa[1] = {valid ? ga * fr.e : 0.f};
+            wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
+        }
+        // colour -> texels (and -> uv -> barycentrics)
+        const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
+        const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
+        if (__ballot(tex) != 0ull) {
+            // lanes sharing the same top-left texel share all four addresses
+            unsigned long long rem = __ballot(tex);
+            int iter = 0;
+            while (rem) {
+                if (iter >= 8) {
+                    if (tex && ((rem >> lane) & 1ull)) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            unsafeAtomicAdd(gmaps + s.a00 + ch, gc[ch] * s.w00);
+                            unsafeAtomicAdd(gmaps + s.a01 + ch, gc[ch] * s.w01);
+                            unsafeAtomicAdd(gmaps + s.a10 + ch, gc[ch] * s.w10);
+                            unsafeAtomicAdd(gmaps + s.a11 + ch, gc[ch] * s.w11);
+                        }
+                    }
+                    break;
+                }
+                const int leader = __ffsll((long long)rem) - 1;
+                const long long k00 = __shfl(s.a00, leader, 64), k11 = __shfl(s.a11, leader, 64);
+                const bool match = tex && s.a00 == k00 && s.a11 == k11;
+                const unsigned long long mm = __ballot(match);
+                if (__popcll(mm) > 1) {
+                    const long long k01 = __shfl(s.a01, leader, 64), k10 = __shfl(s.a10, leader, 64);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float v00 = wave_sum(match ? gc[ch] * s.w00 : 0.f);
+                        const float v01 = wave_sum(match ? gc[ch] * s.w01 : 0.f);
+                        const float v10 = wave_sum(match ? gc[ch] * s.w10 : 0.f);
+                        const float v11 = wave_sum(match ? gc[ch] * s.w11 : 0.f);
+                        if (lane == leader) {
+                            unsafeAtomicAdd(gmaps + k00 + ch, v00);
+                            unsafeAtomicAdd(gmaps + k01 + ch, v01);
+                            unsafeAtomicAdd(gmaps + k10 + ch, v10);
+                            unsafeAtomicAdd(gmaps + k11 + ch, v11);
+                        }
+                    }
+                } else if (match) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        unsafeAtomicAdd(gmaps + s.a00 + ch, gc[ch] * s.w00);
+                        unsafeAtomicAdd(gmaps + s.a01 + ch, gc[ch] * s.w01);
+                        unsafeAtomicAdd(gmaps + s.a10 + ch, gc[ch] * s.w10);
+                        unsafeAtomicAdd(gmaps + s.a11 + ch, gc[ch] * s.w11);
+                    }
+                }
+                rem &= ~mm;
+                ++iter;
+            }
+        }
+        if (gbary && in_img) {
+            float gb[3] = {0.f, 0.f, 0.f};
+            if (tex) {
+                float gix = 0.f, giy = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float t00 = A.maps[s.a00 + ch], t01 = A.maps[s.a01 + ch], t10 = A.maps[s.a10 + ch], t11 = A.maps[s.a11 + ch];
+                    gix += gc[ch] * ((t01 - t00) * s.wy0 + (t11 - t10) * s.wy1);
+                    giy += gc[ch] * ((t10 - t00) * s.wx0 + (t11 - t01) * s.wx1);
+                }
+                const float gu = gix * s.dudx, gv = giy * s.dvdy;
+                const float *uv = A.face_uvs + (long long)fr.j * 6;
+                const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
+                convert_bary_bwd(fr.cd, fr.w2, fr.w3, go, gb);
+            }
+            const long long o = (pix * A.K + k) * 3;
+            gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
+        }
+    }
+}
+
+int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+              const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+              const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
+              int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3) {
+    DBW_REQUIRE(pix_to_face && bary && dists && face_uvs && face_map && map_desc && maps, "null pointer");
+    DBW_REQUIRE((c2o && clip_code && clip_w) || (!c2o && !clip_code && !clip_w), "c2o/clip_code/clip_w: all or none");
+    DBW_REQUIRE(N >= 0 && H > 0 && W > 0 && K > 0 && F > 0, "bad size");
+    DBW_REQUIRE(!faces_alpha || alpha_len == F || (long long)alpha_len == (long long)N * F, "faces_alpha length must be F or N*F");
+    DBW_REQUIRE(sigma >= 0.f, "sigma < 0");
+    A.p2f = pix_to_face; A.bary = bary; A.dists = dists; A.c2o = c2o; A.code = clip_code; A.cw = clip_w;
+    A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;
+    A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma;
+    for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
+    return DBW_OK;
+}
+
+}  // namespace
+
+extern "C" int dbw_shade_blend_fwd(const int32_t *pix_to_face, const float *bary, const float *dists,
+                                   const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
+                                   const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                                   const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
+                                   int K, int F, float sigma, const float *background3, float *image,
+                                   dbw_stream_t stream) {
+    ShadeArgs A;
+    int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
+                       maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
+    if (rc) return rc;
+    DBW_REQUIRE(image, "null pointer");
+    if (N == 0) return DBW_OK;
+    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    hipLaunchKernelGGL(shade_blend_fwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), 0, (hipStream_t)stream, A, total, image);
+    return dbw_check_launch("shade_blend_fwd_kernel");
+}
+
+extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const float *dists,
+                                   const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
+                                   const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                                   const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
+                                   int K, int F, float sigma, const float *background3, const float *grad_image,
+                                   float *grad_maps, float *grad_faces_alpha, float *grad_dists, float *grad_bary,
+                                   dbw_stream_t stream) {
+    ShadeArgs A;
+    int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
+                       maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
+    if (rc) return rc;
+    DBW_REQUIRE(grad_image && grad_maps, "null pointer");
+    DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
+    if (K > DBW_MAX_FACES_PER_PIXEL) {
+        dbw_set_error("dbw_shade_blend_bwd: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
+        return DBW_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return DBW_OK;
+    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * K * NT * sizeof(float);
+    hipLaunchKernelGGL(shade_blend_bwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image,
+                       grad_maps, grad_faces_alpha, grad_dists, grad_bary);
+    return dbw_check_launch("shade_blend_bwd_kernel");
+}

@@ -1,0 +1,247 @@
+// Texture-side kernels: sigmoid + decimation (dbw.py:273-278,288-293,306,331-334), TV regulariser with gradient
+// (dbw.py:378-387, loss.py:46) and the fused decoupled composite + MSE forward/backward (dbw.py:223,366-367).
+// All are streaming, HBM-bound passes over O(10 MB) per optimisation step (not per view).
+#include "dbw_common.h"
+#include "../../include/dbw_hip.h"
+
+using namespace dbw;
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threads, returns the total in every thread
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wv] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / DBW_WAVE; ++w) t += s_red[w];
+    return t;
+}
+
+// d == 1: elementwise.  d > 1: one thread per (d x d) cell and channel triple.
+__global__ void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
+                                        float *__restrict__ maps, float *__restrict__ sig) {
+    if (d <= 1) {
+        const long long total = (long long)n * h * w * 3;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const float s = sigmoidf(tex[i]);
+            maps[i] = s;
+            if (sig) sig[i] = s;
+        }
+        return;
+    }
+    const int ch_ = h / d, cw_ = w / d;
+    const long long cells = (long long)n * ch_ * cw_;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(c / (ch_ * cw_));
+        const int r = (int)(c % (ch_ * cw_));
+        const int cy = r / cw_, cx = r % cw_;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int y = 0; y < d; ++y)
+            for (int x = 0; x < d; ++x) {
+                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float s = sigmoidf(tex[o + k]);
+                    if (sig) sig[o + k] = s;
+                    acc[k] += s;
+                }
+            }
+        const float inv = 1.f / (float)(d * d);
+        for (int y = 0; y < d; ++y)
+            for (int x = 0; x < d; ++x) {
+                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) maps[o + k] = acc[k] * inv;
+            }
+    }
+}
+
+__global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
+                                        const float *__restrict__ gmaps, const float *__restrict__ gsig,
+                                        float *__restrict__ gtex) {
+    if (d <= 1) {
+        const long long total = (long long)n * h * w * 3;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const float s = sigmoidf(tex[i]);
+            const float g = gmaps[i] + (gsig ? gsig[i] : 0.f);
+            gtex[i] = g * s * (1.f - s);
+        }
+        return;
+    }
+    const int ch_ = h / d, cw_ = w / d;
+    const long long cells = (long long)n * ch_ * cw_;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(c / (ch_ * cw_));
+        const int r = (int)(c % (ch_ * cw_));
+        const int cy = r / cw_, cx = r % cw_;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int y = 0; y < d; ++y)
+            for (int x = 0; x < d; ++x) {
+                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k] += gmaps[o + k];
+            }
+        const float inv = 1.f / (float)(d * d);
+        for (int y = 0; y < d; ++y)
+            for (int x = 0; x < d; ++x) {
+                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float s = sigmoidf(tex[o + k]);
+                    gtex[o + k] = (acc[k] * inv + (gsig ? gsig[o + k] : 0.f)) * s * (1.f - s);
+                }
+            }
+    }
+}
+
+// one thread per (map, y, x, channel)
+__global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m, int n, int h, int w, int wrap,
+                                                     float scale, float *__restrict__ loss, float *__restrict__ gm) {
+    __shared__ float s_red[NT / DBW_WAVE];
+    const long long total = (long long)n * h * w * 3;
+    const float sx = 1.f / ((float)h * (float)(w - 1 + (wrap ? 1 : 0)));
+    const float sy = 1.f / ((float)(h - 1) * (float)w);
+    float part = 0.f;
+    for (long long i0 = (long long)blockIdx.x * NT; i0 < total; i0 += (long long)gridDim.x * NT) {
+        const long long i = i0 + threadIdx.x;
+        if (i < total) {
+            const int c = (int)(i % 3);
+            const long long t = i / 3;
+            const int x = (int)(t % w), y = (int)((t / w) % h);
+            (void)c;
+            const float v = m[i];
+            float g = 0.f;
+            // forward difference owned by this texel (x -> x+1, wrapping to column 0 when wrap)
+            if (x + 1 < w) { const float dxf = m[i + 3] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
+            else if (wrap) { const float dxf = m[i - (long long)(w - 1) * 3] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
+            if (x > 0) { const float dxb = v - m[i - 3]; g += 2.f * dxb * sx; }
+            else if (wrap) { const float dxb = v - m[i + (long long)(w - 1) * 3]; g += 2.f * dxb * sx; }
+            if (y + 1 < h) { const float dyf = m[i + (long long)w * 3] - v; part += dyf * dyf * sy; g -= 2.f * dyf * sy; }
+            if (y > 0) { const float dyb = v - m[i - (long long)w * 3]; g += 2.f * dyb * sy; }
+            if (gm) gm[i] += scale * g;
+        }
+    }
+    const float tot = block_sum(part, s_red);
+    if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(loss, scale * tot);
+}
+
+__global__ __launch_bounds__(NT) void composite_mse_kernel(const float *__restrict__ fg, const float *__restrict__ env,
+                                                           const float *__restrict__ img, int N, long long plane,
+                                                           float scale, float *__restrict__ rec,
+                                                           float *__restrict__ loss, float *__restrict__ gfg,
+                                                           float *__restrict__ genv) {
+    __shared__ float s_red[NT / DBW_WAVE];
+    const long long total = (long long)N * plane;
+    float part = 0.f;
+    for (long long i0 = (long long)blockIdx.x * NT; i0 < total; i0 += (long long)gridDim.x * NT) {
+        const long long i = i0 + threadIdx.x;
+        if (i < total) {
+            const long long n = i / plane, p = i % plane;
+            const float *f = fg + n * 4 * plane + p, *e = env + n * 4 * plane + p;
+            const float *t = img ? img + n * 3 * plane + p : nullptr;
+            const float mask = f[3 * plane];
+            float gmask = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float fc = f[c * plane], ec = e[c * plane];
+                const float r = fc * mask + (1.f - mask) * ec;
+                const float d = t ? r - t[c * plane] : 0.f;
+                part += d * d;
+                if (rec) rec[n * 3 * plane + c * plane + p] = r;
+                if (gfg) {
+                    const float gr = 2.f * scale * d;
+                    gfg[n * 4 * plane + c * plane + p] = gr * mask;
+                    genv[n * 4 * plane + c * plane + p] = gr * (1.f - mask);
+                    gmask += gr * (fc - ec);
+                }
+            }
+            if (gfg) { gfg[n * 4 * plane + 3 * plane + p] = gmask; genv[n * 4 * plane + 3 * plane + p] = 0.f; }
+        }
+    }
+    const float tot = block_sum(part, s_red);
+    if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, tot);
+}
+
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
+                            float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+inline unsigned grid_for(long long work) {
+    long long b = (work + NT - 1) / NT;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;   // 256 CUs x 8 resident blocks, grid-stride beyond that
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, int decim, float *maps_out,
+                                    float *sig_out, dbw_stream_t stream) {
+    DBW_REQUIRE(texture && maps_out, "null pointer");
+    DBW_REQUIRE(n > 0 && h > 0 && w > 0 && decim >= 1, "bad size");
+    DBW_REQUIRE(decim == 1 || (h % decim == 0 && w % decim == 0), "map size must be a multiple of the decimation factor");
+    const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) : (long long)n * h * w * 3;
+    hipLaunchKernelGGL(texture_prep_fwd_kernel, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, texture, n, h,
+                       w, decim, maps_out, sig_out);
+    return dbw_check_launch("texture_prep_fwd_kernel");
+}
+
+extern "C" int dbw_texture_prep_bwd(const float *texture, int n, int h, int w, int decim, const float *grad_maps,
+                                    const float *grad_sig, float *grad_texture, dbw_stream_t stream) {
+    DBW_REQUIRE(texture && grad_maps && grad_texture, "null pointer");
+    DBW_REQUIRE(n > 0 && h > 0 && w > 0 && decim >= 1, "bad size");
+    DBW_REQUIRE(decim == 1 || (h % decim == 0 && w % decim == 0), "map size must be a multiple of the decimation factor");
+    const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) : (long long)n * h * w * 3;
+    hipLaunchKernelGGL(texture_prep_bwd_kernel, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, texture, n, h,
+                       w, decim, grad_maps, grad_sig, grad_texture);
+    return dbw_check_launch("texture_prep_bwd_kernel");
+}
+
+extern "C" int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, float scale, float *loss,
+                           float *grad_maps, dbw_stream_t stream) {
+    DBW_REQUIRE(maps && loss, "null pointer");
+    DBW_REQUIRE(n > 0 && h > 1 && w > 1, "bad size");
+    hipLaunchKernelGGL(tv_l2sq_kernel, dim3(grid_for((long long)n * h * w * 3)), dim3(NT), 0, (hipStream_t)stream, maps,
+                       n, h, w, wrap_x, scale, loss, grad_maps);
+    return dbw_check_launch("tv_l2sq_kernel");
+}
+
+extern "C" int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W,
+                                 float scale, float *rec, float *loss_sum, float *grad_fg, float *grad_env,
+                                 dbw_stream_t stream) {
+    DBW_REQUIRE(fg && env, "null pointer");
+    DBW_REQUIRE((imgs && loss_sum) || (!imgs && !loss_sum && !grad_fg && rec), "imgs/loss_sum: both, or neither with rec only");
+    DBW_REQUIRE((grad_fg && grad_env) || (!grad_fg && !grad_env), "grad_fg/grad_env: both or none");
+    DBW_REQUIRE(N >= 0 && H > 0 && W > 0, "bad size");
+    if (N == 0) return DBW_OK;
+    const long long plane = (long long)H * W;
+    hipLaunchKernelGGL(composite_mse_kernel, dim3(grid_for((long long)N * plane)), dim3(NT), 0, (hipStream_t)stream, fg,
+                       env, imgs, N, plane, scale, rec, loss_sum, grad_fg, grad_env);
+    return dbw_check_launch("composite_mse_kernel");
+}
+
+extern "C" int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int step, dbw_stream_t stream) {
+    DBW_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    DBW_REQUIRE(n >= 0 && step >= 1, "bad size/step");
+    if (n == 0) return DBW_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (long long)n, (float)(lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+    return dbw_check_launch("adam_kernel");
+}

@@ -1,0 +1,75 @@
+"""ctypes binding of libdbw_hip.so (C ABI declared in include/dbw_hip.h).
+
+The library is the product: there is NO CPU fallback.  If it cannot be loaded, or a call fails, a RuntimeError is
+raised (never a silent eager/PyTorch path)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdbw_hip.so')
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_i64 = ctypes.c_int64
+c_sz = ctypes.c_size_t
+
+# name -> argtypes, exactly the prototypes of include/dbw_hip.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    'dbw_project_clip_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_project_clip_bwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_rasterize_fwd': [c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p],
+    'dbw_rasterize_bwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    'dbw_shade_blend_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    'dbw_shade_blend_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
+                            c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_texture_prep_fwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    'dbw_texture_prep_bwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    'dbw_sq_blocks_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
+    'dbw_sq_blocks_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_posed_mesh_fwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
+    'dbw_posed_mesh_bwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
+    'dbw_composite_mse': [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p],
+    'dbw_tv_l2sq': [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    'dbw_overlap_loss': [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_adam_step': [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i, c_p],
+}
+
+
+def load():
+    """Load (building in-tree with hipcc if the .so is absent or stale and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('_dbw_build', os.path.join(_HERE, '..', 'build.py'))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        if b.needs_build() and os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+            b.build()
+    except Exception as e:                      # a stale-but-present library is still usable; a missing one is fatal below
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'libdbw_hip.so is missing and could not be built: {e}') from e
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} not found: run `python differentiable-blocksworld_amd/build.py` '
+                           '(there is no CPU fallback for the render path)')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dbw_last_error.restype = ctypes.c_char_p
+    lib.dbw_abi_version.restype = c_i
+    lib.dbw_rasterize_workspace_bytes.restype = c_sz
+    lib.dbw_rasterize_workspace_bytes.argtypes = [c_i64]
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed (rc={rc}): {lib.dbw_last_error().decode()}')

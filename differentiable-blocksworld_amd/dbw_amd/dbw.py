@@ -1,0 +1,386 @@
+"""DifferentiableBlocksWorld -- host-side mirror of the reference model (src/model/dbw.py:38-462): same constructor
+keywords (cfg.model.{mesh,renderer,rend_optim,loss}), same 10 parameters and buffer names/shapes (checkpoints
+interchange), same `forward(inp, labels) -> {'rgb','parsimony','tv','overlap','total'}` contract that
+src/trainer.py:137-147 drives, with every per-iteration computation executed by libdbw_hip.so:
+
+  build_blocks / build_ground / build_bkg  -> dbw_sq_blocks_*, dbw_posed_mesh_*, dbw_texture_prep_*
+  Renderer (x3: coarse, fine, env)         -> dbw_project_clip_*, dbw_rasterize_*, dbw_shade_blend_*
+  decoupled composite + MSE                -> dbw_composite_mse
+  TV / overlap regularisers                -> dbw_tv_l2sq, dbw_overlap_loss
+Only O(K)-scalar glue (opacity sigmoid/noise, parsimony over K numbers, loss weighting) stays in torch.
+
+The perceptual term needs the third-party `lpips` package + VGG weights (absent here): it is a pluggable callable
+(`perceptual_fn`), excluded from the HIP path as SURVEY.md 8(a) A10 prescribes."""
+import warnings
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import mesh as M
+from . import ops
+from .renderer import Renderer
+from .structures import PackedScene
+
+DECIMATE_FACTOR = 8            # dbw.py:32
+OVERLAP_N_POINTS = 1000        # dbw.py:33
+OVERLAP_N_BLOCKS = 1.95        # dbw.py:34
+OVERLAP_TEMPERATURE = 0.005    # dbw.py:35
+
+
+def safe_pow(t, exponent, eps=1e-6):      # utils/pytorch.py:35-36
+    return t.clamp(eps).pow(exponent)
+
+
+class DifferentiableBlocksWorld(nn.Module):
+    name = 'dbw'
+
+    def __init__(self, img_size, **kwargs):
+        super().__init__()
+        self._init_kwargs = deepcopy(kwargs)
+        self._init_kwargs['img_size'] = img_size
+        self.img_size = tuple(img_size) if not isinstance(img_size, int) else (img_size, img_size)
+        self._init_blocks(**kwargs.get('mesh', {}))
+        self._init_renderer(self.img_size, **kwargs.get('renderer', {}))
+        self._init_rend_optim(**kwargs.get('rend_optim', {}))
+        self._init_loss(**kwargs.get('loss', {}))
+        self.cur_epoch = 0
+        self.perceptual_fn = None
+        self.world_size, self.rank = 1, 0     # view-sharded data parallel (parallel.py)
+        self._noise_override = None
+        self._overlap_u_override = None
+
+    @property
+    def init_kwargs(self):
+        return deepcopy(self._init_kwargs)
+
+    # ------------------------------------------------------------------------------------------------ init (dbw.py:55-119)
+    def _init_blocks(self, **kwargs):
+        self.n_blocks = kwargs.pop('n_blocks', 1)
+        self.S_world = kwargs.pop('S_world', 1)
+        elev, azim, roll = kwargs.pop('R_world', [0, 0, 0])
+        self.register_buffer('R_world', M.world_rotation(elev, azim, roll)[None])
+        self.register_buffer('T_world', torch.Tensor(kwargs.pop('T_world', [0., 0., 0.]))[None])
+        self.z_far = kwargs.pop('z_far', 10)
+        self.ratio_block_scene = kwargs.pop('ratio_block_scene', 1 / 4)
+        self.txt_size = kwargs.pop('txt_size', 256)
+        self.txt_bkg_upscale = kwargs.pop('txt_bkg_upscale', 1)
+        self.scale_min = kwargs.pop('scale_min', 0.2)
+        opacity_init = kwargs.pop('opacity_init', 0.5)
+        T_range = kwargs.pop('T_range', [1, 1, 1])
+        T_init_mode = kwargs.pop('T_init_mode', 'gauss')
+        assert len(kwargs) == 0, kwargs
+        N, TS = self.n_blocks, self.txt_size
+
+        # sky dome + ground plane (dbw.py:74-79)
+        bkg_v, bkg_f = M.get_icosphere(level=2, flip_faces=True)
+        bkg_v = bkg_v * self.z_far
+        self.register_buffer('bkg_verts_uvs', M.point_to_uv_sphericalmap(bkg_v))
+        g_v, g_f = M.get_plane()
+        g_v = g_v * torch.Tensor([self.z_far, 1, self.z_far])[None]
+        for _ in range(3):
+            g_v, g_f = M.subdivide_mesh(g_v, g_f)
+        self.register_buffer('ground_verts_uvs', (g_v[:, [0, 2]] / self.z_far + 1) / 2)
+
+        # block primitive = icosphere-1 superquadric (dbw.py:82-96)
+        b_v, b_f = M.get_icosphere(level=1)
+        self.sq_eps = nn.Parameter(torch.zeros(N, 2))
+        self.register_buffer('sq_eta', torch.asin(b_v[:, 1])[None].repeat(N, 1))
+        self.register_buffer('sq_omega', torch.atan2(b_v[:, 0], b_v[:, 2])[None].repeat(N, 1))
+        faces_uvs, verts_uvs = M.get_icosphere_uvs(level=1, fix_continuity=True, fix_poles=True)
+        p_left = abs(int(np.floor(verts_uvs.min(0)[0][0].item() * TS)))
+        p_right = int(np.ceil((verts_uvs.max(0)[0][0].item() - 1) * TS))
+        verts_u = (verts_uvs[..., 0] * TS + p_left) / (TS + p_left + p_right)
+        verts_uvs = torch.stack([verts_u, verts_uvs[..., 1]], dim=-1)
+        self.txt_padding = p_left, p_right
+        self.BNF = len(faces_uvs)
+        self.register_buffer('block_faces_uvs', faces_uvs)
+        self.register_buffer('block_verts_uvs', verts_uvs)
+
+        # learnable pose parameters; RNG draw order = dbw.py:99-119 (same seed -> same init as the reference)
+        self.R_6d_ground = nn.Parameter(torch.Tensor([[1., 0., 0., 0., 1., 0.]]))
+        self.T_ground = nn.Parameter(torch.Tensor([[0., -0.9 * T_range[1], 0.]]))
+        S_init = (torch.rand(N, 3) + 0.5 - self.scale_min).log()
+        R_6d_init = M.matrix_to_rotation_6d(M.random_rotations(N))
+        if T_init_mode == 'gauss':
+            T_init = torch.randn(N, 3) / 2 * torch.Tensor(T_range)
+        elif T_init_mode == 'uni':
+            T_init = (2 * torch.rand(N, 3) - 1) * torch.Tensor(T_range)
+        else:
+            raise NotImplementedError
+        self.S = nn.Parameter(S_init.clone())
+        self.R_6d = nn.Parameter(R_6d_init.clone())
+        self.T = nn.Parameter(T_init.clone())
+        self.alpha_logit = nn.Parameter(torch.logit(torch.ones(N) * opacity_init) + 1e-3)
+        u = self.txt_bkg_upscale
+        self.texture_bkg = nn.Parameter(torch.randn(1, TS * u, TS * u, 3) / 10)
+        self.texture_ground = nn.Parameter(torch.randn(1, TS * u, TS * u, 3) / 10)
+        self.textures = nn.Parameter(torch.randn(N, TS, TS, 3) / 10)
+
+        # ---- constant device tables for the kernels (non-persistent: not part of checkpoints) ----
+        nvb = bkg_v.shape[0]
+        reg = lambda n, t: self.register_buffer(n, t.contiguous(), persistent=False)
+        reg('_bkg_verts', bkg_v)
+        reg('_ground_base', g_v)
+        reg('_env_faces', torch.cat([bkg_f, g_f + nvb], 0).to(torch.int32))
+        reg('_env_face_uvs', torch.cat([self.bkg_verts_uvs[bkg_f], self.ground_verts_uvs[g_f]], 0).float())
+        reg('_env_face_map', torch.cat([torch.zeros(len(bkg_f)), torch.ones(len(g_f))]).to(torch.int32))
+        desc, _ = PackedScene.describe_maps([(TS * u, TS * u)] * 2, [(0, 0)] * 2, 'cpu')
+        reg('_env_map_desc', desc)
+        self._n_bkg_faces, self._n_ground_faces = len(bkg_f), len(g_f)
+        # cos/sin tables of the constant angle buffers, evaluated once on the host (include/dbw_hip.h: `trig`)
+        reg('_trig', torch.stack([torch.cos(self.sq_eta), torch.sin(self.sq_eta), torch.cos(self.sq_omega), torch.sin(self.sq_omega)], 0))
+        nv = b_v.shape[0]
+        self._block_nv = nv
+        reg('_block_faces_all', torch.cat([b_f + k * nv for k in range(N)], 0).to(torch.int32))
+        reg('_block_face_uvs_all', verts_uvs[faces_uvs].repeat(N, 1, 1).float())
+        reg('_block_face_map_all', torch.arange(N).repeat_interleave(self.BNF).to(torch.int32))
+        desc, _ = PackedScene.describe_maps([(TS, TS)] * N, [self.txt_padding] * N, 'cpu')
+        reg('_block_map_desc_all', desc)
+        reg('_block_faces_one', b_f)
+
+    def _init_rend_optim(self, **kwargs):          # dbw.py:121-129
+        self.opacity_noise = kwargs.pop('opacity_noise', False)
+        self.decouple_rendering = kwargs.pop('decouple_rendering', False)
+        self.coarse_learning = kwargs.pop('coarse_learning', True)
+        self.decimate_txt = kwargs.pop('decimate_txt', False)
+        self.decim_factor = kwargs.pop('decimate_factor', DECIMATE_FACTOR)
+        self.kill_blocks = kwargs.pop('kill_blocks', False)
+        assert len(kwargs) == 0, kwargs
+
+    def _init_renderer(self, img_size, **kwargs):  # dbw.py:131-143 (renderer_light is visualisation-only: not built)
+        kwargs = deepcopy(kwargs)
+        self.renderer = Renderer(img_size, **kwargs)
+        kwargs['sigma'] = 5e-6
+        self.renderer_fine = Renderer(img_size, **kwargs)
+        kwargs['faces_per_pixel'] = 1
+        kwargs['sigma'] = 0
+        kwargs['detach_bary'] = False
+        self.renderer_env = Renderer(img_size, **kwargs)
+
+    def _init_loss(self, **kwargs):                # dbw.py:145-163
+        weights = {'rgb': kwargs.pop('rgb_weight', 1.0), 'perceptual': kwargs.pop('perceptual_weight', 0),
+                   'parsimony': kwargs.pop('parsimony_weight', 0), 'scale': kwargs.pop('scale_weight', 0),
+                   'tv': kwargs.pop('tv_weight', 0), 'overlap': kwargs.pop('overlap_weight', 0)}
+        name = kwargs.pop('name', 'mse')
+        kwargs.pop('perceptual_name', 'lpips')
+        tv_type = kwargs.pop('tv_type', 'l2sq')
+        assert len(kwargs) == 0, kwargs
+        if name not in ('mse', 'l2'):
+            raise NotImplementedError(f"loss '{name}': the HIP path implements the MSE criterion (default.yml)")
+        if tv_type != 'l2sq':
+            raise NotImplementedError(f"tv_type '{tv_type}': only 'l2sq' (default) is implemented")
+        self.loss_weights = {k: v for k, v in weights.items() if v > 0}
+        self.loss_names = [f'loss_{n}' for n in list(self.loss_weights.keys()) + ['total']]
+
+    def set_perceptual(self, fn):
+        """fn(imgs, rec) -> scalar, e.g. lpips.LPIPS(net='vgg') with normalize=True (loss.py:32-40)."""
+        self.perceptual_fn = fn
+
+    # ------------------------------------------------------------------------------------------------ bookkeeping
+    def set_cur_epoch(self, epoch):
+        self.cur_epoch = epoch
+
+    def step(self):
+        self.cur_epoch += 1
+
+    def to(self, device):
+        super().to(device)
+        for r in (self.renderer, self.renderer_fine, self.renderer_env):
+            r.to(device)
+        return self
+
+    def is_live(self, name):                        # dbw.py:457-462
+        milestone = getattr(self, name)
+        if isinstance(milestone, bool):
+            return milestone
+        return True if self.cur_epoch < milestone else False
+
+    @property
+    def bkg_n_faces(self):
+        return self._n_bkg_faces
+
+    @property
+    def ground_n_faces(self):
+        return self._n_ground_faces
+
+    @property
+    def env_n_faces(self):
+        return self._n_bkg_faces + self._n_ground_faces
+
+    @property
+    def blocks_n_faces(self):
+        return self.n_blocks * self.BNF
+
+    def get_opacities(self):                        # dbw.py:410-414
+        alpha = torch.sigmoid(self.alpha_logit)
+        if self.kill_blocks:
+            alpha = alpha * (alpha > 0.01)
+        return alpha
+
+    @torch.no_grad()
+    def get_nb_opaque_blocks(self):
+        return (self.get_opacities() > 0.5).sum().item()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict, strict=False):   # tolerant by-name copy, spq_ -> sq_ (dbw.py:440-455)
+        state = self.state_dict()
+        missing = []
+        for name, param in state_dict.items():
+            name = name.replace('module.', '').replace('spq_', 'sq_')
+            if name in state:
+                state[name].copy_(param.data if isinstance(param, nn.Parameter) else param)
+            else:
+                missing.append(name)
+        if missing:
+            warnings.warn(f'load_state_dict: {missing} not found')
+
+    # ------------------------------------------------------------------------------------------------ scene building
+    def _world_consts(self):
+        return float(self.S_world), self.R_world[0].contiguous(), self.T_world[0].contiguous()
+
+    def build_env_scene(self):
+        """join(build_bkg(world_coord=True), build_ground(world_coord=True))  (dbw.py:214,267-295) as a PackedScene."""
+        S_w, R_w, T_w = self._world_consts()
+        bkg_v = (self._bkg_verts * S_w) @ R_w + T_w                       # constant geometry (no parameter involved)
+        ground_v = ops.posed_mesh(self.R_6d_ground, self.T_ground, self._ground_base, S_w, R_w, T_w)
+        decim = self.decim_factor if (self.training and self.is_live('decimate_txt')) else 1
+        bkg_maps, self._bkg_maps = ops.texture_prep(self.texture_bkg, decim)
+        g_maps, self._ground_maps = ops.texture_prep(self.texture_ground, decim)
+        verts = torch.cat([bkg_v, ground_v], 0)
+        maps = torch.cat([bkg_maps.reshape(-1), g_maps.reshape(-1)])
+        return PackedScene(verts, self._env_faces, self._env_face_uvs, self._env_face_map, self._env_map_desc, maps)
+
+    def get_blocks_verts(self):
+        """Block-frame superquadric vertices * ratio (dbw.py:348-352), for callers that want them unposed."""
+        dev = self.sq_eps.device
+        ident6 = torch.tensor([[1., 0., 0., 0., 1., 0.]], device=dev).repeat(self.n_blocks, 1)
+        zeros = torch.zeros(self.n_blocks, 3, device=dev)
+        logS = torch.log(torch.full((self.n_blocks, 3), 1.0 - self.scale_min, device=dev))
+        eye = torch.eye(3, device=dev)
+        return ops.sq_blocks(self.sq_eps, logS, ident6, zeros, self._trig, None, self.n_blocks, self.ratio_block_scene,
+                             self.scale_min, 1.0, eye, None)
+
+    def build_blocks_scene(self, filter_transparent=False):
+        """build_blocks(filter_transparent, as_scene=True) (dbw.py:297-346) as a PackedScene, or None if no block is left.
+        Sets self._alpha (live blocks), self._alpha_full, self._blocks_maps like the reference."""
+        coarse = self.training and self.is_live('coarse_learning')
+        if self.opacity_noise and coarse:
+            noise = self._noise_override if self._noise_override is not None else self._shared_randn_like(self.alpha_logit)
+            alpha_logit = self.alpha_logit + self.opacity_noise * noise
+        else:
+            alpha_logit = self.alpha_logit
+        self._alpha = torch.sigmoid(alpha_logit)
+        self._alpha_full = self._alpha.clone()
+        keep, nb = None, self.n_blocks
+        if filter_transparent or self.kill_blocks:
+            mask = torch.sigmoid(self.alpha_logit) > (0.5 if filter_transparent else 0.01)
+            self._alpha_full = self._alpha_full * mask
+            nb = int(mask.sum().item())                              # same host sync as dbw.py:322
+            if nb < self.n_blocks:
+                keep = mask.to(torch.int32)
+                self._alpha = self._alpha[mask]
+        decim = self.decim_factor if (coarse and self.is_live('decimate_txt')) else 1
+        maps_all, self._blocks_maps = ops.texture_prep(self.textures, decim)
+        self._keep_mask = keep
+        if nb == 0:
+            return None
+        S_w, R_w, T_w = self._world_consts()
+        verts = ops.sq_blocks(self.sq_eps, self.S, self.R_6d, self.T, self._trig, keep, nb, self.ratio_block_scene,
+                              self.scale_min, S_w, R_w, T_w)
+        maps = maps_all if keep is None else maps_all[keep.bool()]
+        F_ = nb * self.BNF
+        return PackedScene(verts.reshape(-1, 3), self._block_faces_all[:F_], self._block_face_uvs_all[:F_],
+                           self._block_face_map_all[:F_], self._block_map_desc_all[:nb], maps.reshape(-1))
+
+    def _shared_randn_like(self, t):
+        """Opacity noise must be identical on every data-parallel rank: drawn from a generator that all
+        ranks seed identically and advance in lockstep."""
+        return torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=self._shared_generator(t.device))
+
+    def _shared_generator(self, device):
+        g = getattr(self, '_shared_gen', None)
+        if g is None or g.device != torch.device(device):
+            g = torch.Generator(device=device)
+            g.manual_seed(1234567 + 0)
+            self._shared_gen = g
+        return g
+
+    # ------------------------------------------------------------------------------------------------ rendering
+    def _ensure_cameras(self, inp):
+        if 'K' in inp and self.renderer.cameras.K is None:          # intrinsics frozen from the first sample (dbw.py:204-208)
+            for r in (self.renderer, self.renderer_fine, self.renderer_env):
+                r.update_cameras(device=inp['imgs'].device, K=inp['K'][0:1])
+
+    def render_layers(self, inp, filter_transparent=False):
+        """-> fg (B,4,H,W), env (B,4,H,W): the two passes of the decoupled rendering (dbw.py:213-222)."""
+        if not self.decouple_rendering:
+            raise NotImplementedError('decouple_rendering=False (every shipped config sets it True, default.yml:19)')
+        self._ensure_cameras(inp)
+        R, T = inp['R'], inp['T']
+        fine = not self.is_live('coarse_learning')
+        filter_tsp = filter_transparent or fine
+        renderer = self.renderer_fine if fine else self.renderer
+        env = self.renderer_env.render_packed(self.build_env_scene(), R, T)
+        blocks = self.build_blocks_scene(filter_transparent=filter_tsp)
+        if blocks is not None:
+            alpha = None if filter_tsp else self._alpha.repeat_interleave(self.BNF)   # shared by all views (== .repeat(B))
+            fg = renderer.render_packed(blocks, R, T, faces_alpha=alpha)
+        else:
+            fg = torch.zeros_like(env)
+        return fg, env
+
+    def predict(self, inp, labels=None, w_edges=False, filter_transparent=False):
+        if w_edges:
+            raise NotImplementedError('edge overlays are visualisation-only (SURVEY.md 8f N4)')
+        fg, env = self.render_layers(inp, filter_transparent)
+        return ops.composite(fg, env)                                  # rec = rec_fg*mask + (1-mask)*rec_env (dbw.py:223)
+
+    def forward(self, inp, labels=None):
+        fg, env = self.render_layers(inp)
+        return self.compute_losses(inp['imgs'], None, layers=(fg, env))
+
+    # ------------------------------------------------------------------------------------------------ losses (dbw.py:361-408)
+    def compute_losses(self, imgs, rec, layers=None):
+        w = self.loss_weights
+        dev = imgs.device
+        losses = {k: torch.tensor(0.0, device=dev) for k in w}
+        coarse = self.is_live('coarse_learning')
+        ws = self.world_size
+        if 'rgb' in losses:
+            if layers is not None:   # fused composite + MSE; count = elements of the GLOBAL batch under view sharding
+                count = imgs.numel() if getattr(self, '_global_count', None) is None else self._global_count
+                losses['rgb'] = w['rgb'] * ops.composite_mse(layers[0], layers[1], imgs, count)
+            else:
+                losses['rgb'] = w['rgb'] * F.mse_loss(imgs, rec)
+        if 'perceptual' in losses:
+            if self.perceptual_fn is None:
+                raise RuntimeError('perceptual_weight > 0 needs model.set_perceptual(fn): lpips is a third-party network '
+                                   'outside the HIP path (SURVEY.md 8a A10)')
+            if rec is None:
+                rec = ops.composite(*layers)
+            losses['perceptual'] = w['perceptual'] * (1 if coarse else 0.1) * self.perceptual_fn(imgs, rec)
+        # view-independent regularisers: every rank computes them identically; scaled by 1/world_size so that the
+        # sum all-reduce of gradients counts them once
+        rs = 1.0 / ws
+        if 'parsimony' in losses:
+            factor = 1 if coarse else 0
+            alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()
+            losses['parsimony'] = w['parsimony'] * factor * rs * safe_pow(alpha, 0.5).mean()
+        if 'tv' in losses:
+            factor = 1 if coarse else 0.1
+            tv = ops.tv_l2sq(self._bkg_maps) + ops.tv_l2sq(self._blocks_maps, wrap_x=True) + ops.tv_l2sq(self._ground_maps) * factor
+            losses['tv'] = w['tv'] * factor * rs * tv
+        if 'overlap' in losses:
+            factor = 1 if coarse else 0
+            u = self._overlap_u_override
+            if u is None:
+                u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev, generator=self._shared_generator(dev))
+            alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()
+            ov = ops.overlap_loss(self.sq_eps, self.S, self.R_6d, self.T, alpha, u, self.ratio_block_scene, self.scale_min,
+                                  OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS)
+            losses['overlap'] = w['overlap'] * factor * rs * ov
+        losses['total'] = sum(losses.values())
+        return losses

@@ -1,0 +1,438 @@
+"""torch.autograd wrappers over the C ABI (include/dbw_hip.h).  PyTorch is plumbing here: device memory, the current
+HIP stream and autograd bookkeeping; every arithmetic step of the path is a kernel of libdbw_hip.so.
+
+Operator-level mirrors of what the reference reaches in PyTorch3D:
+  rasterize_meshes(...)            <-> pytorch3d.renderer.mesh.rasterize_meshes._C.rasterize_meshes (+ backward)
+  render_scene(...)                <-> MeshRasterizer.transform + clip_faces + rasterize + TexturesUV.sample_textures
+                                        + layered_rgb_blend (src/model/renderer.py:84-98,219-273)
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+MAX_FACES_PER_PIXEL = 25
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _bg_ptr(bg):
+    """background colour: HOST pointer to 3 floats (include/dbw_hip.h) -- a ctypes array kept alive by the caller."""
+    return 0 if bg is None else ctypes.cast(bg, ctypes.c_void_p).value
+
+
+def make_bg(color):
+    return (ctypes.c_float * 3)(*[float(c) for c in color])
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on the GPU: the dbw_amd render path has no CPU implementation')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rasterize_meshes  (operator-level drop-in, int64 indices at the Python boundary like PyTorch3D)
+# ---------------------------------------------------------------------------------------------------------------------
+def _raster_fwd(face_verts, first, num, neighbor, N, H, W, K, blur, pc, cb, cull, need_zbuf=True):
+    dev = face_verts.device
+    Ft = face_verts.shape[0]
+    ws_bytes = _lib.load().dbw_rasterize_workspace_bytes(Ft)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    p2f = torch.empty(N, H, W, K, dtype=torch.int32, device=dev)
+    zbuf = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if need_zbuf else None
+    bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev)
+    dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev)
+    _lib.call('dbw_rasterize_fwd', _ptr(face_verts), _ptr(first), _ptr(num), _ptr(neighbor), N, Ft, H, W, K, float(blur),
+              int(pc), int(cb), int(cull), _ptr(p2f), _ptr(zbuf), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _stream(face_verts))
+    return p2f, zbuf, bary, dists
+
+
+class _RasterizeMeshes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, face_verts, first, num, neighbor, image_size, blur, K, pc, cb, cull):
+        H, W = image_size
+        fv = _chk(face_verts.detach(), torch.float32, 'face_verts')
+        p2f, zbuf, bary, dists = _raster_fwd(fv, first, num, neighbor, first.numel(), H, W, K, blur, pc, cb, cull)
+        ctx.save_for_backward(fv, p2f)
+        ctx.cfg = (pc, cb)
+        p2f64 = p2f.long()
+        ctx.mark_non_differentiable(p2f64)
+        return p2f64, zbuf, bary, dists
+
+    @staticmethod
+    def backward(ctx, _g, g_zbuf, g_bary, g_dists):
+        fv, p2f = ctx.saved_tensors
+        pc, cb = ctx.cfg
+        N, H, W, K = p2f.shape
+        g = torch.zeros_like(fv)
+        gz = None if g_zbuf is None else g_zbuf.contiguous()
+        gb = None if g_bary is None else g_bary.contiguous()
+        gd = None if g_dists is None else g_dists.contiguous()
+        _lib.call('dbw_rasterize_bwd', _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), N, fv.shape[0], H, W, K, int(pc),
+                  int(cb), _ptr(g), _stream(fv))
+        return g, None, None, None, None, None, None, None, None, None
+
+
+def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+                     blur_radius=0.0, faces_per_pixel=8, perspective_correct=False, clip_barycentric_coords=False,
+                     cull_backfaces=False):
+    """face_verts (F,3,3) packed NDC faces of N meshes -> (pix_to_face int64, zbuf, bary_coords, dists), each
+    (N,H,W,K[,3]), -1 where empty.  Same contract as PyTorch3D's `_C.rasterize_meshes`; gradients flow to face_verts
+    through zbuf, bary_coords and dists."""
+    if isinstance(image_size, int):
+        image_size = (image_size, image_size)
+    if faces_per_pixel > MAX_FACES_PER_PIXEL:
+        raise ValueError(f'faces_per_pixel={faces_per_pixel} > {MAX_FACES_PER_PIXEL}')
+    first = _chk(mesh_to_face_first_idx.to(torch.int32), torch.int32, 'mesh_to_face_first_idx')
+    num = _chk(num_faces_per_mesh.to(torch.int32), torch.int32, 'num_faces_per_mesh')
+    nb = None if clipped_faces_neighbor_idx is None else _chk(clipped_faces_neighbor_idx.to(torch.int32), torch.int32, 'neighbor')
+    return _RasterizeMeshes.apply(face_verts, first, num, nb, tuple(image_size), float(blur_radius), int(faces_per_pixel),
+                                  bool(perspective_correct), bool(clip_barycentric_coords), bool(cull_backfaces))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# project + clip
+# ---------------------------------------------------------------------------------------------------------------------
+def project_clip(verts, faces_i32, R, T, Kmat, eps=1e-8, z_clip=0.001, perspective_correct=True):
+    """-> dict of device tensors (no grad): face_verts (B,2F,3,3), first_idx, num_faces, c2o, neighbor, clip_code, clip_w."""
+    dev = verts.device
+    B, V, F_ = R.shape[0], verts.shape[0], faces_i32.shape[0]
+    out = dict(face_verts=torch.empty(B, 2 * F_, 3, 3, dtype=torch.float32, device=dev),
+               first_idx=torch.empty(B, dtype=torch.int32, device=dev), num_faces=torch.empty(B, dtype=torch.int32, device=dev),
+               c2o=torch.empty(B, 2 * F_, dtype=torch.int32, device=dev), neighbor=torch.empty(B, 2 * F_, dtype=torch.int32, device=dev),
+               clip_code=torch.empty(B, 2 * F_, dtype=torch.int32, device=dev),
+               clip_w=torch.empty(B, 2 * F_, 2, dtype=torch.float32, device=dev))
+    _lib.call('dbw_project_clip_fwd', _ptr(verts), _ptr(faces_i32), _ptr(R), _ptr(T), _ptr(Kmat), B, V, F_, float(eps),
+              int(z_clip is not None), float(z_clip or 0.0), int(perspective_correct), _ptr(out['face_verts']),
+              _ptr(out['first_idx']), _ptr(out['num_faces']), _ptr(out['c2o']), _ptr(out['neighbor']), _ptr(out['clip_code']),
+              _ptr(out['clip_w']), _stream(verts))
+    return out
+
+
+def project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_face_verts, eps=1e-8, z_clip=0.001, perspective_correct=True):
+    B, V, F_ = R.shape[0], verts.shape[0], faces_i32.shape[0]
+    g = torch.zeros_like(verts)
+    _lib.call('dbw_project_clip_bwd', _ptr(verts), _ptr(faces_i32), _ptr(R), _ptr(T), _ptr(Kmat), B, V, F_, float(eps),
+              float(z_clip or 0.0), int(perspective_correct), _ptr(cl['num_faces']), _ptr(cl['c2o']), _ptr(cl['clip_code']),
+              _ptr(cl['clip_w']), _ptr(g_face_verts), _ptr(g), _stream(verts))
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# shade + blend on given fragments
+# ---------------------------------------------------------------------------------------------------------------------
+def _shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg):
+    N, H, W, K = p2f.shape
+    c2o, code, cw = (cl['c2o'], cl['clip_code'], cl['clip_w']) if cl is not None else (None, None, None)
+    return (_ptr(p2f), _ptr(bary), _ptr(dists), _ptr(c2o), _ptr(code), _ptr(cw), 2 * F_, _ptr(face_uvs), _ptr(face_map),
+            _ptr(map_desc), _ptr(maps), _ptr(faces_alpha), 0 if faces_alpha is None else faces_alpha.numel(), N, H, W, K, F_,
+            float(sigma), _bg_ptr(bg))
+
+
+def shade_blend_fwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg):
+    N, H, W, K = p2f.shape
+    img = torch.empty(N, 4, H, W, dtype=torch.float32, device=p2f.device)
+    _lib.call('dbw_shade_blend_fwd', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg),
+              _ptr(img), _stream(p2f))
+    return img
+
+
+def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg, g_img,
+                    want_dists=True, want_bary=False):
+    dev = p2f.device
+    N, H, W, K = p2f.shape
+    g_maps = torch.zeros_like(maps)
+    g_alpha = torch.zeros_like(faces_alpha) if faces_alpha is not None else None
+    g_dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_dists else None
+    g_bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev) if want_bary else None
+    _lib.call('dbw_shade_blend_bwd', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg),
+              _ptr(g_img), _ptr(g_maps), _ptr(g_alpha), _ptr(g_dists), _ptr(g_bary), _stream(p2f))
+    return g_maps, g_alpha, g_dists, g_bary
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole Renderer.forward as ONE autograd node: verts/maps/faces_alpha -> (B,4,H,W)
+# ---------------------------------------------------------------------------------------------------------------------
+class RenderCfg:
+    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F')
+
+    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8):
+        self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
+        self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
+        self.detach_bary, self.eps, self.F = detach_bary, eps, F_
+
+
+class _RenderScene(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):
+        verts_c = _chk(verts.detach(), torch.float32, 'verts')
+        maps_c = _chk(maps.detach(), torch.float32, 'maps')
+        fa = None if faces_alpha is None else _chk(faces_alpha.detach(), torch.float32, 'faces_alpha')
+        B = R.shape[0]
+        cl = project_clip(verts_c, faces_i32, R, T, Kmat, cfg.eps, cfg.z_clip, cfg.persp)
+        fvc = cl['face_verts'].view(-1, 3, 3)
+        p2f, _, bary, dists = _raster_fwd(fvc, cl['first_idx'], cl['num_faces'], cl['neighbor'].view(-1), B, cfg.H, cfg.W, cfg.K,
+                                          cfg.blur, cfg.persp, True, False, need_zbuf=False)
+        img = shade_blend_fwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps_c, fa, cfg.F, cfg.sigma, bg)
+        ctx.cfg, ctx.cl = cfg, cl
+        ctx.has_alpha = fa is not None
+        ctx.bg = bg
+        ctx.save_for_backward(verts_c, maps_c, fa if fa is not None else verts_c.new_empty(0), faces_i32, R, T, Kmat, face_uvs,
+                              face_map, map_desc, p2f, bary, dists)
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        verts, maps, fa, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, p2f, bary, dists = ctx.saved_tensors
+        cfg, cl, bg = ctx.cfg, ctx.cl, ctx.bg
+        fa = fa if ctx.has_alpha else None
+        need_geom = ctx.needs_input_grad[0]
+        want_dists = need_geom and cfg.sigma > 0
+        want_bary = need_geom and not cfg.detach_bary
+        g_maps, g_alpha, g_dists, g_bary = shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F,
+                                                           cfg.sigma, bg, g_img.contiguous(), want_dists, want_bary)
+        g_verts = None
+        if need_geom and (want_dists or want_bary):
+            fvc = cl['face_verts'].view(-1, 3, 3)
+            g_fvc = torch.zeros_like(fvc)
+            B = R.shape[0]
+            _lib.call('dbw_rasterize_bwd', _ptr(fvc), _ptr(p2f), 0, _ptr(g_bary), _ptr(g_dists), B, fvc.shape[0], cfg.H, cfg.W,
+                      cfg.K, int(cfg.persp), 1, _ptr(g_fvc), _stream(fvc))
+            g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp)
+        elif need_geom:
+            g_verts = torch.zeros_like(verts)
+        return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
+
+
+def render_scene(verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):
+    """verts (V,3) world, maps flat fp32, faces_alpha None | (F,) | (B*F,) -> image (B,4,H,W)."""
+    if cfg.K > MAX_FACES_PER_PIXEL:
+        raise ValueError(f'faces_per_pixel={cfg.K} > {MAX_FACES_PER_PIXEL}')
+    return _RenderScene.apply(verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg)
+
+
+def render_fragments(verts, faces_i32, R, T, Kmat, cfg):
+    """Debug/parity helper (no grad): the raw fragments of a render pass, in clipped indexing + the clip tables."""
+    cl = project_clip(verts, faces_i32, R, T, Kmat, cfg.eps, cfg.z_clip, cfg.persp)
+    fvc = cl['face_verts'].view(-1, 3, 3)
+    p2f, zbuf, bary, dists = _raster_fwd(fvc, cl['first_idx'], cl['num_faces'], cl['neighbor'].view(-1), R.shape[0], cfg.H, cfg.W,
+                                         cfg.K, cfg.blur, cfg.persp, True, False, need_zbuf=True)
+    return cl, p2f, zbuf, bary, dists
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# texture preparation, param -> mesh, losses, optimiser
+# ---------------------------------------------------------------------------------------------------------------------
+class _TexturePrep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, texture, decim):
+        tex = _chk(texture.detach(), torch.float32, 'texture')
+        n, h, w, _ = tex.shape
+        maps = torch.empty_like(tex)
+        sig = torch.empty_like(tex) if decim > 1 else None
+        _lib.call('dbw_texture_prep_fwd', _ptr(tex), n, h, w, int(decim), _ptr(maps), _ptr(sig), _stream(tex))
+        ctx.save_for_backward(tex)
+        ctx.decim = decim
+        if sig is None:
+            sig = maps
+            ctx.alias = True
+        else:
+            ctx.alias = False
+        return maps, sig
+
+    @staticmethod
+    def backward(ctx, g_maps, g_sig):
+        (tex,) = ctx.saved_tensors
+        n, h, w, _ = tex.shape
+        if ctx.alias:          # maps and sig are the same tensor: autograd hands two grads for it
+            g = None
+            for t in (g_maps, g_sig):
+                if t is not None:
+                    g = t if g is None else g + t
+            g_maps, g_sig = g, None
+        if g_maps is None:
+            g_maps = torch.zeros_like(tex)
+        out = torch.empty_like(tex)
+        _lib.call('dbw_texture_prep_bwd', _ptr(tex), n, h, w, int(ctx.decim), _ptr(g_maps.contiguous()),
+                  _ptr(None if g_sig is None else g_sig.contiguous()), _ptr(out), _stream(tex))
+        return out, None
+
+
+def texture_prep(texture, decim=1):
+    """(n,h,w,3) logits -> (maps sampled by the renderer, undecimated sigmoid for the TV loss)."""
+    maps, sig = _TexturePrep.apply(texture, int(decim))
+    return maps, sig
+
+
+def sq_blocks(sq_eps, S, R6, T, trig, keep, nb, ratio, scale_min, S_world, R_world, T_world):
+    """-> world verts (NB,nv,3) of the kept blocks.  `nb` = number of kept blocks (host int, avoids a sync)."""
+    if keep is not None and nb == 0:
+        return trig.new_empty(0, trig.shape[2], 3)
+    return _SqBlocks.apply(sq_eps, S, R6, T, trig, keep, nb, (float(ratio), float(scale_min), float(S_world), R_world, T_world))
+
+
+class _SqBlocks(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sq_eps, S, R6, T, trig, keep, nb, consts):
+        ratio, scale_min, S_world, Rw, Tw = consts
+        args = [_chk(t.detach(), torch.float32, 'pose param') for t in (sq_eps, S, R6, T)]
+        Kb, nv = trig.shape[1], trig.shape[2]
+        verts = torch.empty(nb, nv, 3, dtype=torch.float32, device=trig.device)
+        _lib.call('dbw_sq_blocks_fwd', *[_ptr(a) for a in args], _ptr(trig), _ptr(keep), Kb, nv, ratio, scale_min, S_world,
+                  _ptr(Rw), _ptr(Tw), _ptr(verts), _stream(trig))
+        ctx.save_for_backward(*args, trig, keep if keep is not None else trig.new_empty(0), Rw)
+        ctx.consts = (ratio, scale_min, S_world, keep is not None)
+        return verts
+
+    @staticmethod
+    def backward(ctx, g_verts):
+        sq_eps, S, R6, T, trig, keep, Rw = ctx.saved_tensors
+        ratio, scale_min, S_world, has_keep = ctx.consts
+        keep = keep if has_keep else None
+        Kb, nv = trig.shape[1], trig.shape[2]
+        gs = [torch.zeros_like(t) for t in (sq_eps, S, R6, T)]
+        _lib.call('dbw_sq_blocks_bwd', _ptr(sq_eps), _ptr(S), _ptr(R6), _ptr(T), _ptr(trig), _ptr(keep), Kb, nv, ratio, scale_min,
+                  S_world, _ptr(Rw), _ptr(g_verts.contiguous()), *[_ptr(g) for g in gs], _stream(trig))
+        return gs[0], gs[1], gs[2], gs[3], None, None, None, None
+
+
+class _PosedMesh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R6, T, base, S_world, Rw, Tw):
+        r6, t = _chk(R6.detach(), torch.float32, 'R6'), _chk(T.detach(), torch.float32, 'T')
+        nv = base.shape[0]
+        verts = torch.empty(nv, 3, dtype=torch.float32, device=base.device)
+        _lib.call('dbw_posed_mesh_fwd', _ptr(base), nv, _ptr(r6), _ptr(t), float(S_world), _ptr(Rw), _ptr(Tw), _ptr(verts), _stream(base))
+        ctx.save_for_backward(r6, t, base, Rw)
+        ctx.S_world = float(S_world)
+        return verts
+
+    @staticmethod
+    def backward(ctx, g):
+        r6, t, base, Rw = ctx.saved_tensors
+        g6, gt = torch.zeros_like(r6), torch.zeros_like(t)
+        _lib.call('dbw_posed_mesh_bwd', _ptr(base), base.shape[0], _ptr(r6), _ptr(t), ctx.S_world, _ptr(Rw), _ptr(g.contiguous()),
+                  _ptr(g6), _ptr(gt), _stream(base))
+        return g6, gt, None, None, None, None
+
+
+def posed_mesh(R6, T, base, S_world, R_world, T_world):
+    return _PosedMesh.apply(R6, T, base, S_world, R_world, T_world)
+
+
+class _CompositeMSE(torch.autograd.Function):
+    """loss = mean((imgs - (fg_rgb*mask + (1-mask)*env_rgb))^2) over `count` elements; backward computed in the same pass."""
+
+    @staticmethod
+    def forward(ctx, fg, env, imgs, count):
+        N, _, H, W = fg.shape
+        fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
+        imgs = _chk(imgs, torch.float32, 'imgs')
+        loss = torch.zeros(1, dtype=torch.float32, device=fg.device)
+        g_fg, g_env = torch.empty_like(fg_c), torch.empty_like(env_c)
+        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, 1.0 / count, 0, _ptr(loss), _ptr(g_fg),
+                  _ptr(g_env), _stream(fg))
+        ctx.save_for_backward(g_fg, g_env)
+        return loss[0] / count
+
+    @staticmethod
+    def backward(ctx, g):
+        g_fg, g_env = ctx.saved_tensors
+        return g_fg * g, g_env * g, None, None
+
+
+def composite_mse(fg, env, imgs, count=None):
+    """fg (N,4,H,W), env (N,4,H,W), imgs (N,3,H,W) -> scalar MSE of the decoupled composite (dbw.py:223,366-367).
+    `count` = number of elements of the GLOBAL batch (view-sharded data parallel), default this batch."""
+    count = float(imgs.numel() if count is None else count)
+    return _CompositeMSE.apply(fg, env, imgs, count)
+
+
+def composite(fg, env):
+    """rec = fg_rgb*mask + (1-mask)*env_rgb as an image (API-compat path for predict(); HIP forward, elementwise torch
+    backward -- the training path uses composite_mse)."""
+    return _Composite.apply(fg, env)
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fg, env):
+        N, _, H, W = fg.shape
+        fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
+        rec = torch.empty(N, 3, H, W, dtype=torch.float32, device=fg.device)
+        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), 0, N, H, W, 0.0, _ptr(rec), 0, 0, 0, _stream(fg))
+        ctx.save_for_backward(fg_c, env_c)
+        return rec
+
+    @staticmethod
+    def backward(ctx, g):
+        fg, env = ctx.saved_tensors
+        mask = fg[:, 3:4]
+        g_fg = torch.cat([g * mask, (g * (fg[:, :3] - env[:, :3])).sum(1, keepdim=True)], 1)
+        g_env = torch.cat([g * (1 - mask), torch.zeros_like(mask)], 1)
+        return g_fg, g_env
+
+
+class _TV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, maps, wrap, scale):
+        m = _chk(maps.detach(), torch.float32, 'maps')
+        n, h, w, _ = m.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=m.device)
+        g = torch.zeros_like(m)
+        _lib.call('dbw_tv_l2sq', _ptr(m), n, h, w, int(wrap), float(scale), _ptr(loss), _ptr(g), _stream(m))
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, None, None
+
+
+def tv_l2sq(maps, wrap_x=False, scale=1.0):
+    """sum-over-maps l2sq total variation (dbw.py:380-386, loss.py:46), forward + gradient in one kernel."""
+    return _TV.apply(maps, bool(wrap_x), float(scale))
+
+
+class _Overlap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sq_eps, S, R6, T, alpha, u, consts):
+        ratio, scale_min, temp, thresh = consts
+        args = [_chk(t.detach(), torch.float32, 'overlap param') for t in (sq_eps, S, R6, T, alpha)]
+        Kb, npts = u.shape[0], u.shape[1]
+        dev = u.device
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        gs = [torch.zeros_like(t) for t in args]
+        ws = torch.zeros(Kb * 18, dtype=torch.float32, device=dev)
+        _lib.call('dbw_overlap_loss', _ptr(u), npts, *[_ptr(a) for a in args], Kb, ratio, scale_min, temp, thresh, 1.0, _ptr(loss),
+                  *[_ptr(g) for g in gs], _ptr(ws), _stream(u))
+        ctx.save_for_backward(*gs)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        gs = ctx.saved_tensors
+        return gs[0] * go, gs[1] * go, gs[2] * go, gs[3] * go, gs[4] * go, None, None
+
+
+def overlap_loss(sq_eps, S, R6, T, alpha, u, ratio, scale_min, temperature=0.005, n_blocks=1.95):
+    """dbw.py:389-405.  u (Kb,npts,3) uniform samples in [0,1)."""
+    return _Overlap.apply(sq_eps, S, R6, T, alpha, _chk(u, torch.float32, 'u'), (float(ratio), float(scale_min), float(temperature), float(n_blocks)))
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """In-place fused Adam on flat fp32 buffers (torch.optim.Adam defaults; optimizer.py:6-18)."""
+    _lib.call('dbw_adam_step', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+              float(betas[1]), float(eps), int(step), _stream(param))

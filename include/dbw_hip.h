@@ -1,0 +1,185 @@
+/*
+ * dbw_hip.h -- C ABI of libdbw_hip.so: the MI355X (gfx950) differentiable superquadric render path.
+ *
+ * Drop-in boundary: these entry points are what the reference's Python would bind in place of the
+ * third-party ops it reaches through src/model/renderer.py:53-54,92-94,226,236 (PyTorch3D `_C.rasterize_meshes`,
+ * `_C.rasterize_meshes_backward`, `interpolate_face_attributes`, `grid_sample`, and the ~12 torch kernels of
+ * `layered_rgb_blend`, renderer.py:241-273) and through src/model/dbw.py:250-408 (param -> mesh, losses).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch tensors on the host side), contiguous, fp32/int32;
+ *  - no allocation, no host synchronisation, no state between calls; kernels are enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream);
+ *  - return 0 on success, a negative DBW_ERR_* otherwise (never throws); dbw_last_error() gives the text;
+ *  - "accumulate" outputs must be zeroed by the caller, all others are fully written;
+ *  - empty fragment slots hold -1 in all four fragment tensors (PyTorch3D convention);
+ *  - indices are int32 in this ABI; the Python boundary widens to int64 where PyTorch3D returns int64.
+ */
+#ifndef DBW_HIP_H
+#define DBW_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBW_OK 0
+#define DBW_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, K out of range ...) */
+#define DBW_ERR_UNSUPPORTED (-2) /* configuration not compiled in (faces_per_pixel > DBW_MAX_FACES_PER_PIXEL) */
+#define DBW_ERR_LAUNCH (-3)      /* HIP launch failure */
+#define DBW_MAX_FACES_PER_PIXEL 25
+
+typedef void *dbw_stream_t;
+
+int dbw_abi_version(void);
+const char *dbw_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Camera transform + z-clipping of one scene seen from B cameras.
+ * Replaces MeshRasterizer.transform + clip_faces (pytorch3d 0.7.1; called from renderer.py:92-94 with eps=1e-8,
+ * z_clip from renderer.py:35,46).  SURVEY.md A.2, A.4.  No host sync (PyTorch3D's clip_faces syncs via .item()).
+ *
+ *  verts_world (V,3)  faces (F,3)  R (B,3,3) row-vector convention  T (B,3)  Kmat (4,4)
+ * Outputs, per view b, at most 2F clipped faces stored at [b*2F, b*2F + num_faces[b]):
+ *  face_verts_c (B,2F,3,3): x,y NDC, z view depth     first_idx (B) = b*2F      num_faces (B)
+ *  c2o (B,2F): local original face id of each clipped face
+ *  neighbor (B,2F): packed index of the sibling triangle of a split quad, else -1
+ *  clip_code (B,2F): -1 = unclipped copy; else p1_index | (kind<<2), kind 0 = case-3 triangle (p4,p5,p1),
+ *                    1 = case-4 t1 (p4,p2,p5), 2 = case-4 t2 (p5,p2,p3)
+ *  clip_w (B,2F,2): interpolation weights (w2,w3) of the intersection points p4,p5
+ * z_clip_enabled = 0 reproduces z_clip_value=None (plain copy).
+ */
+int dbw_project_clip_fwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,
+                         const float *Kmat, int B, int V, int F, float eps, int z_clip_enabled, float z_clip,
+                         int perspective_correct, float *face_verts_c, int32_t *first_idx, int32_t *num_faces,
+                         int32_t *c2o, int32_t *neighbor, int32_t *clip_code, float *clip_w, dbw_stream_t stream);
+
+/* Backward of the above: grad_face_verts_c (B,2F,3,3) -> grad_verts_world (V,3) (accumulate, summed over views). */
+int dbw_project_clip_bwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,
+                         const float *Kmat, int B, int V, int F, float eps, float z_clip, int perspective_correct,
+                         const int32_t *num_faces, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
+                         const float *grad_face_verts_c, float *grad_verts_world, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Rasteriser.  Mirrors pytorch3d `_C.rasterize_meshes` / `_C.rasterize_meshes_backward`;
+ * canonical semantics = the CPU naive path, list kept sorted by (z, face index).
+ *  face_verts (F_total,3,3)   first_idx/num_faces (N)   neighbor (F_total) or NULL
+ *  pix_to_face i32 (N,H,W,K)  zbuf (N,H,W,K)  bary (N,H,W,K,3)  dists (N,H,W,K); zbuf may be NULL (not stored).
+ *  workspace: dbw_rasterize_workspace_bytes(F_total) bytes of scratch.
+ */
+size_t dbw_rasterize_workspace_bytes(int64_t F_total);
+int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_idx, const int32_t *num_faces,
+                      const int32_t *neighbor, int N, int64_t F_total, int H, int W, int K, float blur_radius,
+                      int perspective_correct, int clip_barycentric_coords, int cull_backfaces, int32_t *pix_to_face,
+                      float *zbuf, float *bary, float *dists, void *workspace, size_t workspace_bytes,
+                      dbw_stream_t stream);
+/* grad_zbuf / grad_bary / grad_dists may each be NULL (treated as zero). grad_face_verts: accumulate. */
+int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const float *grad_zbuf,
+                      const float *grad_bary, const float *grad_dists, int N, int64_t F_total, int H, int W, int K,
+                      int perspective_correct, int clip_barycentric_coords, float *grad_face_verts,
+                      dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Shading + layered blend, fused: barycentric conversion of clipped faces, UV interpolation, bilinear texture
+ * sampling (TexturesUV.sample_textures: align_corners=True, border, v flipped) with the circular
+ * u-padding of dbw.py:339-341 resolved by index arithmetic instead of a padded copy, and the front-to-back alpha
+ * compositing of renderer.py:241-273 (clip_inside=True) with per-face learned opacity.
+ *
+ *  pix_to_face/bary/dists: fragments in CLIPPED face indexing (as produced by dbw_rasterize_fwd on the output of
+ *    dbw_project_clip_fwd); c2o/clip_code/clip_w as above, or all NULL when the fragments already index original
+ *    faces (then pix_to_face = b*F + j).
+ *  face_uvs (F,3,2)   face_map (F) -> row of map_desc
+ *  map_desc (M,4) int32: {offset in floats into maps, height, width (unpadded), pad_left | pad_right<<16}
+ *  maps: flat fp32 buffer of (h,w,3) RGB maps in [0,1]
+ *  faces_alpha: NULL, or alpha_len floats with alpha_len == F (shared by all views) or N*F (packed per view).
+ *  background3: HOST pointer to 3 floats (blend background colour, renderer.py:32), NULL = black.
+ *  image (N,4,H,W): premultiplied RGB + alpha (BCHW).
+ */
+int dbw_shade_blend_fwd(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+                        const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                        const int32_t *face_map, const int32_t *map_desc, const float *maps,
+                        const float *faces_alpha, int alpha_len, int N, int H, int W, int K, int F, float sigma,
+                        const float *background3, float *image, dbw_stream_t stream);
+/* grad_image (N,4,H,W).  Outputs: grad_maps (same layout as maps; accumulate), grad_faces_alpha (alpha_len;
+ * accumulate; may be NULL), grad_dists (N,H,W,K; fully written; may be NULL), grad_bary (N,H,W,K,3 in CLIPPED
+ * barycentrics; fully written; NULL = detach_bary, renderer.py:222-223). */
+int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+                        const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                        const int32_t *face_map, const int32_t *map_desc, const float *maps,
+                        const float *faces_alpha, int alpha_len, int N, int H, int W, int K, int F, float sigma,
+                        const float *background3, const float *grad_image, float *grad_maps,
+                        float *grad_faces_alpha, float *grad_dists, float *grad_bary, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"
+ * (avg_pool2d(d) then nearest upsample by d, dbw.py:276-278,331-334).  n maps of (h,w,3).
+ *  maps_out: what the renderer samples;  sig_out (may be NULL): undecimated sigmoid kept for the TV loss.
+ * Backward: grad_texture = (decimate^T grad_maps + grad_sig) * s(1-s).  grad_sig may be NULL.
+ */
+int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, int decim, float *maps_out, float *sig_out,
+                         dbw_stream_t stream);
+int dbw_texture_prep_bwd(const float *texture, int n, int h, int w, int decim, const float *grad_maps,
+                         const float *grad_sig, float *grad_texture, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Superquadric deformation + posing of the K block meshes (dbw.py:297-311,343-344,348-352; superquadric.py:10-14):
+ *   eps = sigmoid(sq_eps)*1.8+0.1; v = parametric_sq(eta,omega,eps)*ratio; S = exp(S)+scale_min;
+ *   R = rotation_6d_to_matrix(R_6d); verts = ((v*S)@R + T) * S_world @ R_world + T_world
+ * sq_eps (Kb,2) S (Kb,3) R6 (Kb,6) T (Kb,3); trig (4,Kb,nv) = cos(eta), sin(eta), cos(omega), sin(omega) of the
+ * constant buffers sq_eta/sq_omega (dbw.py:86-87), tabulated once at init; R_world (3,3) T_world (3).
+ * `keep` (Kb) int32 or NULL: blocks with keep==0 are skipped; kept blocks are written densely in order.
+ * verts (NB,nv,3).
+ */
+int dbw_sq_blocks_fwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
+                      const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                      const float *R_world, const float *T_world, float *verts, dbw_stream_t stream);
+/* grad_verts (NB,nv,3) -> grads of sq_eps,S,R6,T (accumulate). */
+int dbw_sq_blocks_bwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
+                      const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                      const float *R_world, const float *grad_verts, float *g_sq_eps, float *g_S, float *g_R6,
+                      float *g_T, dbw_stream_t stream);
+/* Generic posed mesh (ground plane, dbw.py:282-287): verts = ((base*1)@rot6d(R6)+T)*S_world@R_world+T_world. */
+int dbw_posed_mesh_fwd(const float *base, int nv, const float *R6, const float *T, float S_world,
+                       const float *R_world, const float *T_world, float *verts, dbw_stream_t stream);
+int dbw_posed_mesh_bwd(const float *base, int nv, const float *R6, const float *T, float S_world,
+                       const float *R_world, const float *grad_verts, float *g_R6, float *g_T, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Decoupled composite + MSE, forward and backward in one pass (dbw.py:223, 366-367):
+ *   rec = fg_rgb*mask + (1-mask)*env_rgb ; loss_sum += sum((imgs-rec)^2)
+ *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) are d(scale*sum)/d(.) with scale = weight/count.
+ * fg (N,4,H,W) premultiplied RGB + mask, env (N,4,H,W), imgs (N,3,H,W), rec (N,3,H,W) or NULL,
+ * loss_sum: 1 float, accumulate.  grad_fg/grad_env may both be NULL (forward only).  imgs and loss_sum may both be
+ * NULL to obtain `rec` alone.
+ */
+int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W, float scale,
+                      float *rec, float *loss_sum, float *grad_fg, float *grad_env, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Regularisers, forward + gradient in one pass (dbw.py:373-405, loss.py:46).
+ * TV (l2sq) of n maps (h,w,3): loss += scale * [ sum_k |m[:,:,x+1]-m[:,:,x]|^2 (wrap_x closes the seam, dbw.py:383)
+ *   / (h*(w-1+wrap)) + sum |m[:,y+1]-m[:,y]|^2 / ((h-1)*w) ]  (sum over maps first = "each map receives same grad")
+ * grad_maps accumulate.
+ */
+int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, float scale, float *loss, float *grad_maps,
+                dbw_stream_t stream);
+/* Overlap (dbw.py:389-405; implicit_sq superquadric.py:17-38 safe=True, as_sdf=2).  u (Kb,npts,3) uniform [0,1)
+ * samples; sample p of block k is ((u*2-1)*ratio*S_k)@R_k+T_k (no grad), tested against EVERY block.
+ * loss += scale*mean_p(clamp(sum_k sigmoid(-sdf_k/temperature)*alpha_k - n_blocks_thresh, 0)).
+ * alpha (Kb) = _alpha_full.  Grads accumulate into g_sq_eps,g_S,g_R6,g_T,g_alpha.
+ * workspace: Kb*17 floats, zeroed by the caller. */
+int dbw_overlap_loss(const float *u, int npts, const float *sq_eps, const float *S, const float *R6, const float *T,
+                     const float *alpha, int Kb, float ratio, float scale_min, float temperature,
+                     float n_blocks_thresh, float scale, float *loss, float *g_sq_eps, float *g_S, float *g_R6,
+                     float *g_T, float *g_alpha, float *workspace, dbw_stream_t stream);
+
+/* Fused Adam over a flat fp32 buffer (optimizer.py:6-18 -> torch.optim.Adam defaults, no weight decay/amsgrad).
+ * step is the 1-based step count; bias corrections computed on the host. */
+int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int step, dbw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBW_HIP_H */

@@ -1,0 +1,62 @@
+"""CPU: libdbw_hip.so builds for gfx950, loads without a GPU, exports every symbol include/dbw_hip.h declares, and the
+ctypes signatures in dbw_amd/_lib.py match the header prototypes argument by argument.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from dbw_amd import _lib
+
+HEADER = os.path.join(ROOT, 'include', 'dbw_hip.h')
+CTYPE = {'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t,
+         'dbw_stream_t': ctypes.c_void_p}
+
+
+def parse_header():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r'\b(int|size_t|const char \*)\s*(dbw_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        args = ' '.join(args.split())
+        types = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    types.append(CTYPE[a.replace('const ', '').split()[0]])
+        protos[name] = (ret.strip(), types)
+    return protos
+
+
+def test_library_builds_and_loads_without_gpu():
+    lib = _lib.load()
+    assert os.path.exists(_lib.LIB_PATH)
+    assert lib.dbw_abi_version() == 1
+    assert lib.dbw_last_error() is not None
+
+
+def test_every_declared_symbol_is_exported_with_matching_signature():
+    lib = _lib.load()
+    protos = parse_header()
+    assert len(protos) == 19
+    for name, (ret, types) in protos.items():
+        assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
+        if name in _lib.SIGNATURES:
+            assert _lib.SIGNATURES[name] == types, f'{name}: ctypes signature differs from the header'
+    missing = set(_lib.SIGNATURES) - set(protos)
+    assert not missing, f'bound but not declared: {missing}'
+    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_last_error', 'dbw_rasterize_workspace_bytes'}
+    assert not undeclared_compute, f'declared but not bound: {undeclared_compute}'
+
+
+def test_argument_validation_happens_before_any_launch():
+    """Null pointers are rejected by the ABI itself (no GPU needed: validation precedes the launch)."""
+    lib = _lib.load()
+    rc = lib.dbw_rasterize_fwd(0, 0, 0, 0, 1, 0, 8, 8, 2, 0.0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -1 and b'null pointer' in lib.dbw_last_error()
+    with pytest.raises(RuntimeError, match='null pointer'):
+        _lib.call('dbw_tv_l2sq', 0, 1, 4, 4, 0, 1.0, 0, 0, 0)

@@ -1,0 +1,215 @@
+"""GPU parity of the model-level path and of the small kernels around the renderer (param -> mesh, texture prep,
+regularisers, composite+MSE, Adam) against the CPU oracle / torch fp32 references.  `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O                                              # noqa: E402  (checker only)
+import dbw_amd                                                  # noqa: E402
+from dbw_amd import ops                                         # noqa: E402
+
+DEV = 'cuda:0'
+REL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def test_texture_prep_and_decimation():
+    torch.manual_seed(0)
+    tex = torch.randn(3, 32, 48, 3)
+    for d in (1, 8):
+        t_ref = tex.clone().requires_grad_(True)
+        sig = torch.sigmoid(t_ref)
+        maps = sig if d == 1 else F.interpolate(F.avg_pool2d(sig.permute(0, 3, 1, 2), d, stride=d), scale_factor=d).permute(0, 2, 3, 1)
+        w1, w2 = torch.rand_like(tex), torch.rand_like(tex)
+        ((maps * w1).sum() + (sig * w2).sum()).backward()
+        t = tex.to(DEV).requires_grad_(True)
+        m_h, s_h = ops.texture_prep(t, d)
+        ((m_h * w1.to(DEV)).sum() + (s_h * w2.to(DEV)).sum()).backward()
+        assert rel_err(m_h, maps) < 1e-6 and rel_err(s_h, sig) < 1e-6
+        assert rel_err(t.grad, t_ref.grad) < REL
+
+
+def test_tv_l2sq_matches_reference_golden(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, 'implicit_misc.npz'))
+    m = torch.from_numpy(g['tv_maps']).to(DEV).requires_grad_(True)
+    tv = ops.tv_l2sq(m, wrap_x=True)
+    tv.backward()
+    assert abs(tv.item() - float(g['tv'])) < 1e-5 * abs(float(g['tv']))
+    assert rel_err(m.grad, torch.from_numpy(g['tv_grad'])) < REL
+    # non-wrapping variant (bkg / ground, dbw.py:380,386)
+    mm = torch.rand(1, 16, 20, 3)
+    ref = mm.clone().requires_grad_(True)
+    tvr = sum(O.tv_l2sq(torch.diff(ref, dim=k)).mean() for k in [1, 2])
+    tvr.backward()
+    h = mm.to(DEV).requires_grad_(True)
+    tvh = ops.tv_l2sq(h, wrap_x=False)
+    tvh.backward()
+    assert abs(tvh.item() - tvr.item()) < 1e-5 * tvr.item() and rel_err(h.grad, ref.grad) < REL
+
+
+def test_sq_blocks_and_ground_match_oracle():
+    m = O.OracleDBW((8, 8), n_blocks=5, txt_size=8, seed=2)
+    with torch.no_grad():
+        m.p['sq_eps'].copy_(torch.tensor([[-3., 3.], [0., 0.], [2., -1.], [4., 4.], [-4., -4.]]))   # eps from ~0.1 to ~1.9
+    verts = m._world((m.get_blocks_verts() * (m.p['S'].exp() + m.scale_min)[:, None]) @ O.rotation_6d_to_matrix(m.p['R_6d']) + m.p['T'][:, None])
+    w = torch.rand(verts.shape, generator=torch.Generator().manual_seed(0))
+    (verts * w).sum().backward()
+    hp = {k: v.detach().to(DEV).requires_grad_(True) for k, v in m.p.items() if k in ('sq_eps', 'S', 'R_6d', 'T', 'R_6d_ground', 'T_ground')}
+    trig = torch.stack([torch.cos(m.sq_eta), torch.sin(m.sq_eta), torch.cos(m.sq_omega), torch.sin(m.sq_omega)], 0).to(DEV)
+    Rw, Tw = m.R_world[0].to(DEV).contiguous(), m.T_world[0].to(DEV).contiguous()
+    v_h = ops.sq_blocks(hp['sq_eps'], hp['S'], hp['R_6d'], hp['T'], trig, None, 5, m.ratio, m.scale_min, m.S_world, Rw, Tw)
+    (v_h * w.to(DEV)).sum().backward()
+    assert rel_err(v_h, verts) < 1e-5
+    for k in ('sq_eps', 'S', 'R_6d', 'T'):
+        assert rel_err(hp[k].grad, m.p[k].grad) < REL, k
+    # kept subset is written densely
+    keep = torch.tensor([1, 0, 1, 1, 0], dtype=torch.int32, device=DEV)
+    v_k = ops.sq_blocks(hp['sq_eps'], hp['S'], hp['R_6d'], hp['T'], trig, keep, 3, m.ratio, m.scale_min, m.S_world, Rw, Tw)
+    assert torch.equal(v_k, v_h[keep.bool()])
+    # ground plane
+    for v in m.p.values():
+        v.grad = None
+    gv = m._world(m.ground_verts[None] @ O.rotation_6d_to_matrix(m.p['R_6d_ground'] + torch.tensor([[0.1, -0.2, 0.05, 0.3, 0.0, 0.1]])) + m.p['T_ground'][:, None])[0]
+    # (perturbed 6D vector so that the Gram-Schmidt backward is exercised off the identity)
+    r6 = (m.p['R_6d_ground'].detach() + torch.tensor([[0.1, -0.2, 0.05, 0.3, 0.0, 0.1]])).requires_grad_(True)
+    gv = m._world(m.ground_verts[None] @ O.rotation_6d_to_matrix(r6) + m.p['T_ground'][:, None])[0]
+    wg = torch.rand(gv.shape, generator=torch.Generator().manual_seed(1))
+    (gv * wg).sum().backward()
+    r6h = r6.detach().to(DEV).requires_grad_(True)
+    g_h = ops.posed_mesh(r6h, hp['T_ground'], m.ground_verts.to(DEV).contiguous(), m.S_world, Rw, Tw)
+    (g_h * wg.to(DEV)).sum().backward()
+    assert rel_err(g_h, gv) < 1e-5
+    assert rel_err(r6h.grad, r6.grad) < REL and rel_err(hp['T_ground'].grad, m.p['T_ground'].grad) < REL
+
+
+def test_overlap_loss_matches_oracle():
+    m = O.OracleDBW((8, 8), n_blocks=4, txt_size=8, seed=4)
+    with torch.no_grad():
+        m.p['T'].mul_(0.2)                                  # pull the blocks together so that they do overlap
+        m.p['sq_eps'].copy_(torch.tensor([[-1., 1.], [0., 0.], [2., -2.], [0.5, 0.3]]))
+    m.build_blocks(True, True, False, None, kill_blocks=False)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(0))
+    m.loss_weights = dict(overlap=1.0)
+    m._bkg_maps = m._ground_maps = None
+    ov = m.compute_losses(torch.zeros(1), torch.zeros(1), True, overlap_points=u)['overlap']
+    assert ov.item() > 1e-4
+    ov.backward()
+    hp = {k: v.detach().to(DEV).requires_grad_(True) for k, v in m.p.items() if k in ('sq_eps', 'S', 'R_6d', 'T', 'alpha_logit')}
+    alpha = torch.sigmoid(hp['alpha_logit'])
+    ov_h = ops.overlap_loss(hp['sq_eps'], hp['S'], hp['R_6d'], hp['T'], alpha, u.to(DEV), m.ratio, m.scale_min)
+    ov_h.backward()
+    assert abs(ov_h.item() - ov.item()) < 2e-4 * ov.item()
+    for k in ('sq_eps', 'S', 'R_6d', 'T', 'alpha_logit'):
+        assert rel_err(hp[k].grad, m.p[k].grad) < 5e-4, k
+
+
+def test_composite_mse_and_composite():
+    torch.manual_seed(0)
+    fg, env, img = torch.rand(2, 4, 9, 11), torch.rand(2, 4, 9, 11), torch.rand(2, 3, 9, 11)
+    a, b = fg.clone().requires_grad_(True), env.clone().requires_grad_(True)
+    rec = a[:, :3] * a[:, 3:4] + (1 - a[:, 3:4]) * b[:, :3]
+    loss = F.mse_loss(img, rec)
+    (loss * 3).backward()
+    ah, bh = fg.to(DEV).requires_grad_(True), env.to(DEV).requires_grad_(True)
+    lh = ops.composite_mse(ah, bh, img.to(DEV))
+    (lh * 3).backward()
+    assert abs(lh.item() - loss.item()) < 1e-6
+    assert rel_err(ah.grad, a.grad) < REL and rel_err(bh.grad[:, :3], b.grad[:, :3]) < REL and torch.all(bh.grad[:, 3] == 0)
+    ah.grad = bh.grad = None
+    rh = ops.composite(ah, bh)
+    assert rel_err(rh, rec) < 1e-6
+    (rh * img.to(DEV)).sum().backward()
+    a.grad = b.grad = None
+    (rec * img).sum().backward()
+    assert rel_err(ah.grad, a.grad) < REL
+
+
+def test_fused_adam_matches_torch():
+    torch.manual_seed(0)
+    p0 = torch.randn(1000)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=5e-3)
+    ph, m, v = p0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 6):
+        g = torch.randn(1000)
+        p.grad = g.clone()
+        opt.step()
+        ops.adam_step_(ph, g.to(DEV), m, v, 5e-3, step)
+    assert rel_err(ph, p) < 1e-5
+
+
+def _dtu_like_cfg(n_blocks=4, ts=32, fpp=6):
+    return {'model': {'name': 'dbw',
+                      'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},
+                      'renderer': {'faces_per_pixel': fpp, 'cameras': {'name': 'perspective'}, 'detach_bary': True, 'z_clip': 0.001},
+                      'rend_optim': {'coarse_learning': 1500, 'decimate_txt': 750, 'decimate_factor': 8, 'kill_blocks': True,
+                                     'decouple_rendering': True, 'opacity_noise': True},
+                      'loss': {'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1, 'overlap_weight': 1}}}
+
+
+@pytest.mark.parametrize('epoch,decimate', [(0, True), (800, False), (1600, False)])
+def test_model_losses_and_param_grads_match_oracle(epoch, decimate):
+    """One full training iteration (dbw.py:198-200 -> trainer.py:141-142): all losses and the gradient of every one of
+    the 10 parameter tensors, coarse+decimated (epoch 0), coarse (epoch 800) and fine (epoch 1600) phases."""
+    H, W, nb, ts, fpp = 48, 64, 4, 32, 6
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, fpp), (H, W))
+    orc = O.OracleDBW((H, W), n_blocks=nb, txt_size=ts, faces_per_pixel=fpp, seed=227391)
+    for k, v in orc.p.items():                                       # same seed, same draw order -> identical init
+        assert torch.equal(v.detach(), getattr(model, k).detach()), k
+    with torch.no_grad():                                            # move off the symmetric init: varied shapes/opacities
+        g = torch.Generator().manual_seed(1)
+        for name, scale in (('sq_eps', 1.5), ('alpha_logit', 1.0), ('R_6d_ground', 0.05), ('T', 0.0)):
+            d = torch.randn(orc.p[name].shape, generator=g) * scale
+            orc.p[name].add_(d)
+            getattr(model, name).add_(d)
+        orc.p['T'].mul_(0.5)
+        model.T.mul_(0.5)
+        if epoch >= 1500:
+            orc.p['alpha_logit'][0] = -6.0                           # one block below the 0.5 filter, one killed
+            model.alpha_logit[0] = -6.0
+    model = model.to(DEV)
+    model.train()
+    model.set_cur_epoch(epoch)
+    coarse = epoch < 1500
+    R, T, Km = O.synthetic_cameras(3, R_world=orc.R_world[0])
+    imgs = torch.rand(3, 3, H, W, generator=torch.Generator().manual_seed(2))
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3))
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4))
+    inp = dict(imgs=imgs, R=R, T=T, K=Km)
+    ref = orc.forward(inp, training=True, coarse=coarse, decimate=decimate, opacity_noise=noise, overlap_points=u, n_threads=8)
+    ref['total'].backward()
+    model._noise_override, model._overlap_u_override = noise.to(DEV), u.to(DEV)
+    out = model({k: v.to(DEV) for k, v in inp.items()}, None)
+    out['total'].backward()
+    assert set(out) == set(ref)
+    for k in ref:
+        assert abs(out[k].item() - ref[k].item()) <= REL * max(abs(ref[k].item()), 1e-3), (k, out[k].item(), ref[k].item())
+    for k, v in orc.p.items():
+        gh = getattr(model, k).grad
+        assert gh is not None, k
+        tol = 1e-3 if k in ('R_6d_ground', 'T_ground') else 3e-4
+        assert rel_err(gh, v.grad) < tol, (k, rel_err(gh, v.grad))
+
+
+def test_predict_returns_reference_shaped_image_and_state_dict_roundtrip():
+    model = dbw_amd.create_model(_dtu_like_cfg(), (48, 64)).to(DEV)
+    model.eval()
+    R, T, Km = O.synthetic_cameras(2, R_world=model.R_world[0].cpu())
+    inp = dict(imgs=torch.rand(2, 3, 48, 64), R=R, T=T, K=Km)
+    with torch.no_grad():
+        rec = model.predict({k: v.to(DEV) for k, v in inp.items()}, None)
+    assert rec.shape == (2, 3, 48, 64) and torch.isfinite(rec).all() and rec.min() >= 0 and rec.max() <= 1 + 1e-5
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    other = dbw_amd.create_model(_dtu_like_cfg(), (48, 64))
+    other.load_state_dict({'module.' + k.replace('sq_', 'spq_'): v for k, v in sd.items()})
+    for k, v in other.state_dict().items():
+        assert torch.equal(v, sd[k]), k

@@ -1,0 +1,305 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bars (BASELINE.json north_star): face indices bit-exact; rendered RGB and gradients
+within 1e-4 relative fp32.  The rasteriser/clipper arithmetic is additionally required to be BIT-exact in its float
+outputs (same op order, no FMA contraction)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O                                              # noqa: E402  (checker only)
+from dbw_amd import ops                                         # noqa: E402
+from dbw_amd.structures import PackedScene                      # noqa: E402
+
+DEV = 'cuda:0'
+REL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def random_faces(n_faces, seed, zmin=0.5, zmax=5.0, spread=1.2, size=0.5):
+    g = torch.Generator().manual_seed(seed)
+    c = (torch.rand(n_faces, 1, 2, generator=g) * 2 - 1) * spread
+    xy = c + (torch.rand(n_faces, 3, 2, generator=g) * 2 - 1) * size
+    z = torch.rand(n_faces, 3, 1, generator=g) * (zmax - zmin) + zmin
+    return torch.cat([xy, z], -1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rasteriser: operator-level drop-in
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('H,W,K,nf,blur,persp,clipb', [
+    (33, 47, 4, 60, 1e-3, True, True),        # ragged image size (partial tiles)
+    (64, 48, 10, 300, math.log(1e4 - 1) * 1e-4, True, True),   # the coarse renderer's setting, H > W
+    (40, 40, 1, 100, 0.0, True, True),        # hard raster (env pass)
+    (32, 64, 16, 20, 5e-3, False, False),     # K > faces hit, no perspective correction / clipping
+    (48, 80, 25, 700, 2e-4, True, True),      # > LIST_CAP faces per tile flush path, max K
+])
+def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb):
+    fv = random_faces(nf, seed=nf + K)
+    # two meshes packed back to back, the second one a shifted copy
+    fv = torch.cat([fv, fv * torch.tensor([0.9, -1.1, 1.0])], 0)
+    first, num = torch.tensor([0, nf]), torch.tensor([nf, nf])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), blur, K, persp, clipb, n_threads=8)
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (H, W), blur, K, persp, clipb, False)
+    assert out[0].dtype == torch.int64
+    assert torch.equal(out[0].cpu(), ref[0]), f'pix_to_face mismatch on {(out[0].cpu() != ref[0]).sum().item()} slots'
+    for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
+        assert torch.equal(a.cpu(), b), f'{name}: max abs diff {(a.cpu() - b).abs().max().item()}'
+
+
+def test_rasterize_ties_and_degenerates():
+    """Coincident faces (identical z everywhere: tie broken by face id), zero-area faces, faces behind the camera."""
+    base = random_faces(8, seed=5)
+    fv = torch.cat([base, base, base[:2] * torch.tensor([1., 1., 0.]) + torch.tensor([0., 0., -1.])], 0)
+    fv[3, 2] = fv[3, 1]                                          # zero-area face
+    first, num = torch.tensor([0]), torch.tensor([fv.shape[0]])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (37, 29), 1e-3, 6)
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (37, 29), 1e-3, 6, True, True, False)
+    assert torch.equal(out[0].cpu(), ref[0])
+    assert torch.equal(out[3].cpu(), ref[3])
+    p = ref[0]
+    both = (p[..., 0] >= 0) & (p[..., 1] >= 0)
+    assert both.any() and torch.all(p[..., 1][both] != p[..., 0][both])
+
+
+def test_rasterize_empty_and_errors():
+    fv = random_faces(4, seed=1).to(DEV)
+    first, num = torch.tensor([0, 4], device=DEV), torch.tensor([4, 0], device=DEV)      # second mesh is empty
+    p2f, zbuf, bary, dists = ops.rasterize_meshes(fv, first, num, None, (16, 16), 1e-3, 3, True, True)
+    assert torch.all(p2f[1] == -1) and torch.all(zbuf[1] == -1) and torch.all(bary[1] == -1) and torch.all(dists[1] == -1)
+    with pytest.raises(ValueError):
+        ops.rasterize_meshes(fv, first, num, None, (16, 16), 1e-3, 26)
+    with pytest.raises(RuntimeError):
+        ops.rasterize_meshes(fv.cpu(), first, num, None, (16, 16), 1e-3, 3)       # no CPU fallback
+    with pytest.raises(RuntimeError):
+        ops.rasterize_meshes(fv, first, num, None, (16, 16), -1.0, 3)             # C ABI rejects blur < 0
+
+
+def test_rasterize_backward_matches_oracle():
+    H, W, K, nf = 40, 56, 5, 80
+    fv = random_faces(nf, seed=11)
+    first, num = torch.tensor([0]), torch.tensor([nf])
+    g = torch.Generator().manual_seed(3)
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), 2e-3, K)
+    gz, gb, gd = torch.randn(ref[1].shape, generator=g), torch.randn(ref[2].shape, generator=g), torch.randn(ref[3].shape, generator=g)
+    g_ref = O.rasterize_bwd_raw(fv, ref[0], gz, gb, gd)
+    fvd = fv.to(DEV).requires_grad_(True)
+    out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, True, True, False)
+    (out[1] * gz.to(DEV) + (out[2] * gb.to(DEV)).sum(-1) + out[3] * gd.to(DEV)).sum().backward()
+    assert rel_err(fvd.grad, g_ref) < REL
+    # each gradient stream alone (NULL pointers for the others)
+    for sel in range(3):
+        fvd.grad = None
+        out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, True, True, False)
+        z = torch.zeros
+        parts = [gz, gb, gd]
+        (out[1 + sel] * parts[sel].to(DEV)).sum().backward()
+        zeros = [z(gz.shape), z(gb.shape), z(gd.shape)]
+        zeros[sel] = parts[sel]
+        assert rel_err(fvd.grad, O.rasterize_bwd_raw(fv, ref[0], *zeros)) < REL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# camera transform + z clipping
+# ---------------------------------------------------------------------------------------------------------------------
+def _camera_inside_scene(seed, B=3):
+    """A closed icosphere around the cameras (like the sky dome): many faces straddle z = z_clip (cases 3 and 4)."""
+    torch.manual_seed(seed)
+    verts, faces = O.get_icosphere(2, flip_faces=True)
+    verts = verts * 3.0 + 0.05 * torch.randn_like(verts)
+    C = torch.randn(B, 3) * 0.4
+    R, T = O.look_at_cameras(C, at=(0.3, 0.2, 2.5))
+    Kmat = torch.tensor([[2.1, 0, 0.05, 0], [0, 2.1, -0.03, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=torch.float32)
+    return verts, faces, R, T, Kmat
+
+
+@pytest.mark.parametrize('persp', [True, False])
+def test_project_clip_bit_exact(persp):
+    verts, faces, R, T, Kmat = _camera_inside_scene(0)
+    B, Fs = R.shape[0], faces.shape[0]
+    zc = 0.25
+    ndc = O.transform_to_ndc(verts, R, T, Kmat, 1e-8)
+    fv = ndc[:, faces].reshape(B * Fs, 3, 3)
+    ref = O.clip_faces(fv, torch.arange(B) * Fs, torch.full((B,), Fs), zc, persp)
+    cl = ops.project_clip(verts.to(DEV), faces.to(torch.int32).to(DEV), R.to(DEV), T.to(DEV), Kmat.to(DEV), 1e-8, zc, persp)
+    num = cl['num_faces'].cpu().long()
+    assert torch.equal(num, ref['num_faces'])
+    assert (ref['neighbor'] >= 0).any() and ref['has_conv'].any(), 'test scene must exercise cases 3 and 4'
+    for b in range(B):
+        n, s = int(num[b]), int(ref['first_idx'][b])
+        got = cl['face_verts'][b, :n].cpu()
+        exp = ref['face_verts'][s:s + n]
+        assert torch.equal(got, exp), f'view {b}: max diff {(got - exp).abs().max().item()}'
+        assert torch.equal(cl['c2o'][b, :n].cpu().long(), ref['clipped_to_orig'][s:s + n] - b * Fs)
+        nb_ref = ref['neighbor'][s:s + n]
+        nb_ref = torch.where(nb_ref >= 0, nb_ref - s + b * 2 * Fs, nb_ref)
+        assert torch.equal(cl['neighbor'][b, :n].cpu().long(), nb_ref)
+        assert torch.equal(cl['clip_code'][b, :n].cpu() >= 0, ref['has_conv'][s:s + n])
+
+
+def test_project_clip_disabled_is_plain_projection():
+    verts, faces, R, T, Kmat = _camera_inside_scene(1)
+    cl = ops.project_clip(verts.to(DEV), faces.to(torch.int32).to(DEV), R.to(DEV), T.to(DEV), Kmat.to(DEV), 1e-8, None, True)
+    ndc = O.transform_to_ndc(verts, R, T, Kmat, 1e-8)
+    Fs = faces.shape[0]
+    assert torch.all(cl['num_faces'].cpu() == Fs)
+    assert torch.equal(cl['face_verts'][:, :Fs].cpu(), ndc[:, faces])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full render pass (project -> clip -> raster -> shade -> blend) forward + backward
+# ---------------------------------------------------------------------------------------------------------------------
+def _packed(scene, pads=None):
+    maps = scene['maps']
+    pads = pads or [(0, 0)] * len(maps)
+    desc, _ = PackedScene.describe_maps([m.shape[:2] for m in maps], pads, DEV)
+    flat = torch.cat([m.reshape(-1) for m in maps]).detach().to(DEV)
+    return PackedScene(scene['verts'].detach().to(DEV), scene['faces'].to(torch.int32).to(DEV), scene['face_uvs'].float().to(DEV),
+                       scene['face_map'].to(torch.int32).to(DEV), desc, flat)
+
+
+def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_clip=0.001, bg=(0., 0., 0.), seed=0):
+    """-> dict of (hip, oracle) pairs: image, grad verts, grad maps, grad alpha."""
+    verts_o = scene['verts'].detach().clone().requires_grad_(True)
+    maps_o = [m.detach().clone().requires_grad_(True) for m in scene['maps']]
+    fa_o = None if faces_alpha is None else faces_alpha.detach().clone().requires_grad_(True)
+    sc = dict(scene, verts=verts_o, maps=maps_o)
+    fa_rep = None if fa_o is None else fa_o.repeat(R.shape[0])          # the reference passes alpha.repeat(B) (dbw.py:219)
+    img_o = O.render(sc, R, T, Kmat, (H, W), sigma, K, detach_bary, fa_rep, z_clip, bg, n_threads=8)
+    w = torch.rand(img_o.shape, generator=torch.Generator().manual_seed(seed))
+    (img_o * w).sum().backward()
+
+    ps = _packed(scene)
+    ps.verts.requires_grad_(True)
+    ps.maps.requires_grad_(True)
+    fa_h = None if faces_alpha is None else faces_alpha.detach().to(DEV).requires_grad_(True)
+    cfg = ops.RenderCfg(H, W, K, sigma, z_clip, True, detach_bary, scene['faces'].shape[0])
+    img_h = ops.render_scene(ps.verts, ps.maps, fa_h, ps.faces, R.to(DEV), T.to(DEV), Kmat.to(DEV), ps.face_uvs, ps.face_map,
+                             ps.map_desc, ops.make_bg(bg), cfg)
+    (img_h * w.to(DEV)).sum().backward()
+    res = {'image': (img_h, img_o), 'g_maps': (ps.maps.grad, torch.cat([m.grad.reshape(-1) for m in maps_o]))}
+    if verts_o.grad is not None:
+        res['g_verts'] = (ps.verts.grad, verts_o.grad)
+    if fa_o is not None:
+        res['g_alpha'] = (fa_h.grad, fa_o.grad)
+    return res
+
+
+def _model(seed=3, n_blocks=4, ts=32, hw=(48, 64), fpp=6):
+    m = O.OracleDBW(hw, n_blocks=n_blocks, txt_size=ts, faces_per_pixel=fpp, seed=seed)
+    R, T, Km = O.synthetic_cameras(3, R_world=m.R_world[0], dist=2.8)
+    return m, R, T, Km
+
+
+def test_render_blocks_soft_pass_matches_oracle():
+    """fg pass: sigma=1e-4, learned opacities, detach_bary=True (geometry gradient through dists only)."""
+    m, R, T, Km = _model()
+    with torch.no_grad():
+        scene = m.build_blocks(True, True, False, None, kill_blocks=False)
+    fa = (torch.rand(scene['faces'].shape[0] // m.BNF, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1).repeat_interleave(m.BNF)
+    res = _render_both(scene, R, T, Km[0], 48, 64, 1e-4, 6, True, fa, bg=(0., 0., 0.))
+    for k, (a, b) in res.items():
+        assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
+    assert res['g_verts'][1].abs().max() > 0
+
+
+def test_render_fine_pass_no_alpha_matches_oracle():
+    m, R, T, Km = _model(seed=5)
+    with torch.no_grad():
+        scene = m.build_blocks(True, False, False, None, kill_blocks=False)
+    res = _render_both(scene, R, T, Km[0], 48, 64, 5e-6, 6, True, None)
+    for k, (a, b) in res.items():
+        assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
+
+
+def test_render_env_hard_pass_with_clipping_matches_oracle():
+    """env pass: sigma=0, 1 face per pixel, detach_bary=False -> geometry gradient only through barycentrics -> uv;
+    the camera sits inside the dome so z-clipping (cases 3/4 + barycentric back-conversion) is live."""
+    m, R, T, Km = _model(seed=7, ts=16)
+    with torch.no_grad():
+        scene = m.build_env(True, False)
+    res = _render_both(scene, R, T, Km[0], 48, 64, 0.0, 1, False, None, bg=(0.1, 0.2, 0.3))
+    for k, (a, b) in res.items():
+        assert rel_err(a, b) < (REL if k != 'g_verts' else 5e-4), f'{k}: rel err {rel_err(a, b)}'
+    assert res['g_verts'][1].abs().max() > 0
+
+
+def test_render_pixel_faces_bit_exact_through_clipping():
+    """Face indices after mapping clipped -> original faces are identical to the oracle's converted pix_to_face."""
+    m, R, T, Km = _model(seed=9, ts=16)
+    with torch.no_grad():
+        scene = m.build_env(False, False)
+        _, frag = O.render(scene, R, T, Km[0], (48, 64), 0.0, 2, False, None, 0.001, n_threads=8, return_fragments=True)
+    ps = _packed(scene)
+    cfg = ops.RenderCfg(48, 64, 2, 0.0, 0.001, True, False, scene['faces'].shape[0])
+    cl, p2f, zbuf, bary, dists = ops.render_fragments(ps.verts, ps.faces, R.to(DEV), T.to(DEV), Km[0].to(DEV), cfg)
+    Fs = scene['faces'].shape[0]
+    c2o = cl['c2o'].view(-1).long()
+    view = torch.arange(R.shape[0], device=DEV).view(-1, 1, 1, 1)
+    orig = torch.where(p2f >= 0, c2o[p2f.clamp(min=0).long()] + view * Fs, torch.full_like(p2f, -1).long())
+    assert torch.equal(orig.cpu(), frag['pix_to_face'])
+    assert torch.equal(dists.cpu(), frag['dists']) and torch.equal(zbuf.cpu(), frag['zbuf'])
+
+
+def test_circular_padding_by_index_wrap_equals_padded_copy():
+    """dbw.py:339-341: sampling the UNPADDED map with (pad_left, pad_right) wrap == sampling the circularly padded copy."""
+    m, R, T, Km = _model(seed=11, ts=32)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)      # maps are padded copies here
+    pl, pr = m.txt_padding
+    assert pr > 0
+    ps_pad = _packed(scene)
+    unpadded = [mp[:, pl:mp.shape[1] - pr] for mp in scene['maps']]
+    ps_wrap = _packed(dict(scene, maps=unpadded), pads=[(pl, pr)] * len(unpadded))
+    cfg = ops.RenderCfg(48, 64, 6, 1e-4, 0.001, True, True, scene['faces'].shape[0])
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    a = ops.render_scene(ps_pad.verts, ps_pad.maps, None, ps_pad.faces, *args, ps_pad.face_uvs, ps_pad.face_map, ps_pad.map_desc, None, cfg)
+    b = ops.render_scene(ps_wrap.verts, ps_wrap.maps, None, ps_wrap.faces, *args, ps_wrap.face_uvs, ps_wrap.face_map, ps_wrap.map_desc, None, cfg)
+    assert torch.equal(a, b)
+    assert a[:, 3].max() > 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE config-2 resolution (300x400, K=10, 10 blocks)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    torch.manual_seed(0)
+    m = O.OracleDBW((300, 400), n_blocks=10, txt_size=64, faces_per_pixel=10, seed=227391)
+    R, T, Km = O.synthetic_cameras(6, R_world=m.R_world[0])
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    ps = _packed(scene)
+    cfg = ops.RenderCfg(300, 400, 10, 1e-4, 0.001, True, True, scene['faces'].shape[0])
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    cl, p2f, zbuf, bary, dists = ops.render_fragments(ps.verts, ps.faces, *args, cfg)
+    cl2, p2f2, zbuf2, _, _ = ops.render_fragments(ps.verts, ps.faces, *args, cfg)
+    assert torch.equal(p2f, p2f2) and torch.equal(zbuf, zbuf2)                      # deterministic / idempotent
+    valid = p2f >= 0
+    assert 0.02 < valid[..., 0].float().mean() < 0.9                                # blocks cover part of the image
+    z = torch.where(valid, zbuf, torch.full_like(zbuf, float('inf')))
+    assert torch.all(z[..., 1:] >= z[..., :-1])                                     # front-to-back order
+    assert torch.all(valid[..., 1:] <= valid[..., :-1])                             # no holes in the lists
+    torch.testing.assert_close(bary[valid].sum(-1), torch.ones(int(valid.sum()), device=DEV), rtol=0, atol=2e-6)
+    assert torch.all(dists[valid] < cfg.blur)
+    srt = torch.where(valid, p2f, -torch.arange(1, 11, device=DEV, dtype=torch.int32).expand_as(p2f)).sort(-1)[0]
+    assert torch.all(srt[..., 1:] != srt[..., :-1])                                 # a face appears once per pixel
+    first = cl['first_idx'].long().view(-1, 1, 1, 1)
+    assert torch.all((p2f[valid] >= 0)) and torch.all(((p2f - first) < cl['num_faces'].view(-1, 1, 1, 1))[valid])
+    # image-level: alpha in [0,1]; zero opacity -> empty image; opacity scales linearly for single-layer pixels
+    img = ops.render_scene(ps.verts, ps.maps, None, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+    assert img[:, 3].min() >= 0 and img[:, 3].max() <= 1 + 1e-6 and torch.isfinite(img).all()
+    zero = torch.zeros(scene['faces'].shape[0], device=DEV)
+    img0 = ops.render_scene(ps.verts, ps.maps, zero, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+    assert torch.all(img0 == 0)
+    # a strided subset of the views against the oracle (one view, bit-exact indices at full resolution)
+    ref = O.render(scene, R[:1], T[:1], Km[0], (300, 400), 1e-4, 10, True, None, 0.001, n_threads=8, return_fragments=True)[1]
+    c2o = cl['c2o'].view(-1).long()
+    orig = torch.where(p2f[:1] >= 0, c2o[p2f[:1].clamp(min=0).long()], torch.full_like(p2f[:1], -1).long())
+    assert torch.equal(orig.cpu(), ref['pix_to_face'])

@@ -1,0 +1,120 @@
+"""CPU: host-side logic of the product package (topology, containers, model construction, config handling) -- everything
+that does not launch a kernel.  The product's topology generators are checked against the oracle's independent ones."""
+import pytest
+import torch
+import yaml
+
+import oracle as O
+import dbw_amd
+from dbw_amd import mesh as M
+from dbw_amd.structures import Meshes, PackedScene, TexturesUV, join_meshes_as_scene
+
+
+def test_topology_generators_agree_with_oracle():
+    for level in (0, 1, 2):
+        a, b = O.get_icosphere(level)
+        c, d = M.get_icosphere(level)
+        assert torch.equal(a, c) and torch.equal(b, d)
+    assert torch.equal(O.get_icosphere(2, True)[1], M.get_icosphere(2, True)[1])
+    for level in (1, 2):
+        fa, ua = O.get_icosphere_uvs(level)
+        fb, ub = M.get_icosphere_uvs(level, True, True)
+        assert torch.equal(fa, fb) and torch.equal(ua, ub)
+    v, f = O.get_plane()
+    v2, f2 = M.get_plane()
+    for _ in range(3):
+        v, f = O.subdivide(v, f)
+        v2, f2 = M.subdivide_mesh(v2, f2)
+    assert torch.equal(v, v2) and torch.equal(f, f2)
+    assert torch.equal(O.world_rotation(115, 0, 0), M.world_rotation(115, 0, 0))
+    assert torch.equal(O.world_rotation(130, 50, 0), M.world_rotation(130, 50, 0))
+    torch.manual_seed(1)
+    r1 = O.random_rotations(4)
+    torch.manual_seed(1)
+    r2 = M.random_rotations(4)
+    assert torch.equal(r1, r2)
+    d6 = torch.randn(5, 6)
+    assert torch.equal(O.rotation_6d_to_matrix(d6), M.rotation_6d_to_matrix(d6))
+    C = torch.randn(3, 3) + 2
+    for a, b in zip(O.look_at_cameras(C), M.look_at_view_transform(C)):
+        assert torch.equal(a, b)
+
+
+def _cfg():
+    cfg = yaml.safe_load('''
+model:
+  name: dbw
+  mesh: {n_blocks: 10, S_world: 0.5, R_world: [115, 0, 0], txt_size: 256}
+  renderer: {faces_per_pixel: 10, cameras: {name: perspective}, detach_bary: True, z_clip: 0.001}
+  rend_optim: {coarse_learning: 1500, decimate_txt: 750, decimate_factor: 8, kill_blocks: True, decouple_rendering: True, opacity_noise: True}
+  loss: {rgb_weight: 1, perceptual_weight: 0, parsimony_weight: 0.01, tv_weight: 0.1, overlap_weight: 1}
+''')
+    return cfg
+
+
+def test_model_matches_reference_state_layout_and_oracle_init():
+    """Parameter names/shapes of dbw.py:84,99-119 + buffers and same-seed initialisation (draw order)."""
+    torch.manual_seed(227391)
+    m = dbw_amd.create_model(_cfg(), (300, 400))
+    shapes = {k: tuple(v.shape) for k, v in m.named_parameters()}
+    assert shapes == {'sq_eps': (10, 2), 'R_6d_ground': (1, 6), 'T_ground': (1, 3), 'S': (10, 3), 'R_6d': (10, 6), 'T': (10, 3),
+                      'alpha_logit': (10,), 'texture_bkg': (1, 256, 256, 3), 'texture_ground': (1, 256, 256, 3),
+                      'textures': (10, 256, 256, 3)}
+    assert set(m.state_dict()) == set(shapes) | {'R_world', 'T_world', 'bkg_verts_uvs', 'ground_verts_uvs', 'sq_eta', 'sq_omega',
+                                                   'block_faces_uvs', 'block_verts_uvs'}
+    assert m.loss_names == ['loss_rgb', 'loss_parsimony', 'loss_tv', 'loss_overlap', 'loss_total']
+    assert m.BNF == 80 and m.txt_padding == (0, 23) and m.env_n_faces == 448 and m.blocks_n_faces == 800
+    o = O.OracleDBW((300, 400), seed=227391)
+    for k, v in o.p.items():
+        assert torch.equal(v.detach(), getattr(m, k).detach()), k
+    assert torch.equal(m.block_verts_uvs, o.block_verts_uvs) and torch.equal(m.R_world, o.R_world)
+    # texture params go to their own lr group by name (optimizer.py:11-13)
+    assert [n for n, _ in m.named_parameters() if n.startswith('texture')] == ['texture_bkg', 'texture_ground', 'textures']
+    # milestones (dbw.py:457-462)
+    assert m.is_live('coarse_learning') and m.is_live('decimate_txt')
+    m.set_cur_epoch(750)
+    assert m.is_live('coarse_learning') and not m.is_live('decimate_txt')
+    m.set_cur_epoch(1499)
+    m.step()
+    assert not m.is_live('coarse_learning')
+
+
+def test_config_key_guards_like_the_reference():
+    cfg = _cfg()
+    cfg['model']['mesh']['unknown_key'] = 1
+    with pytest.raises(AssertionError):                      # dbw.py:71 `assert len(kwargs) == 0`
+        dbw_amd.create_model(cfg, (8, 8))
+    cfg = _cfg()
+    cfg['model']['renderer']['shading_type'] = 'phong'
+    with pytest.raises(NotImplementedError):
+        dbw_amd.create_model(cfg, (8, 8))
+    with pytest.raises(KeyError):
+        dbw_amd.create_model({'model': {'name': 'nope'}}, (8, 8))
+
+
+def test_render_path_refuses_to_run_without_gpu():
+    """There is no CPU fallback: CPU tensors are rejected loudly."""
+    m = dbw_amd.create_model(_cfg(), (16, 16))
+    R, T, K = O.synthetic_cameras(1)
+    with pytest.raises(RuntimeError, match='GPU'):
+        m(dict(imgs=torch.rand(1, 3, 16, 16), R=R, T=T, K=K), None)
+
+
+def test_meshes_join_and_packed_scene_layout():
+    """join order = list order, faces offset, packed face id of copy b = b*F + j."""
+    v1, f1 = M.get_icosphere(0)
+    v2, f2 = M.get_plane()
+    t1 = TexturesUV(torch.rand(1, 4, 6, 3), f1, torch.rand(12, 2))
+    t2 = TexturesUV(torch.rand(1, 8, 8, 3), f2, torch.rand(4, 2), circular_pad=(1, 2))
+    scene = join_meshes_as_scene([Meshes(v1, f1, t1), Meshes(v2, f2, t2)])
+    assert len(scene) == 1 and len(scene.extend(5)) == 5
+    verts, faces = scene.get_mesh_verts_faces(0)
+    assert verts.shape == (16, 3) and faces.shape == (22, 3) and faces[20:].min() >= 12
+    ps = PackedScene.from_meshes(scene.extend(3))
+    assert ps.faces.dtype == torch.int32 and ps.face_uvs.shape == (22, 3, 2)
+    assert ps.face_map.tolist() == [0] * 20 + [1] * 2
+    assert ps.map_desc.tolist() == [[0, 4, 6, 0], [72, 8, 8, 1 | (2 << 16)]]
+    assert ps.maps.numel() == 72 + 192
+    batch = Meshes(torch.rand(3, 12, 3), f1[None].expand(3, -1, -1), TexturesUV(torch.rand(3, 4, 4, 3), f1, torch.rand(12, 2)))
+    js = join_meshes_as_scene(batch)
+    assert js.get_mesh_verts_faces(0)[1].max() == 35 and len(js.textures.maps) == 3
