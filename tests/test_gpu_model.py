@@ -128,6 +128,7 @@ def test_composite_mse_and_composite():
     assert rel_err(rh, rec) < 1e-6
     (rh * img.to(DEV)).sum().backward()
     a.grad = b.grad = None
+    rec = a[:, :3] * a[:, 3:4] + (1 - a[:, 3:4]) * b[:, :3]
     (rec * img).sum().backward()
     assert rel_err(ah.grad, a.grad) < REL
 
@@ -195,7 +196,9 @@ def test_model_losses_and_param_grads_match_oracle(epoch, decimate):
         assert abs(out[k].item() - ref[k].item()) <= REL * max(abs(ref[k].item()), 1e-3), (k, out[k].item(), ref[k].item())
     for k, v in orc.p.items():
         gh = getattr(model, k).grad
-        assert gh is not None, k
+        if gh is None or v.grad is None:      # no path in this phase (e.g. opacities in the fine phase): both must agree
+            assert (gh is None or gh.abs().max() == 0) and (v.grad is None or v.grad.abs().max() == 0), k
+            continue
         tol = 1e-3 if k in ('R_6d_ground', 'T_ground') else 3e-4
         assert rel_err(gh, v.grad) < tol, (k, rel_err(gh, v.grad))
 

@@ -184,7 +184,7 @@ def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_
     img_h = ops.render_scene(ps.verts, ps.maps, fa_h, ps.faces, R.to(DEV), T.to(DEV), Kmat.to(DEV), ps.face_uvs, ps.face_map,
                              ps.map_desc, ops.make_bg(bg), cfg)
     (img_h * w.to(DEV)).sum().backward()
-    res = {'image': (img_h, img_o), 'g_maps': (ps.maps.grad, torch.cat([m.grad.reshape(-1) for m in maps_o]))}
+    res = {'image': (img_h, img_o), 'g_maps': (ps.maps.grad, torch.cat([(m.grad if m.grad is not None else torch.zeros_like(m)).reshape(-1) for m in maps_o]))}
     if verts_o.grad is not None:
         res['g_verts'] = (ps.verts.grad, verts_o.grad)
     if fa_o is not None:
