@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: rendered views/sec (fwd+bwd) per node, DTU-like 400x300, K=10 blocks.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one full optimisation iteration of the hot path over this rank's batch of synthetic views (config 2 of
+BASELINE.json: V=49 views per GPU, 300x400 (HxW), 10 superquadric blocks + ground + sky dome, faces_per_pixel=10, 256^2
+textures, coarse phase at epoch 0: sigma=1e-4, opacity noise, decimated textures): param -> mesh, env pass + fg pass
+(project/clip, raster, shade+blend), composite + MSE, parsimony/TV/overlap regularisers, backward to all 10 parameter
+tensors, [RCCL all-reduce of the flat gradient buffer when N > 1], fused Adam on both lr groups.  LPIPS is excluded
+(SURVEY.md 8a A10).  Inputs are resident in HBM before the timed region.  Weak scaling: every rank renders V views per
+step; value = N * V * steps / max-over-ranks time.
+
+Rank 0 prints ONE JSON line, with `roofline` for the dominant kernel (HIP-event timed on the launch stream) and, at N=1,
+`cpu_baseline` (the CPU oracle -- a port, the reference's PyTorch3D path cannot run here -- on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
+
+import torch                                                            # noqa: E402
+import torch.distributed as dist                                        # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_cfg(n_blocks, fpp, ts):
+    return {'model': {'name': 'dbw',
+                      'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},
+                      'renderer': {'faces_per_pixel': fpp, 'cameras': {'name': 'perspective'}, 'detach_bary': True, 'z_clip': 0.001},
+                      'rend_optim': {'coarse_learning': 1500, 'decimate_txt': 750, 'decimate_factor': 8, 'kill_blocks': True,
+                                     'decouple_rendering': True, 'opacity_noise': True},
+                      'loss': {'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1, 'overlap_weight': 1}}}
+
+
+def build_workload(args, dev):
+    import dbw_amd
+    from dbw_amd import mesh as M
+    torch.manual_seed(227391)                                           # configs/dtu/default.yml:42
+    model = dbw_amd.create_model(make_cfg(args.blocks, args.fpp, args.txt), (args.H, args.W)).to(dev)
+    R, T, K = M.synthetic_cameras(args.views, R_world=model.R_world[0])
+    # targets: a self-render of a perturbed scene (realistic coverage), fp32 (B,3,H,W) in [0,1]
+    target = dbw_amd.create_model(make_cfg(args.blocks, args.fpp, args.txt), (args.H, args.W)).to(dev)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(99)
+        target.T.add_(torch.randn(target.T.shape, generator=g).to(dev) * 0.2)
+        target.alpha_logit.add_(2.0)
+        target.textures.add_(torch.randn(target.textures.shape, generator=g).to(dev))
+        target.texture_bkg.add_(torch.randn(target.texture_bkg.shape, generator=g).to(dev))
+        target.eval()
+        inp = {'imgs': torch.zeros(args.views, 3, args.H, args.W, device=dev), 'R': R.to(dev), 'T': T.to(dev), 'K': K.to(dev)}
+        inp['imgs'] = target.predict(inp, None).clamp(0, 1).contiguous()
+    del target
+    model.train()
+    return model, inp
+
+
+def kernel_breakdown(model, inp, reps=5):
+    """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the
+    kernels of the fg pass, each launched alone on the real step-0 geometry.  -> {name: (avg_ms, algorithmic_bytes)}."""
+    from dbw_amd import ops
+    with torch.no_grad():
+        scene = model.build_blocks_scene()
+    B, H, W, K = inp['R'].shape[0], model.img_size[0], model.img_size[1], model.renderer.faces_per_pixel
+    P = H * W
+    r = model.renderer
+    cfg = r._cfg(scene.faces.shape[0])
+    Kmat = r.cameras.K[0].contiguous()
+    verts, maps = scene.verts.detach(), scene.maps.detach()
+    alpha = model._alpha.detach().repeat_interleave(model.BNF).contiguous()
+    cl = ops.project_clip(verts, scene.faces, inp['R'], inp['T'], Kmat, cfg.eps, cfg.z_clip, cfg.persp)
+    fvc = cl['face_verts'].view(-1, 3, 3)
+    nb = cl['neighbor'].view(-1)
+    p2f, _, bary, dists = ops._raster_fwd(fvc, cl['first_idx'], cl['num_faces'], nb, B, H, W, K, cfg.blur, True, True, False, need_zbuf=False)
+    img = ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F, cfg.sigma, r._bg)
+    g_img = torch.rand_like(img)
+    _, _, g_dists, _ = ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
+                                           cfg.sigma, r._bg, g_img, True, False)
+    g_fvc = torch.zeros_like(fvc)
+
+    def t(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {
+        'raster_fwd_kernel': (t(lambda: ops._raster_fwd(fvc, cl['first_idx'], cl['num_faces'], nb, B, H, W, K, cfg.blur, True, True, False,
+                                                         need_zbuf=False)), 20 * P * K * B),
+        'shade_blend_fwd_kernel': (t(lambda: ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
+                                                                  alpha, cfg.F, cfg.sigma, r._bg)), (20 * P * K + 16 * P) * B),
+        'shade_blend_bwd_kernel': (t(lambda: ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
+                                                                  alpha, cfg.F, cfg.sigma, r._bg, g_img, True, False)),
+                                   (20 * P * K + 16 * P + 4 * P * K) * B),
+        'raster_bwd_kernel': (t(lambda: ops._lib.call('dbw_rasterize_bwd', fvc.data_ptr(), p2f.data_ptr(), 0, 0, g_dists.data_ptr(), B,
+                                                      fvc.shape[0], H, W, K, 1, 1, g_fvc.data_ptr(), ops._stream(fvc))), 8 * P * K * B),
+    }
+    return res
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/: C rasteriser + torch-CPU for the rest) timed on this box's host cores on a bounded sample
+    of the SAME workload.  kind = 'port': the reference's own path needs PyTorch3D, which cannot be installed here."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    nv = 4
+    m = O.OracleDBW((args.H, args.W), n_blocks=args.blocks, txt_size=args.txt, faces_per_pixel=args.fpp, seed=227391)
+    R, T, K = O.synthetic_cameras(args.views, R_world=m.R_world[0])
+    g = torch.Generator().manual_seed(0)
+    inp = dict(imgs=torch.rand(nv, 3, args.H, args.W, generator=g), R=R[:nv], T=T[:nv], K=K[:nv])
+
+    def it():
+        for v in m.p.values():
+            v.grad = None
+        loss = m.forward(inp, training=True, coarse=True, decimate=True, opacity_noise=torch.randn(args.blocks, generator=g),
+                         overlap_points=torch.rand(args.blocks, 1000, 3, generator=g), n_threads=cores)
+        loss['total'].backward()
+    it()
+    t0, n = time.time(), 0
+    while n < 3 or (time.time() - t0 < 10 and n < 20):
+        it()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': nv / dt, 'unit': 'views/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} fwd+bwd iterations of {nv} views of the same config (oracle/: OpenMP C rasteriser on {cores} threads + '
+                      f'torch-CPU sampling/blend/losses/autograd), {dt:.2f} s/iter'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--views', type=int, default=49, help='views per GPU per step (weak scaling)')
+    ap.add_argument('--H', type=int, default=300)
+    ap.add_argument('--W', type=int, default=400)
+    ap.add_argument('--blocks', type=int, default=10)
+    ap.add_argument('--fpp', type=int, default=10)
+    ap.add_argument('--txt', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs MI355X GPUs: the render path has no CPU implementation')
+    if world != args.gpus:
+        raise RuntimeError(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from dbw_amd.parallel import ShardedTrainStep
+    model, inp = build_workload(args, dev)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(inp)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(inp)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    total_loss = losses['total'].item()
+    assert total_loss == total_loss, 'loss is NaN'
+
+    if rank == 0:
+        views_per_s = world * args.views * args.steps / dt
+        P = args.H * args.W
+        bytes_per_view = 64 * P * args.fpp + 140 * P                      # whole-path algorithmic bytes
+        kb = kernel_breakdown(model, inp)
+        dom = max(kb, key=lambda k: kb[k][0])
+        ms, nbytes = kb[dom]
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        out = {
+            'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DTU-scan24-like synthetic: {args.views} views/GPU/step, {args.W}x{args.H}, {args.blocks} superquadric '
+                                   f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, coarse phase '
+                                   f'(sigma=1e-4, opacity noise, decimated textures), MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
+                       'views_per_gpu': args.views, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks, 'faces_per_pixel': args.fpp,
+                       'txt_size': args.txt, 'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
+                         'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()},
+                         'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS},
+            'final_loss': total_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -153,3 +153,19 @@ def look_at_view_transform(centers, at=(0., 0., 0.), up=(0., 1., 0.)):
     y = torch.nn.functional.normalize(torch.cross(z, x, dim=-1), dim=-1)
     R = torch.stack([x, y, z], dim=-1)
     return R, -(C[:, None] @ R)[:, 0]
+
+
+def synthetic_cameras(n_views, R_world=None, dist=2.8, f_ndc=4.82, elev_deg=30.0):
+    """Synthetic DTU-like rig: a wobbling ring of cameras above the ground plane looking at the origin,
+    shared NDC intrinsics K = [[f,0,px,0],[0,f,py,0],[0,0,0,1],[0,0,1,0]] with f ~ 2892 px / 600 (dtu.py:95-106).
+    The ring lives in the model frame and is mapped to the world frame by R_world (dbw.py:59,264).
+    -> R (V,3,3), T (V,3), K (V,4,4)."""
+    az = torch.arange(n_views, dtype=torch.float32) * (2 * math.pi / n_views) + 0.1
+    el = torch.full((n_views,), elev_deg * math.pi / 180) + 0.15 * torch.sin(3 * az)
+    C = torch.stack([torch.cos(el) * torch.sin(az), torch.sin(el), torch.cos(el) * torch.cos(az)], -1) * dist
+    up = torch.tensor([[0., 1., 0.]])
+    if R_world is not None:
+        C, up = C @ R_world.reshape(3, 3).cpu(), up @ R_world.reshape(3, 3).cpu()
+    R, T = look_at_view_transform(C, up=tuple(up[0].tolist()))
+    K = torch.tensor([[f_ndc, 0, 0, 0], [0, f_ndc, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=torch.float32)
+    return R, T, K[None].repeat(n_views, 1, 1)

@@ -1,0 +1,87 @@
+"""View-sharded data parallelism: one process per GPU, identical replicated parameters, each rank renders
+its own views, ONE in-place RCCL all-reduce (sum, fp32) of a single flat gradient buffer per optimisation step, then the
+same fused Adam update on every rank.  No other collective exists on the path (views are independent units).
+
+The reference has no live distributed code (dead `DDPCust`, src/model/__init__.py:44-53); this is the MI355X design for
+what `trainer.py:137-147` does on one GPU: zero_grad -> model(inp) -> total.backward() -> optimizer.step()
+(Adam, two groups: names starting with 'texture' use their own lr, optimizer.py:9-15)."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_views(n_views, world_size, rank):
+    """Contiguous ceil-split of view indices: 49 views over 8 ranks -> 7,6,6,6,6,6,6,6."""
+    base, extra = divmod(n_views, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+class FlatParams:
+    """Re-homes the model's parameters into two contiguous fp32 buffers (group 0: pose/shape/opacity, group 1: names
+    starting with 'texture') and pre-binds each `.grad` to a view of one flat gradient buffer, so that backward
+    accumulates straight into the buffer the all-reduce and the fused Adam consume (no gather/scatter copies)."""
+
+    def __init__(self, model):
+        named = list(model.named_parameters())
+        groups = [[(n, p) for n, p in named if not n.startswith('texture')], [(n, p) for n, p in named if n.startswith('texture')]]
+        dev = named[0][1].device
+        sizes = [sum(p.numel() for _, p in g) for g in groups]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.bounds = [(0, sizes[0]), (sizes[0], sizes[0] + sizes[1])]
+        self.names = []
+        off = 0
+        for g in groups:
+            for n, p in g:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                self.names.append((n, off, k))
+                off += k
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class ShardedTrainStep:
+    def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None):
+        self.model, self.pg = model, process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        model.world_size, model.rank = self.world_size, self.rank
+        self.params = FlatParams(model)
+        self.lrs, self.betas, self.eps = (lr, lr_texture), betas, eps
+        self.exp_avg = torch.zeros_like(self.params.flat)
+        self.exp_avg_sq = torch.zeros_like(self.params.flat)
+        self.n_steps = 0
+        self.adam_fn = adam_fn or ops.adam_step_
+        self._count_cache = {}
+
+    def _global_count(self, imgs):
+        """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367)."""
+        if self.world_size == 1:
+            return imgs.numel()
+        key = imgs.numel()
+        if key not in self._count_cache:
+            t = torch.tensor([float(key)], device=imgs.device)
+            dist.all_reduce(t, group=self.pg)
+            self._count_cache[key] = t.item()
+        return self._count_cache[key]
+
+    def __call__(self, inp, labels=None):
+        """One optimisation step on this rank's shard of views; returns the (local) loss dict (device tensors, no sync)."""
+        self.params.zero_grad()
+        self.model._global_count = self._global_count(inp['imgs'])
+        losses = self.model(inp, labels)
+        losses['total'].backward()
+        if self.world_size > 1:
+            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)     # RCCL over xGMI, in place
+        self.n_steps += 1
+        for (a, b), lr in zip(self.params.bounds, self.lrs):
+            if b > a:
+                self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,
+                             self.betas, self.eps)
+        return losses
