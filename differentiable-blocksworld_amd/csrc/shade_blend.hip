@@ -29,6 +29,7 @@ struct ShadeArgs {
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
     int N, H, W, K, F; float sigma; float bg[3];
+    int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
 };
 
 struct Sample {   // bilinear footprint of one fragment
@@ -228,19 +229,19 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         float gd = 0.f;
         if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (-1.f / A.sigma);
         if (gdists && in_img) gdists[pix * A.K + k] = gd;
-        if (galpha) {
+        if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
             wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
         }
         // colour -> texels (and -> uv -> barycentrics)
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
-        if (__ballot(tex) != 0ull) {
+        if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
             // lanes sharing the same top-left texel share all four addresses
             unsigned long long rem = __ballot(tex);
             int iter = 0;
             while (rem) {
-                if (iter >= 8) {
+                if (iter >= 8 || (A.dbg & 4)) {
                     if (tex && ((rem >> lane) & 1ull)) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     }
 }
 
+int g_dbg_flags = 0;
+
 int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
               const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
               const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
@@ -318,6 +321,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;
     A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma;
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
+    A.dbg = g_dbg_flags;
     return DBW_OK;
 }
 
@@ -365,3 +369,6 @@ extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary
                        grad_maps, grad_faces_alpha, grad_dists, grad_bary);
     return dbw_check_launch("shade_blend_bwd_kernel");
 }
+
+// Ablation hook for profiling scripts (tools/): not part of the rendering contract.
+extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags; }

@@ -34,6 +34,8 @@ typedef void *dbw_stream_t;
 
 int dbw_abi_version(void);
 const char *dbw_last_error(void);
+/* profiling/ablation switches used by tools/ (0 = product behaviour) */
+void dbw_debug_set_flags(int flags);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Camera transform + z-clipping of one scene seen from B cameras.

@@ -18,7 +18,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
-    for ret, name, args in re.findall(r'\b(int|size_t|const char \*)\s*(dbw_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+    for ret, name, args in re.findall(r'\b(int|size_t|void|const char \*)\s*(dbw_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
         args = ' '.join(args.split())
         types = []
         if args and args != 'void':
@@ -42,14 +42,14 @@ def test_library_builds_and_loads_without_gpu():
 def test_every_declared_symbol_is_exported_with_matching_signature():
     lib = _lib.load()
     protos = parse_header()
-    assert len(protos) == 19
+    assert len(protos) == 20
     for name, (ret, types) in protos.items():
         assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
         if name in _lib.SIGNATURES:
             assert _lib.SIGNATURES[name] == types, f'{name}: ctypes signature differs from the header'
     missing = set(_lib.SIGNATURES) - set(protos)
     assert not missing, f'bound but not declared: {missing}'
-    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_last_error', 'dbw_rasterize_workspace_bytes'}
+    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_debug_set_flags'}
     assert not undeclared_compute, f'declared but not bound: {undeclared_compute}'
 
 

@@ -1,0 +1,19 @@
+"""GPU profiling helper (not product code): times the kernels of the fg pass on the bench workload under ablation flags."""
+import ctypes, os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
+import torch
+import bench
+from dbw_amd import _lib
+
+class A: pass
+args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 300, 400, 10, 10, 256
+dev = torch.device('cuda', 0)
+model, inp = bench.build_workload(args, dev)
+model(inp, None)   # sets cameras
+lib = _lib.load()
+for flags in [0, 1, 2, 3, 4, 7]:
+    lib.dbw_debug_set_flags(flags)
+    kb = bench.kernel_breakdown(model, inp, reps=5)
+    print(flags, {k: round(v[0], 3) for k, v in kb.items()})
+lib.dbw_debug_set_flags(0)
