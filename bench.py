@@ -79,8 +79,9 @@ def kernel_breakdown(model, inp, reps=5):
     p2f, _, bary, dists = ops._raster_fwd(fvc, cl['first_idx'], cl['num_faces'], nb, B, H, W, K, cfg.blur, True, True, False, need_zbuf=False)
     img = ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F, cfg.sigma, r._bg)
     g_img = torch.rand_like(img)
+    agg = bool(model._blocks_decimated)                  # same backward mode as the training step uses for this pass
     _, _, g_dists, _ = ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
-                                           cfg.sigma, r._bg, g_img, True, False)
+                                           cfg.sigma, r._bg, g_img, True, False, agg)
     g_fvc = torch.zeros_like(fvc)
 
     def t(fn):
@@ -100,7 +101,7 @@ def kernel_breakdown(model, inp, reps=5):
         'shade_blend_fwd_kernel': (t(lambda: ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
                                                                   alpha, cfg.F, cfg.sigma, r._bg)), (20 * P * K + 16 * P) * B),
         'shade_blend_bwd_kernel': (t(lambda: ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
-                                                                  alpha, cfg.F, cfg.sigma, r._bg, g_img, True, False)),
+                                                                  alpha, cfg.F, cfg.sigma, r._bg, g_img, True, False, agg)),
                                    (20 * P * K + 16 * P + 4 * P * K) * B),
         'raster_bwd_kernel': (t(lambda: ops._lib.call('dbw_rasterize_bwd', fvc.data_ptr(), p2f.data_ptr(), 0, 0, g_dists.data_ptr(), B,
                                                       fvc.shape[0], H, W, K, 1, 1, g_fvc.data_ptr(), ops._stream(fvc))), 8 * P * K * B),

@@ -209,6 +209,53 @@ __device__ __forceinline__ void wave_agg_atomic(float *__restrict__ base, long l
     }
 }
 
+// Workgroup-level pre-aggregation of scattered gradient updates in LDS (open-addressing hash keyed by the destination
+// index).  Measured on MI355X (profiles/r01_atomic_scope_ubench.txt): scattered global fp32 atomics run at a flat
+// ~21 G lane-ops/s whatever the scope / working set, while LDS atomics are ~100x cheaper -- so every update first lands
+// in LDS (ds_cmpst + ds_add_f32) and each DISTINCT destination of the tile is flushed to memory once.  Updates that do
+// not find a slot within 8 probes go straight to memory, so the result is exact regardless of table pressure.
+template <int NV, int LOG2_SLOTS>
+struct LdsAgg {
+    static constexpr int NSLOT = 1 << LOG2_SLOTS;
+    static constexpr size_t BYTES = (size_t)NSLOT * (NV + 1) * 4;
+    int *keys;
+    float *vals;
+    __device__ __forceinline__ void bind(void *lds) { keys = (int *)lds; vals = (float *)lds + NSLOT; }
+    __device__ __forceinline__ void clear(int tid, int nthreads) {
+        for (int i = tid; i < NSLOT; i += nthreads) keys[i] = -1;
+        for (int i = tid; i < NSLOT * NV; i += nthreads) vals[i] = 0.f;
+    }
+    __device__ __forceinline__ void add(float *__restrict__ gbase, int key, const float (&v)[NV]) {
+        unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2_SLOTS);
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            const int old = atomicCAS(&keys[h], -1, key);
+            if (old == -1 || old == key) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], v[c]);
+                return;
+            }
+            h = (h + 1) & (NSLOT - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+            if (v[c] != 0.f) unsafeAtomicAdd(gbase + (long long)key * NV + c, v[c]);
+    }
+    __device__ __forceinline__ void flush(float *__restrict__ gbase, int tid, int nthreads) {
+        for (int i = tid; i < NSLOT; i += nthreads) {
+            const int k = keys[i];
+            if (k >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const float x = vals[i * NV + c];
+                    if (x != 0.f) unsafeAtomicAdd(gbase + (long long)k * NV + c, x);
+                }
+            }
+        }
+    }
+};
+
 // XCD-aware block remap (cdna_hip_programming.md T1): hardware places block b on XCD b % 8; we want consecutive
 // LOGICAL blocks (tiles of one view: same face list, same texture footprint, adjacent output rows) on one XCD/L2.
 // Grid must be launched with 8*ceil(total/8) blocks; returns -1 for padding blocks.

@@ -23,12 +23,16 @@ namespace {
 constexpr int NT = 256;
 constexpr int TILE = 16;
 
+typedef LdsAgg<3, 11> TexAgg;     // 2048 texels x (key + rgb) = 32 KB
+typedef LdsAgg<1, 10> AlphaAgg;   // 1024 faces            =  8 KB
+
 struct ShadeArgs {
     const int *p2f; const float *bary; const float *dists;
     const int *c2o; const int *code; const float *cw; int Fc_stride;
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
     int N, H, W, K, F; float sigma; float bg[3];
+    int agg;   // backward: 0 = wave-aggregated global atomics, 1 = LDS hash pre-aggregation
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
 };
 
@@ -107,9 +111,9 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     const float *uv = A.face_uvs + (long long)fr.j * 6;
     const float u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
     const float v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
-    const int *md = A.map_desc + A.face_map[fr.j] * 4;
+    const int *md = A.map_desc + A.face_map[fr.j] * 8;
     const long long off = md[0];
-    const int h = md[1], w = md[2], pl = md[3] & 0xffff, pr = (md[3] >> 16) & 0xffff;
+    const int h = md[1], w = md[2], pl = md[3], pr = md[4], sh = md[5];
     const int wp = w + pl + pr;
     float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
     float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
@@ -125,9 +129,12 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     // padded column -> source column (circular pad), flipped row -> source row
     int c0 = (x0 - pl) % w; if (c0 < 0) c0 += w;
     int c1 = (x1 - pl) % w; if (c1 < 0) c1 += w;
-    const int r0 = h - 1 - y0, r1 = h - 1 - y1;
-    s.a00 = off + ((long long)r0 * w + c0) * 3; s.a01 = off + ((long long)r0 * w + c1) * 3;
-    s.a10 = off + ((long long)r1 * w + c0) * 3; s.a11 = off + ((long long)r1 * w + c1) * 3;
+    // stored resolution = (h >> sh, w >> sh): a decimated map (avg_pool d + nearest upsample, dbw.py:276-278,331-334) is
+    // kept at cell resolution and the nearest upsampling is this shift
+    const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;
+    c0 >>= sh; c1 >>= sh;
+    s.a00 = off + ((long long)r0 * ws + c0) * 3; s.a01 = off + ((long long)r0 * ws + c1) * 3;
+    s.a10 = off + ((long long)r1 * ws + c0) * 3; s.a11 = off + ((long long)r1 * ws + c1) * 3;
     s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
 }
 
@@ -180,10 +187,20 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
                                                              float *__restrict__ gbary) {
-    extern __shared__ float s_layers[];           // [2][K][NT]: alpha_k and T_k of every pixel of the tile
+    extern __shared__ __attribute__((aligned(16))) float s_layers[];   // [2][K][NT]: alpha_k, T_k of every pixel of the tile
     float *s_a = s_layers + threadIdx.x, *s_T = s_layers + (long long)A.K * NT + threadIdx.x;
+    TexAgg tex_agg;
+    AlphaAgg alpha_agg;
+    const bool use_lds = A.agg != 0;
+    if (use_lds) {                                 // block-uniform
+        tex_agg.bind(s_layers + 2 * (long long)A.K * NT);
+        alpha_agg.bind((char *)tex_agg.keys + TexAgg::BYTES);
+        tex_agg.clear(threadIdx.x, NT);
+        alpha_agg.clear(threadIdx.x, NT);
+    }
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    if (use_lds) __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
     const long long pix = ((long long)n * A.H + yi) * A.W + xi;
@@ -231,12 +248,30 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         if (gdists && in_img) gdists[pix * A.K + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
-            wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
+            if (use_lds) { if (valid && gfa[0] != 0.f) alpha_agg.add(galpha, (int)fr.aidx, gfa); }
+            else wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
         }
         // colour -> texels (and -> uv -> barycentrics)
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
-        if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
+        if (use_lds && !(A.dbg & 1)) {
+            if (tex) {      // merge the footprint's texels that fall into the same stored cell, then one LDS insert per cell
+                float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
+                if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
+                if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
+                if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
+                else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
+                else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
+                const long long ad[4] = {s.a00, s.a01, s.a10, s.a11};
+                const float wt[4] = {w00, w01, w10, w11};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (wt[q] != 0.f) {
+                        const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                        tex_agg.add(gmaps, (int)(ad[q] / 3), v);
+                    }
+            }
+        } else if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
             // lanes sharing the same top-left texel share all four addresses
             unsigned long long rem = __ballot(tex);
             int iter = 0;
@@ -304,6 +339,11 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
         }
     }
+    if (use_lds) {
+        __syncthreads();
+        tex_agg.flush(gmaps, threadIdx.x, NT);
+        if (galpha) alpha_agg.flush(galpha, threadIdx.x, NT);
+    }
 }
 
 int g_dbg_flags = 0;
@@ -322,6 +362,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma;
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
     A.dbg = g_dbg_flags;
+    A.agg = 0;
     return DBW_OK;
 }
 
@@ -350,7 +391,7 @@ extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary
                                    const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
                                    int K, int F, float sigma, const float *background3, const float *grad_image,
                                    float *grad_maps, float *grad_faces_alpha, float *grad_dists, float *grad_bary,
-                                   dbw_stream_t stream) {
+                                   int lds_aggregate, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -364,7 +405,19 @@ extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary
     if (N == 0) return DBW_OK;
     const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * K * NT * sizeof(float);
+    size_t lds = (size_t)2 * K * NT * sizeof(float);
+    A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 1 : 0;
+    if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                dbw_set_error("dbw_shade_blend_bwd: cannot raise the dynamic LDS limit");
+                return DBW_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL(shade_blend_bwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image,
                        grad_maps, grad_faces_alpha, grad_dists, grad_bary);
     return dbw_check_launch("shade_blend_bwd_kernel");

@@ -24,7 +24,7 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threa
     return t;
 }
 
-// d == 1: elementwise.  d > 1: one thread per (d x d) cell and channel triple.
+// d == 1: elementwise.  d > 1: one thread per (d x d) cell; `maps` is written at CELL resolution (n, h/d, w/d, 3).
 __global__ void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
                                         float *__restrict__ maps, float *__restrict__ sig) {
     if (d <= 1) {
@@ -54,12 +54,8 @@ __global__ void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, in
                 }
             }
         const float inv = 1.f / (float)(d * d);
-        for (int y = 0; y < d; ++y)
-            for (int x = 0; x < d; ++x) {
-                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) maps[o + k] = acc[k] * inv;
-            }
+        for (int k = 0; k < 3; ++k) maps[c * 3 + k] = acc[k] * inv;     // cell resolution (n, h/d, w/d, 3)
     }
 }
 
@@ -81,13 +77,7 @@ __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, in
         const int m = (int)(c / (ch_ * cw_));
         const int r = (int)(c % (ch_ * cw_));
         const int cy = r / cw_, cx = r % cw_;
-        float acc[3] = {0.f, 0.f, 0.f};
-        for (int y = 0; y < d; ++y)
-            for (int x = 0; x < d; ++x) {
-                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] += gmaps[o + k];
-            }
+        const float acc[3] = {gmaps[c * 3], gmaps[c * 3 + 1], gmaps[c * 3 + 2]};   // gradient of the cell's mean
         const float inv = 1.f / (float)(d * d);
         for (int y = 0; y < d; ++y)
             for (int x = 0; x < d; ++x) {
@@ -194,6 +184,7 @@ extern "C" int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, i
                                     float *sig_out, dbw_stream_t stream) {
     DBW_REQUIRE(texture && maps_out, "null pointer");
     DBW_REQUIRE(n > 0 && h > 0 && w > 0 && decim >= 1, "bad size");
+    DBW_REQUIRE(decim == 1 || sig_out, "sig_out is required when decimating");
     DBW_REQUIRE(decim == 1 || (h % decim == 0 && w % decim == 0), "map size must be a multiple of the decimation factor");
     const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) : (long long)n * h * w * 3;
     hipLaunchKernelGGL(texture_prep_fwd_kernel, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, texture, n, h,

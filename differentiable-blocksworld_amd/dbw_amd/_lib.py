@@ -23,7 +23,7 @@ SIGNATURES = {
     'dbw_rasterize_bwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     'dbw_shade_blend_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     'dbw_shade_blend_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
-                            c_p, c_p, c_p, c_p, c_p, c_p],
+                            c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     'dbw_texture_prep_fwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_texture_prep_bwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     'dbw_sq_blocks_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],

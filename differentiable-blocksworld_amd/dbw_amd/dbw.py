@@ -127,8 +127,7 @@ class DifferentiableBlocksWorld(nn.Module):
         reg('_env_faces', torch.cat([bkg_f, g_f + nvb], 0).to(torch.int32))
         reg('_env_face_uvs', torch.cat([self.bkg_verts_uvs[bkg_f], self.ground_verts_uvs[g_f]], 0).float())
         reg('_env_face_map', torch.cat([torch.zeros(len(bkg_f)), torch.ones(len(g_f))]).to(torch.int32))
-        desc, _ = PackedScene.describe_maps([(TS * u, TS * u)] * 2, [(0, 0)] * 2, 'cpu')
-        reg('_env_map_desc', desc)
+        reg('_env_map_desc', PackedScene.describe_maps([(TS * u, TS * u)] * 2, [(0, 0)] * 2, 'cpu')[0])
         self._n_bkg_faces, self._n_ground_faces = len(bkg_f), len(g_f)
         # cos/sin tables of the constant angle buffers, evaluated once on the host (include/dbw_hip.h: `trig`)
         reg('_trig', torch.stack([torch.cos(self.sq_eta), torch.sin(self.sq_eta), torch.cos(self.sq_omega), torch.sin(self.sq_omega)], 0))
@@ -137,8 +136,7 @@ class DifferentiableBlocksWorld(nn.Module):
         reg('_block_faces_all', torch.cat([b_f + k * nv for k in range(N)], 0).to(torch.int32))
         reg('_block_face_uvs_all', verts_uvs[faces_uvs].repeat(N, 1, 1).float())
         reg('_block_face_map_all', torch.arange(N).repeat_interleave(self.BNF).to(torch.int32))
-        desc, _ = PackedScene.describe_maps([(TS, TS)] * N, [self.txt_padding] * N, 'cpu')
-        reg('_block_map_desc_all', desc)
+        reg('_block_map_desc_all', PackedScene.describe_maps([(TS, TS)] * N, [self.txt_padding] * N, 'cpu')[0])
         reg('_block_faces_one', b_f)
 
     def _init_rend_optim(self, **kwargs):          # dbw.py:121-129
@@ -149,6 +147,16 @@ class DifferentiableBlocksWorld(nn.Module):
         self.decim_factor = kwargs.pop('decimate_factor', DECIMATE_FACTOR)
         self.kill_blocks = kwargs.pop('kill_blocks', False)
         assert len(kwargs) == 0, kwargs
+        d = int(self.decim_factor)
+        if d < 1 or (d & (d - 1)) or self.txt_size % d:
+            raise NotImplementedError(f'decimate_factor={d}: the sampler keeps decimated maps at cell resolution and needs a '
+                                      'power of two that divides txt_size')
+        # descriptors of the decimated maps: same (h, w), stored at (h >> shift, w >> shift)
+        shift, TS, u, N = d.bit_length() - 1, self.txt_size, self.txt_bkg_upscale, self.n_blocks
+        dev = self._env_map_desc.device
+        self.register_buffer('_env_map_desc_dec', PackedScene.describe_maps([(TS * u, TS * u)] * 2, [(0, 0)] * 2, dev, shift)[0], persistent=False)
+        self.register_buffer('_block_map_desc_dec', PackedScene.describe_maps([(TS, TS)] * N, [self.txt_padding] * N, dev, shift)[0],
+                             persistent=False)
 
     def _init_renderer(self, img_size, **kwargs):  # dbw.py:131-143 (renderer_light is visualisation-only: not built)
         kwargs = deepcopy(kwargs)
@@ -251,7 +259,8 @@ class DifferentiableBlocksWorld(nn.Module):
         g_maps, self._ground_maps = ops.texture_prep(self.texture_ground, decim)
         verts = torch.cat([bkg_v, ground_v], 0)
         maps = torch.cat([bkg_maps.reshape(-1), g_maps.reshape(-1)])
-        return PackedScene(verts, self._env_faces, self._env_face_uvs, self._env_face_map, self._env_map_desc, maps)
+        desc = self._env_map_desc if decim == 1 else self._env_map_desc_dec
+        return PackedScene(verts, self._env_faces, self._env_face_uvs, self._env_face_map, desc, maps)
 
     def get_blocks_verts(self):
         """Block-frame superquadric vertices * ratio (dbw.py:348-352), for callers that want them unposed."""
@@ -292,8 +301,10 @@ class DifferentiableBlocksWorld(nn.Module):
                               self.scale_min, S_w, R_w, T_w)
         maps = maps_all if keep is None else maps_all[keep.bool()]
         F_ = nb * self.BNF
+        desc = (self._block_map_desc_all if decim == 1 else self._block_map_desc_dec)[:nb]
+        self._blocks_decimated = decim > 1
         return PackedScene(verts.reshape(-1, 3), self._block_faces_all[:F_], self._block_face_uvs_all[:F_],
-                           self._block_face_map_all[:F_], self._block_map_desc_all[:nb], maps.reshape(-1))
+                           self._block_face_map_all[:F_], desc, maps.reshape(-1))
 
     def _shared_randn_like(self, t):
         """Opacity noise must be identical on every data-parallel rank: drawn from a generator that all
@@ -323,11 +334,11 @@ class DifferentiableBlocksWorld(nn.Module):
         fine = not self.is_live('coarse_learning')
         filter_tsp = filter_transparent or fine
         renderer = self.renderer_fine if fine else self.renderer
-        env = self.renderer_env.render_packed(self.build_env_scene(), R, T)
+        env = self.renderer_env.render_packed(self.build_env_scene(), R, T, lds_aggregate=True)     # magnified textures
         blocks = self.build_blocks_scene(filter_transparent=filter_tsp)
         if blocks is not None:
             alpha = None if filter_tsp else self._alpha.repeat_interleave(self.BNF)   # shared by all views (== .repeat(B))
-            fg = renderer.render_packed(blocks, R, T, faces_alpha=alpha)
+            fg = renderer.render_packed(blocks, R, T, faces_alpha=alpha, lds_aggregate=self._blocks_decimated)
         else:
             fg = torch.zeros_like(env)
         return fg, env

@@ -149,7 +149,7 @@ def shade_blend_fwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 
 
 def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg, g_img,
-                    want_dists=True, want_bary=False):
+                    want_dists=True, want_bary=False, lds_aggregate=False):
     dev = p2f.device
     N, H, W, K = p2f.shape
     g_maps = torch.zeros_like(maps)
@@ -157,7 +157,7 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
     g_dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_dists else None
     g_bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev) if want_bary else None
     _lib.call('dbw_shade_blend_bwd', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg),
-              _ptr(g_img), _ptr(g_maps), _ptr(g_alpha), _ptr(g_dists), _ptr(g_bary), _stream(p2f))
+              _ptr(g_img), _ptr(g_maps), _ptr(g_alpha), _ptr(g_dists), _ptr(g_bary), int(lds_aggregate), _stream(p2f))
     return g_maps, g_alpha, g_dists, g_bary
 
 
@@ -165,9 +165,10 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 # The whole Renderer.forward as ONE autograd node: verts/maps/faces_alpha -> (B,4,H,W)
 # ---------------------------------------------------------------------------------------------------------------------
 class RenderCfg:
-    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F')
+    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate')
 
-    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8):
+    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False):
+        self.lds_aggregate = lds_aggregate
         self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
         self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
@@ -201,7 +202,7 @@ class _RenderScene(torch.autograd.Function):
         want_dists = need_geom and cfg.sigma > 0
         want_bary = need_geom and not cfg.detach_bary
         g_maps, g_alpha, g_dists, g_bary = shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F,
-                                                           cfg.sigma, bg, g_img.contiguous(), want_dists, want_bary)
+                                                           cfg.sigma, bg, g_img.contiguous(), want_dists, want_bary, cfg.lds_aggregate)
         g_verts = None
         if need_geom and (want_dists or want_bary):
             fvc = cl['face_verts'].view(-1, 3, 3)
@@ -239,7 +240,7 @@ class _TexturePrep(torch.autograd.Function):
     def forward(ctx, texture, decim):
         tex = _chk(texture.detach(), torch.float32, 'texture')
         n, h, w, _ = tex.shape
-        maps = torch.empty_like(tex)
+        maps = torch.empty_like(tex) if decim == 1 else torch.empty(n, h // decim, w // decim, 3, dtype=tex.dtype, device=tex.device)
         sig = torch.empty_like(tex) if decim > 1 else None
         _lib.call('dbw_texture_prep_fwd', _ptr(tex), n, h, w, int(decim), _ptr(maps), _ptr(sig), _stream(tex))
         ctx.save_for_backward(tex)
@@ -262,7 +263,8 @@ class _TexturePrep(torch.autograd.Function):
                     g = t if g is None else g + t
             g_maps, g_sig = g, None
         if g_maps is None:
-            g_maps = torch.zeros_like(tex)
+            d = ctx.decim
+            g_maps = torch.zeros(n, h // d, w // d, 3, dtype=tex.dtype, device=tex.device)
         out = torch.empty_like(tex)
         _lib.call('dbw_texture_prep_bwd', _ptr(tex), n, h, w, int(ctx.decim), _ptr(g_maps.contiguous()),
                   _ptr(None if g_sig is None else g_sig.contiguous()), _ptr(out), _stream(tex))
@@ -270,7 +272,8 @@ class _TexturePrep(torch.autograd.Function):
 
 
 def texture_prep(texture, decim=1):
-    """(n,h,w,3) logits -> (maps sampled by the renderer, undecimated sigmoid for the TV loss)."""
+    """(n,h,w,3) logits -> (maps sampled by the renderer: (n,h/d,w/d,3) cell means when decim > 1 -- pair them with
+    `shift = log2(decim)` in the map descriptor --, undecimated sigmoid for the TV loss)."""
     maps, sig = _TexturePrep.apply(texture, int(decim))
     return maps, sig
 

@@ -121,17 +121,19 @@ class _SceneTextures:
 
 class PackedScene:
     """What the kernels consume: verts (V,3) world [may require grad], faces int32 (F,3), face_uvs (F,3,2), face_map int32
-    (F,), map_desc int32 (M,4) = {offset, h, w, pad_left | pad_right << 16}, maps: flat fp32 [may require grad]."""
+    (F,), map_desc int32 (M,8) = {offset, h, w, pad_left, pad_right, shift, 0, 0} (map stored as (h>>shift, w>>shift, 3)),
+    maps: flat fp32 [may require grad]."""
 
     def __init__(self, verts, faces_i32, face_uvs, face_map, map_desc, maps):
         self.verts, self.faces, self.face_uvs, self.face_map, self.map_desc, self.maps = verts, faces_i32, face_uvs, face_map, map_desc, maps
 
     @staticmethod
-    def describe_maps(shapes, pads, device):
+    def describe_maps(shapes, pads, device, shift=0):
+        """shapes: full-resolution (h, w) of every map; shift: log2 of the decimation they are stored at."""
         rows, off = [], 0
         for (h, w), (pl, pr) in zip(shapes, pads):
-            rows.append([off, h, w, pl | (pr << 16)])
-            off += h * w * 3
+            rows.append([off, h, w, pl, pr, shift, 0, 0])
+            off += (h >> shift) * (w >> shift) * 3
         return torch.tensor(rows, dtype=torch.int32, device=device), off
 
     @staticmethod

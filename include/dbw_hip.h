@@ -92,8 +92,9 @@ int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const
  *    dbw_project_clip_fwd); c2o/clip_code/clip_w as above, or all NULL when the fragments already index original
  *    faces (then pix_to_face = b*F + j).
  *  face_uvs (F,3,2)   face_map (F) -> row of map_desc
- *  map_desc (M,4) int32: {offset in floats into maps, height, width (unpadded), pad_left | pad_right<<16}
- *  maps: flat fp32 buffer of (h,w,3) RGB maps in [0,1]
+ *  map_desc (M,8) int32: {offset in floats into maps, height h, width w (unpadded), pad_left, pad_right, shift, 0, 0}
+ *  maps: flat fp32 buffer of RGB maps in [0,1]; map m is STORED as (h>>shift, w>>shift, 3): shift > 0 is a decimated map
+ *    (avg_pool2d(2^shift) kept at cell resolution; the nearest upsampling of dbw.py:278,334 is the shift)
  *  faces_alpha: NULL, or alpha_len floats with alpha_len == F (shared by all views) or N*F (packed per view).
  *  background3: HOST pointer to 3 floats (blend background colour, renderer.py:32), NULL = black.
  *  image (N,4,H,W): premultiplied RGB + alpha (BCHW).
@@ -105,19 +106,23 @@ int dbw_shade_blend_fwd(const int32_t *pix_to_face, const float *bary, const flo
                         const float *background3, float *image, dbw_stream_t stream);
 /* grad_image (N,4,H,W).  Outputs: grad_maps (same layout as maps; accumulate), grad_faces_alpha (alpha_len;
  * accumulate; may be NULL), grad_dists (N,H,W,K; fully written; may be NULL), grad_bary (N,H,W,K,3 in CLIPPED
- * barycentrics; fully written; NULL = detach_bary, renderer.py:222-223). */
+ * barycentrics; fully written; NULL = detach_bary, renderer.py:222-223).
+ * lds_aggregate != 0: pre-aggregate texel/opacity gradients of each 16x16 tile in an LDS hash table before touching
+ * memory (pays whenever neighbouring fragments share destination texels: magnified or decimated maps). */
 int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                         const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                         const int32_t *face_map, const int32_t *map_desc, const float *maps,
                         const float *faces_alpha, int alpha_len, int N, int H, int W, int K, int F, float sigma,
                         const float *background3, const float *grad_image, float *grad_maps,
-                        float *grad_faces_alpha, float *grad_dists, float *grad_bary, dbw_stream_t stream);
+                        float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate,
+                        dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"
- * (avg_pool2d(d) then nearest upsample by d, dbw.py:276-278,331-334).  n maps of (h,w,3).
- *  maps_out: what the renderer samples;  sig_out (may be NULL): undecimated sigmoid kept for the TV loss.
- * Backward: grad_texture = (decimate^T grad_maps + grad_sig) * s(1-s).  grad_sig may be NULL.
+ * (avg_pool2d(d), dbw.py:276-278,331-334; the nearest upsampling by d is left to the sampler's `shift`).
+ * n maps of (h,w,3).  maps_out (n, h/d, w/d, 3): what the renderer samples;  sig_out (n,h,w,3) (may be NULL when d == 1,
+ * required when d > 1): undecimated sigmoid kept for the TV loss.
+ * Backward: grad_texture = (grad_maps[cell] / d^2 + grad_sig) * s(1-s).  grad_sig may be NULL.
  */
 int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, int decim, float *maps_out, float *sig_out,
                          dbw_stream_t stream);

@@ -30,9 +30,11 @@ def test_texture_prep_and_decimation():
         w1, w2 = torch.rand_like(tex), torch.rand_like(tex)
         ((maps * w1).sum() + (sig * w2).sum()).backward()
         t = tex.to(DEV).requires_grad_(True)
-        m_h, s_h = ops.texture_prep(t, d)
-        ((m_h * w1.to(DEV)).sum() + (s_h * w2.to(DEV)).sum()).backward()
-        assert rel_err(m_h, maps) < 1e-6 and rel_err(s_h, sig) < 1e-6
+        m_h, s_h = ops.texture_prep(t, d)          # decimated maps come back at cell resolution (nearest upsample = sampler shift)
+        assert m_h.shape == (3, 32 // d, 48 // d, 3)
+        m_up = m_h if d == 1 else m_h.repeat_interleave(d, 1).repeat_interleave(d, 2)
+        ((m_up * w1.to(DEV)).sum() + (s_h * w2.to(DEV)).sum()).backward()
+        assert rel_err(m_up, maps) < 1e-6 and rel_err(s_h, sig) < 1e-6
         assert rel_err(t.grad, t_ref.grad) < REL
 
 

@@ -266,6 +266,55 @@ def test_circular_padding_by_index_wrap_equals_padded_copy():
     assert a[:, 3].max() > 0.5
 
 
+@pytest.mark.parametrize('agg', [False, True])
+def test_decimated_maps_at_cell_resolution_match_upsampled_copy(agg):
+    """dbw.py:331-334: rendering from cell-resolution maps + descriptor shift == rendering from the nearest-upsampled copy,
+    forward and gradients (gradient of a cell = sum over its texels), with and without LDS pre-aggregation."""
+    m, R, T, Km = _model(seed=13, ts=32)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    pl, pr = m.txt_padding
+    d, sh = 8, 3
+    g = torch.Generator().manual_seed(0)
+    cells = [torch.rand(32 // d, 32 // d, 3, generator=g) for _ in scene['maps']]
+    full = [c.repeat_interleave(d, 0).repeat_interleave(d, 1) for c in cells]
+    ps_full = _packed(dict(scene, maps=full), pads=[(pl, pr)] * len(full))
+    ps_cell = _packed(dict(scene, maps=cells), pads=[(pl, pr)] * len(cells))
+    ps_cell.map_desc = PackedScene.describe_maps([(32, 32)] * len(cells), [(pl, pr)] * len(cells), DEV, shift=sh)[0]
+    fa = torch.full((scene['faces'].shape[0],), 0.7, device=DEV)
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    outs = []
+    for ps, lds in ((ps_full, False), (ps_cell, agg)):
+        ps.maps.requires_grad_(True)
+        fa_ = fa.clone().requires_grad_(True)
+        cfg = ops.RenderCfg(48, 64, 6, 1e-4, 0.001, True, True, scene['faces'].shape[0], lds_aggregate=lds)
+        img = ops.render_scene(ps.verts, ps.maps, fa_, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        w = torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        (img * w).sum().backward()
+        outs.append((img.detach(), ps.maps.grad, fa_.grad))
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-6
+    g_full = outs[0][1].view(len(full), 32 // d, d, 32 // d, d, 3).sum((2, 4)).reshape(-1)
+    assert rel_err(outs[1][1], g_full) < REL
+    assert rel_err(outs[1][2], outs[0][2]) < REL
+
+
+def test_lds_aggregation_is_equivalent_on_magnified_env_pass():
+    m, R, T, Km = _model(seed=17, ts=16)
+    with torch.no_grad():
+        scene = m.build_env(False, False)
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    grads = []
+    for lds in (False, True):
+        ps = _packed(scene)
+        ps.maps.requires_grad_(True)
+        ps.verts.requires_grad_(True)
+        cfg = ops.RenderCfg(48, 64, 1, 0.0, 0.001, True, False, scene['faces'].shape[0], lds_aggregate=lds)
+        img = ops.render_scene(ps.verts, ps.maps, None, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        (img * torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)).sum().backward()
+        grads.append((ps.maps.grad, ps.verts.grad))
+    assert rel_err(grads[1][0], grads[0][0]) < 1e-5 and rel_err(grads[1][1], grads[0][1]) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE config-2 resolution (300x400, K=10, 10 blocks)
 # ---------------------------------------------------------------------------------------------------------------------

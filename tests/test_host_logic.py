@@ -113,7 +113,8 @@ def test_meshes_join_and_packed_scene_layout():
     ps = PackedScene.from_meshes(scene.extend(3))
     assert ps.faces.dtype == torch.int32 and ps.face_uvs.shape == (22, 3, 2)
     assert ps.face_map.tolist() == [0] * 20 + [1] * 2
-    assert ps.map_desc.tolist() == [[0, 4, 6, 0], [72, 8, 8, 1 | (2 << 16)]]
+    assert ps.map_desc.tolist() == [[0, 4, 6, 0, 0, 0, 0, 0], [72, 8, 8, 1, 2, 0, 0, 0]]
+    assert PackedScene.describe_maps([(16, 16)] * 2, [(0, 3)] * 2, 'cpu', shift=3)[0].tolist() == [[0, 16, 16, 0, 3, 3, 0, 0], [12, 16, 16, 0, 3, 3, 0, 0]]
     assert ps.maps.numel() == 72 + 192
     batch = Meshes(torch.rand(3, 12, 3), f1[None].expand(3, -1, -1), TexturesUV(torch.rand(3, 4, 4, 3), f1, torch.rand(12, 2)))
     js = join_meshes_as_scene(batch)
