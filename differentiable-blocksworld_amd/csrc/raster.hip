@@ -111,29 +111,31 @@ struct TopK {
     }
 };
 
-template <int KMAX>
-__global__ __launch_bounds__(NT) void raster_fwd_kernel(
+template <int KMAX, int TW, int TH>
+__global__ __launch_bounds__(TW * TH) void raster_fwd_kernel(
     const float *__restrict__ fv, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
     const int *__restrict__ num_faces, const int *__restrict__ neighbor, int N, int H, int W, int K, float blur,
     int persp, int clipb, long long total_blocks, int *__restrict__ p2f, float *__restrict__ zbuf,
-    float *__restrict__ bary, float *__restrict__ dists) {
-    __shared__ FaceRec s_face[LIST_CAP];
-    __shared__ int s_wcnt[NT / DBW_WAVE];
+    float *__restrict__ bary, float *__restrict__ dists, int dbg) {
+    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = NT >= 256 ? LIST_CAP : 4 * NT;
+    __shared__ FaceRec s_face[CAP];
+    __shared__ int s_wcnt[NW];
 
     const long long logical = xcd_remap(blockIdx.x, total_blocks);
     if (logical < 0) return;
-    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int n = (int)(logical / (tiles_x * tiles_y));
     const int t = (int)(logical % (tiles_x * tiles_y));
     const int ty = t / tiles_x, tx = t % tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int xi = tx * TILE + (tid & (TILE - 1)), yi = ty * TILE + (tid >> 4);
+    // a wave always owns an 8-aligned compact footprint: lanes 0..63 -> 8x8 (TW == 8) or 16x4 (TW == 16) pixels
+    const int xi = tx * TW + (tid % TW), yi = ty * TH + (tid / TW);
     const bool in_img = xi < W && yi < H;
     f2 p;
     p.x = pix_to_ndc(W - 1 - xi, W, H);
     p.y = pix_to_ndc(H - 1 - yi, H, W);
-    const int x0 = tx * TILE, y0 = ty * TILE;
-    const int x1 = min(x0 + TILE - 1, W - 1), y1 = min(y0 + TILE - 1, H - 1);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int x1 = min(x0 + TW - 1, W - 1), y1 = min(y0 + TH - 1, H - 1);
     const float txmax = pix_to_ndc(W - 1 - x0, W, H), txmin = pix_to_ndc(W - 1 - x1, W, H);
     const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
 
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NT) void raster_fwd_kernel(
         __syncthreads();
         int woff = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < NT / DBW_WAVE; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+        for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
         if (hit) {
             FaceRec &r = s_face[cnt + woff + prefix];
             const float *src = fv + (long long)(f_begin + j) * 9;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NT) void raster_fwd_kernel(
         }
         cnt += tot;
         __syncthreads();
-        if (cnt > LIST_CAP - NT || base + NT >= nf) {
+        if (cnt > CAP - NT || base + NT >= nf) {
             for (int i = 0; i < cnt; ++i) {
                 const FaceRec &r = s_face[i];
                 if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NT) void raster_fwd_kernel(
     const long long o = (((long long)n * H + yi) * W + xi) * K;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        if (k < K) {
+        if (k < K && !((dbg & 16) && q.pz[k] != 12345.678f)) {     // dbg 16: ablate the stores (tools/ablate.py)
             const bool valid = q.fi[k] != 0x7fffffff;
             p2f[o + k] = valid ? q.fi[k] : -1;
             if (zbuf) zbuf[o + k] = valid ? q.pz[k] : -1.f;
@@ -264,14 +266,27 @@ __global__ __launch_bounds__(NT) void raster_bwd_kernel(
     }
 }
 
+int g_raster_dbg = 0;
+
+template <int KMAX, int TW, int TH>
+int launch_fwd_t(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
+                 int N, int H, int W, int K, float blur, int persp, int clipb, int *p2f, float *zbuf, float *bary,
+                 float *dists, hipStream_t s) {
+    const long long total = (long long)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    hipLaunchKernelGGL((raster_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
+                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, p2f, zbuf, bary, dists, g_raster_dbg);
+    return dbw_check_launch("raster_fwd_kernel");
+}
+
 template <int KMAX>
 int launch_fwd(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
                int N, int H, int W, int K, float blur, int persp, int clipb, int *p2f, float *zbuf, float *bary,
                float *dists, hipStream_t s) {
-    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    hipLaunchKernelGGL(raster_fwd_kernel<KMAX>, dim3(dbw_xcd_grid(total)), dim3(NT), 0, s, fv, bbox, first_idx,
-                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, p2f, zbuf, bary, dists);
-    return dbw_check_launch("raster_fwd_kernel");
+    const int shape = (g_raster_dbg >> 5) & 3;      // tile-shape experiment switch (tools/ablate_raster.py)
+    if (shape == 1) return launch_fwd_t<KMAX, 8, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
+    if (shape == 2) return launch_fwd_t<KMAX, 16, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
+    if (shape == 3) return launch_fwd_t<KMAX, 8, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
+    return launch_fwd_t<KMAX, 16, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
 }
 
 }  // namespace
@@ -324,3 +339,5 @@ extern "C" int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_
                        clip_barycentric_coords, total, grad_face_verts);
     return dbw_check_launch("raster_bwd_kernel");
 }
+
+extern "C" void dbw_debug_set_raster_flags(int flags) { g_raster_dbg = flags; }

@@ -25,6 +25,7 @@ constexpr int TILE = 16;
 
 typedef LdsAgg<3, 11> TexAgg;     // 2048 texels x (key + rgb) = 32 KB
 typedef LdsAgg<1, 10> AlphaAgg;   // 1024 faces            =  8 KB
+typedef LdsAgg<9, 9> FaceAgg;     // 512 faces x (key + 3x3) = 20 KB
 
 struct ShadeArgs {
     const int *p2f; const float *bary; const float *dists;
@@ -183,26 +184,38 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     o[3 * plane] = 1.f - T;
 }
 
+// FUSED = true additionally runs the rasteriser backward on the fly: d/d dists and d/d barycentrics are
+// consumed in registers and only d/d face_verts leaves the kernel (pre-aggregated per face in LDS).
+template <bool FUSED>
 __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
-                                                             float *__restrict__ gbary) {
+                                                             float *__restrict__ gbary, const float *__restrict__ fv,
+                                                             float *__restrict__ gfv, int want_bary, int persp) {
     extern __shared__ __attribute__((aligned(16))) float s_layers[];   // [2][K][NT]: alpha_k, T_k of every pixel of the tile
     float *s_a = s_layers + threadIdx.x, *s_T = s_layers + (long long)A.K * NT + threadIdx.x;
     TexAgg tex_agg;
     AlphaAgg alpha_agg;
     const bool use_lds = A.agg != 0;
-    if (use_lds) {                                 // block-uniform
-        tex_agg.bind(s_layers + 2 * (long long)A.K * NT);
-        alpha_agg.bind((char *)tex_agg.keys + TexAgg::BYTES);
-        tex_agg.clear(threadIdx.x, NT);
-        alpha_agg.clear(threadIdx.x, NT);
+    FaceAgg face_agg;
+    {
+        char *nxt = (char *)(s_layers + 2 * (long long)A.K * NT);
+        if (use_lds) {                             // block-uniform
+            tex_agg.bind(nxt); nxt += TexAgg::BYTES;
+            alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES;
+            tex_agg.clear(threadIdx.x, NT);
+            alpha_agg.clear(threadIdx.x, NT);
+        }
+        if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); }
     }
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
-    if (use_lds) __syncthreads();
+    if (use_lds || FUSED) __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
+    f2 pndc;
+    pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
+    pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
     const long long pix = ((long long)n * A.H + yi) * A.W + xi;
     const long long plane = (long long)A.H * A.W;
     float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
         if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (-1.f / A.sigma);
-        if (gdists && in_img) gdists[pix * A.K + k] = gd;
+        if (!FUSED && gdists && in_img) gdists[pix * A.K + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
             if (use_lds) { if (valid && gfa[0] != 0.f) alpha_agg.add(galpha, (int)fr.aidx, gfa); }
@@ -320,8 +333,9 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 ++iter;
             }
         }
-        if (gbary && in_img) {
+        if ((FUSED ? (want_bary != 0) : (gbary != nullptr)) && in_img || (FUSED && in_img)) {
             float gb[3] = {0.f, 0.f, 0.f};
+            if (FUSED ? (want_bary != 0) : true)
             if (tex) {
                 float gix = 0.f, giy = 0.f;
 #pragma unroll
@@ -335,15 +349,42 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
                 convert_bary_bwd(fr.cd, fr.w2, fr.w3, go, gb);
             }
-            const long long o = (pix * A.K + k) * 3;
-            gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
+            if (!FUSED) {
+                const long long o = (pix * A.K + k) * 3;
+                gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
+            } else if (valid && (gd != 0.f || gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f)) {
+                // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0)
+                const int fc = A.p2f[pix * A.K + k];
+                const float *q = fv + (long long)fc * 9;
+                const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
+                const float z0 = q[2], z1 = q[5], z2 = q[8];
+                const f3 bary0 = bary_fwd(pndc, a, b, c);
+                const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
+                const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
+                f2 d0, d1, d2;
+                point_tri_dist_bwd(pndc, a, b, c, (inside ? -1.f : 1.f) * gd, d0, d1, d2);
+                float g9[9] = {d0.x, d0.y, 0.f, d1.x, d1.y, 0.f, d2.x, d2.y, 0.f};
+                if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
+                    f3 gg{gb[0], gb[1], gb[2]};
+                    gg = clip_bwd(bp, gg);
+                    float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
+                    if (persp) gg = persp_bwd(bary0, z0, z1, z2, gg, pz0, pz1, pz2);
+                    f2 e0, e1, e2;
+                    bary_bwd(pndc, a, b, c, gg, e0, e1, e2);
+                    g9[0] += e0.x; g9[1] += e0.y; g9[2] += pz0;
+                    g9[3] += e1.x; g9[4] += e1.y; g9[5] += pz1;
+                    g9[6] += e2.x; g9[7] += e2.y; g9[8] += pz2;
+                }
+                face_agg.add(gfv, fc, g9);
+            }
         }
     }
+    if (use_lds || FUSED) __syncthreads();
     if (use_lds) {
-        __syncthreads();
         tex_agg.flush(gmaps, threadIdx.x, NT);
         if (galpha) alpha_agg.flush(galpha, threadIdx.x, NT);
     }
+    if (FUSED) face_agg.flush(gfv, threadIdx.x, NT);
 }
 
 int g_dbg_flags = 0;
@@ -385,6 +426,38 @@ extern "C" int dbw_shade_blend_fwd(const int32_t *pix_to_face, const float *bary
     return dbw_check_launch("shade_blend_fwd_kernel");
 }
 
+static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *grad_image, float *grad_maps,
+                      float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate, const float *fv,
+                      float *gfv, int want_bary, int persp, hipStream_t s) {
+    if (K > DBW_MAX_FACES_PER_PIXEL) {
+        dbw_set_error("shade/blend backward: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
+        return DBW_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return DBW_OK;
+    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    size_t lds = (size_t)2 * K * NT * sizeof(float);
+    A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 1 : 0;
+    if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
+    const bool fused = gfv != nullptr;
+    if (fused) lds += FaceAgg::BYTES;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            dbw_set_error("shade/blend backward: cannot raise the dynamic LDS limit");
+            return DBW_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    if (fused)
+        hipLaunchKernelGGL(shade_blend_bwd_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+                           grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
+    else
+        hipLaunchKernelGGL(shade_blend_bwd_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+                           grad_faces_alpha, grad_dists, grad_bary, nullptr, nullptr, 0, 1);
+    return dbw_check_launch("shade_blend_bwd_kernel");
+}
+
 extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const float *dists,
                                    const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
                                    const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
@@ -398,30 +471,28 @@ extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary
     if (rc) return rc;
     DBW_REQUIRE(grad_image && grad_maps, "null pointer");
     DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
-    if (K > DBW_MAX_FACES_PER_PIXEL) {
-        dbw_set_error("dbw_shade_blend_bwd: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
-        return DBW_ERR_UNSUPPORTED;
-    }
-    if (N == 0) return DBW_OK;
-    const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    hipStream_t s = (hipStream_t)stream;
-    size_t lds = (size_t)2 * K * NT * sizeof(float);
-    A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 1 : 0;
-    if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
-    if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                dbw_set_error("dbw_shade_blend_bwd: cannot raise the dynamic LDS limit");
-                return DBW_ERR_LAUNCH;
-            }
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(shade_blend_bwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image,
-                       grad_maps, grad_faces_alpha, grad_dists, grad_bary);
-    return dbw_check_launch("shade_blend_bwd_kernel");
+    return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, grad_dists, grad_bary, lds_aggregate, nullptr,
+                      nullptr, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists,
+                                    const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
+                                    const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                                    const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
+                                    int K, int F, float sigma, const float *background3, const float *grad_image,
+                                    const float *face_verts_c, int perspective_correct, int detach_bary,
+                                    float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
+                                    int lds_aggregate, dbw_stream_t stream) {
+    ShadeArgs A;
+    int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
+                       maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
+    if (rc) return rc;
+    DBW_REQUIRE(grad_image && grad_maps && face_verts_c && grad_face_verts_c, "null pointer");
+    DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
+    return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
+                      grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
 }
 
 // Ablation hook for profiling scripts (tools/): not part of the rendering contract.
-extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags; }
+extern "C" void dbw_debug_set_raster_flags(int flags);
+extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags; dbw_debug_set_raster_flags(flags); }

@@ -24,9 +24,10 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threa
     return t;
 }
 
-// d == 1: elementwise.  d > 1: one thread per (d x d) cell; `maps` is written at CELL resolution (n, h/d, w/d, 3).
-__global__ void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
-                                        float *__restrict__ maps, float *__restrict__ sig) {
+// d == 1: elementwise.  d > 1: one WAVE per (d x d) cell (lane <-> texel, wave-sum for the cell mean); `maps` is written
+// at CELL resolution (n, h/d, w/d, 3).
+__global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
+                                                               float *__restrict__ maps, float *__restrict__ sig) {
     if (d <= 1) {
         const long long total = (long long)n * h * w * 3;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -36,58 +37,51 @@ __global__ void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, in
         }
         return;
     }
-    const int ch_ = h / d, cw_ = w / d;
+    const int ch_ = h / d, cw_ = w / d, lane = threadIdx.x & 63;
     const long long cells = (long long)n * ch_ * cw_;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long c = wave; c < cells; c += nwaves) {
         const int m = (int)(c / (ch_ * cw_));
         const int r = (int)(c % (ch_ * cw_));
         const int cy = r / cw_, cx = r % cw_;
         float acc[3] = {0.f, 0.f, 0.f};
-        for (int y = 0; y < d; ++y)
-            for (int x = 0; x < d; ++x) {
-                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
+        for (int t = lane; t < d * d; t += 64) {
+            const long long o = (((long long)m * h + cy * d + t / d) * w + cx * d + t % d) * 3;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float s = sigmoidf(tex[o + k]);
-                    if (sig) sig[o + k] = s;
-                    acc[k] += s;
-                }
+            for (int k = 0; k < 3; ++k) {
+                const float s = sigmoidf(tex[o + k]);
+                sig[o + k] = s;
+                acc[k] += s;
             }
+        }
         const float inv = 1.f / (float)(d * d);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) maps[c * 3 + k] = acc[k] * inv;     // cell resolution (n, h/d, w/d, 3)
+        for (int k = 0; k < 3; ++k) {
+            const float tot = wave_sum(acc[k]);
+            if (lane == 0) maps[c * 3 + k] = tot * inv;
+        }
     }
 }
 
+// elementwise: gtex = (gcell[cell of the texel] / d^2 + gsig) * s(1-s)
 __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
                                         const float *__restrict__ gmaps, const float *__restrict__ gsig,
                                         float *__restrict__ gtex) {
-    if (d <= 1) {
-        const long long total = (long long)n * h * w * 3;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-            const float s = sigmoidf(tex[i]);
-            const float g = gmaps[i] + (gsig ? gsig[i] : 0.f);
-            gtex[i] = g * s * (1.f - s);
-        }
-        return;
-    }
+    const long long total = (long long)n * h * w * 3;
+    const float inv = 1.f / (float)(d * d);
     const int ch_ = h / d, cw_ = w / d;
-    const long long cells = (long long)n * ch_ * cw_;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
-        const int m = (int)(c / (ch_ * cw_));
-        const int r = (int)(c % (ch_ * cw_));
-        const int cy = r / cw_, cx = r % cw_;
-        const float acc[3] = {gmaps[c * 3], gmaps[c * 3 + 1], gmaps[c * 3 + 2]};   // gradient of the cell's mean
-        const float inv = 1.f / (float)(d * d);
-        for (int y = 0; y < d; ++y)
-            for (int x = 0; x < d; ++x) {
-                const long long o = (((long long)m * h + cy * d + y) * w + cx * d + x) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float s = sigmoidf(tex[o + k]);
-                    gtex[o + k] = (acc[k] * inv + (gsig ? gsig[o + k] : 0.f)) * s * (1.f - s);
-                }
-            }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float s = sigmoidf(tex[i]);
+        float g;
+        if (d <= 1) g = gmaps[i];
+        else {
+            const int k = (int)(i % 3);
+            const long long t = i / 3;
+            const int x = (int)(t % w), y = (int)((t / w) % h), m = (int)(t / ((long long)w * h));
+            g = gmaps[(((long long)m * ch_ + y / d) * cw_ + x / d) * 3 + k] * inv;
+        }
+        if (gsig) g += gsig[i];
+        gtex[i] = g * s * (1.f - s);
     }
 }
 
@@ -186,7 +180,7 @@ extern "C" int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, i
     DBW_REQUIRE(n > 0 && h > 0 && w > 0 && decim >= 1, "bad size");
     DBW_REQUIRE(decim == 1 || sig_out, "sig_out is required when decimating");
     DBW_REQUIRE(decim == 1 || (h % decim == 0 && w % decim == 0), "map size must be a multiple of the decimation factor");
-    const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) : (long long)n * h * w * 3;
+    const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) * 64 : (long long)n * h * w * 3;
     hipLaunchKernelGGL(texture_prep_fwd_kernel, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, texture, n, h,
                        w, decim, maps_out, sig_out);
     return dbw_check_launch("texture_prep_fwd_kernel");
@@ -197,7 +191,7 @@ extern "C" int dbw_texture_prep_bwd(const float *texture, int n, int h, int w, i
     DBW_REQUIRE(texture && grad_maps && grad_texture, "null pointer");
     DBW_REQUIRE(n > 0 && h > 0 && w > 0 && decim >= 1, "bad size");
     DBW_REQUIRE(decim == 1 || (h % decim == 0 && w % decim == 0), "map size must be a multiple of the decimation factor");
-    const long long work = decim > 1 ? (long long)n * (h / decim) * (w / decim) : (long long)n * h * w * 3;
+    const long long work = (long long)n * h * w * 3;
     hipLaunchKernelGGL(texture_prep_bwd_kernel, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, texture, n, h,
                        w, decim, grad_maps, grad_sig, grad_texture);
     return dbw_check_launch("texture_prep_bwd_kernel");

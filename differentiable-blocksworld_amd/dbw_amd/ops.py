@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+FUSED_BACKWARD = True     # one kernel for blend-backward + rasteriser-backward (False: the two operator-level kernels)
 
 
 def _ptr(t):
@@ -201,6 +202,15 @@ class _RenderScene(torch.autograd.Function):
         need_geom = ctx.needs_input_grad[0]
         want_dists = need_geom and cfg.sigma > 0
         want_bary = need_geom and not cfg.detach_bary
+        if need_geom and (want_dists or want_bary) and FUSED_BACKWARD:
+            fvc = cl['face_verts'].view(-1, 3, 3)
+            g_maps, g_alpha = torch.zeros_like(maps), (torch.zeros_like(fa) if fa is not None else None)
+            g_fvc = torch.zeros_like(fvc)
+            _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg),
+                      _ptr(g_img.contiguous()), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
+                      int(cfg.lds_aggregate), _stream(fvc))
+            g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp)
+            return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
         g_maps, g_alpha, g_dists, g_bary = shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F,
                                                            cfg.sigma, bg, g_img.contiguous(), want_dists, want_bary, cfg.lds_aggregate)
         g_verts = None

@@ -117,6 +117,18 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
                         float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate,
                         dbw_stream_t stream);
 
+/* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
+ * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
+ * face_verts_c (the rasteriser's input).  detach_bary != 0 reproduces renderer.py:222-223 (geometry gradient through
+ * dists only).  grad_face_verts_c (B*2F,3,3): accumulate. */
+int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+                         const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
+                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3,
+                         const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
+                         float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
+                         dbw_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"
  * (avg_pool2d(d), dbw.py:276-278,331-334; the nearest upsampling by d is left to the sampler's `shift`).

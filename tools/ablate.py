@@ -12,7 +12,7 @@ dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model(inp, None)   # sets cameras
 lib = _lib.load()
-for flags in [0, 1, 2, 3, 8, 9, 11]:   # 8 = force the non-LDS (wave-aggregated global atomics) backward
+for flags in [0, 16]:   # 8 = force the non-LDS backward; 16 = rasteriser without its stores
     lib.dbw_debug_set_flags(flags)
     kb = bench.kernel_breakdown(model, inp, reps=5)
     print(flags, {k: round(v[0], 3) for k, v in kb.items()})
