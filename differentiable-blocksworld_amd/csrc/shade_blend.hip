@@ -23,9 +23,9 @@ namespace {
 constexpr int NT = 256;
 constexpr int TILE = 16;
 
-typedef LdsAgg<3, 11> TexAgg;     // 2048 texels x (key + rgb) = 32 KB
-typedef LdsAgg<1, 10> AlphaAgg;   // 1024 faces            =  8 KB
-typedef LdsAgg<9, 9> FaceAgg;     // 512 faces x (key + 3x3) = 20 KB
+typedef LdsAgg<3, 10> TexAgg;     // 1024 texels x (key + rgb) = 16 KB
+typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces             =  2 KB
+typedef LdsAgg<9, 8> FaceAgg;     // 256 faces x (key + 3x3) = 10 KB
 
 struct ShadeArgs {
     const int *p2f; const float *bary; const float *dists;
@@ -192,14 +192,14 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
                                                              float *__restrict__ gbary, const float *__restrict__ fv,
                                                              float *__restrict__ gfv, int want_bary, int persp) {
-    extern __shared__ __attribute__((aligned(16))) float s_layers[];   // [2][K][NT]: alpha_k, T_k of every pixel of the tile
-    float *s_a = s_layers + threadIdx.x, *s_T = s_layers + (long long)A.K * NT + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float s_layers[];   // [K][NT]: transmittance T_k in front of layer k
+    float *s_T = s_layers + threadIdx.x;
     TexAgg tex_agg;
     AlphaAgg alpha_agg;
     const bool use_lds = A.agg != 0;
     FaceAgg face_agg;
     {
-        char *nxt = (char *)(s_layers + 2 * (long long)A.K * NT);
+        char *nxt = (char *)(s_layers + (long long)A.K * NT);
         if (use_lds) {                             // block-uniform
             tex_agg.bind(nxt); nxt += TexAgg::BYTES;
             alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES;
@@ -230,7 +230,6 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             float ak = 0.f;
             Frag fr;
             if (in_img && load_frag(A, n, pix * A.K + k, fr)) ak = fr.e * fr.fa;
-            s_a[k * NT] = ak;
             s_T[k * NT] = T;
             T *= (1.f - ak);
         }
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         Frag fr;
         bool valid = false;
         if (in_img) valid = load_frag(A, n, pix * A.K + k, fr);
-        const float ak = s_a[k * NT], Tk = s_T[k * NT];
+        const float ak = valid ? fr.e * fr.fa : 0.f, Tk = s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
         float c[3] = {0.f, 0.f, 0.f};
@@ -435,7 +434,7 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     }
     if (N == 0) return DBW_OK;
     const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    size_t lds = (size_t)2 * K * NT * sizeof(float);
+    size_t lds = (size_t)K * NT * sizeof(float);
     A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 1 : 0;
     if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
     const bool fused = gfv != nullptr;
