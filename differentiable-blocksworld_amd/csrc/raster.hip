@@ -15,7 +15,7 @@
 //  * blockIdx -> tile mapping is XCD-aware: all tiles of a view run on one XCD so its face table and its output
 //    rows stay in that XCD's L2;
 //  * the kernel is HBM-write bound: 24*K bytes of fragments per pixel, compute is ~1% of the time.
-#include "dbw_common.h"
+#include "raster_common.h"
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
@@ -26,16 +26,6 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int NT = 256;
-constexpr int LIST_CAP = 512;
-
-struct __attribute__((aligned(16))) FaceRec {
-    float v[9];
-    float xlo, xhi, ylo, yhi;
-    int nb;
-    int id;
-    int pad;
-};
-static_assert(sizeof(FaceRec) == 64, "FaceRec must be 64 B");
 
 // Per-face screen bbox expanded by sqrt(blur_radius); faces that can never be hit (touching/behind the camera plane,
 // zero area, culled) get an empty box.  One rounding per value, same as the oracle's per-pixel expression.
@@ -59,143 +49,16 @@ __global__ void face_setup_kernel(const float *__restrict__ fv, long long F, flo
     bbox[i] = o;
 }
 
-template <int KMAX>
-struct TopK {
-    float pz[KMAX], ds[KMAX], b0[KMAX], b1[KMAX], b2[KMAX];
-    int fi[KMAX];
-
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) { pz[i] = INFINITY; fi[i] = 0x7fffffff; ds[i] = b0[i] = b1[i] = b2[i] = -1.f; }
-    }
-    __device__ __forceinline__ static bool less(float pa, int fa, float pb, int fb) {
-        return (pa < pb) || (!(pb < pa) && fa < fb);
-    }
-    __device__ __forceinline__ void swap_with(int i, float &cp, int &cf, float &cd, float &c0, float &c1, float &c2) {
-        float t;
-        int ti;
-        t = pz[i]; pz[i] = cp; cp = t;
-        ti = fi[i]; fi[i] = cf; cf = ti;
-        t = ds[i]; ds[i] = cd; cd = t;
-        t = b0[i]; b0[i] = c0; c0 = t;
-        t = b1[i]; b1[i] = c1; c1 = t;
-        t = b2[i]; b2[i] = c2; c2 = t;
-    }
-    // sorted insert; the displaced largest entry falls off the end (== emplace_back, sort, pop_back if size > K)
-    __device__ __forceinline__ void insert(int K, float cp, int cf, float cd, float c0, float c1, float c2) {
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i)
-            if (i < K && less(cp, cf, pz[i], fi[i])) swap_with(i, cp, cf, cd, c0, c1, c2);
-    }
-    __device__ __forceinline__ void cswap(int i) {  // order entries i, i+1
-        if (less(pz[i + 1], fi[i + 1], pz[i], fi[i])) swap_with(i, pz[i + 1], fi[i + 1], ds[i + 1], b0[i + 1], b1[i + 1], b2[i + 1]);
-    }
-    // sibling rule: returns true if `nb` was found (entry possibly replaced, list re-sorted)
-    __device__ __forceinline__ bool sibling(int K, int nb, float dist, float cp, int cf, float cd, float c0, float c1, float c2) {
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) {
-            if (i < K && !found && fi[i] == nb) {
-                found = true;
-                const float nd = ds[i] < 0.f ? -ds[i] : ds[i];
-                if (dist < nd) { pz[i] = cp; fi[i] = cf; ds[i] = cd; b0[i] = c0; b1[i] = c1; b2[i] = c2; }
-            }
-        }
-        if (found) {  // one entry may be out of place: one forward + one backward adjacent pass restores the order
-#pragma unroll
-            for (int i = 0; i < KMAX - 1; ++i) if (i + 1 < K) cswap(i);
-#pragma unroll
-            for (int i = KMAX - 2; i >= 0; --i) if (i + 1 < K) cswap(i);
-        }
-        return found;
-    }
-};
-
 template <int KMAX, int TW, int TH>
-__global__ __launch_bounds__(TW * TH) void raster_fwd_kernel(
+__global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void raster_fwd_kernel(
     const float *__restrict__ fv, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
     const int *__restrict__ num_faces, const int *__restrict__ neighbor, int N, int H, int W, int K, float blur,
     int persp, int clipb, long long total_blocks, int *__restrict__ p2f, float *__restrict__ zbuf,
     float *__restrict__ bary, float *__restrict__ dists, int dbg) {
-    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = NT >= 256 ? LIST_CAP : 4 * NT;
-    __shared__ FaceRec s_face[CAP];
-    __shared__ int s_wcnt[NW];
-
-    const long long logical = xcd_remap(blockIdx.x, total_blocks);
-    if (logical < 0) return;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int n = (int)(logical / (tiles_x * tiles_y));
-    const int t = (int)(logical % (tiles_x * tiles_y));
-    const int ty = t / tiles_x, tx = t % tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // a wave always owns an 8-aligned compact footprint: lanes 0..63 -> 8x8 (TW == 8) or 16x4 (TW == 16) pixels
-    const int xi = tx * TW + (tid % TW), yi = ty * TH + (tid / TW);
-    const bool in_img = xi < W && yi < H;
-    f2 p;
-    p.x = pix_to_ndc(W - 1 - xi, W, H);
-    p.y = pix_to_ndc(H - 1 - yi, H, W);
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int x1 = min(x0 + TW - 1, W - 1), y1 = min(y0 + TH - 1, H - 1);
-    const float txmax = pix_to_ndc(W - 1 - x0, W, H), txmin = pix_to_ndc(W - 1 - x1, W, H);
-    const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
-
+    int n, xi, yi;
     TopK<KMAX> q;
-    q.init();
-
-    const int f_begin = first_idx[n], nf = num_faces[n];
-    int cnt = 0;
-    for (int base = 0; base < nf; base += NT) {
-        const int j = base + tid;
-        bool hit = false;
-        float4 bb;
-        if (j < nf) {
-            bb = bbox[f_begin + j];
-            hit = !(txmax < bb.x || txmin > bb.y || tymax < bb.z || tymin > bb.w);
-        }
-        const unsigned long long m = __ballot(hit);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
-        if (hit) {
-            FaceRec &r = s_face[cnt + woff + prefix];
-            const float *src = fv + (long long)(f_begin + j) * 9;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) r.v[i] = src[i];
-            r.xlo = bb.x; r.xhi = bb.y; r.ylo = bb.z; r.yhi = bb.w;
-            r.nb = neighbor ? neighbor[f_begin + j] : -1;
-            r.id = f_begin + j;
-        }
-        cnt += tot;
-        __syncthreads();
-        if (cnt > CAP - NT || base + NT >= nf) {
-            for (int i = 0; i < cnt; ++i) {
-                const FaceRec &r = s_face[i];
-                if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
-                    const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
-                    const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
-                    const f3 bary0 = bary_fwd(p, a, b, c);
-                    const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
-                    const f3 bc = clipb ? clip_fwd(bp) : bp;
-                    const float pzv = bc.x * z0 + bc.y * z1 + bc.z * z2;
-                    if (!(pzv < 0.f)) {
-                        const float dist = point_tri_dist(p, a, b, c);
-                        const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
-                        if (inside || !(dist >= blur)) {
-                            const float sd = inside ? -dist : dist;
-                            bool done = false;
-                            if (r.nb != -1) done = q.sibling(K, r.nb, dist, pzv, r.id, sd, bc.x, bc.y, bc.z);
-                            if (!done) q.insert(K, pzv, r.id, sd, bc.x, bc.y, bc.z);
-                        }
-                    }
-                }
-            }
-            cnt = 0;
-            __syncthreads();
-        }
-    }
+    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, H, W, K, blur, persp, clipb, total_blocks, n, xi, yi, q)) return;
+    const bool in_img = xi < W && yi < H;
     if (!in_img) return;
     const long long o = (((long long)n * H + yi) * W + xi) * K;
 #pragma unroll
@@ -290,6 +153,12 @@ int launch_fwd(const float *fv, const float4 *bbox, const int *first_idx, const 
 }
 
 }  // namespace
+
+int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s) {
+    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, F_total, margin, cull,
+                       (float4 *)bbox);
+    return dbw_check_launch("face_setup_kernel");
+}
 
 extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) { return (size_t)(F_total > 0 ? F_total : 1) * sizeof(float4); }
 

@@ -1,0 +1,116 @@
+// Fused forward of one render pass: tile rasterisation -> per-pixel top-K (registers) -> shading + layered blend, in ONE
+// kernel.  The image is produced straight from the register-resident fragment lists; the fragments are also stored (once)
+// because the backward pass consumes them, but they are never read back in the forward direction -- the reference path
+// (PyTorch3D rasterize -> interpolate -> grid_sample -> ~12 blend kernels, renderer.py:92-94,219-273) re-reads them ~15x.
+#include "raster_common.h"
+#include "shade_common.h"
+#include "../../include/dbw_hip.h"
+
+#include <math.h>
+
+using namespace dbw;
+
+// implemented in raster.hip / shade_blend.hip
+int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s);
+int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+                        const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                        const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
+                        int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
+
+namespace {
+
+template <int KMAX, int TW, int TH>
+__global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const float *__restrict__ fv, const float4 *__restrict__ bbox,
+                                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces,
+                                                             const int *__restrict__ neighbor, float blur, int persp,
+                                                             long long total_blocks, ShadeArgs A, int *__restrict__ p2f,
+                                                             float *__restrict__ bary, float *__restrict__ dists,
+                                                             float *__restrict__ image) {
+    int n, xi, yi;
+    TopK<KMAX> q;
+    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, n, xi, yi, q)) return;
+    if (xi >= A.W || yi >= A.H) return;
+    const long long pix = ((long long)n * A.H + yi) * A.W + xi;
+    const long long o = pix * A.K;
+    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < A.K) {
+            const bool valid = q.fi[k] != 0x7fffffff;
+            p2f[o + k] = valid ? q.fi[k] : -1;
+            dists[o + k] = q.ds[k];
+            bary[(o + k) * 3 + 0] = q.b0[k];
+            bary[(o + k) * 3 + 1] = q.b1[k];
+            bary[(o + k) * 3 + 2] = q.b2[k];
+            if (valid) {
+                Frag fr;
+                const float bc[3] = {q.b0[k], q.b1[k], q.b2[k]};
+                decode_frag(A, n, q.fi[k], bc, q.ds[k], fr);
+                const float a = fr.e * fr.fa;
+                if (a != 0.f) {
+                    Sample s;
+                    footprint(A, fr, s);
+                    float c[3];
+                    fetch(A.maps, s, c);
+                    const float wgt = T * a;
+                    r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+                }
+                T *= (1.f - a);
+            }
+        }
+    }
+    const long long plane = (long long)A.H * A.W;
+    float *out = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+    out[0] = r + T * A.bg[0];
+    out[plane] = g + T * A.bg[1];
+    out[2 * plane] = b + T * A.bg[2];
+    out[3 * plane] = 1.f - T;
+}
+
+template <int KMAX>
+int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
+           int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+    constexpr int TW = 8, TH = 8;     // single-wave tiles: best measured shape for the raster phase (profiles/)
+    const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
+    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx, num_faces,
+                       neighbor, blur, persp, total, A, p2f, bary, dists, image);
+    return dbw_check_launch("render_fwd_kernel");
+}
+
+}  // namespace
+
+extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+                                    const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code,
+                                    const float *clip_w, int Fc_stride, const float *face_uvs, const int32_t *face_map,
+                                    const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len,
+                                    int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
+                                    int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
+                                    float *dists, float *image, void *workspace, size_t workspace_bytes,
+                                    dbw_stream_t stream) {
+    DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && image && workspace, "null pointer");
+    DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
+    DBW_REQUIRE(blur_radius >= 0.f && F_total >= 0, "bad blur_radius / F_total");
+    ShadeArgs A;
+    int rc = dbw_fill_shade_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
+                                 faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
+    if (rc) return rc;
+    if (K > DBW_MAX_FACES_PER_PIXEL) {
+        dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
+        return DBW_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return DBW_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float margin = (float)sqrt((double)blur_radius);
+    if (F_total > 0) {
+        rc = dbw_launch_face_setup(face_verts_c, F_total, margin, 0, workspace, s);
+        if (rc) return rc;
+    }
+    const float4 *bbox = (const float4 *)workspace;
+#define DBW_RF(KM) launch<KM>(face_verts_c, bbox, first_idx, num_faces, neighbor, blur_radius, perspective_correct, A, pix_to_face, bary, dists, image, s)
+    if (K == 1) return DBW_RF(1);
+    if (K <= 4) return DBW_RF(4);
+    if (K <= 10) return DBW_RF(10);
+    if (K <= 16) return DBW_RF(16);
+    return DBW_RF(25);
+#undef DBW_RF
+}

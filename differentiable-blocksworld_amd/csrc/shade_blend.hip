@@ -13,7 +13,7 @@
 //   d rgb / d a_k = T_k (c_k - U_k),  d A / d a_k = T_k V_k        (no division by (1 - a_k))
 // and scatters: texel gradients (wave-aggregated atomics: under magnification -- sky dome, ground -- most lanes of a
 // wave share one bilinear footprint), per-face opacity gradients, d/d dists, and optionally d/d barycentrics.
-#include "dbw_common.h"
+#include "shade_common.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -22,128 +22,6 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int TILE = 16;
-
-typedef LdsAgg<3, 10> TexAgg;     // 1024 texels x (key + rgb) = 16 KB
-typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces             =  2 KB
-typedef LdsAgg<9, 8> FaceAgg;     // 256 faces x (key + 3x3) = 10 KB
-
-struct ShadeArgs {
-    const int *p2f; const float *bary; const float *dists;
-    const int *c2o; const int *code; const float *cw; int Fc_stride;
-    const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
-    const float *faces_alpha; int alpha_len;
-    int N, H, W, K, F; float sigma; float bg[3];
-    int agg;   // backward: 0 = wave-aggregated global atomics, 1 = LDS hash pre-aggregation
-    int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
-};
-
-struct Sample {   // bilinear footprint of one fragment
-    long long a00, a01, a10, a11;   // float offsets of the 4 texels (RGB triplets) in `maps`
-    float w00, w01, w10, w11;
-    float dudx, dvdy;               // d(ix)/du, d(iy)/dv (0 when clamped at the border)
-    float wx0, wx1, wy0, wy1;
-};
-
-struct Frag {
-    int j;            // local original face id
-    int cd;           // clip code
-    float w2, w3;
-    float bo[3];      // barycentrics w.r.t. the original face
-    float e;          // geometric alpha exp(-max(d,0)/sigma) or hard indicator
-    float fa;         // learned face opacity (1 if none)
-    long long aidx;   // index into faces_alpha
-    float d;
-};
-
-__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
-
-__device__ __forceinline__ void convert_bary(int cd, float w2, float w3, const float b[3], float bo[3]) {
-    if (cd < 0) { bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2]; return; }
-    const int i1 = cd & 3, kind = cd >> 2;
-    float o1, o2, o3;
-    if (kind == 0) { o1 = b[0] * (1.f - w2) + b[1] * (1.f - w3) + b[2]; o2 = b[0] * w2; o3 = b[1] * w3; }
-    else if (kind == 1) { o1 = b[0] * (1.f - w2) + b[2] * (1.f - w3); o2 = b[0] * w2 + b[1]; o3 = b[2] * w3; }
-    else { o1 = b[0] * (1.f - w3); o2 = b[1]; o3 = b[0] * w3 + b[2]; }
-    // slot i1 <- o1, slot i1+1 <- o2, slot i1+2 <- o3 (mod 3)
-    bo[0] = sel3(i1, o1, o3, o2);
-    bo[1] = sel3(i1, o2, o1, o3);
-    bo[2] = sel3(i1, o3, o2, o1);
-}
-
-__device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, const float go[3], float gb[3]) {
-    if (cd < 0) { gb[0] = go[0]; gb[1] = go[1]; gb[2] = go[2]; return; }
-    const int i1 = cd & 3, kind = cd >> 2;
-    const float g1 = sel3(i1, go[0], go[1], go[2]), g2 = sel3(i1, go[1], go[2], go[0]), g3 = sel3(i1, go[2], go[0], go[1]);
-    if (kind == 0) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g1 * (1.f - w3) + g3 * w3; gb[2] = g1; }
-    else if (kind == 1) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g2; gb[2] = g1 * (1.f - w3) + g3 * w3; }
-    else { gb[0] = g1 * (1.f - w3) + g3 * w3; gb[1] = g2; gb[2] = g3; }
-}
-
-// fetch + decode one fragment slot; returns false for empty slots
-__device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, long long o, Frag &fr) {
-    const int fc = A.p2f[o];
-    if (fc < 0) return false;
-    float b[3] = {A.bary[o * 3], A.bary[o * 3 + 1], A.bary[o * 3 + 2]};
-    if (A.c2o) {
-        fr.j = A.c2o[fc];
-        fr.cd = A.code[fc];
-        fr.w2 = A.cw[(long long)fc * 2];
-        fr.w3 = A.cw[(long long)fc * 2 + 1];
-    } else {
-        fr.j = fc - n * A.F;
-        fr.cd = -1;
-        fr.w2 = fr.w3 = 0.f;
-    }
-    convert_bary(fr.cd, fr.w2, fr.w3, b, fr.bo);
-    fr.d = A.dists[o];
-    if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
-    else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
-    fr.fa = 1.f;
-    fr.aidx = 0;
-    if (A.faces_alpha) {
-        fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
-        fr.fa = A.faces_alpha[fr.aidx];
-    }
-    return true;
-}
-
-// grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
-__device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
-    const float *uv = A.face_uvs + (long long)fr.j * 6;
-    const float u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
-    const float v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
-    const int *md = A.map_desc + A.face_map[fr.j] * 8;
-    const long long off = md[0];
-    const int h = md[1], w = md[2], pl = md[3], pr = md[4], sh = md[5];
-    const int wp = w + pl + pr;
-    float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
-    float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
-    s.dudx = (float)(wp - 1); s.dvdy = (float)(h - 1);
-    // clip_coordinates_set_grad of torch's grid_sampler: no gradient at or beyond the border
-    if (!(ix > 0.f)) { ix = 0.f; s.dudx = 0.f; } else if (ix >= (float)(wp - 1)) { ix = (float)(wp - 1); s.dudx = 0.f; }
-    if (!(iy > 0.f)) { iy = 0.f; s.dvdy = 0.f; } else if (iy >= (float)(h - 1)) { iy = (float)(h - 1); s.dvdy = 0.f; }
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const int x1 = min(x0 + 1, wp - 1), y1 = min(y0 + 1, h - 1);
-    s.wx1 = ix - fx; s.wx0 = 1.f - s.wx1;
-    s.wy1 = iy - fy; s.wy0 = 1.f - s.wy1;
-    // padded column -> source column (circular pad), flipped row -> source row
-    int c0 = (x0 - pl) % w; if (c0 < 0) c0 += w;
-    int c1 = (x1 - pl) % w; if (c1 < 0) c1 += w;
-    // stored resolution = (h >> sh, w >> sh): a decimated map (avg_pool d + nearest upsample, dbw.py:276-278,331-334) is
-    // kept at cell resolution and the nearest upsampling is this shift
-    const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;
-    c0 >>= sh; c1 >>= sh;
-    s.a00 = off + ((long long)r0 * ws + c0) * 3; s.a01 = off + ((long long)r0 * ws + c1) * 3;
-    s.a10 = off + ((long long)r1 * ws + c0) * 3; s.a11 = off + ((long long)r1 * ws + c1) * 3;
-    s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
-}
-
-__device__ __forceinline__ void fetch(const float *maps, const Sample &s, float c[3]) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-        c[ch] = maps[s.a00 + ch] * s.w00 + maps[s.a01 + ch] * s.w01 + maps[s.a10 + ch] * s.w10 + maps[s.a11 + ch] * s.w11;
-}
 
 __device__ __forceinline__ bool pixel_of_block(const ShadeArgs &A, long long total_blocks, int &n, int &xi, int &yi) {
     const long long logical = xcd_remap(blockIdx.x, total_blocks);
@@ -423,6 +301,14 @@ extern "C" int dbw_shade_blend_fwd(const int32_t *pix_to_face, const float *bary
     const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     hipLaunchKernelGGL(shade_blend_fwd_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), 0, (hipStream_t)stream, A, total, image);
     return dbw_check_launch("shade_blend_fwd_kernel");
+}
+
+int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
+                        const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                        const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
+                        int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3) {
+    return fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps, faces_alpha,
+                     alpha_len, N, H, W, K, F, sigma, background3);
 }
 
 static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *grad_image, float *grad_maps,

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+FUSED_FORWARD = True      # one kernel for raster + shade + blend (False: the two operator-level kernels)
 FUSED_BACKWARD = True     # one kernel for blend-backward + rasteriser-backward (False: the two operator-level kernels)
 
 
@@ -175,6 +176,22 @@ class RenderCfg:
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
 
 
+def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg):
+    dev = fvc.device
+    Ft = fvc.shape[0]
+    ws_bytes = _lib.load().dbw_rasterize_workspace_bytes(Ft)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
+    dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
+    img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+    _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
+              _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
+              0 if fa is None else fa.numel(), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
+              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, _stream(fvc))
+    return p2f, bary, dists, img
+
+
 class _RenderScene(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):
@@ -184,9 +201,12 @@ class _RenderScene(torch.autograd.Function):
         B = R.shape[0]
         cl = project_clip(verts_c, faces_i32, R, T, Kmat, cfg.eps, cfg.z_clip, cfg.persp)
         fvc = cl['face_verts'].view(-1, 3, 3)
-        p2f, _, bary, dists = _raster_fwd(fvc, cl['first_idx'], cl['num_faces'], cl['neighbor'].view(-1), B, cfg.H, cfg.W, cfg.K,
-                                          cfg.blur, cfg.persp, True, False, need_zbuf=False)
-        img = shade_blend_fwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps_c, fa, cfg.F, cfg.sigma, bg)
+        if FUSED_FORWARD:
+            p2f, bary, dists, img = _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps_c, fa, bg)
+        else:
+            p2f, _, bary, dists = _raster_fwd(fvc, cl['first_idx'], cl['num_faces'], cl['neighbor'].view(-1), B, cfg.H, cfg.W, cfg.K,
+                                              cfg.blur, cfg.persp, True, False, need_zbuf=False)
+            img = shade_blend_fwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps_c, fa, cfg.F, cfg.sigma, bg)
         ctx.cfg, ctx.cl = cfg, cl
         ctx.has_alpha = fa is not None
         ctx.bg = bg

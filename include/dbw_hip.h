@@ -117,6 +117,18 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
                         float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate,
                         dbw_stream_t stream);
 
+/* Fused forward of one render pass: dbw_rasterize_fwd (clip_barycentric_coords = 1, no culling, zbuf not stored) followed
+ * by dbw_shade_blend_fwd in ONE kernel: the image is blended from the register-resident per-pixel lists; the fragments
+ * (pix_to_face, bary, dists) are stored once for the backward pass and never re-read in the forward direction.
+ * Arguments as in those two entry points. */
+int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+                         const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
+                         int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                         const float *maps, const float *faces_alpha, int alpha_len, int N, int64_t F_total, int H, int W,
+                         int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
+                         int32_t *pix_to_face, float *bary, float *dists, float *image, void *workspace,
+                         size_t workspace_bytes, dbw_stream_t stream);
+
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
  * face_verts_c (the rasteriser's input).  detach_bary != 0 reproduces renderer.py:222-223 (geometry gradient through
