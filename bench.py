@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--fpp', type=int, default=10)
     ap.add_argument('--txt', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of the iteration')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -168,14 +169,15 @@ def main():
 
     from dbw_amd.parallel import ShardedTrainStep
     model, inp = build_workload(args, dev)
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2)
+    model.sync_free = True
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=not args.no_graph, graph_warmup=1, seed=227391)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if not args.no_graph else 0)):     # graph capture happens in the second iteration
         step(inp)
     sync()
     t0 = time.perf_counter()
@@ -206,7 +208,8 @@ def main():
                                    f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, coarse phase '
                                    f'(sigma=1e-4, opacity noise, decimated textures), MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
                        'views_per_gpu': args.views, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks, 'faces_per_pixel': args.fpp,
-                       'txt_size': args.txt, 'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
+                       'txt_size': args.txt, 'launch': 'eager' if args.no_graph else 'hipGraph replay of zero_grad+forward+backward',
+                       'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()},

@@ -159,12 +159,16 @@ __device__ __forceinline__ int dense_index(const int *keep, int k) {
 }
 
 __global__ __launch_bounds__(64) void sq_blocks_fwd_kernel(const float *sq_eps, const float *S, const float *R6, const float *T,
-                                                           const float *trig, const int *keep, int Kb, int nv, float ratio,
+                                                           const float *trig, const int *keep, int dense, int Kb, int nv, float ratio,
                                                            float scale_min, float S_world, const float *Rw, const float *Tw,
                                                            float *verts) {
     const int k = blockIdx.x;
-    if (keep && !keep[k]) return;
-    const int ko = dense_index(keep, k);
+    if (keep && !keep[k]) {
+        if (!dense)      // collapse the dead block to one point: zero-area faces, dropped by the rasteriser
+            for (int v = threadIdx.x; v < nv * 3; v += 64) verts[(long long)k * nv * 3 + v] = 0.f;
+        return;
+    }
+    const int ko = dense ? dense_index(keep, k) : k;
     Pose p;
     load_pose(sq_eps, S, R6, T, k, scale_min, p);
     const long long plane = (long long)Kb * nv;
@@ -179,13 +183,13 @@ __global__ __launch_bounds__(64) void sq_blocks_fwd_kernel(const float *sq_eps, 
 }
 
 __global__ __launch_bounds__(64) void sq_blocks_bwd_kernel(const float *sq_eps, const float *S, const float *R6, const float *T,
-                                                           const float *trig, const int *keep, int Kb, int nv, float ratio,
+                                                           const float *trig, const int *keep, int dense, int Kb, int nv, float ratio,
                                                            float scale_min, float S_world, const float *Rw,
                                                            const float *gverts, float *g_sq_eps, float *g_S, float *g_R6,
                                                            float *g_T) {
     const int k = blockIdx.x;
     if (keep && !keep[k]) return;
-    const int ko = dense_index(keep, k);
+    const int ko = dense ? dense_index(keep, k) : k;
     Pose p;
     load_pose(sq_eps, S, R6, T, k, scale_min, p);
     const long long plane = (long long)Kb * nv;
@@ -351,22 +355,22 @@ __global__ void overlap_finish_kernel(const float *sq_eps, const float *S, const
 }  // namespace
 
 extern "C" int dbw_sq_blocks_fwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
-                                 const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                                 const int32_t *keep, int dense, int Kb, int nv, float ratio, float scale_min, float S_world,
                                  const float *R_world, const float *T_world, float *verts, dbw_stream_t stream) {
     DBW_REQUIRE(sq_eps && S && R6 && T && trig && R_world && verts, "null pointer");
     DBW_REQUIRE(Kb > 0 && nv > 0, "bad size");
-    hipLaunchKernelGGL(sq_blocks_fwd_kernel, dim3(Kb), dim3(64), 0, (hipStream_t)stream, sq_eps, S, R6, T, trig, keep, Kb,
+    hipLaunchKernelGGL(sq_blocks_fwd_kernel, dim3(Kb), dim3(64), 0, (hipStream_t)stream, sq_eps, S, R6, T, trig, keep, dense, Kb,
                        nv, ratio, scale_min, S_world, R_world, T_world, verts);
     return dbw_check_launch("sq_blocks_fwd_kernel");
 }
 
 extern "C" int dbw_sq_blocks_bwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
-                                 const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                                 const int32_t *keep, int dense, int Kb, int nv, float ratio, float scale_min, float S_world,
                                  const float *R_world, const float *grad_verts, float *g_sq_eps, float *g_S, float *g_R6,
                                  float *g_T, dbw_stream_t stream) {
     DBW_REQUIRE(sq_eps && S && R6 && T && trig && R_world && grad_verts && g_sq_eps && g_S && g_R6 && g_T, "null pointer");
     DBW_REQUIRE(Kb > 0 && nv > 0, "bad size");
-    hipLaunchKernelGGL(sq_blocks_bwd_kernel, dim3(Kb), dim3(64), 0, (hipStream_t)stream, sq_eps, S, R6, T, trig, keep, Kb,
+    hipLaunchKernelGGL(sq_blocks_bwd_kernel, dim3(Kb), dim3(64), 0, (hipStream_t)stream, sq_eps, S, R6, T, trig, keep, dense, Kb,
                        nv, ratio, scale_min, S_world, R_world, grad_verts, g_sq_eps, g_S, g_R6, g_T);
     return dbw_check_launch("sq_blocks_bwd_kernel");
 }

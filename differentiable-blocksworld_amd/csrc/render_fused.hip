@@ -70,7 +70,9 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
 template <int KMAX>
 int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
            int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-    constexpr int TW = 8, TH = 8;     // single-wave tiles: best measured shape for the raster phase (profiles/)
+    // single-wave 8x8 tiles for the soft multi-layer pass (best measured shape, profiles/); 16x16 tiles for the hard K=1 pass
+    // whose faces (sky dome, ground) are large: fewer tiles re-scan the same face list
+    constexpr int TW = KMAX == 1 ? 16 : 8, TH = KMAX == 1 ? 16 : 8;
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
     hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx, num_faces,
                        neighbor, blur, persp, total, A, p2f, bary, dists, image);

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m
             else if (wrap) { const float dxb = v - m[i + (long long)(w - 1) * 3]; g += 2.f * dxb * sx; }
             if (y + 1 < h) { const float dyf = m[i + (long long)w * 3] - v; part += dyf * dyf * sy; g -= 2.f * dyf * sy; }
             if (y > 0) { const float dyb = v - m[i - (long long)w * 3]; g += 2.f * dyb * sy; }
-            if (gm) gm[i] += scale * g;
+            if (gm) gm[i] = scale * g;
         }
     }
     const float tot = block_sum(part, s_red);

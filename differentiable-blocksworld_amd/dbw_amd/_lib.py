@@ -30,8 +30,8 @@ SIGNATURES = {
                              c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p],
     'dbw_texture_prep_fwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_texture_prep_bwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
-    'dbw_sq_blocks_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
-    'dbw_sq_blocks_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'dbw_sq_blocks_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
+    'dbw_sq_blocks_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'dbw_posed_mesh_fwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     'dbw_posed_mesh_bwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
     'dbw_composite_mse': [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p],

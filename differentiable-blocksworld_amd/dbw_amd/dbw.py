@@ -51,6 +51,10 @@ class DifferentiableBlocksWorld(nn.Module):
         self.world_size, self.rank = 1, 0     # view-sharded data parallel (parallel.py)
         self._noise_override = None
         self._overlap_u_override = None
+        # sync_free=True: dead blocks (kill_blocks / filter_transparent) keep their slot and are collapsed to a point by the
+        # kernel instead of being packed away on the host -> no device->host sync per iteration (dbw.py:322 `.item()`), same
+        # images/losses/gradients, and the whole iteration becomes hipGraph-capturable.
+        self.sync_free = False
 
     @property
     def init_kwargs(self):
@@ -200,6 +204,13 @@ class DifferentiableBlocksWorld(nn.Module):
             r.to(device)
         return self
 
+    def release_graph(self):
+        """Drop the tensors cached by the last forward (they keep its autograd graph -- and the parameters' AccumulateGrad
+        nodes, which are bound to the stream they were created on -- alive)."""
+        for n in ('_alpha', '_alpha_full', '_blocks_maps', '_bkg_maps', '_ground_maps', '_keep_mask'):
+            if hasattr(self, n):
+                setattr(self, n, None)
+
     def is_live(self, name):                        # dbw.py:457-462
         milestone = getattr(self, name)
         if isinstance(milestone, bool):
@@ -287,10 +298,13 @@ class DifferentiableBlocksWorld(nn.Module):
         if filter_transparent or self.kill_blocks:
             mask = torch.sigmoid(self.alpha_logit) > (0.5 if filter_transparent else 0.01)
             self._alpha_full = self._alpha_full * mask
-            nb = int(mask.sum().item())                              # same host sync as dbw.py:322
-            if nb < self.n_blocks:
+            if self.sync_free:
                 keep = mask.to(torch.int32)
-                self._alpha = self._alpha[mask]
+            else:
+                nb = int(mask.sum().item())                          # same host sync as dbw.py:322
+                if nb < self.n_blocks:
+                    keep = mask.to(torch.int32)
+                    self._alpha = self._alpha[mask]
         decim = self.decim_factor if (coarse and self.is_live('decimate_txt')) else 1
         maps_all, self._blocks_maps = ops.texture_prep(self.textures, decim)
         self._keep_mask = keep
@@ -298,8 +312,8 @@ class DifferentiableBlocksWorld(nn.Module):
             return None
         S_w, R_w, T_w = self._world_consts()
         verts = ops.sq_blocks(self.sq_eps, self.S, self.R_6d, self.T, self._trig, keep, nb, self.ratio_block_scene,
-                              self.scale_min, S_w, R_w, T_w)
-        maps = maps_all if keep is None else maps_all[keep.bool()]
+                              self.scale_min, S_w, R_w, T_w, dense=not self.sync_free)
+        maps = maps_all if (keep is None or self.sync_free) else maps_all[keep.bool()]
         F_ = nb * self.BNF
         desc = (self._block_map_desc_all if decim == 1 else self._block_map_desc_dec)[:nb]
         self._blocks_decimated = decim > 1
@@ -307,17 +321,10 @@ class DifferentiableBlocksWorld(nn.Module):
                            self._block_face_map_all[:F_], desc, maps.reshape(-1))
 
     def _shared_randn_like(self, t):
-        """Opacity noise must be identical on every data-parallel rank: drawn from a generator that all
-        ranks seed identically and advance in lockstep."""
-        return torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=self._shared_generator(t.device))
-
-    def _shared_generator(self, device):
-        g = getattr(self, '_shared_gen', None)
-        if g is None or g.device != torch.device(device):
-            g = torch.Generator(device=device)
-            g.manual_seed(1234567 + 0)
-            self._shared_gen = g
-        return g
+        """Opacity noise (and the overlap samples) must be identical on every data-parallel rank: they are
+        drawn from the device's default generator, which ShardedTrainStep seeds identically on all ranks and which every
+        rank advances in lockstep (the default generator is also the one hipGraph capture knows how to replay)."""
+        return torch.randn(t.shape, device=t.device, dtype=t.dtype)
 
     # ------------------------------------------------------------------------------------------------ rendering
     def _ensure_cameras(self, inp):
@@ -357,7 +364,7 @@ class DifferentiableBlocksWorld(nn.Module):
     def compute_losses(self, imgs, rec, layers=None):
         w = self.loss_weights
         dev = imgs.device
-        losses = {k: torch.tensor(0.0, device=dev) for k in w}
+        losses = {k: torch.zeros((), device=dev) for k in w}          # (fill kernel: hipGraph-capturable, unlike an H2D copy)
         coarse = self.is_live('coarse_learning')
         ws = self.world_size
         if 'rgb' in losses:
@@ -388,7 +395,7 @@ class DifferentiableBlocksWorld(nn.Module):
             factor = 1 if coarse else 0
             u = self._overlap_u_override
             if u is None:
-                u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev, generator=self._shared_generator(dev))
+                u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev)
             alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()
             ov = ops.overlap_loss(self.sq_eps, self.S, self.R_6d, self.T, alpha, u, self.ratio_block_scene, self.scale_min,
                                   OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS)

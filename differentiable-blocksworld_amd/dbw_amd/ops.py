@@ -308,34 +308,37 @@ def texture_prep(texture, decim=1):
     return maps, sig
 
 
-def sq_blocks(sq_eps, S, R6, T, trig, keep, nb, ratio, scale_min, S_world, R_world, T_world):
-    """-> world verts (NB,nv,3) of the kept blocks.  `nb` = number of kept blocks (host int, avoids a sync)."""
-    if keep is not None and nb == 0:
+def sq_blocks(sq_eps, S, R6, T, trig, keep, nb, ratio, scale_min, S_world, R_world, T_world, dense=True):
+    """-> world verts of the blocks.  dense=True: (nb,nv,3), only the kept blocks, packed (`nb` = their number, a host int);
+    dense=False: (Kb,nv,3), skipped blocks collapsed to a point (no host knowledge of `keep` needed)."""
+    if dense and keep is not None and nb == 0:
         return trig.new_empty(0, trig.shape[2], 3)
-    return _SqBlocks.apply(sq_eps, S, R6, T, trig, keep, nb, (float(ratio), float(scale_min), float(S_world), R_world, T_world))
+    if not dense:
+        nb = trig.shape[1]
+    return _SqBlocks.apply(sq_eps, S, R6, T, trig, keep, nb, (float(ratio), float(scale_min), float(S_world), R_world, T_world, bool(dense)))
 
 
 class _SqBlocks(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sq_eps, S, R6, T, trig, keep, nb, consts):
-        ratio, scale_min, S_world, Rw, Tw = consts
+        ratio, scale_min, S_world, Rw, Tw, dense = consts
         args = [_chk(t.detach(), torch.float32, 'pose param') for t in (sq_eps, S, R6, T)]
         Kb, nv = trig.shape[1], trig.shape[2]
         verts = torch.empty(nb, nv, 3, dtype=torch.float32, device=trig.device)
-        _lib.call('dbw_sq_blocks_fwd', *[_ptr(a) for a in args], _ptr(trig), _ptr(keep), Kb, nv, ratio, scale_min, S_world,
+        _lib.call('dbw_sq_blocks_fwd', *[_ptr(a) for a in args], _ptr(trig), _ptr(keep), int(dense), Kb, nv, ratio, scale_min, S_world,
                   _ptr(Rw), _ptr(Tw), _ptr(verts), _stream(trig))
         ctx.save_for_backward(*args, trig, keep if keep is not None else trig.new_empty(0), Rw)
-        ctx.consts = (ratio, scale_min, S_world, keep is not None)
+        ctx.consts = (ratio, scale_min, S_world, keep is not None, dense)
         return verts
 
     @staticmethod
     def backward(ctx, g_verts):
         sq_eps, S, R6, T, trig, keep, Rw = ctx.saved_tensors
-        ratio, scale_min, S_world, has_keep = ctx.consts
+        ratio, scale_min, S_world, has_keep, dense = ctx.consts
         keep = keep if has_keep else None
         Kb, nv = trig.shape[1], trig.shape[2]
         gs = [torch.zeros_like(t) for t in (sq_eps, S, R6, T)]
-        _lib.call('dbw_sq_blocks_bwd', _ptr(sq_eps), _ptr(S), _ptr(R6), _ptr(T), _ptr(trig), _ptr(keep), Kb, nv, ratio, scale_min,
+        _lib.call('dbw_sq_blocks_bwd', _ptr(sq_eps), _ptr(S), _ptr(R6), _ptr(T), _ptr(trig), _ptr(keep), int(dense), Kb, nv, ratio, scale_min,
                   S_world, _ptr(Rw), _ptr(g_verts.contiguous()), *[_ptr(g) for g in gs], _stream(trig))
         return gs[0], gs[1], gs[2], gs[3], None, None, None, None
 
@@ -423,7 +426,7 @@ class _TV(torch.autograd.Function):
         m = _chk(maps.detach(), torch.float32, 'maps')
         n, h, w, _ = m.shape
         loss = torch.zeros(1, dtype=torch.float32, device=m.device)
-        g = torch.zeros_like(m)
+        g = torch.empty_like(m)
         _lib.call('dbw_tv_l2sq', _ptr(m), n, h, w, int(wrap), float(scale), _ptr(loss), _ptr(g), _stream(m))
         ctx.save_for_backward(g)
         return loss[0]

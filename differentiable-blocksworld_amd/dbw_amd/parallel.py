@@ -47,8 +47,16 @@ class FlatParams:
 
 
 class ShardedTrainStep:
-    def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None):
+    """use_graph=True captures zero_grad + forward + backward of one iteration into a hipGraph after `graph_warmup` eager
+    iterations (the ~135 kernel launches of an iteration then replay from one host call); requires model.sync_free and inputs
+    of constant shape.  The gradient all-reduce and the two Adam launches stay outside the graph."""
+
+    def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
+                 use_graph=False, graph_warmup=3, seed=None):
         self.model, self.pg = model, process_group
+        self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
+        if use_graph and not getattr(model, 'sync_free', False):
+            raise ValueError('use_graph=True needs model.sync_free = True (no device->host sync inside the iteration)')
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         model.world_size, model.rank = self.world_size, self.rank
@@ -59,6 +67,15 @@ class ShardedTrainStep:
         self.n_steps = 0
         self.adam_fn = adam_fn or ops.adam_step_
         self._count_cache = {}
+        if dist.is_initialized() or seed is not None:
+            # identical noise / overlap samples on every rank: same seed for the default generator everywhere
+            s = torch.tensor([seed if seed is not None else 0], dtype=torch.int64)
+            if seed is None:
+                s.random_()
+            if dist.is_initialized():
+                s = s.to(self.params.flat.device if dist.get_backend(process_group) == 'nccl' else 'cpu')
+                dist.broadcast(s, src=0, group=process_group)
+            torch.manual_seed(int(s.item()))
 
     def _global_count(self, imgs):
         """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367)."""
@@ -73,10 +90,14 @@ class ShardedTrainStep:
 
     def __call__(self, inp, labels=None):
         """One optimisation step on this rank's shard of views; returns the (local) loss dict (device tensors, no sync)."""
-        self.params.zero_grad()
         self.model._global_count = self._global_count(inp['imgs'])
-        losses = self.model(inp, labels)
-        losses['total'].backward()
+        if self.use_graph and self.n_steps >= self.graph_warmup:
+            losses = self._graph_iteration(inp)
+        else:
+            self.params.zero_grad()
+            losses = self.model(inp, labels)
+            losses['total'].backward()
+            losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
         if self.world_size > 1:
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)     # RCCL over xGMI, in place
         self.n_steps += 1
@@ -85,3 +106,30 @@ class ShardedTrainStep:
                 self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,
                              self.betas, self.eps)
         return losses
+
+    def _graph_iteration(self, inp):
+        if self._graph is None:
+            self._static_inp = {k: v.clone() for k, v in inp.items()}
+            # torch's capture recipe: warm up on a side stream so that the AccumulateGrad nodes live on the capture stream
+            if hasattr(self.model, 'release_graph'):
+                self.model.release_graph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.params.zero_grad()
+                    self.model(self._static_inp, None)['total'].backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.params.zero_grad()
+                losses = self.model(self._static_inp, None)
+                losses['total'].backward()
+                self._static_losses = {k: v.detach() for k, v in losses.items()}
+            del losses
+        for k, v in inp.items():
+            if v.data_ptr() != self._static_inp[k].data_ptr():
+                self._static_inp[k].copy_(v)
+        self._graph.replay()
+        return self._static_losses

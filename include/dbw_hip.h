@@ -159,15 +159,17 @@ int dbw_texture_prep_bwd(const float *texture, int n, int h, int w, int decim, c
  *   R = rotation_6d_to_matrix(R_6d); verts = ((v*S)@R + T) * S_world @ R_world + T_world
  * sq_eps (Kb,2) S (Kb,3) R6 (Kb,6) T (Kb,3); trig (4,Kb,nv) = cos(eta), sin(eta), cos(omega), sin(omega) of the
  * constant buffers sq_eta/sq_omega (dbw.py:86-87), tabulated once at init; R_world (3,3) T_world (3).
- * `keep` (Kb) int32 or NULL: blocks with keep==0 are skipped; kept blocks are written densely in order.
- * verts (NB,nv,3).
+ * `keep` (Kb) int32 or NULL: blocks with keep==0 are skipped.  dense != 0: kept blocks are written densely in order
+ * (verts (NB,nv,3), PyTorch3D packing of dbw.py:326); dense == 0: every block keeps its slot (verts (Kb,nv,3)) and a
+ * skipped block collapses to a single point -- zero-area faces that the rasteriser drops -- which renders identically
+ * without the host having to know how many blocks are alive (no device->host sync, graph-capturable).
  */
 int dbw_sq_blocks_fwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
-                      const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                      const int32_t *keep, int dense, int Kb, int nv, float ratio, float scale_min, float S_world,
                       const float *R_world, const float *T_world, float *verts, dbw_stream_t stream);
 /* grad_verts (NB,nv,3) -> grads of sq_eps,S,R6,T (accumulate). */
 int dbw_sq_blocks_bwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
-                      const int32_t *keep, int Kb, int nv, float ratio, float scale_min, float S_world,
+                      const int32_t *keep, int dense, int Kb, int nv, float ratio, float scale_min, float S_world,
                       const float *R_world, const float *grad_verts, float *g_sq_eps, float *g_S, float *g_R6,
                       float *g_T, dbw_stream_t stream);
 /* Generic posed mesh (ground plane, dbw.py:282-287): verts = ((base*1)@rot6d(R6)+T)*S_world@R_world+T_world. */
@@ -191,7 +193,7 @@ int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int 
  * Regularisers, forward + gradient in one pass (dbw.py:373-405, loss.py:46).
  * TV (l2sq) of n maps (h,w,3): loss += scale * [ sum_k |m[:,:,x+1]-m[:,:,x]|^2 (wrap_x closes the seam, dbw.py:383)
  *   / (h*(w-1+wrap)) + sum |m[:,y+1]-m[:,y]|^2 / ((h-1)*w) ]  (sum over maps first = "each map receives same grad")
- * grad_maps accumulate.
+ * grad_maps (may be NULL): fully written.
  */
 int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, float scale, float *loss, float *grad_maps,
                 dbw_stream_t stream);
