@@ -61,51 +61,51 @@ def build_workload(args, dev):
 
 
 def kernel_breakdown(model, inp, reps=5):
-    """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the
-    kernels of the fg pass, each launched alone on the real step-0 geometry.  -> {name: (avg_ms, algorithmic_bytes)}."""
-    from dbw_amd import ops
-    with torch.no_grad():
-        scene = model.build_blocks_scene()
-    B, H, W, K = inp['R'].shape[0], model.img_size[0], model.img_size[1], model.renderer.faces_per_pixel
+    """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the four
+    kernels that dominate an iteration -- the fused forward and fused backward of the fg (soft, K faces per pixel) and env
+    (hard, 1 face per pixel) passes -- each launched alone on the real step geometry.
+    -> {name: (avg_ms, algorithmic_bytes_per_launch)}; bytes per view: forward writes 20*P*K of fragments + 16*P of image,
+    backward reads them back plus the 16*P image gradient (zbuf not materialised)."""
+    from dbw_amd import _lib, ops
+    B, H, W = inp['R'].shape[0], model.img_size[0], model.img_size[1]
     P = H * W
-    r = model.renderer
-    cfg = r._cfg(scene.faces.shape[0])
-    Kmat = r.cameras.K[0].contiguous()
-    verts, maps = scene.verts.detach(), scene.maps.detach()
-    alpha = model._alpha.detach().repeat_interleave(model.BNF).contiguous()
-    cl = ops.project_clip(verts, scene.faces, inp['R'], inp['T'], Kmat, cfg.eps, cfg.z_clip, cfg.persp)
-    fvc = cl['face_verts'].view(-1, 3, 3)
-    nb = cl['neighbor'].view(-1)
-    p2f, _, bary, dists = ops._raster_fwd(fvc, cl['first_idx'], cl['num_faces'], nb, B, H, W, K, cfg.blur, True, True, False, need_zbuf=False)
-    img = ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F, cfg.sigma, r._bg)
-    g_img = torch.rand_like(img)
-    agg = bool(model._blocks_decimated)                  # same backward mode as the training step uses for this pass
-    _, _, g_dists, _ = ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
-                                           cfg.sigma, r._bg, g_img, True, False, agg)
-    g_fvc = torch.zeros_like(fvc)
+    res = {}
+    with torch.no_grad():
+        passes = [('fg', model.renderer, model.build_blocks_scene(), model._alpha.detach().repeat_interleave(model.BNF).contiguous(),
+                   bool(model._blocks_decimated)),
+                  ('env', model.renderer_env, model.build_env_scene(), None, True)]
+    for tag, r, scene, alpha, agg in passes:
+        cfg = r._cfg(scene.faces.shape[0], lds_aggregate=agg)
+        K = cfg.K
+        Kmat = r.cameras.K[0].contiguous()
+        verts, maps = scene.verts.detach(), scene.maps.detach()
+        cl = ops.project_clip(verts, scene.faces, inp['R'], inp['T'], Kmat, cfg.eps, cfg.z_clip, cfg.persp)
+        fvc = cl['face_verts'].view(-1, 3, 3)
+        fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg)
+        p2f, bary, dists, img = fwd()
+        g_img = torch.rand_like(img)
+        g_maps, g_fvc = torch.zeros_like(maps), torch.zeros_like(fvc)
+        g_alpha = torch.zeros_like(alpha) if alpha is not None else None
 
-    def t(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        def bwd():
+            _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
+                                                               alpha, cfg.F, cfg.sigma, r._bg),
+                      g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), ops._stream(fvc))
+
+        def t(fn):
             fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
 
-    res = {
-        'raster_fwd_kernel': (t(lambda: ops._raster_fwd(fvc, cl['first_idx'], cl['num_faces'], nb, B, H, W, K, cfg.blur, True, True, False,
-                                                         need_zbuf=False)), 20 * P * K * B),
-        'shade_blend_fwd_kernel': (t(lambda: ops.shade_blend_fwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
-                                                                  alpha, cfg.F, cfg.sigma, r._bg)), (20 * P * K + 16 * P) * B),
-        'shade_blend_bwd_kernel': (t(lambda: ops.shade_blend_bwd(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
-                                                                  alpha, cfg.F, cfg.sigma, r._bg, g_img, True, False, agg)),
-                                   (20 * P * K + 16 * P + 4 * P * K) * B),
-        'raster_bwd_kernel': (t(lambda: ops._lib.call('dbw_rasterize_bwd', fvc.data_ptr(), p2f.data_ptr(), 0, 0, g_dists.data_ptr(), B,
-                                                      fvc.shape[0], H, W, K, 1, 1, g_fvc.data_ptr(), ops._stream(fvc))), 8 * P * K * B),
-    }
+        res[f'render_fwd_kernel<{K}> ({tag} pass)'] = (t(fwd), (20 * P * K + 16 * P) * B)
+        res[f'shade_blend_bwd_kernel<fused> ({tag} pass)'] = (t(bwd), (20 * P * K + 16 * P) * B)
     return res
 
 

@@ -23,7 +23,7 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -49,4 +49,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, extra_flags=[a for a in sys.argv[1:] if a.startswith('-D')]))

@@ -71,7 +71,7 @@ struct TopK {
 
 // Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n.
 // Returns false for the padding blocks of the XCD-aware grid.  All threads of the block must call it.
-template <int KMAX, int TW, int TH>
+template <int KMAX, int TW, int TH, int GROUP = 2>
 __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces,
                                             const int *__restrict__ neighbor, int H, int W, int K, float blur, int persp,
@@ -103,15 +103,28 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
 
     const int f_begin = first_idx[n], nf = num_faces[n];
     int cnt = 0;
+    // The face scan is latency bound (every tile walks the whole per-view bbox table): fetch the boxes of GROUP chunks with
+    // independent loads before consuming them, so a tile pays nf / (GROUP * NT) memory round trips instead of nf / NT.
 #pragma unroll 1
-    for (int base = 0; base < nf; base += NT) {
-        const int j = base + tid;
-        bool hit = false;
-        float4 bb;
-        if (j < nf) {
-            bb = bbox[f_begin + j];
-            hit = !(txmax < bb.x || txmin > bb.y || tymax < bb.z || tymin > bb.w);
+    for (int base0 = 0; base0 < nf; base0 += GROUP * NT) {
+        float4 bbs[GROUP];
+        bool hits[GROUP];
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            const int j = base0 + g * NT + tid;
+            hits[g] = false;
+            if (j < nf) {
+                bbs[g] = bbox[f_begin + j];
+                hits[g] = !(txmax < bbs[g].x || txmin > bbs[g].y || tymax < bbs[g].z || tymin > bbs[g].w);
+            }
         }
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+        const int base = base0 + g * NT;
+        if (base >= nf) break;
+        const int j = base + tid;
+        const bool hit = hits[g];
+        const float4 bb = bbs[g];
         const unsigned long long m = __ballot(hit);
         const int prefix = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) s_wcnt[wv] = __popcll(m);
@@ -131,9 +144,11 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
         cnt += tot;
         __syncthreads();
         if (cnt > CAP - NT || base + NT >= nf) {
+            FaceRec nxt = s_face[0];          // software pipeline: the next record's LDS read overlaps this face's arithmetic
 #pragma unroll 1
             for (int i = 0; i < cnt; ++i) {
-                const FaceRec &r = s_face[i];
+                const FaceRec r = nxt;
+                nxt = s_face[i + 1 < cnt ? i + 1 : i];
                 if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
                     const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
                     const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
@@ -155,6 +170,7 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
             }
             cnt = 0;
             __syncthreads();
+        }
         }
     }
     return true;

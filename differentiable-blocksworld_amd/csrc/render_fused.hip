@@ -17,9 +17,12 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
 
+int g_render_variant = 0;
+extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
+
 namespace {
 
-template <int KMAX, int TW, int TH>
+template <int KMAX, int TW, int TH, int GROUP>
 __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const float *__restrict__ fv, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
                                                              const int *__restrict__ neighbor, float blur, int persp,
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
                                                              float *__restrict__ image) {
     int n, xi, yi;
     TopK<KMAX> q;
-    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, n, xi, yi, q)) return;
+    if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, n, xi, yi, q)) return;
     if (xi >= A.W || yi >= A.H) return;
     const long long pix = ((long long)n * A.H + yi) * A.W + xi;
     const long long o = pix * A.K;
@@ -67,16 +70,33 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     out[3 * plane] = 1.f - T;
 }
 
+template <int KMAX, int TW, int TH, int GROUP>
+int launch_v(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
+             int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+    const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
+    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
+                       num_faces, neighbor, blur, persp, total, A, p2f, bary, dists, image);
+    return dbw_check_launch("render_fwd_kernel");
+}
+
 template <int KMAX>
 int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
            int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-    // single-wave 8x8 tiles for the soft multi-layer pass (best measured shape, profiles/); 16x16 tiles for the hard K=1 pass
-    // whose faces (sky dome, ground) are large: fewer tiles re-scan the same face list
-    constexpr int TW = KMAX == 1 ? 16 : 8, TH = KMAX == 1 ? 16 : 8;
-    const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
-    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx, num_faces,
-                       neighbor, blur, persp, total, A, p2f, bary, dists, image);
-    return dbw_check_launch("render_fwd_kernel");
+#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(fv, bbox, first_idx, num_faces, neighbor, blur, persp, A, p2f, bary, dists, image, s)
+    if (KMAX == 1) return DBW_V(16, 16, 4);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list
+#ifdef DBW_TUNE_VARIANTS
+    switch (g_render_variant) {               // tile-shape / load-batching sweep (tools/sweep_render_fwd.py)
+        case 1: return DBW_V(8, 8, 1);
+        case 2: return DBW_V(8, 8, 2);
+        case 3: return DBW_V(16, 16, 1);
+        case 4: return DBW_V(16, 16, 4);
+        case 5: return DBW_V(16, 8, 2);
+        case 6: return DBW_V(8, 16, 2);
+        default: break;
+    }
+#endif
+    return DBW_V(8, 8, 4);
+#undef DBW_V
 }
 
 }  // namespace

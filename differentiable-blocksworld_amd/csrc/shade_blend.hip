@@ -104,7 +104,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     // pass 1 (front to back): alpha and transmittance per layer; no texture access
     {
         float T = 1.f;
-        for (int k = 0; k < A.K; ++k) {
+#pragma unroll 5
+        for (int k = 0; k < A.K; ++k) {     // unrolled: the fragment loads of several layers are in flight together
             float ak = 0.f;
             Frag fr;
             if (in_img && load_frag(A, n, pix * A.K + k, fr)) ak = fr.e * fr.fa;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     }
     // pass 2 (back to front)
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
-    for (int k = A.K - 1; k >= 0; --k) {
+#pragma unroll 2
+    for (int k = A.K - 1; k >= 0; --k) {     // unrolled by 2: the gather chains of two layers overlap
         Frag fr;
         bool valid = false;
         if (in_img) valid = load_frag(A, n, pix * A.K + k, fr);

@@ -6,9 +6,9 @@
 
 namespace dbw {
 
-typedef LdsAgg<3, 10> TexAgg;     // 1024 texels x (key + rgb) = 16 KB
+typedef LdsAgg<3, 9> TexAgg;      // 512 texels x (key + rgb) = 8 KB
 typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces             =  2 KB
-typedef LdsAgg<9, 8> FaceAgg;     // 256 faces x (key + 3x3) = 10 KB
+typedef LdsAgg<9, 7> FaceAgg;     // 128 faces x (key + 3x3) = 5 KB
 
 struct ShadeArgs {
     const int *p2f; const float *bary; const float *dists;

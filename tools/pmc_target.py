@@ -1,0 +1,16 @@
+"""Workload for rocprofv3 --pmc runs: a few full training iterations of the bench config (eager launches)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
+import torch
+import bench
+from dbw_amd.parallel import ShardedTrainStep
+class A: pass
+args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 300, 400, 10, 10, 256
+dev = torch.device('cuda', 0)
+model, inp = bench.build_workload(args, dev)
+model.sync_free = True
+step = ShardedTrainStep(model, seed=1)
+for _ in range(3):
+    step(inp)
+torch.cuda.synchronize()
