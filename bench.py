@@ -89,9 +89,9 @@ def kernel_breakdown(model, inp, reps=5):
 
         def bwd():
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
-                                                               alpha, cfg.F, cfg.sigma, r._bg),
+                                                               alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), ops._stream(fvc))
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), int(ops.TILED_FRAGMENTS), ops._stream(fvc))
 
         def t(fn):
             fn()
@@ -200,6 +200,13 @@ def main():
         dom = max(kb, key=lambda k: kb[k][0])
         ms, nbytes = kb[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, see its _how)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))
+            if args.views == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt) == (300, 400, 10, 10, 256) and dom in pmc:
+                traffic = pmc[dom]['hbm_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -211,7 +218,7 @@ def main():
                        'txt_size': args.txt, 'launch': 'eager' if args.no_graph else 'hipGraph replay of zero_grad+forward+backward',
                        'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
+                         'traffic': traffic, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()},
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS},
             'final_loss': total_loss,

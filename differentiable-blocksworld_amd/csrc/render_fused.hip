@@ -33,18 +33,17 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     TopK<KMAX> q;
     if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, n, xi, yi, q)) return;
     if (xi >= A.W || yi >= A.H) return;
-    const long long pix = ((long long)n * A.H + yi) * A.W + xi;
-    const long long o = pix * A.K;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < A.K) {
             const bool valid = q.fi[k] != 0x7fffffff;
-            p2f[o + k] = valid ? q.fi[k] : -1;
-            dists[o + k] = q.ds[k];
-            bary[(o + k) * 3 + 0] = q.b0[k];
-            bary[(o + k) * 3 + 1] = q.b1[k];
-            bary[(o + k) * 3 + 2] = q.b2[k];
+            const FragAddr o = frag_addr(A, n, yi, xi, k);
+            p2f[o.s] = valid ? q.fi[k] : -1;
+            dists[o.s] = q.ds[k];
+            bary[o.b] = q.b0[k];
+            bary[o.b + o.bstride] = q.b1[k];
+            bary[o.b + 2 * o.bstride] = q.b2[k];
             if (valid) {
                 Frag fr;
                 const float bc[3] = {q.b0[k], q.b1[k], q.b2[k]};
@@ -108,7 +107,7 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    dbw_stream_t stream) {
+                                    int frag_layout, dbw_stream_t stream) {
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && image && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
     DBW_REQUIRE(blur_radius >= 0.f && F_total >= 0, "bad blur_radius / F_total");
@@ -116,6 +115,8 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     int rc = dbw_fill_shade_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                                  faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
     if (rc) return rc;
+    DBW_REQUIRE(frag_layout == 0 || frag_layout == 1, "frag_layout must be 0 (N,H,W,K) or 1 (8x8-tile planar)");
+    A.tiled = frag_layout;
     if (K > DBW_MAX_FACES_PER_PIXEL) {
         dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
         return DBW_ERR_UNSUPPORTED;

@@ -29,8 +29,11 @@ __device__ __forceinline__ bool pixel_of_block(const ShadeArgs &A, long long tot
     const int tiles_x = (A.W + TILE - 1) / TILE, tiles_y = (A.H + TILE - 1) / TILE;
     n = (int)(logical / (tiles_x * tiles_y));
     const int t = (int)(logical % (tiles_x * tiles_y));
-    xi = (t % tiles_x) * TILE + (threadIdx.x & (TILE - 1));
-    yi = (t / tiles_x) * TILE + (threadIdx.x >> 4);
+    // wave w owns the 8x8 quadrant (w & 1, w >> 1) of the 16x16 tile, lane l the pixel (l & 7, l >> 3) of it: matches the
+    // 8x8-tile planar fragment layout, so fragment loads are fully coalesced
+    const int wq = threadIdx.x >> 6, l = threadIdx.x & 63;
+    xi = (t % tiles_x) * TILE + ((wq & 1) << 3) + (l & 7);
+    yi = (t / tiles_x) * TILE + ((wq >> 1) << 3) + (l >> 3);
     return true;
 }
 
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
     for (int k = 0; k < A.K; ++k) {
         Frag fr;
-        if (!load_frag(A, n, pix * A.K + k, fr)) continue;
+        if (!load_frag(A, n, frag_addr(A, n, yi, xi, k), fr)) continue;
         const float a = fr.e * fr.fa;
         if (a != 0.f) {
             Sample s;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         for (int k = 0; k < A.K; ++k) {     // unrolled: the fragment loads of several layers are in flight together
             float ak = 0.f;
             Frag fr;
-            if (in_img && load_frag(A, n, pix * A.K + k, fr)) ak = fr.e * fr.fa;
+            if (in_img && load_frag(A, n, frag_addr(A, n, yi, xi, k), fr)) ak = fr.e * fr.fa;
             s_T[k * NT] = T;
             T *= (1.f - ak);
         }
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     for (int k = A.K - 1; k >= 0; --k) {     // unrolled by 2: the gather chains of two layers overlap
         Frag fr;
         bool valid = false;
-        if (in_img) valid = load_frag(A, n, pix * A.K + k, fr);
+        const FragAddr fo = frag_addr(A, n, yi, xi, k);
+        if (in_img) valid = load_frag(A, n, fo, fr);
         const float ak = valid ? fr.e * fr.fa : 0.f, Tk = s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
             } else if (valid && (gd != 0.f || gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f)) {
                 // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0)
-                const int fc = A.p2f[pix * A.K + k];
+                const int fc = A.p2f[fo.s];
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
                 const float z0 = q[2], z1 = q[5], z2 = q[8];
@@ -283,6 +287,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
     A.dbg = g_dbg_flags;
     A.agg = 0;
+    A.tiled = 0;
     return DBW_OK;
 }
 
@@ -369,13 +374,15 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     int K, int F, float sigma, const float *background3, const float *grad_image,
                                     const float *face_verts_c, int perspective_correct, int detach_bary,
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
-                                    int lds_aggregate, dbw_stream_t stream) {
+                                    int lds_aggregate, int frag_layout, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
     if (rc) return rc;
     DBW_REQUIRE(grad_image && grad_maps && face_verts_c && grad_face_verts_c, "null pointer");
     DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
+    DBW_REQUIRE(frag_layout == 0 || frag_layout == 1, "frag_layout must be 0 (N,H,W,K) or 1 (8x8-tile planar)");
+    A.tiled = frag_layout;
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
 }

@@ -16,6 +16,8 @@ struct ShadeArgs {
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
     int N, H, W, K, F; float sigma; float bg[3];
+    int tiled; // fragment layout: 0 = (N,H,W,K[,3]) as PyTorch3D returns them; 1 = internal 8x8-tile planar layout of the
+               // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair
     int agg;   // backward: 0 = wave-aggregated global atomics, 1 = LDS hash pre-aggregation
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
 };
@@ -86,12 +88,35 @@ __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, c
     }
 }
 
+// Addressing of fragment slot k of pixel (n, yi, xi): `s` indexes pix_to_face / dists, `b + c * bstride` the barycentric c.
+struct FragAddr {
+    long long s, b;
+    int bstride;
+};
+
+__device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi, int xi, int k) {
+    FragAddr a;
+    if (A.tiled) {
+        const int tx = (A.W + 7) >> 3, ty = (A.H + 7) >> 3;
+        const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
+        const int lane = ((yi & 7) << 3) | (xi & 7);
+        a.s = ((tile * A.K + k) << 6) + lane;
+        a.b = (((tile * A.K + k) * 3) << 6) + lane;
+        a.bstride = 64;
+    } else {
+        a.s = (((long long)n * A.H + yi) * A.W + xi) * A.K + k;
+        a.b = a.s * 3;
+        a.bstride = 1;
+    }
+    return a;
+}
+
 // fetch + decode one fragment slot from memory; returns false for empty slots
-__device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, long long o, Frag &fr) {
-    const int fc = A.p2f[o];
+__device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragAddr &o, Frag &fr) {
+    const int fc = A.p2f[o.s];
     if (fc < 0) return false;
-    const float b[3] = {A.bary[o * 3], A.bary[o * 3 + 1], A.bary[o * 3 + 2]};
-    decode_frag(A, n, fc, b, A.dists[o], fr);
+    const float b[3] = {A.bary[o.b], A.bary[o.b + o.bstride], A.bary[o.b + 2 * o.bstride]};
+    decode_frag(A, n, fc, b, A.dists[o.s], fr);
     return true;
 }
 

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+TILED_FRAGMENTS = True    # fused path keeps its fragments in the 8x8-tile planar layout (coalesced); needs both FUSED_* = True
 FUSED_FORWARD = True      # one kernel for raster + shade + blend (False: the two operator-level kernels)
 FUSED_BACKWARD = True     # one kernel for blend-backward + rasteriser-backward (False: the two operator-level kernels)
 
@@ -134,8 +135,8 @@ def project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_face_verts, eps=1e-8, z
 # ---------------------------------------------------------------------------------------------------------------------
 # shade + blend on given fragments
 # ---------------------------------------------------------------------------------------------------------------------
-def _shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg):
-    N, H, W, K = p2f.shape
+def _shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg, dims=None):
+    N, H, W, K = p2f.shape if dims is None else dims      # dims: explicit (N,H,W,K) when the fragments use the tiled layout
     c2o, code, cw = (cl['c2o'], cl['clip_code'], cl['clip_w']) if cl is not None else (None, None, None)
     return (_ptr(p2f), _ptr(bary), _ptr(dists), _ptr(c2o), _ptr(code), _ptr(cw), 2 * F_, _ptr(face_uvs), _ptr(face_map),
             _ptr(map_desc), _ptr(maps), _ptr(faces_alpha), 0 if faces_alpha is None else faces_alpha.numel(), N, H, W, K, F_,
@@ -176,19 +177,26 @@ class RenderCfg:
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
 
 
-def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg):
+def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None):
+    TILED_FRAGMENTS = globals()['TILED_FRAGMENTS'] if tiled is None else tiled
     dev = fvc.device
     Ft = fvc.shape[0]
     ws_bytes = _lib.load().dbw_rasterize_workspace_bytes(Ft)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
-    bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
-    dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
+    if TILED_FRAGMENTS:     # internal 8x8-tile planar layout (include/dbw_hip.h: frag_layout = 1)
+        ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
+        p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
+        bary = torch.empty(B, ty, tx, cfg.K, 3, 64, dtype=torch.float32, device=dev)
+        dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
+    else:
+        p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
+        bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
+        dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
     img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               0 if fa is None else fa.numel(), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
-              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, _stream(fvc))
+              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), _stream(fvc))
     return p2f, bary, dists, img
 
 
@@ -201,8 +209,9 @@ class _RenderScene(torch.autograd.Function):
         B = R.shape[0]
         cl = project_clip(verts_c, faces_i32, R, T, Kmat, cfg.eps, cfg.z_clip, cfg.persp)
         fvc = cl['face_verts'].view(-1, 3, 3)
+        ctx.tiled = FUSED_FORWARD and FUSED_BACKWARD and TILED_FRAGMENTS
         if FUSED_FORWARD:
-            p2f, bary, dists, img = _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps_c, fa, bg)
+            p2f, bary, dists, img = _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps_c, fa, bg, ctx.tiled)
         else:
             p2f, _, bary, dists = _raster_fwd(fvc, cl['first_idx'], cl['num_faces'], cl['neighbor'].view(-1), B, cfg.H, cfg.W, cfg.K,
                                               cfg.blur, cfg.persp, True, False, need_zbuf=False)
@@ -222,15 +231,18 @@ class _RenderScene(torch.autograd.Function):
         need_geom = ctx.needs_input_grad[0]
         want_dists = need_geom and cfg.sigma > 0
         want_bary = need_geom and not cfg.detach_bary
-        if need_geom and (want_dists or want_bary) and FUSED_BACKWARD:
+        if FUSED_BACKWARD and (ctx.tiled or (need_geom and (want_dists or want_bary))):
             fvc = cl['face_verts'].view(-1, 3, 3)
             g_maps, g_alpha = torch.zeros_like(maps), (torch.zeros_like(fa) if fa is not None else None)
             g_fvc = torch.zeros_like(fvc)
-            _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg),
+            _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
+                                                           (R.shape[0], cfg.H, cfg.W, cfg.K)),
                       _ptr(g_img.contiguous()), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
-                      int(cfg.lds_aggregate), _stream(fvc))
-            g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp)
+                      int(cfg.lds_aggregate), int(ctx.tiled), _stream(fvc))
+            g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp) if need_geom else None
             return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
+        if ctx.tiled:
+            raise RuntimeError('tiled fragments can only be consumed by the fused backward')
         g_maps, g_alpha, g_dists, g_bary = shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F,
                                                            cfg.sigma, bg, g_img.contiguous(), want_dists, want_bary, cfg.lds_aggregate)
         g_verts = None

@@ -120,14 +120,17 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
 /* Fused forward of one render pass: dbw_rasterize_fwd (clip_barycentric_coords = 1, no culling, zbuf not stored) followed
  * by dbw_shade_blend_fwd in ONE kernel: the image is blended from the register-resident per-pixel lists; the fragments
  * (pix_to_face, bary, dists) are stored once for the backward pass and never re-read in the forward direction.
- * Arguments as in those two entry points. */
+ * Arguments as in those two entry points.  frag_layout selects how the fragments are stored: 0 = (N,H,W,K[,3]) like
+ * dbw_rasterize_fwd; 1 = internal 8x8-tile planar layout [N][ceil(H/8)][ceil(W/8)][K][64] (bary [..][K][3][64]), in which
+ * every wave access is fully coalesced -- buffers must then hold N*ceil(H/8)*ceil(W/8)*K*64 (x3) elements and can only be
+ * consumed by dbw_render_bwd_fused with the same frag_layout. */
 int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                          const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
                          int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
                          const float *maps, const float *faces_alpha, int alpha_len, int N, int64_t F_total, int H, int W,
                          int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
                          int32_t *pix_to_face, float *bary, float *dists, float *image, void *workspace,
-                         size_t workspace_bytes, dbw_stream_t stream);
+                         size_t workspace_bytes, int frag_layout, dbw_stream_t stream);
 
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
@@ -139,7 +142,7 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
                          int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3,
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
-                         dbw_stream_t stream);
+                         int frag_layout, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"

@@ -298,6 +298,33 @@ def test_decimated_maps_at_cell_resolution_match_upsampled_copy(agg):
     assert rel_err(outs[1][2], outs[0][2]) < REL
 
 
+@pytest.mark.parametrize('which', ['fg', 'env'])
+def test_operator_level_kernels_equal_fused_path(which, monkeypatch):
+    """The stand-alone rasterise / shade-blend / raster-backward kernels (operator-level ABI, (N,H,W,K) fragments) and the
+    fused forward/backward kernels (8x8-tile planar fragments) produce the same image (bit-equal) and gradients."""
+    m, R, T, Km = _model(seed=21, ts=16)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False) if which == 'fg' else m.build_env(False, False)
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    fa = None if which == 'env' else torch.full((scene['faces'].shape[0],), 0.6, device=DEV)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'FUSED_FORWARD', fused)
+        monkeypatch.setattr(ops, 'FUSED_BACKWARD', fused)
+        ps = _packed(scene)
+        ps.maps.requires_grad_(True)
+        ps.verts.requires_grad_(True)
+        fa_ = None if fa is None else fa.clone().requires_grad_(True)
+        cfg = ops.RenderCfg(45, 61, 6 if which == 'fg' else 1, 1e-4 if which == 'fg' else 0.0, 0.001, True, which == 'fg', scene['faces'].shape[0])
+        img = ops.render_scene(ps.verts, ps.maps, fa_, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        (img * torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)).sum().backward()
+        outs.append((img.detach(), ps.maps.grad, ps.verts.grad, None if fa_ is None else fa_.grad))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        if a is not None:
+            assert rel_err(a, b) < 1e-5
+
+
 def test_lds_aggregation_is_equivalent_on_magnified_env_pass():
     m, R, T, Km = _model(seed=17, ts=16)
     with torch.no_grad():
