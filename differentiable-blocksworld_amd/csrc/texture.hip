@@ -118,12 +118,13 @@ __global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m
 
 __global__ __launch_bounds__(NT) void composite_mse_kernel(const float *__restrict__ fg, const float *__restrict__ env,
                                                            const float *__restrict__ img, int N, long long plane,
-                                                           float scale, float *__restrict__ rec,
+                                                           float scale, const float *__restrict__ scale_dev, float *__restrict__ rec,
                                                            float *__restrict__ loss, float *__restrict__ gfg,
                                                            float *__restrict__ genv) {
     __shared__ float s_red[NT / DBW_WAVE];
     const long long total = (long long)N * plane;
     float part = 0.f;
+    if (scale_dev) scale *= scale_dev[0];
     for (long long i0 = (long long)blockIdx.x * NT; i0 < total; i0 += (long long)gridDim.x * NT) {
         const long long i = i0 + threadIdx.x;
         if (i < total) {
@@ -207,16 +208,16 @@ extern "C" int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, f
 }
 
 extern "C" int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W,
-                                 float scale, float *rec, float *loss_sum, float *grad_fg, float *grad_env,
-                                 dbw_stream_t stream) {
+                                 float scale, const float *scale_dev, float *rec, float *loss_sum, float *grad_fg,
+                                 float *grad_env, dbw_stream_t stream) {
     DBW_REQUIRE(fg && env, "null pointer");
-    DBW_REQUIRE((imgs && loss_sum) || (!imgs && !loss_sum && !grad_fg && rec), "imgs/loss_sum: both, or neither with rec only");
+    DBW_REQUIRE(imgs || (!loss_sum && !grad_fg && rec), "imgs may only be NULL when just `rec` is wanted");
     DBW_REQUIRE((grad_fg && grad_env) || (!grad_fg && !grad_env), "grad_fg/grad_env: both or none");
     DBW_REQUIRE(N >= 0 && H > 0 && W > 0, "bad size");
     if (N == 0) return DBW_OK;
     const long long plane = (long long)H * W;
     hipLaunchKernelGGL(composite_mse_kernel, dim3(grid_for((long long)N * plane)), dim3(NT), 0, (hipStream_t)stream, fg,
-                       env, imgs, N, plane, scale, rec, loss_sum, grad_fg, grad_env);
+                       env, imgs, N, plane, scale, scale_dev, rec, loss_sum, grad_fg, grad_env);
     return dbw_check_launch("composite_mse_kernel");
 }
 

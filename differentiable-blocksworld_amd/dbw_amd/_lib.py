@@ -34,7 +34,7 @@ SIGNATURES = {
     'dbw_sq_blocks_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'dbw_posed_mesh_fwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     'dbw_posed_mesh_bwd': [c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
-    'dbw_composite_mse': [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p],
+    'dbw_composite_mse': [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p],
     'dbw_tv_l2sq': [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     'dbw_overlap_loss': [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'dbw_adam_step': [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i, c_p],

@@ -263,7 +263,9 @@ class DifferentiableBlocksWorld(nn.Module):
     def build_env_scene(self):
         """join(build_bkg(world_coord=True), build_ground(world_coord=True))  (dbw.py:214,267-295) as a PackedScene."""
         S_w, R_w, T_w = self._world_consts()
-        bkg_v = (self._bkg_verts * S_w) @ R_w + T_w                       # constant geometry (no parameter involved)
+        bkg_v = getattr(self, '_bkg_world', None)                         # constant geometry (no parameter involved): cached
+        if bkg_v is None or bkg_v.device != self._bkg_verts.device:
+            bkg_v = self._bkg_world = ((self._bkg_verts * S_w) @ R_w + T_w).detach()
         ground_v = ops.posed_mesh(self.R_6d_ground, self.T_ground, self._ground_base, S_w, R_w, T_w)
         decim = self.decim_factor if (self.training and self.is_live('decimate_txt')) else 1
         bkg_maps, self._bkg_maps = ops.texture_prep(self.texture_bkg, decim)

@@ -380,7 +380,9 @@ def posed_mesh(R6, T, base, S_world, R_world, T_world):
 
 
 class _CompositeMSE(torch.autograd.Function):
-    """loss = mean((imgs - (fg_rgb*mask + (1-mask)*env_rgb))^2) over `count` elements; backward computed in the same pass."""
+    """loss = mean((imgs - (fg_rgb*mask + (1-mask)*env_rgb))^2) over `count` elements.  Forward: one streaming pass that only
+    reduces; backward: one streaming pass that writes d/dfg and d/denv already scaled by the upstream gradient (read from
+    device memory by the kernel -- no host sync, no extra elementwise multiply over the image-sized gradients)."""
 
     @staticmethod
     def forward(ctx, fg, env, imgs, count):
@@ -388,16 +390,20 @@ class _CompositeMSE(torch.autograd.Function):
         fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
         imgs = _chk(imgs, torch.float32, 'imgs')
         loss = torch.zeros(1, dtype=torch.float32, device=fg.device)
-        g_fg, g_env = torch.empty_like(fg_c), torch.empty_like(env_c)
-        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, 1.0 / count, 0, _ptr(loss), _ptr(g_fg),
-                  _ptr(g_env), _stream(fg))
-        ctx.save_for_backward(g_fg, g_env)
+        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, 1.0 / count, 0, 0, _ptr(loss), 0, 0, _stream(fg))
+        ctx.save_for_backward(fg_c, env_c, imgs)
+        ctx.count = count
         return loss[0] / count
 
     @staticmethod
     def backward(ctx, g):
-        g_fg, g_env = ctx.saved_tensors
-        return g_fg * g, g_env * g, None, None
+        fg, env, imgs = ctx.saved_tensors
+        N, _, H, W = fg.shape
+        g_fg, g_env = torch.empty_like(fg), torch.empty_like(env)
+        g = g.detach().to(torch.float32).reshape(1).contiguous()
+        _lib.call('dbw_composite_mse', _ptr(fg), _ptr(env), _ptr(imgs), N, H, W, 1.0 / ctx.count, _ptr(g), 0, 0, _ptr(g_fg), _ptr(g_env),
+                  _stream(fg))
+        return g_fg, g_env, None, None
 
 
 def composite_mse(fg, env, imgs, count=None):
@@ -419,7 +425,7 @@ class _Composite(torch.autograd.Function):
         N, _, H, W = fg.shape
         fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
         rec = torch.empty(N, 3, H, W, dtype=torch.float32, device=fg.device)
-        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), 0, N, H, W, 0.0, _ptr(rec), 0, 0, 0, _stream(fg))
+        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), 0, N, H, W, 0.0, 0, _ptr(rec), 0, 0, 0, _stream(fg))
         ctx.save_for_backward(fg_c, env_c)
         return rec
 

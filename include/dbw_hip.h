@@ -184,13 +184,15 @@ int dbw_posed_mesh_bwd(const float *base, int nv, const float *R6, const float *
 /* ------------------------------------------------------------------------------------------------------------------
  * Decoupled composite + MSE, forward and backward in one pass (dbw.py:223, 366-367):
  *   rec = fg_rgb*mask + (1-mask)*env_rgb ; loss_sum += sum((imgs-rec)^2)
- *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) are d(scale*sum)/d(.) with scale = weight/count.
+ *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) are d(s*sum)/d(.) with s = scale * (scale_dev ? *scale_dev : 1)
+ *   (scale = weight/count from the host, scale_dev = the upstream gradient scalar living on the device).
  * fg (N,4,H,W) premultiplied RGB + mask, env (N,4,H,W), imgs (N,3,H,W), rec (N,3,H,W) or NULL,
- * loss_sum: 1 float, accumulate.  grad_fg/grad_env may both be NULL (forward only).  imgs and loss_sum may both be
- * NULL to obtain `rec` alone.
+ * loss_sum: 1 float, accumulate, may be NULL.  grad_fg/grad_env may both be NULL (forward only).  imgs may be NULL to
+ * obtain `rec` alone.
  */
 int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W, float scale,
-                      float *rec, float *loss_sum, float *grad_fg, float *grad_env, dbw_stream_t stream);
+                      const float *scale_dev, float *rec, float *loss_sum, float *grad_fg, float *grad_env,
+                      dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Regularisers, forward + gradient in one pass (dbw.py:373-405, loss.py:46).
