@@ -161,11 +161,18 @@ def main():
         raise RuntimeError('bench.py needs MI355X GPUs: the render path has no CPU implementation')
     if world != args.gpus:
         raise RuntimeError(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # DBW_BENCH_BACKEND=gloo + DBW_BENCH_SHARE_GPU=1 let the N>1 code path be exercised on a single-GPU box (ranks share cuda:0,
+    # gloo all-reduce); the measured configuration is always one rank per GPU over RCCL
+    backend = os.environ.get('DBW_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get('DBW_BENCH_SHARE_GPU') else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from dbw_amd.parallel import ShardedTrainStep
     model, inp = build_workload(args, dev)

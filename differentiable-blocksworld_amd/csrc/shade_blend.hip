@@ -34,6 +34,10 @@ __device__ __forceinline__ bool pixel_of_block(const ShadeArgs &A, long long tot
     const int wq = threadIdx.x >> 6, l = threadIdx.x & 63;
     xi = (t % tiles_x) * TILE + ((wq & 1) << 3) + (l & 7);
     yi = (t / tiles_x) * TILE + ((wq >> 1) << 3) + (l >> 3);
+    if (A.dbg & 32) {      // profiling switch: 16x4 strip per wave (tools/sweep_bwd.py)
+        xi = (t % tiles_x) * TILE + (threadIdx.x & 15);
+        yi = (t / tiles_x) * TILE + (threadIdx.x >> 4);
+    }
     return true;
 }
 
