@@ -325,6 +325,47 @@ def test_operator_level_kernels_equal_fused_path(which, monkeypatch):
             assert rel_err(a, b) < 1e-5
 
 
+def test_renderer_class_with_meshes_api_and_viz_purpose():
+    """The reference-shaped entry: Renderer(img_size, **cfg.model.renderer).forward(Meshes.extend(B), R, T, faces_alpha=...)
+    (renderer.py:84-98) through Meshes / TexturesUV / join_meshes_as_scene, against the oracle; plus viz_purpose=True
+    (4x supersampled hard render + avg_pool, renderer.py:56-60,178-183)."""
+    from dbw_amd import Renderer, Meshes, TexturesUV, join_meshes_as_scene
+    m, R, T, Km = _model(seed=23, ts=16, hw=(40, 56))
+    with torch.no_grad():
+        bkg_maps = torch.sigmoid(m.p['texture_bkg']).to(DEV)
+        g_maps = torch.sigmoid(m.p['texture_ground']).to(DEV)
+        env_o = m.build_env(False, False)
+    nb = m.bkg_verts.shape[0]
+    bkg = Meshes(env_o['verts'][:nb].to(DEV), m.bkg_faces.to(DEV), TexturesUV(bkg_maps, m.bkg_faces.to(DEV), m.bkg_verts_uvs.to(DEV)))
+    ground = Meshes(env_o['verts'][nb:].to(DEV), m.ground_faces.to(DEV), TexturesUV(g_maps, m.ground_faces.to(DEV), m.ground_verts_uvs.to(DEV)))
+    scene = join_meshes_as_scene([bkg, ground])
+    r = Renderer((40, 56), faces_per_pixel=1, cameras={'name': 'perspective'}, sigma=0, z_clip=0.001, detach_bary=False)
+    with pytest.raises(NotImplementedError):
+        r(scene.extend(3), R.to(DEV), T.to(DEV))                   # K not set yet (dbw.py:204-208)
+    r.update_cameras(device=DEV, K=Km[0:1].to(DEV))
+    assert r.cameras.K.shape == (1, 4, 4) and r.img_size == (40, 56) and r.init_kwargs['faces_per_pixel'] == 1
+    img = r(scene.extend(3), R.to(DEV), T.to(DEV))
+    ref = O.render(env_o, R, T, Km[0], (40, 56), 0.0, 1, False, None, 0.001, n_threads=8)
+    assert img.shape == (3, 4, 40, 56) and rel_err(img, ref) < REL
+    viz = r(scene.extend(3), R.to(DEV), T.to(DEV), viz_purpose=True)
+    ref4 = O.render(env_o, R, T, Km[0], (160, 224), 0.0, 1, False, None, 0.001, n_threads=8)
+    assert rel_err(viz, torch.nn.functional.avg_pool2d(ref4, 4, 4)) < REL
+    # blocks with the circular u padding passed symbolically (dbw.py:339-342) and per-face opacities packed per view
+    with torch.no_grad():
+        blk_o = m.build_blocks(False, True, False, None, kill_blocks=False)
+        verts = blk_o['verts'].reshape(m.n_blocks, -1, 3).to(DEV)
+        maps = torch.sigmoid(m.p['textures']).to(DEV)
+    blocks = Meshes(verts, m.block_faces[None].expand(m.n_blocks, -1, -1).to(DEV),
+                    TexturesUV(maps, m.block_faces_uvs.to(DEV), m.block_verts_uvs.to(DEV), circular_pad=m.txt_padding))
+    fg_scene = join_meshes_as_scene(blocks)
+    rf = Renderer((40, 56), faces_per_pixel=6, cameras={'name': 'perspective'}, z_clip=0.001, detach_bary=True)
+    rf.update_cameras(device=DEV, K=Km[0:1].to(DEV))
+    alpha = torch.rand(m.n_blocks, generator=torch.Generator().manual_seed(0)).repeat_interleave(m.BNF).repeat(3)
+    out = rf(fg_scene.extend(3), R.to(DEV), T.to(DEV), faces_alpha=alpha.to(DEV))
+    ref = O.render(blk_o, R, T, Km[0], (40, 56), 1e-4, 6, True, alpha, 0.001, n_threads=8)
+    assert rel_err(out, ref) < REL
+
+
 def test_lds_aggregation_is_equivalent_on_magnified_env_pass():
     m, R, T, Km = _model(seed=17, ts=16)
     with torch.no_grad():
