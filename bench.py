@@ -151,7 +151,10 @@ def main():
     ap.add_argument('--fpp', type=int, default=10)
     ap.add_argument('--txt', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of the iteration')
+    ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
+                    'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
+    ap.add_argument('--no-graph', action='store_true', help='(default) eager launches')
+    ap.add_argument('--no-overlap', action='store_true', help='run the env pass on the main stream instead of a side stream')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -177,14 +180,15 @@ def main():
     from dbw_amd.parallel import ShardedTrainStep
     model, inp = build_workload(args, dev)
     model.sync_free = True
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=not args.no_graph, graph_warmup=1, seed=227391)
+    model.overlap_passes = not args.no_overlap
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2 if not args.no_graph else 0)):     # graph capture happens in the second iteration
+    for _ in range(max(args.warmup, 2 if args.graph else 0)):     # graph capture happens in the second iteration
         step(inp)
     sync()
     t0 = time.perf_counter()
@@ -222,7 +226,8 @@ def main():
                                    f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, coarse phase '
                                    f'(sigma=1e-4, opacity noise, decimated textures), MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
                        'views_per_gpu': args.views, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks, 'faces_per_pixel': args.fpp,
-                       'txt_size': args.txt, 'launch': 'eager' if args.no_graph else 'hipGraph replay of zero_grad+forward+backward',
+                       'txt_size': args.txt, 'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
+                                 ('' if args.no_overlap else ', env pass on a side stream'),
                        'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,

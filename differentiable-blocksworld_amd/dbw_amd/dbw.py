@@ -55,6 +55,7 @@ class DifferentiableBlocksWorld(nn.Module):
         # kernel instead of being packed away on the host -> no device->host sync per iteration (dbw.py:322 `.item()`), same
         # images/losses/gradients, and the whole iteration becomes hipGraph-capturable.
         self.sync_free = False
+        self.overlap_passes = False   # render the env pass on a side stream, concurrently with the fg pass
 
     @property
     def init_kwargs(self):
@@ -343,13 +344,25 @@ class DifferentiableBlocksWorld(nn.Module):
         fine = not self.is_live('coarse_learning')
         filter_tsp = filter_transparent or fine
         renderer = self.renderer_fine if fine else self.renderer
-        env = self.renderer_env.render_packed(self.build_env_scene(), R, T, lds_aggregate=True)     # magnified textures
+        if self.overlap_passes:
+            # the env pass (hard, 1 face/pixel) and the fg pass are independent until the composite: issue the env pass on a
+            # side stream so its latency-bound kernels overlap the fg kernels (autograd replays the same streams in backward)
+            cur = torch.cuda.current_stream()
+            side = self._side_stream = getattr(self, '_side_stream', None) or torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                env = self.renderer_env.render_packed(self.build_env_scene(), R, T, lds_aggregate=True)
+            env.record_stream(cur)
+        else:
+            env = self.renderer_env.render_packed(self.build_env_scene(), R, T, lds_aggregate=True)     # magnified textures
         blocks = self.build_blocks_scene(filter_transparent=filter_tsp)
         if blocks is not None:
             alpha = None if filter_tsp else self._alpha.repeat_interleave(self.BNF)   # shared by all views (== .repeat(B))
             fg = renderer.render_packed(blocks, R, T, faces_alpha=alpha, lds_aggregate=self._blocks_decimated)
         else:
             fg = torch.zeros_like(env)
+        if self.overlap_passes:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
         return fg, env
 
     def predict(self, inp, labels=None, w_edges=False, filter_transparent=False):

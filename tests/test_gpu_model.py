@@ -213,22 +213,24 @@ def test_sync_free_block_culling_equals_host_packed_path_and_graph_replay_matche
     R, T, Km = O.synthetic_cameras(3, R_world=O.world_rotation(115, 0, 0))
     inp = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(3, 3, H, W, generator=torch.Generator().manual_seed(2)), R=R, T=T, K=Km).items()}
     res = []
-    for sync_free in (False, True):
+    for sync_free in (False, True, 'overlap'):
         torch.manual_seed(7)
         model = dbw_amd.create_model(_dtu_like_cfg(5, 32, 6), (H, W)).to(DEV).train()
         with torch.no_grad():
             model.alpha_logit[1] = -8.0          # sigmoid < 0.01 -> killed
             model.alpha_logit[3] = -7.0
-        model.sync_free = sync_free
+        model.sync_free = bool(sync_free)
+        model.overlap_passes = sync_free == 'overlap'      # env pass on a side stream: same numbers
         model._noise_override = torch.zeros(5, device=DEV)
         model._overlap_u_override = torch.rand(5, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
         out = model(inp, None)
         out['total'].backward()
         res.append((out, {k: v.grad.clone() for k, v in model.named_parameters()}))
-    for k in res[0][0]:
-        assert abs(res[0][0][k].item() - res[1][0][k].item()) <= 1e-6 * max(1.0, abs(res[0][0][k].item())), k
-    for k in res[0][1]:
-        assert rel_err(res[1][1][k], res[0][1][k]) < 1e-5, k
+    for other in (1, 2):
+        for k in res[0][0]:
+            assert abs(res[0][0][k].item() - res[other][0][k].item()) <= 1e-6 * max(1.0, abs(res[0][0][k].item())), k
+        for k in res[0][1]:
+            assert rel_err(res[other][1][k], res[0][1][k]) < 1e-5, k
     assert res[1][1]['S'][1].abs().max() == 0 and res[1][1]['R_6d'][3].abs().max() == 0     # dead blocks get no pose gradient
     # hipGraph replay == eager (3 iterations each, deterministic noise)
     finals = []
