@@ -81,7 +81,8 @@ def kernel_breakdown(model, inp, reps=5):
         verts, maps = scene.verts.detach(), scene.maps.detach()
         cl = ops.project_clip(verts, scene.faces, inp['R'], inp['T'], Kmat, cfg.eps, cfg.z_clip, cfg.persp)
         fvc = cl['face_verts'].view(-1, 3, 3)
-        fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg)
+        mode = 2 if (cfg.detach_bary and ops.UV_FRAGMENTS) else 1          # fragment layout the training step uses for this pass
+        fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode)
         p2f, bary, dists, img = fwd()
         g_img = torch.rand_like(img)
         g_maps, g_fvc = torch.zeros_like(maps), torch.zeros_like(fvc)
@@ -91,7 +92,7 @@ def kernel_breakdown(model, inp, reps=5):
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
                                                                alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), int(ops.TILED_FRAGMENTS), ops._stream(fvc))
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, ops._stream(fvc))
 
         def t(fn):
             fn()

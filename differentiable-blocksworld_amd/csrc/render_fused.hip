@@ -41,13 +41,20 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
             const FragAddr o = frag_addr(A, n, yi, xi, k);
             p2f[o.s] = valid ? q.fi[k] : -1;
             dists[o.s] = q.ds[k];
-            bary[o.b] = q.b0[k];
-            bary[o.b + o.bstride] = q.b1[k];
-            bary[o.b + 2 * o.bstride] = q.b2[k];
+            if (A.tiled != 2) {
+                bary[o.b] = q.b0[k];
+                bary[o.b + o.bstride] = q.b1[k];
+                bary[o.b + 2 * o.bstride] = q.b2[k];
+            }
             if (valid) {
                 Frag fr;
                 const float bc[3] = {q.b0[k], q.b1[k], q.b2[k]};
                 decode_frag(A, n, q.fi[k], bc, q.ds[k], fr);
+                if (A.tiled == 2) {       // hand the resolved shading inputs to the backward pass
+                    bary[o.b] = fr.u;
+                    bary[o.b + o.bstride] = fr.v;
+                    bary[o.b + 2 * o.bstride] = __int_as_float(fr.j | (fr.map << 20));
+                }
                 const float a = fr.e * fr.fa;
                 if (a != 0.f) {
                     Sample s;
@@ -115,7 +122,8 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     int rc = dbw_fill_shade_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                                  faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
     if (rc) return rc;
-    DBW_REQUIRE(frag_layout == 0 || frag_layout == 1, "frag_layout must be 0 (N,H,W,K) or 1 (8x8-tile planar)");
+    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
+    DBW_REQUIRE(frag_layout != 2 || F < (1 << 20), "frag_layout 2 packs the face id in 20 bits");
     A.tiled = frag_layout;
     if (K > DBW_MAX_FACES_PER_PIXEL) {
         dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);

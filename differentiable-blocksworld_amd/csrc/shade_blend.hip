@@ -385,7 +385,8 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     if (rc) return rc;
     DBW_REQUIRE(grad_image && grad_maps && face_verts_c && grad_face_verts_c, "null pointer");
     DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
-    DBW_REQUIRE(frag_layout == 0 || frag_layout == 1, "frag_layout must be 0 (N,H,W,K) or 1 (8x8-tile planar)");
+    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
+    DBW_REQUIRE(frag_layout != 2 || detach_bary, "frag_layout 2 carries no barycentrics: only valid with detach_bary");
     A.tiled = frag_layout;
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);

@@ -16,8 +16,9 @@ struct ShadeArgs {
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
     int N, H, W, K, F; float sigma; float bg[3];
-    int tiled; // fragment layout: 0 = (N,H,W,K[,3]) as PyTorch3D returns them; 1 = internal 8x8-tile planar layout of the
-               // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair
+    int tiled; // fragment layout: 0 = (N,H,W,K[,3]) as PyTorch3D returns them; 1, 2 = internal 8x8-tile planar layout of the
+               // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair;
+               // 2 = same, with the bary planes holding (u, v, bitcast(face | map << 20)) for detach_bary passes
     int agg;   // backward: 0 = wave-aggregated global atomics, 1 = LDS hash pre-aggregation
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
 };
@@ -38,6 +39,8 @@ struct Frag {
     float fa;         // learned face opacity (1 if none)
     long long aidx;   // index into faces_alpha
     float d;
+    float u, v;       // texture coordinates
+    int map;          // row of map_desc
 };
 
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
@@ -64,6 +67,18 @@ __device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, con
     else { gb[0] = g1 * (1.f - w3) + g3 * w3; gb[1] = g2; gb[2] = g3; }
 }
 
+// geometric alpha from the signed distance + learned per-face opacity (renderer.py:252-260)
+__device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) {
+    if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
+    fr.fa = 1.f;
+    fr.aidx = 0;
+    if (A.faces_alpha) {
+        fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
+        fr.fa = A.faces_alpha[fr.aidx];
+    }
+}
+
 // decode one fragment (clipped face id fc >= 0, clipped barycentrics b, signed distance d)
 __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, const float b[3], float d, Frag &fr) {
     if (A.c2o) {
@@ -77,15 +92,12 @@ __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, c
         fr.w2 = fr.w3 = 0.f;
     }
     convert_bary(fr.cd, fr.w2, fr.w3, b, fr.bo);
+    const float *uv = A.face_uvs + (long long)fr.j * 6;
+    fr.u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
+    fr.v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
+    fr.map = A.face_map[fr.j];
     fr.d = d;
-    if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
-    else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
-    fr.fa = 1.f;
-    fr.aidx = 0;
-    if (A.faces_alpha) {
-        fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
-        fr.fa = A.faces_alpha[fr.aidx];
-    }
+    frag_alpha(A, n, fr);
 }
 
 // Addressing of fragment slot k of pixel (n, yi, xi): `s` indexes pix_to_face / dists, `b + c * bstride` the barycentric c.
@@ -96,7 +108,7 @@ struct FragAddr {
 
 __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi, int xi, int k) {
     FragAddr a;
-    if (A.tiled) {
+    if (A.tiled) {       // 1: barycentrics, 2: (u, v, face|map) -- same addressing
         const int tx = (A.W + 7) >> 3, ty = (A.H + 7) >> 3;
         const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
         const int lane = ((yi & 7) << 3) | (xi & 7);
@@ -115,6 +127,18 @@ __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi,
 __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragAddr &o, Frag &fr) {
     const int fc = A.p2f[o.s];
     if (fc < 0) return false;
+    if (A.tiled == 2) {   // shading inputs were resolved by the forward pass: no table gathers, the dependent-load chain is
+                          // fragment -> {opacity, map descriptor} -> texels
+        fr.u = A.bary[o.b];
+        fr.v = A.bary[o.b + o.bstride];
+        const int jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
+        fr.j = jm & 0xfffff;
+        fr.map = jm >> 20;
+        fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
+        fr.d = A.dists[o.s];
+        frag_alpha(A, n, fr);
+        return true;
+    }
     const float b[3] = {A.bary[o.b], A.bary[o.b + o.bstride], A.bary[o.b + 2 * o.bstride]};
     decode_frag(A, n, fc, b, A.dists[o.s], fr);
     return true;
@@ -122,10 +146,8 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
 
 // grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
 __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
-    const float *uv = A.face_uvs + (long long)fr.j * 6;
-    const float u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
-    const float v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
-    const int *md = A.map_desc + A.face_map[fr.j] * 8;
+    const float u = fr.u, v = fr.v;
+    const int *md = A.map_desc + fr.map * 8;
     const long long off = md[0];
     const int h = md[1], w = md[2], pl = md[3], pr = md[4], sh = md[5];
     const int wp = w + pl + pr;

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+UV_FRAGMENTS = True       # detach_bary passes: the forward stores resolved (u, v, face|map) per fragment for the backward
 TILED_FRAGMENTS = True    # fused path keeps its fragments in the 8x8-tile planar layout (coalesced); needs both FUSED_* = True
 FUSED_FORWARD = True      # one kernel for raster + shade + blend (False: the two operator-level kernels)
 FUSED_BACKWARD = True     # one kernel for blend-backward + rasteriser-backward (False: the two operator-level kernels)
@@ -196,7 +197,7 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               0 if fa is None else fa.numel(), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
-              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), _stream(fvc))
+              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), _stream(fvc))   # 0 / 1 / 2
     return p2f, bary, dists, img
 
 
@@ -209,7 +210,9 @@ class _RenderScene(torch.autograd.Function):
         B = R.shape[0]
         cl = project_clip(verts_c, faces_i32, R, T, Kmat, cfg.eps, cfg.z_clip, cfg.persp)
         fvc = cl['face_verts'].view(-1, 3, 3)
-        ctx.tiled = FUSED_FORWARD and FUSED_BACKWARD and TILED_FRAGMENTS
+        ctx.tiled = int(FUSED_FORWARD and FUSED_BACKWARD and TILED_FRAGMENTS)
+        if ctx.tiled and UV_FRAGMENTS and cfg.detach_bary and cfg.F < (1 << 20) and map_desc.shape[0] < (1 << 11):
+            ctx.tiled = 2          # fragments carry (u, v, face|map) instead of barycentrics
         if FUSED_FORWARD:
             p2f, bary, dists, img = _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps_c, fa, bg, ctx.tiled)
         else:
