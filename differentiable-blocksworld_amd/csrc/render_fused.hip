@@ -40,11 +40,15 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
             const bool valid = q.fi[k] != 0x7fffffff;
             const FragAddr o = frag_addr(A, n, yi, xi, k);
             p2f[o.s] = valid ? q.fi[k] : -1;
-            dists[o.s] = q.ds[k];
-            if (A.tiled != 2) {
-                bary[o.b] = q.b0[k];
-                bary[o.b + o.bstride] = q.b1[k];
-                bary[o.b + 2 * o.bstride] = q.b2[k];
+            // internal layouts: empty slots carry only the -1 face id (the backward never reads the rest; a wave whose 64
+            // pixels are all empty at this depth issues no store at all); the PyTorch3D-shaped layout 0 is filled with -1
+            if (valid || A.tiled == 0) {
+                dists[o.s] = q.ds[k];
+                if (A.tiled != 2) {
+                    bary[o.b] = q.b0[k];
+                    bary[o.b + o.bstride] = q.b1[k];
+                    bary[o.b + 2 * o.bstride] = q.b2[k];
+                }
             }
             if (valid) {
                 Frag fr;
