@@ -198,13 +198,15 @@ def _model(seed=3, n_blocks=4, ts=32, hw=(48, 64), fpp=6):
     return m, R, T, Km
 
 
-def test_render_blocks_soft_pass_matches_oracle():
-    """fg pass: sigma=1e-4, learned opacities, detach_bary=True (geometry gradient through dists only)."""
-    m, R, T, Km = _model()
+@pytest.mark.parametrize('fpp', [6, 16, 25])
+def test_render_blocks_soft_pass_matches_oracle(fpp):
+    """fg pass: sigma=1e-4, learned opacities, detach_bary=True (geometry gradient through dists only); every compiled
+    faces_per_pixel bucket of the fused kernels (<=10, <=16, <=25)."""
+    m, R, T, Km = _model(fpp=fpp)
     with torch.no_grad():
         scene = m.build_blocks(True, True, False, None, kill_blocks=False)
     fa = (torch.rand(scene['faces'].shape[0] // m.BNF, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1).repeat_interleave(m.BNF)
-    res = _render_both(scene, R, T, Km[0], 48, 64, 1e-4, 6, True, fa, bg=(0., 0., 0.))
+    res = _render_both(scene, R, T, Km[0], 48, 64, 1e-4, fpp, True, fa, bg=(0., 0., 0.))
     for k, (a, b) in res.items():
         assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
     assert res['g_verts'][1].abs().max() > 0
