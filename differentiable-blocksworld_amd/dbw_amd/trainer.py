@@ -1,0 +1,134 @@
+"""The step either side of the render path: learning-rate schedule, optimisation loop and
+checkpointing with the semantics of the reference's src/scheduler.py:26-69, src/optimizer.py:6-18 and
+src/trainer.py:109-169,201-209, driving `ShardedTrainStep` (flat parameter buffer, fused Adam, optional RCCL all-reduce).
+
+Host-side scalars only; nothing here touches pixels.  No logging / visualisation / evaluation plumbing (out of scope)."""
+import time
+from collections import Counter
+
+import torch
+
+from .parallel import ShardedTrainStep, shard_views
+
+
+class MultiStepLR:
+    """Per-group learning rates, stepped once per EPOCH (trainer.py:127,163-169).  Reproduces the reference's chainable
+    recurrence including its warm-up quirk (the constructor divides the freshly set warm-up lr by `warmup` once more,
+    scheduler.py:41-46): pinned by tests/golden/lr_schedule.npz."""
+
+    def __init__(self, base_lrs, milestones=None, gamma=0.1, warmup=0):
+        self.base_lrs = [float(x) for x in base_lrs]
+        self.milestones = Counter(milestones or [])
+        self.gamma = [gamma] * len(self.base_lrs) if isinstance(gamma, float) else list(gamma)
+        self.warmup = warmup
+        self.last_epoch = 0
+        self.lrs = self._next(list(self.base_lrs))
+        if warmup > 0:
+            self.lrs = [lr / warmup for lr in self.lrs]
+
+    def _next(self, lrs):
+        if self.warmup > self.last_epoch:
+            return [lr / self.warmup * (self.last_epoch + 1) for lr in self.base_lrs]
+        if self.last_epoch not in self.milestones:
+            return lrs
+        return [lr * g ** self.milestones[self.last_epoch] for lr, g in zip(lrs, self.gamma)]
+
+    def step(self):
+        self.last_epoch += 1
+        self.lrs = self._next(self.lrs)
+        return self.lrs
+
+    def get_last_lr(self):
+        return list(self.lrs)
+
+    def state_dict(self):
+        return {'last_epoch': self.last_epoch, 'lrs': list(self.lrs)}
+
+    def load_state_dict(self, state):
+        self.last_epoch = state['last_epoch']
+        if 'lrs' in state:
+            self.lrs = list(state['lrs'])
+
+
+class Trainer:
+    """cfg: the reference's YAML dict (`model`, `training.{batch_size, optimizer, scheduler, n_epoches, seed}`).
+    views: dict of tensors {'imgs' (V,3,H,W), 'R' (V,3,3), 'T' (V,3), 'K' (V,4,4)} resident on the device (the reference's
+    DataLoader yields the same dict batch by batch, trainer.py:118,141)."""
+
+    def __init__(self, cfg, model, views, process_group=None, sync_free=True):
+        tr = cfg['training']
+        opt = dict(tr.get('optimizer') or {})
+        if opt.pop('name', 'adam') != 'adam':
+            raise NotImplementedError('only Adam (the optimiser of every shipped config, default.yml:31) is fused')
+        txt = opt.pop('texture', {})
+        lr = opt.pop('lr', 1e-3)
+        lr_txt = txt.get('lr', lr)
+        sch = dict(tr.get('scheduler') or {})
+        if sch.pop('name', 'multi_step') != 'multi_step':
+            raise NotImplementedError('only the multi_step scheduler')
+        self.model, self.views = model, views
+        model.sync_free = sync_free
+        self.step_fn = ShardedTrainStep(model, lr=lr, lr_texture=lr_txt, betas=opt.pop('betas', (0.9, 0.999)), eps=opt.pop('eps', 1e-8),
+                                        process_group=process_group, seed=tr.get('seed'))
+        self.scheduler = MultiStepLR([lr, lr_txt], **sch)
+        self.step_fn.lrs = tuple(self.scheduler.get_last_lr())
+        self.batch_size = tr.get('batch_size', 4)
+        self.n_epoches = tr.get('n_epoches', 1)
+        self.epoch, self.n_iters, self.time_per_img = 1, 0, 0.0
+        a, b = shard_views(views['imgs'].shape[0], self.step_fn.world_size, self.step_fn.rank)
+        self.local = {k: v[a:b] for k, v in views.items()}
+        self._perm_gen = torch.Generator().manual_seed(int(tr.get('seed') or 0))
+
+    # trainer.py:137-147
+    def run_single_batch_train(self, inp):
+        t0 = time.time()
+        self.model.train()
+        losses = self.step_fn(inp)
+        self.n_iters += 1
+        return losses, t0
+
+    def run_epoch(self, shuffle=True):
+        """One pass over this rank's views in mini-batches (DataLoader(shuffle=True) equivalent), then the per-epoch
+        scheduler / model step (trainer.py:127,163-169)."""
+        V = self.local['imgs'].shape[0]
+        order = torch.randperm(V, generator=self._perm_gen) if shuffle else torch.arange(V)
+        last = None
+        t_start, n_img = time.time(), 0
+        for s in range(0, V, self.batch_size):
+            idx = order[s:s + self.batch_size].to(self.local['imgs'].device)
+            last, _ = self.run_single_batch_train({k: v[idx] for k, v in self.local.items()})
+            n_img += idx.numel()
+        torch.cuda.synchronize()
+        self.time_per_img = (time.time() - t_start) / max(n_img, 1)
+        self.step_fn.lrs = tuple(self.scheduler.step())
+        self.model.step()
+        self.epoch += 1
+        opac = self.model.get_opacities()
+        if (opac > 0.01).sum() == 0:
+            raise RuntimeError('No more blocks....')                   # trainer.py:152-154
+        return last
+
+    def run(self, n_epoches=None):
+        last = None
+        for _ in range(self.epoch, (n_epoches or self.n_epoches) + 1):
+            last = self.run_epoch()
+        return last
+
+    # trainer.py:201-209 / 84-107
+    def state_dict(self):
+        return {'epoch': self.epoch, 'batch': 1, 'model_name': self.model.name, 'model_kwargs': self.model.init_kwargs,
+                'model_state': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'optimizer_state': {'exp_avg': self.step_fn.exp_avg.clone(), 'exp_avg_sq': self.step_fn.exp_avg_sq.clone(),
+                                    'n_steps': self.step_fn.n_steps},
+                'scheduler_state': self.scheduler.state_dict()}
+
+    def load_state_dict(self, ckpt):
+        self.model.load_state_dict(ckpt['model_state'])
+        o = ckpt['optimizer_state']
+        self.step_fn.exp_avg.copy_(o['exp_avg'])
+        self.step_fn.exp_avg_sq.copy_(o['exp_avg_sq'])
+        self.step_fn.n_steps = o['n_steps']
+        self.scheduler.load_state_dict(ckpt['scheduler_state'])
+        self.step_fn.lrs = tuple(self.scheduler.get_last_lr())
+        self.epoch = ckpt['epoch']
+        self.model.set_cur_epoch(self.epoch - 1)

@@ -71,7 +71,7 @@ def import_reference():
     sys.meta_path.insert(0, _Finder())
     sys.path.insert(0, REF)
     mods = {}
-    for name in ['utils.pytorch', 'utils.superquadric', 'utils.mesh', 'model.renderer', 'model.loss', 'model.tools']:
+    for name in ['utils.pytorch', 'utils.superquadric', 'utils.mesh', 'model.renderer', 'model.loss', 'model.tools', 'scheduler', 'optimizer']:
         mods[name] = importlib.import_module(name)
     return mods
 
@@ -180,6 +180,31 @@ def main():
         f_raw, v_raw = mesh.get_icosphere_uvs(level=level)
         out.update({f'l{level}/faces_uvs': _np(f_uv), f'l{level}/verts_uvs': _np(v_uv), f'l{level}/verts_uvs_raw': _np(v_raw)})
     np.savez_compressed(os.path.join(HERE, 'icosphere_uvs.npz'), **out)
+    # ---- 6. MultiStepLR (scheduler.py:26-69) stepped per epoch as trainer.py:127,163-169 does, Adam groups of optimizer.py:6-18
+    sch, opt = m['scheduler'], m['optimizer']
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.S = torch.nn.Parameter(torch.zeros(2))
+            self.textures = torch.nn.Parameter(torch.zeros(3))
+            self.texture_bkg = torch.nn.Parameter(torch.zeros(1))
+    out = {}
+    for tag, kwargs, n_ep in [('dtu', dict(gamma=[0.1, 0.1], milestones=[1700]), 1800),
+                              ('warm', dict(gamma=[0.5, 0.1], milestones=[5, 9, 9], warmup=3), 14),
+                              ('scalar_gamma', dict(gamma=0.3, milestones=[2, 4]), 7)]:
+        model = Tiny()
+        cfg = {'training': {'optimizer': {'name': 'adam', 'lr': 5.0e-3, 'texture': {'lr': 5.0e-2}}}}
+        optimizer = opt.create_optimizer(cfg, model)
+        assert [len(g['params']) for g in optimizer.param_groups] == [1, 2]
+        scheduler = sch.MultiStepLR(optimizer, **kwargs)
+        lrs = [[g['lr'] for g in optimizer.param_groups]]
+        for _ in range(n_ep):
+            optimizer.step()
+            scheduler.step()
+            lrs.append([g['lr'] for g in optimizer.param_groups])
+        out[tag] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'lr_schedule.npz'), **out)
     print('golden fixtures written to', HERE)
 
 

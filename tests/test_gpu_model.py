@@ -264,3 +264,44 @@ def test_predict_returns_reference_shaped_image_and_state_dict_roundtrip():
     other.load_state_dict({'module.' + k.replace('sq_', 'spq_'): v for k, v in sd.items()})
     for k, v in other.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_trainer_driver_optimises_schedules_and_checkpoints():
+    """N1: the loop of src/trainer.py:109-147,163-169 on the HIP path: mini-batches over the views, fused Adam with the two
+    lr groups, per-epoch MultiStepLR + model.step(), checkpoint round trip (trainer.py:201-209)."""
+    from dbw_amd.trainer import Trainer
+    H, W, V = 48, 64, 8
+    cfg = _dtu_like_cfg(4, 32, 6)
+    cfg['model']['rend_optim'].update(coarse_learning=True, decimate_txt=False, opacity_noise=False)
+    cfg['training'] = {'batch_size': 4, 'n_epoches': 6, 'seed': 123,
+                       'optimizer': {'name': 'adam', 'lr': 5.0e-3, 'texture': {'lr': 5.0e-2}},
+                       'scheduler': {'name': 'multi_step', 'gamma': [0.1, 0.1], 'milestones': [4]}}
+    torch.manual_seed(5)
+    target = dbw_amd.create_model(cfg, (H, W)).to(DEV).eval()
+    R, T, Km = O.synthetic_cameras(V, R_world=target.R_world[0].cpu())
+    views = {k: v.to(DEV) for k, v in dict(imgs=torch.zeros(V, 3, H, W), R=R, T=T, K=Km).items()}
+    with torch.no_grad():
+        target.textures.add_(torch.randn_like(target.textures))
+        target.alpha_logit.add_(3.0)
+        views['imgs'] = target.predict(views, None).clamp(0, 1).contiguous()
+    torch.manual_seed(6)
+    model = dbw_amd.create_model(cfg, (H, W)).to(DEV)
+    tr = Trainer(cfg, model, views)
+    assert tr.step_fn.lrs == (5.0e-3, 5.0e-2)
+    first = tr.run_epoch()['rgb'].item()
+    for _ in range(3):
+        last = tr.run_epoch()
+    assert tr.n_iters == 8 and tr.epoch == 5 and model.cur_epoch == 4
+    assert tr.step_fn.lrs == pytest.approx((5.0e-4, 5.0e-3))              # milestone 4 reached: both groups x 0.1
+    assert last['rgb'].item() < 0.9 * first, (first, last['rgb'].item())
+    assert tr.time_per_img > 0
+    ckpt = tr.state_dict()
+    assert set(ckpt) == {'epoch', 'batch', 'model_name', 'model_kwargs', 'model_state', 'optimizer_state', 'scheduler_state'}
+    ref_next = tr.run_epoch(shuffle=False)
+    torch.manual_seed(7)
+    model2 = dbw_amd.create_model(cfg, (H, W)).to(DEV)
+    tr2 = Trainer(cfg, model2, views)
+    tr2.load_state_dict(ckpt)
+    assert tr2.epoch == 5 and model2.cur_epoch == 4 and tr2.step_fn.lrs == pytest.approx(tr.step_fn.lrs)
+    got_next = tr2.run_epoch(shuffle=False)
+    assert abs(got_next['total'].item() - ref_next['total'].item()) < 1e-4 * abs(ref_next['total'].item())

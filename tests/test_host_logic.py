@@ -119,3 +119,48 @@ def test_meshes_join_and_packed_scene_layout():
     batch = Meshes(torch.rand(3, 12, 3), f1[None].expand(3, -1, -1), TexturesUV(torch.rand(3, 4, 4, 3), f1, torch.rand(12, 2)))
     js = join_meshes_as_scene(batch)
     assert js.get_mesh_verts_faces(0)[1].max() == 35 and len(js.textures.maps) == 3
+
+
+def test_multistep_lr_matches_reference_scheduler(golden_dir):
+    """dbw_amd.trainer.MultiStepLR against LR traces of the REAL src/scheduler.py MultiStepLR + src/optimizer.py grouping
+    (tests/golden/lr_schedule.npz), including the warm-up quirk and list/scalar gamma."""
+    import os
+    import numpy as np
+    from dbw_amd.trainer import MultiStepLR
+    g = np.load(os.path.join(golden_dir, 'lr_schedule.npz'))
+    for tag, kwargs in [('dtu', dict(gamma=[0.1, 0.1], milestones=[1700])),
+                        ('warm', dict(gamma=[0.5, 0.1], milestones=[5, 9, 9], warmup=3)),
+                        ('scalar_gamma', dict(gamma=0.3, milestones=[2, 4]))]:
+        sch = MultiStepLR([5.0e-3, 5.0e-2], **kwargs)
+        trace = [sch.get_last_lr()]
+        for _ in range(g[tag].shape[0] - 1):
+            trace.append(list(sch.step()))
+        np.testing.assert_allclose(np.array(trace), g[tag], rtol=1e-12, atol=0)
+
+
+def test_camera_ingest_round_trip_and_pixel_consistency():
+    """N3: P = K_cv [R|t] -> (K_ndc, R, T) -> the render path's NDC projection lands on the same pixels as P."""
+    import numpy as np
+    from dbw_amd.cameras import opencv_KRT_from_proj, pytorch3d_KRT_from_proj
+    rng = np.random.RandomState(0)
+    H, W = 300, 400
+    for _ in range(5):
+        A = rng.randn(3, 3)
+        Q, _ = np.linalg.qr(A)
+        R_w2c = Q * np.sign(np.linalg.det(Q))
+        C = rng.randn(3) * 0.5 + np.array([0, 0, -3.0])
+        Kcv = np.array([[720 + 50 * rng.rand(), 0.0, W / 2 + 10 * rng.randn()], [0, 715.0, H / 2 + 10 * rng.randn()], [0, 0, 1]])
+        P = Kcv @ np.concatenate([R_w2c, (-R_w2c @ C)[:, None]], 1) * 3.7          # arbitrary projective scale
+        K4, R_c2w, Cc = opencv_KRT_from_proj(P)
+        np.testing.assert_allclose(K4[:3, :3], Kcv / Kcv[2, 2], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(R_c2w, R_w2c.T, atol=1e-5)
+        np.testing.assert_allclose(Cc, C, atol=1e-4)
+        Kp, Rp, Tp = pytorch3d_KRT_from_proj(P, (H, W))
+        X = torch.from_numpy(R_w2c.T @ (rng.rand(3, 20) * [[1.0], [0.8], [2.0]] + [[-0.5], [-0.4], [1.5]]) + C[:, None]).float().T
+        ndc = O.transform_to_ndc(X, Rp[None], Tp[None], Kp)[0]
+        uvw = (torch.from_numpy(P).float() @ torch.cat([X, torch.ones(20, 1)], 1).T).T
+        u, v = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+        s = min(H, W) / 2
+        torch.testing.assert_close(W / 2 - ndc[:, 0] * s, u, rtol=1e-4, atol=5e-2)        # NDC +X points left, +Y up
+        torch.testing.assert_close(H / 2 - ndc[:, 1] * s, v, rtol=1e-4, atol=5e-2)
+        assert torch.all(ndc[:, 2] > 0)
