@@ -60,6 +60,9 @@ def build_workload(args, dev):
     return model, inp
 
 
+BIN_STATS = {}
+
+
 def kernel_breakdown(model, inp, reps=5):
     """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the four
     kernels that dominate an iteration -- the fused forward and fused backward of the fg (soft, K faces per pixel) and env
@@ -71,8 +74,10 @@ def kernel_breakdown(model, inp, reps=5):
     P = H * W
     res = {}
     with torch.no_grad():
-        passes = [('fg', model.renderer, model.build_blocks_scene(), model._alpha.detach().repeat_interleave(model.BNF).contiguous(),
-                   bool(model._blocks_decimated)),
+        fine = not model.is_live('coarse_learning')                        # same choices as DifferentiableBlocksWorld.render_layers
+        blocks = model.build_blocks_scene(filter_transparent=fine)
+        alpha = None if fine else model._alpha.detach().repeat_interleave(model.BNF).contiguous()
+        passes = [('fg', model.renderer_fine if fine else model.renderer, blocks, alpha, bool(model._blocks_decimated)),
                   ('env', model.renderer_env, model.build_env_scene(), None, True)]
     for tag, r, scene, alpha, agg in passes:
         cfg = r._cfg(scene.faces.shape[0], lds_aggregate=agg)
@@ -87,12 +92,27 @@ def kernel_breakdown(model, inp, reps=5):
         g_img = torch.rand_like(img)
         g_maps, g_fvc = torch.zeros_like(maps), torch.zeros_like(fvc)
         g_alpha = torch.zeros_like(alpha) if alpha is not None else None
+        bins = scene.texbins if (ops.TEXTURE_BINS and not agg and scene.texbins is not None and scene.texbins[2] > 0) else None
+        bin_base = cursor = records = 0
+        cap = 0
+        if bins is not None:                                               # same sizing as ops._RenderScene.backward
+            nbins = bins[2]
+            cap = int(min(max(B * H * W * K // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+            cursor_t = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
+            records_t = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
+            bin_base, cursor, records = bins[0].data_ptr(), cursor_t.data_ptr(), records_t.data_ptr()
 
         def bwd():
+            if bins is not None:
+                cursor_t.zero_()
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
                                                                alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, ops._stream(fvc))
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap,
+                      ops._stream(fvc))
+
+        def reduce():
+            _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, bins[2], g_maps.data_ptr(), ops._stream(fvc))
 
         def t(fn):
             fn()
@@ -107,6 +127,10 @@ def kernel_breakdown(model, inp, reps=5):
 
         res[f'render_fwd_kernel<{K}> ({tag} pass)'] = (t(fwd), (20 * P * K + 16 * P) * B)
         res[f'shade_blend_bwd_kernel<fused> ({tag} pass)'] = (t(bwd), (20 * P * K + 16 * P) * B)
+        if bins is not None:
+            res[f'texbin_reduce_kernel ({tag} pass)'] = (t(reduce), 64 * int(cursor_t.clamp(max=cap).sum()))  # record write + read
+            BIN_STATS[tag] = {'records_per_fragment_slot': round(float(cursor_t.float().sum() / (B * P * K)), 4), 'bins': bins[2],
+                              'bins_overflowed': int((cursor_t > cap).sum()), 'capacity': cap}
     return res
 
 
@@ -151,6 +175,8 @@ def main():
     ap.add_argument('--blocks', type=int, default=10)
     ap.add_argument('--fpp', type=int, default=10)
     ap.add_argument('--txt', type=int, default=256)
+    ap.add_argument('--epoch', type=int, default=0, help='training phase to measure: 0 = coarse+decimated textures (default, the '
+                    'configuration at the start of training), 800 = coarse, 1600 = fine (dbw.py:210-219, default.yml:15-16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
                     'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
@@ -180,6 +206,7 @@ def main():
 
     from dbw_amd.parallel import ShardedTrainStep
     model, inp = build_workload(args, dev)
+    model.set_cur_epoch(args.epoch)
     model.sync_free = True
     model.overlap_passes = not args.no_overlap
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
@@ -232,7 +259,7 @@ def main():
                        'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
-                         'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()},
+                         'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS},
             'final_loss': total_loss,
         }

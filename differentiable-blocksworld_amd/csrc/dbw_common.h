@@ -211,19 +211,23 @@ __device__ __forceinline__ void wave_agg_atomic(float *__restrict__ base, long l
 
 // Workgroup-level pre-aggregation of scattered gradient updates in LDS (open-addressing hash keyed by the destination
 // index).  Measured on MI355X (profiles/r01_atomic_scope_ubench.txt): scattered global fp32 atomics run at a flat
-// ~21 G lane-ops/s whatever the scope / working set, while LDS atomics are ~100x cheaper -- so every update first lands
-// in LDS (ds_cmpst + ds_add_f32) and each DISTINCT destination of the tile is flushed to memory once.  Updates that do
+// ~21 G lane-ops/s whatever the scope / working set, while LDS atomics are far cheaper -- so every update first lands
+// in LDS (ds_cmpst + ds_add_f64) and each DISTINCT destination of the tile is flushed to memory once.  Updates that do
 // not find a slot within 8 probes go straight to memory, so the result is exact regardless of table pressure.
+// The table accumulates in fp64 because of how gfx950 executes LDS float atomics (profiles/r01_lds_atomic_ubench.txt):
+// ds_add_f32 retires one lane per ~3 clk whatever the addresses (193 clk for a full wave), ds_add_f64 costs ~6-8 clk per wave
+// when the lanes hit distinct slots and ~3 clk per extra lane sharing a slot within a 16-lane group.
 template <int NV, int LOG2_SLOTS>
 struct LdsAgg {
     static constexpr int NSLOT = 1 << LOG2_SLOTS;
-    static constexpr size_t BYTES = (size_t)NSLOT * (NV + 1) * 4;
+    static constexpr size_t BYTES = (size_t)NSLOT * (NV * 8 + 4);
+    static_assert(NSLOT % 2 == 0, "keys must leave the fp64 values 8-byte aligned");
     int *keys;
-    float *vals;
-    __device__ __forceinline__ void bind(void *lds) { keys = (int *)lds; vals = (float *)lds + NSLOT; }
+    double *vals;
+    __device__ __forceinline__ void bind(void *lds) { keys = (int *)lds; vals = (double *)((int *)lds + NSLOT); }
     __device__ __forceinline__ void clear(int tid, int nthreads) {
         for (int i = tid; i < NSLOT; i += nthreads) keys[i] = -1;
-        for (int i = tid; i < NSLOT * NV; i += nthreads) vals[i] = 0.f;
+        for (int i = tid; i < NSLOT * NV; i += nthreads) vals[i] = 0.0;
     }
     __device__ __forceinline__ void add(float *__restrict__ gbase, int key, const float (&v)[NV]) {
         unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2_SLOTS);
@@ -233,7 +237,7 @@ struct LdsAgg {
             if (old == -1 || old == key) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
-                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], v[c]);
+                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
                 return;
             }
             h = (h + 1) & (NSLOT - 1);
@@ -248,7 +252,7 @@ struct LdsAgg {
             if (k >= 0) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
-                    const float x = vals[i * NV + c];
+                    const float x = (float)vals[i * NV + c];
                     if (x != 0.f) unsafeAtomicAdd(gbase + (long long)k * NV + c, x);
                 }
             }

@@ -69,9 +69,18 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     o[3 * plane] = 1.f - T;
 }
 
+constexpr int BIN_LOG2 = 7, BIN_SLOTS = 1 << BIN_LOG2;   // per-block hash table of touched texture bins
+constexpr int BIN_CHUNK = 8192;                           // records one texbin_reduce workgroup accumulates
+
+// a footprint the bin's 33x33 LDS tile can hold: at most one row up and one column right of (r0, c0), no wrap
+__device__ __forceinline__ bool bin_regular(const Sample &s) {
+    return (s.r1 == s.r0 || s.r1 == s.r0 - 1) && (s.c1 == s.c0 || s.c1 == s.c0 + 1) &&
+           ((s.r0 & 31) != 0 || s.r1 == s.r0 || s.r0 > 0) && (s.c1 >> 5) - (s.c0 >> 5) <= 1;
+}
+
 // FUSED = true additionally runs the rasteriser backward on the fly: d/d dists and d/d barycentrics are
 // consumed in registers and only d/d face_verts leaves the kernel (pre-aggregated per face in LDS).
-template <bool FUSED>
+template <bool FUSED, bool BINNED>
 __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
@@ -83,6 +92,9 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     AlphaAgg alpha_agg;
     const bool use_lds = A.agg != 0;
     FaceAgg face_agg;
+    // BINNED: block-level slot reservation.  Pass 1 counts the block's records per bin in a small LDS hash table, one global
+    // cursor atomic per (block, bin) reserves the range, pass 2 writes the records -- a single atomic round trip per block.
+    int *s_key = nullptr, *s_cnt = nullptr, *s_base = nullptr, *s_ent = nullptr;
     {
         char *nxt = (char *)(s_layers + (long long)A.K * NT);
         if (use_lds) {                             // block-uniform
@@ -91,7 +103,11 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             tex_agg.clear(threadIdx.x, NT);
             alpha_agg.clear(threadIdx.x, NT);
         }
-        if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); }
+        if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); nxt += FaceAgg::BYTES; }
+        if (BINNED) {
+            s_key = (int *)nxt; s_cnt = s_key + BIN_SLOTS; s_base = s_cnt + BIN_SLOTS; s_ent = s_base + BIN_SLOTS + threadIdx.x;
+            if (threadIdx.x < BIN_SLOTS) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
+        }
     }
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
@@ -115,10 +131,35 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         for (int k = 0; k < A.K; ++k) {     // unrolled: the fragment loads of several layers are in flight together
             float ak = 0.f;
             Frag fr;
-            if (in_img && load_frag(A, n, frag_addr(A, n, yi, xi, k), fr)) ak = fr.e * fr.fa;
+            const bool valid = in_img && load_frag(A, n, frag_addr(A, n, yi, xi, k), fr);
+            if (valid) ak = fr.e * fr.fa;
             s_T[k * NT] = T;
+            if (BINNED) {
+                int ent = -1;
+                const float wgt = T * ak;
+                if (valid && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f)) {
+                    Sample s;
+                    footprint(A, fr, s);
+                    if (bin_regular(s)) {
+                        const int bin = A.bin_base[fr.map] + (s.r0 >> 5) * ((s.ws + 31) >> 5) + (s.c0 >> 5);
+                        unsigned h = ((unsigned)bin * 2654435761u) >> (32 - BIN_LOG2);
+                        for (int probe = 0; probe < 8; ++probe) {
+                            const int prev = atomicCAS(&s_key[h], -1, bin);
+                            if (prev == -1 || prev == bin) { ent = (int)(h << 16) | atomicAdd(&s_cnt[h], 1); break; }
+                            h = (h + 1) & (BIN_SLOTS - 1);
+                        }
+                    }
+                }
+                s_ent[k * NT] = ent;
+            }
             T *= (1.f - ak);
         }
+    }
+    if (BINNED) {
+        __syncthreads();
+        if (threadIdx.x < BIN_SLOTS && s_key[threadIdx.x] >= 0)
+            s_base[threadIdx.x] = atomicAdd(A.bin_cursor + s_key[threadIdx.x], s_cnt[threadIdx.x]);
+        __syncthreads();
     }
     // pass 2 (back to front)
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
@@ -172,12 +213,30 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                     }
             }
         } else if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
+            bool pending = tex;
+            if (BINNED) {
+                // texture-space binning: append a 32 B record to the bin of the 32x32-texel tile the footprint starts in (the
+                // bin's LDS tile has a 1-texel halo: row r0-1 and column c0+1); irregular footprints (circular wrap, clamped
+                // borders leaving the halo), hash-table misses and bin overflow fall through to the atomic path below
+                const int ent = s_ent[k * NT];
+                if (tex && ent >= 0) {
+                    const int h = ent >> 16, slot = s_base[h] + (ent & 0xffff);
+                    if (slot < A.bin_cap) {
+                        const unsigned packed = (unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) |
+                                                ((unsigned)(s.c1 - s.c0) << 11);
+                        int4 *dst = A.bin_records + ((long long)s_key[h] * A.bin_cap + slot) * 2;
+                        dst[0] = make_int4((int)packed, __float_as_int(s.wx1), __float_as_int(s.wy1), __float_as_int(gc[0]));
+                        dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                        pending = false;
+                    }
+                }
+            }
             // lanes sharing the same top-left texel share all four addresses
-            unsigned long long rem = __ballot(tex);
+            unsigned long long rem = __ballot(pending);
             int iter = 0;
             while (rem) {
                 if (iter >= 8 || (A.dbg & 4)) {
-                    if (tex && ((rem >> lane) & 1ull)) {
+                    if (pending && ((rem >> lane) & 1ull)) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
                             unsafeAtomicAdd(gmaps + s.a00 + ch, gc[ch] * s.w00);
@@ -190,7 +249,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 }
                 const int leader = __ffsll((long long)rem) - 1;
                 const long long k00 = __shfl(s.a00, leader, 64), k11 = __shfl(s.a11, leader, 64);
-                const bool match = tex && s.a00 == k00 && s.a11 == k11;
+                const bool match = pending && s.a00 == k00 && s.a11 == k11;
                 const unsigned long long mm = __ballot(match);
                 if (__popcll(mm) > 1) {
                     const long long k01 = __shfl(s.a01, leader, 64), k10 = __shfl(s.a10, leader, 64);
@@ -274,6 +333,72 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     if (FUSED) face_agg.flush(gfv, threadIdx.x, NT);
 }
 
+// One workgroup per (texture bin, chunk of BIN_CHUNK records): accumulate the records into a (32+1)x(32+1) texel LDS tile
+// (1-texel halo: row -1, column +32), then add the tile to the gradient map.  bin_info (nbins,4) = {offset of the map in floats,
+// stored width ws, stored height hs, tile_y << 16 | tile_x}.
+// The tile is accumulated in fp64: on gfx950 ds_add_f32 retires ~1 lane per 3 clk whatever the addresses (193 clk for a full
+// wave), while ds_add_f64 is pipelined (~10 clk per wave) as long as the lanes hit distinct addresses
+// (profiles/r01_lds_atomic_ubench.txt).  Records arrive in runs of up to 64 written by one wave of the backward (an 8x8 pixel
+// patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
+// transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
+constexpr int BIN_STAGE = 1024, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
+__global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restrict__ bin_info, const int *__restrict__ cursor,
+                                                            const int4 *__restrict__ records, int cap, float *__restrict__ gmaps) {
+    __shared__ double tile[33 * 33 * 3];
+    __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
+    const int bin = blockIdx.x;
+    const int n_all = min(cursor[bin], cap), begin = blockIdx.y * BIN_CHUNK;
+    if (begin >= n_all) return;
+    const int n = min(n_all - begin, BIN_CHUNK);
+    for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0.0;
+    const int4 *rec = records + ((long long)bin * cap + begin) * 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int sb = 0; sb < n; sb += BIN_STAGE) {
+        const int m = min(n - sb, BIN_STAGE);
+        __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
+#pragma unroll
+        for (int it = 0; it < BIN_PER_THREAD; ++it) {
+            const int r = it * 256 + threadIdx.x;
+            if (r < m) {
+                const int4 a = rec[(sb + r) * 2], b = rec[(sb + r) * 2 + 1];
+                stage[r * 2 + r / BIN_LANE_STRIDE] = a;
+                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = b;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < BIN_PER_THREAD; ++j) {
+            const int r = lane * BIN_LANE_STRIDE + wv * BIN_PER_THREAD + j;
+            if (r >= m) continue;
+            const int4 a = stage[r * 2 + r / BIN_LANE_STRIDE], b = stage[r * 2 + r / BIN_LANE_STRIDE + 1];
+            const unsigned p = (unsigned)a.x;
+            const int lr0 = (int)(p & 31) + 1, lc0 = (int)((p >> 5) & 31), dr = (int)((p >> 10) & 1), dc = (int)((p >> 11) & 1);
+            const float wx1 = __int_as_float(a.y), wy1 = __int_as_float(a.z);
+            const float g0 = __int_as_float(a.w), g1 = __int_as_float(b.x), g2 = __int_as_float(b.y);
+            const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+            const int idx[4] = {(lr0 * 33 + lc0) * 3, (lr0 * 33 + lc0 + dc) * 3, ((lr0 - dr) * 33 + lc0) * 3, ((lr0 - dr) * 33 + lc0 + dc) * 3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                atomicAdd(&tile[idx[q]], (double)(g0 * w[q]));
+                atomicAdd(&tile[idx[q] + 1], (double)(g1 * w[q]));
+                atomicAdd(&tile[idx[q] + 2], (double)(g2 * w[q]));
+            }
+        }
+    }
+    __syncthreads();
+    const long long off = bin_info[bin * 4];
+    const int ws = bin_info[bin * 4 + 1], hs = bin_info[bin * 4 + 2];
+    const int ty = bin_info[bin * 4 + 3] >> 16, tx = bin_info[bin * 4 + 3] & 0xffff;
+    for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) {
+        const float v = (float)tile[i];
+        if (v == 0.f) continue;
+        const int ch = i % 3, lc = (i / 3) % 33, lr = i / 99;
+        const int r = ty * 32 - 1 + lr, c = tx * 32 + lc;
+        if (r >= 0 && r < hs && c < ws) unsafeAtomicAdd(gmaps + off + ((long long)r * ws + c) * 3 + ch, v);
+    }
+}
+
 int g_dbg_flags = 0;
 
 int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
@@ -292,6 +417,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.dbg = g_dbg_flags;
     A.agg = 0;
     A.tiled = 0;
+    A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0;
     return DBW_OK;
 }
 
@@ -336,20 +462,25 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
     const bool fused = gfv != nullptr;
     if (fused) lds += FaceAgg::BYTES;
+    if (fused && A.bin_records) lds += (size_t)(3 * BIN_SLOTS + K * NT) * sizeof(int);
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             dbw_set_error("shade/blend backward: cannot raise the dynamic LDS limit");
             return DBW_ERR_LAUNCH;
         }
         raised = true;
     }
-    if (fused)
-        hipLaunchKernelGGL(shade_blend_bwd_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+    if (fused && A.bin_records)
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, true>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+                           grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
+    else if (fused)
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
                            grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
     else
-        hipLaunchKernelGGL(shade_blend_bwd_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<false, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
                            grad_faces_alpha, grad_dists, grad_bary, nullptr, nullptr, 0, 1);
     return dbw_check_launch("shade_blend_bwd_kernel");
 }
@@ -378,7 +509,8 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     int K, int F, float sigma, const float *background3, const float *grad_image,
                                     const float *face_verts_c, int perspective_correct, int detach_bary,
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
-                                    int lds_aggregate, int frag_layout, dbw_stream_t stream) {
+                                    int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
+                                    void *bin_records, int bin_cap, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -388,8 +520,22 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
     DBW_REQUIRE(frag_layout != 2 || detach_bary, "frag_layout 2 carries no barycentrics: only valid with detach_bary");
     A.tiled = frag_layout;
+    DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap > 0) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none");
+    if (bin_records && !lds_aggregate) {
+        A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap;
+    }
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
+}
+
+extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
+                                 int nbins, float *grad_maps, dbw_stream_t stream) {
+    DBW_REQUIRE(bin_info && bin_cursor && bin_records && grad_maps, "null pointer");
+    DBW_REQUIRE(bin_cap > 0 && nbins >= 0, "bad size");
+    if (nbins == 0) return DBW_OK;
+    hipLaunchKernelGGL(texbin_reduce_kernel, dim3(nbins, (bin_cap + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), 0, (hipStream_t)stream, bin_info, bin_cursor,
+                       (const int4 *)bin_records, bin_cap, grad_maps);
+    return dbw_check_launch("texbin_reduce_kernel");
 }
 
 // Ablation hook for profiling scripts (tools/): not part of the rendering contract.

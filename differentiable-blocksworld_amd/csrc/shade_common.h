@@ -6,9 +6,9 @@
 
 namespace dbw {
 
-typedef LdsAgg<3, 9> TexAgg;      // 512 texels x (key + rgb) = 8 KB
-typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces             =  2 KB
-typedef LdsAgg<9, 7> FaceAgg;     // 128 faces x (key + 3x3) = 5 KB
+typedef LdsAgg<3, 9> TexAgg;      // 512 texels x (key + fp64 rgb) = 14 KB
+typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces x (key + fp64)       =  3 KB
+typedef LdsAgg<9, 7> FaceAgg;     // 128 faces x (key + fp64 3x3)   = 9.5 KB
 
 struct ShadeArgs {
     const int *p2f; const float *bary; const float *dists;
@@ -20,6 +20,12 @@ struct ShadeArgs {
                // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair;
                // 2 = same, with the bary planes holding (u, v, bitcast(face | map << 20)) for detach_bary passes
     int agg;   // backward: 0 = wave-aggregated global atomics, 1 = LDS hash pre-aggregation
+    // texture-space binning of texel gradients (backward, agg == 0): fragments are appended as 32 B records to the bin of the
+    // 32x32-texel tile their bilinear footprint starts in; dbw_texbin_reduce then accumulates every bin in LDS.  NULL = off.
+    const int *bin_base;   // (M) first bin of each map
+    int *bin_cursor;       // (nbins) append cursors
+    int4 *bin_records;     // (nbins, bin_cap, 2)
+    int bin_cap;
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
 };
 
@@ -28,6 +34,7 @@ struct Sample {   // bilinear footprint of one fragment
     float w00, w01, w10, w11;
     float dudx, dvdy;               // d(ix)/du, d(iy)/dv (0 when clamped at the border)
     float wx0, wx1, wy0, wy1;
+    int r0, c0, r1, c1, ws;         // stored-resolution texel coordinates of the footprint and stored row width
 };
 
 struct Frag {
@@ -172,6 +179,7 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     s.a00 = off + ((long long)r0 * ws + c0) * 3; s.a01 = off + ((long long)r0 * ws + c1) * 3;
     s.a10 = off + ((long long)r1 * ws + c0) * 3; s.a11 = off + ((long long)r1 * ws + c1) * 3;
     s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
+    s.r0 = r0; s.c0 = c0; s.r1 = r1; s.c1 = c1; s.ws = ws;
 }
 
 __device__ __forceinline__ void fetch(const float *maps, const Sample &s, float c[3]) {

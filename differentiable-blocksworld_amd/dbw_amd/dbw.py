@@ -142,6 +142,10 @@ class DifferentiableBlocksWorld(nn.Module):
         reg('_block_face_uvs_all', verts_uvs[faces_uvs].repeat(N, 1, 1).float())
         reg('_block_face_map_all', torch.arange(N).repeat_interleave(self.BNF).to(torch.int32))
         reg('_block_map_desc_all', PackedScene.describe_maps([(TS, TS)] * N, [self.txt_padding] * N, 'cpu')[0])
+        bb, bi, self._bins_per_block = PackedScene.describe_bins([(TS, TS)], 'cpu')
+        bb, bi, _ = PackedScene.describe_bins([(TS, TS)] * N, 'cpu')
+        reg('_block_bin_base', bb)
+        reg('_block_bin_info', bi)
         reg('_block_faces_one', b_f)
 
     def _init_rend_optim(self, **kwargs):          # dbw.py:121-129
@@ -320,8 +324,13 @@ class DifferentiableBlocksWorld(nn.Module):
         F_ = nb * self.BNF
         desc = (self._block_map_desc_all if decim == 1 else self._block_map_desc_dec)[:nb]
         self._blocks_decimated = decim > 1
+        nbins = nb * self._bins_per_block
+        # binned texel-gradient reduction pays when the soft rasteriser produces dense fragments (coarse sigma) on full-resolution
+        # maps; decimated maps use the in-tile LDS hash, the fine phase (sigma 5e-6, ~1 fragment per pixel) plain atomics
+        fine = not self.is_live('coarse_learning')
+        texbins = None if (decim > 1 or fine) else (self._block_bin_base[:nb], self._block_bin_info[:nbins], nbins)
         return PackedScene(verts.reshape(-1, 3), self._block_faces_all[:F_], self._block_face_uvs_all[:F_],
-                           self._block_face_map_all[:F_], desc, maps.reshape(-1))
+                           self._block_face_map_all[:F_], desc, maps.reshape(-1), texbins)
 
     def _shared_randn_like(self, t):
         """Opacity noise (and the overlap samples) must be identical on every data-parallel rank: they are

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+TEXTURE_BINS = True       # full-resolution texel gradients: bin records by 32x32-texel tile and reduce in LDS (vs 12 atomics/fragment)
 UV_FRAGMENTS = True       # detach_bary passes: the forward stores resolved (u, v, face|map) per fragment for the backward
 TILED_FRAGMENTS = True    # fused path keeps its fragments in the 8x8-tile planar layout (coalesced); needs both FUSED_* = True
 FUSED_FORWARD = True      # one kernel for raster + shade + blend (False: the two operator-level kernels)
@@ -169,10 +170,11 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 # The whole Renderer.forward as ONE autograd node: verts/maps/faces_alpha -> (B,4,H,W)
 # ---------------------------------------------------------------------------------------------------------------------
 class RenderCfg:
-    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate')
+    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins')
 
-    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False):
+    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None):
         self.lds_aggregate = lds_aggregate
+        self.texbins = texbins          # (bin_base, bin_info, nbins): texture-space binning of texel gradients when not aggregating
         self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
         self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
@@ -238,10 +240,21 @@ class _RenderScene(torch.autograd.Function):
             fvc = cl['face_verts'].view(-1, 3, 3)
             g_maps, g_alpha = torch.zeros_like(maps), (torch.zeros_like(fa) if fa is not None else None)
             g_fvc = torch.zeros_like(fvc)
+            bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
+            bin_base = cursor = records = None
+            cap = 0
+            if bins is not None and bins[2] > 0:
+                bin_base, bin_info, nbins = bins
+                # room for half of all fragment slots (the measured occupancy is ~20 %), spread evenly over the bins
+                cap = int(min(max(R.shape[0] * cfg.H * cfg.W * cfg.K // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+                cursor = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
+                records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                            (R.shape[0], cfg.H, cfg.W, cfg.K)),
                       _ptr(g_img.contiguous()), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
-                      int(cfg.lds_aggregate), int(ctx.tiled), _stream(fvc))
+                      int(cfg.lds_aggregate), int(ctx.tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, _stream(fvc))
+            if records is not None:
+                _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
             g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp) if need_geom else None
             return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
         if ctx.tiled:

@@ -124,8 +124,9 @@ class PackedScene:
     (F,), map_desc int32 (M,8) = {offset, h, w, pad_left, pad_right, shift, 0, 0} (map stored as (h>>shift, w>>shift, 3)),
     maps: flat fp32 [may require grad]."""
 
-    def __init__(self, verts, faces_i32, face_uvs, face_map, map_desc, maps):
+    def __init__(self, verts, faces_i32, face_uvs, face_map, map_desc, maps, texbins=None):
         self.verts, self.faces, self.face_uvs, self.face_map, self.map_desc, self.maps = verts, faces_i32, face_uvs, face_map, map_desc, maps
+        self.texbins = texbins      # optional (bin_base, bin_info, nbins) from describe_bins
 
     @staticmethod
     def describe_maps(shapes, pads, device, shift=0):
@@ -135,6 +136,20 @@ class PackedScene:
             rows.append([off, h, w, pl, pr, shift, 0, 0])
             off += (h >> shift) * (w >> shift) * 3
         return torch.tensor(rows, dtype=torch.int32, device=device), off
+
+    @staticmethod
+    def describe_bins(shapes, device, shift=0, tile=32):
+        """Texture-space bins (32x32 stored texels) for the binned texel-gradient reduction of the backward pass
+        (include/dbw_hip.h: dbw_render_bwd_fused / dbw_texbin_reduce).  -> (bin_base (M,), bin_info (nbins,4), nbins)."""
+        base, info, off = [], [], 0
+        for h, w in shapes:
+            hs, ws = h >> shift, w >> shift
+            by, bx = (hs + tile - 1) // tile, (ws + tile - 1) // tile
+            base.append(len(info))
+            info += [[off, ws, hs, (ty << 16) | tx] for ty in range(by) for tx in range(bx)]
+            off += hs * ws * 3
+        return (torch.tensor(base, dtype=torch.int32, device=device), torch.tensor(info, dtype=torch.int32, device=device).reshape(-1, 4),
+                len(info))
 
     @staticmethod
     def from_meshes(meshes):

@@ -137,14 +137,24 @@ int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, co
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
  * face_verts_c (the rasteriser's input).  detach_bary != 0 reproduces renderer.py:222-223 (geometry gradient through
- * dists only).  grad_face_verts_c (B*2F,3,3): accumulate. */
+ * dists only).  grad_face_verts_c (B*2F,3,3): accumulate.
+ * Texture-space binning (optional; used when lds_aggregate == 0, i.e. full-resolution maps under minification, where a
+ * 16x16-pixel tile shares no texels but the whole batch hits every texel ~70 times): instead of 12 scattered atomics per
+ * fragment, each fragment appends one 32 B record to the bin of the 32x32-texel tile its footprint starts in
+ * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins) zeroed by the caller; bin_records
+ * nbins*bin_cap*32 bytes); dbw_texbin_reduce then sums every bin in LDS and adds it to grad_maps.  Records that do not fit
+ * (bin overflow, circular-wrap footprints) fall back to atomics, so the result is exact either way.  All NULL / 0 = off. */
 int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                          const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                          const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
                          int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3,
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
-                         int frag_layout, dbw_stream_t stream);
+                         int frag_layout, const int32_t *bin_base, int32_t *bin_cursor, void *bin_records, int bin_cap,
+                         dbw_stream_t stream);
+/* bin_info (nbins,4) int32 = {offset of the bin's map in floats, stored width, stored height, tile_y << 16 | tile_x}. */
+int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap, int nbins,
+                      float *grad_maps, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"

@@ -368,6 +368,30 @@ def test_renderer_class_with_meshes_api_and_viz_purpose():
     assert rel_err(out, ref) < REL
 
 
+def test_texture_space_binning_equals_atomic_scatter(monkeypatch):
+    """Full-resolution maps under minification: the binned (record append + per-bin LDS reduce) texel-gradient path equals the
+    atomic scatter, including circularly wrapped footprints and a deliberately tiny bin capacity (overflow -> atomics)."""
+    m, R, T, Km = _model(seed=29, ts=64, hw=(72, 96), fpp=8)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    pl, pr = m.txt_padding
+    unpadded = [mp[:, pl:mp.shape[1] - pr] for mp in scene['maps']]
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    w = torch.rand(3, 4, 72, 96, generator=torch.Generator().manual_seed(5)).to(DEV)
+    grads = []
+    for binned in (False, True):
+        monkeypatch.setattr(ops, 'TEXTURE_BINS', binned)
+        ps = _packed(dict(scene, maps=unpadded), pads=[(pl, pr)] * len(unpadded))
+        ps.maps.requires_grad_(True)
+        bins = PackedScene.describe_bins([(64, 64)] * len(unpadded), DEV)
+        cfg = ops.RenderCfg(72, 96, 8, 1e-4, 0.001, True, True, scene['faces'].shape[0], lds_aggregate=False, texbins=bins)
+        img = ops.render_scene(ps.verts, ps.maps, None, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        (img * w).sum().backward()
+        grads.append(ps.maps.grad)
+    assert bins[2] == 4 * len(unpadded) and grads[0].abs().max() > 0
+    assert rel_err(grads[1], grads[0]) < 1e-5
+
+
 def test_lds_aggregation_is_equivalent_on_magnified_env_pass():
     m, R, T, Km = _model(seed=17, ts=16)
     with torch.no_grad():
