@@ -135,15 +135,32 @@ __device__ __forceinline__ float point_line_dist(f2 p, f2 a, f2 b) {
     return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
 
+// FAST = true replaces the IEEE divisions by v_rcp_f32 (1 ulp): used by the fused backward only, whose gradients are compared at
+// 1e-4 relative tolerance -- the forward rasteriser keeps the exact arithmetic that decides the face indices.
+template <bool FAST>
+__device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+
+template <bool FAST = false>
 __device__ __forceinline__ void point_line_dist_bwd(f2 p, f2 a, f2 b, float g, f2 &ga, f2 &gb) {
     const float dx = b.x - a.x, dy = b.y - a.y;
     const float t_bot = dx * dx + dy * dy;
     const float t_top = dx * (p.x - a.x) + dy * (p.y - a.y);
-    const float t = t_top / t_bot;
+    const float t = div_<FAST>(t_top, t_bot);
     const float tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
     const float qx = (1.f - tt) * a.x + tt * b.x, qy = (1.f - tt) * a.y + tt * b.y;
     ga.x = g * (1.f - tt) * 2.f * (qx - p.x); ga.y = g * (1.f - tt) * 2.f * (qy - p.y);
     gb.x = g * tt * 2.f * (qx - p.x);         gb.y = g * tt * 2.f * (qy - p.y);
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ float point_line_dist_t(f2 p, f2 a, f2 b) {
+    const float dx = b.x - a.x, dy = b.y - a.y;
+    const float l2 = dx * dx + dy * dy;
+    if (l2 <= DBW_EPS) return (p.x - b.x) * (p.x - b.x) + (p.y - b.y) * (p.y - b.y);
+    const float t = div_<FAST>(dx * (p.x - a.x) + dy * (p.y - a.y), l2);
+    const float tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = a.x + tt * dx, qy = a.y + tt * dy;
+    return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
 
 __device__ __forceinline__ float point_tri_dist(f2 p, f2 v0, f2 v1, f2 v2) {
@@ -154,14 +171,15 @@ __device__ __forceinline__ float point_tri_dist(f2 p, f2 v0, f2 v1, f2 v2) {
     return m < e12 ? m : e12;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ void point_tri_dist_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g, f2 &g0, f2 &g1, f2 &g2) {
-    const float e01 = point_line_dist(p, v0, v1);
-    const float e02 = point_line_dist(p, v0, v2);
-    const float e12 = point_line_dist(p, v1, v2);
+    const float e01 = point_line_dist_t<FAST>(p, v0, v1);
+    const float e02 = point_line_dist_t<FAST>(p, v0, v2);
+    const float e12 = point_line_dist_t<FAST>(p, v1, v2);
     g0.x = g0.y = g1.x = g1.y = g2.x = g2.y = 0.f;
-    if (e01 <= e02 && e01 <= e12) point_line_dist_bwd(p, v0, v1, g, g0, g1);
-    else if (e02 <= e01 && e02 <= e12) point_line_dist_bwd(p, v0, v2, g, g0, g2);
-    else if (e12 <= e01 && e12 <= e02) point_line_dist_bwd(p, v1, v2, g, g1, g2);
+    if (e01 <= e02 && e01 <= e12) point_line_dist_bwd<FAST>(p, v0, v1, g, g0, g1);
+    else if (e02 <= e01 && e02 <= e12) point_line_dist_bwd<FAST>(p, v0, v2, g, g0, g2);
+    else if (e12 <= e01 && e12 <= e02) point_line_dist_bwd<FAST>(p, v1, v2, g, g1, g2);
 }
 
 // ---- wave-level helpers (wave64) ---------------------------------------------------------------------------------

@@ -20,6 +20,9 @@ using namespace dbw;
 
 namespace {
 
+#ifndef DBW_BWD_UNROLL
+#define DBW_BWD_UNROLL 2
+#endif
 constexpr int NT = 256;
 constexpr int TILE = 16;
 
@@ -124,14 +127,24 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
         gr = gi[0]; gg = gi[plane]; gbl = gi[2 * plane]; gA = gi[3 * plane];
     }
+    // pass 0: the deepest layer in which any pixel of this wave holds a fragment.  Only ~20 % of the slots of a soft render are
+    // occupied and most waves see few layers, so both passes stop there instead of walking all K layers (each layer of pass 2
+    // is a dependent load chain).  Exact for any input: no assumption that the occupied slots of a pixel form a prefix.
+    int kmax = 0;
+#pragma unroll 5
+    for (int k = 0; k < A.K; ++k) {
+        const bool occ = in_img && A.p2f[frag_addr(A, n, yi, xi, k).s] >= 0;
+        if (__ballot(occ) != 0ull) kmax = k + 1;
+    }
+    if (!FUSED) kmax = A.K;                 // the unfused kernel writes d/d dists and d/d barycentrics of every slot
     // pass 1 (front to back): alpha and transmittance per layer; no texture access
     {
         float T = 1.f;
 #pragma unroll 5
-        for (int k = 0; k < A.K; ++k) {     // unrolled: the fragment loads of several layers are in flight together
+        for (int k = 0; k < kmax; ++k) {    // unrolled: the fragment loads of several layers are in flight together
             float ak = 0.f;
             Frag fr;
-            const bool valid = in_img && load_frag(A, n, frag_addr(A, n, yi, xi, k), fr);
+            const bool valid = in_img && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
             if (valid) ak = fr.e * fr.fa;
             s_T[k * NT] = T;
             if (BINNED) {
@@ -163,12 +176,12 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     }
     // pass 2 (back to front)
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
-#pragma unroll 2
-    for (int k = A.K - 1; k >= 0; --k) {     // unrolled by 2: the gather chains of two layers overlap
+#pragma unroll DBW_BWD_UNROLL
+    for (int k = kmax - 1; k >= 0; --k) {    // unrolled by 2: the gather chains of two layers overlap
         Frag fr;
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
-        if (in_img) valid = load_frag(A, n, fo, fr);
+        if (in_img) valid = load_frag<FUSED>(A, n, fo, fr);
         const float ak = valid ? fr.e * fr.fa : 0.f, Tk = s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         Vb = (1.f - ak) * Vb;
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
-        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (-1.f / A.sigma);
+        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
         if (!FUSED && gdists && in_img) gdists[pix * A.K + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
@@ -299,18 +312,22 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 const long long o = (pix * A.K + k) * 3;
                 gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
             } else if (valid && (gd != 0.f || gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f)) {
-                // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0)
+                // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0; divisions by v_rcp_f32).
+                // d/d dist is non-zero only outside the triangle (fr.d >= 0), so its sign is +1 and the barycentrics are only
+                // recomputed when a barycentric gradient has to be propagated.
                 const int fc = A.p2f[fo.s];
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
-                const float z0 = q[2], z1 = q[5], z2 = q[8];
-                const f3 bary0 = bary_fwd(pndc, a, b, c);
-                const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
-                const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
-                f2 d0, d1, d2;
-                point_tri_dist_bwd(pndc, a, b, c, (inside ? -1.f : 1.f) * gd, d0, d1, d2);
-                float g9[9] = {d0.x, d0.y, 0.f, d1.x, d1.y, 0.f, d2.x, d2.y, 0.f};
+                float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (gd != 0.f) {
+                    f2 d0, d1, d2;
+                    point_tri_dist_bwd<true>(pndc, a, b, c, gd, d0, d1, d2);
+                    g9[0] = d0.x; g9[1] = d0.y; g9[3] = d1.x; g9[4] = d1.y; g9[6] = d2.x; g9[7] = d2.y;
+                }
                 if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
+                    const float z0 = q[2], z1 = q[5], z2 = q[8];
+                    const f3 bary0 = bary_fwd(pndc, a, b, c);
+                    const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
                     f3 gg{gb[0], gb[1], gb[2]};
                     gg = clip_bwd(bp, gg);
                     float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                     g9[3] += e1.x; g9[4] += e1.y; g9[5] += pz1;
                     g9[6] += e2.x; g9[7] += e2.y; g9[8] += pz2;
                 }
-                face_agg.add(gfv, fc, g9);
+                if (!(A.dbg & 64)) face_agg.add(gfv, fc, g9);     // dbg 64: ablate the face-gradient aggregation (tools/ablate.py)
             }
         }
     }
@@ -412,7 +429,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     DBW_REQUIRE(sigma >= 0.f, "sigma < 0");
     A.p2f = pix_to_face; A.bary = bary; A.dists = dists; A.c2o = c2o; A.code = clip_code; A.cw = clip_w;
     A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;
-    A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma;
+    A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma; A.inv_sigma = sigma > 0.f ? 1.f / sigma : 0.f;
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
     A.dbg = g_dbg_flags;
     A.agg = 0;

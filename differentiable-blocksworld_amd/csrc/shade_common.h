@@ -15,7 +15,7 @@ struct ShadeArgs {
     const int *c2o; const int *code; const float *cw; int Fc_stride;
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
-    int N, H, W, K, F; float sigma; float bg[3];
+    int N, H, W, K, F; float sigma, inv_sigma; float bg[3];
     int tiled; // fragment layout: 0 = (N,H,W,K[,3]) as PyTorch3D returns them; 1, 2 = internal 8x8-tile planar layout of the
                // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair;
                // 2 = same, with the bary planes holding (u, v, bitcast(face | map << 20)) for detach_bary passes
@@ -75,8 +75,11 @@ __device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, con
 }
 
 // geometric alpha from the signed distance + learned per-face opacity (renderer.py:252-260)
+// FAST (fused backward only, gradients are compared at 1e-4): v_exp_f32 and a multiplication by 1/sigma
+template <bool FAST = false>
 __device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) {
     if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
     else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
     fr.fa = 1.f;
     fr.aidx = 0;
@@ -87,6 +90,7 @@ __device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) 
 }
 
 // decode one fragment (clipped face id fc >= 0, clipped barycentrics b, signed distance d)
+template <bool FAST = false>
 __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, const float b[3], float d, Frag &fr) {
     if (A.c2o) {
         fr.j = A.c2o[fc];
@@ -104,7 +108,7 @@ __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, c
     fr.v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
     fr.map = A.face_map[fr.j];
     fr.d = d;
-    frag_alpha(A, n, fr);
+    frag_alpha<FAST>(A, n, fr);
 }
 
 // Addressing of fragment slot k of pixel (n, yi, xi): `s` indexes pix_to_face / dists, `b + c * bstride` the barycentric c.
@@ -131,6 +135,7 @@ __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi,
 }
 
 // fetch + decode one fragment slot from memory; returns false for empty slots
+template <bool FAST = false>
 __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragAddr &o, Frag &fr) {
     const int fc = A.p2f[o.s];
     if (fc < 0) return false;
@@ -143,12 +148,21 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
         fr.map = jm >> 20;
         fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
         fr.d = A.dists[o.s];
-        frag_alpha(A, n, fr);
+        frag_alpha<FAST>(A, n, fr);
         return true;
     }
     const float b[3] = {A.bary[o.b], A.bary[o.b + o.bstride], A.bary[o.b + 2 * o.bstride]};
-    decode_frag(A, n, fc, b, A.dists[o.s], fr);
+    decode_frag<FAST>(A, n, fc, b, A.dists[o.s], fr);
     return true;
+}
+
+// c mod w for c in [-pad_left, w + pad_right): one conditional add/subtract when the pads do not exceed the width (the integer
+// modulo is ~25 instructions), the general form otherwise
+__device__ __forceinline__ int wrap_col(int c, int w) {
+    if (c < 0) c += w;
+    if (c >= w) c -= w;
+    if ((unsigned)c >= (unsigned)w) { c %= w; if (c < 0) c += w; }
+    return c;
 }
 
 // grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
@@ -170,8 +184,7 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     s.wx1 = ix - fx; s.wx0 = 1.f - s.wx1;
     s.wy1 = iy - fy; s.wy0 = 1.f - s.wy1;
     // padded column -> source column (circular pad), flipped row -> source row
-    int c0 = (x0 - pl) % w; if (c0 < 0) c0 += w;
-    int c1 = (x1 - pl) % w; if (c1 < 0) c1 += w;
+    int c0 = wrap_col(x0 - pl, w), c1 = wrap_col(x1 - pl, w);
     // stored resolution = (h >> sh, w >> sh): a decimated map (avg_pool d + nearest upsample, dbw.py:276-278,331-334) is
     // kept at cell resolution and the nearest upsampling is this shift
     const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;

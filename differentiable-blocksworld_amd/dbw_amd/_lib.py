@@ -60,7 +60,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} not found: run `python differentiable-blocksworld_amd/build.py` '
                            '(there is no CPU fallback for the render path)')
-    lib = ctypes.CDLL(LIB_PATH)
+    # DBW_HIP_LIB: load an alternative build of the same sources (tools/variants.sh, kernel tuning sweeps)
+    lib = ctypes.CDLL(os.environ.get('DBW_HIP_LIB') or LIB_PATH)
     lib.dbw_last_error.restype = ctypes.c_char_p
     lib.dbw_abi_version.restype = c_i
     lib.dbw_rasterize_workspace_bytes.restype = c_sz
