@@ -97,7 +97,7 @@ def kernel_breakdown(model, inp, reps=5):
         cap = 0
         if bins is not None:                                               # same sizing as ops._RenderScene.backward
             nbins = bins[2]
-            cap = int(min(max(B * H * W * K // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+            cap = ops.texbin_capacity(B, H, W, K, nbins)
             cursor_t = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
             records_t = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             bin_base, cursor, records = bins[0].data_ptr(), cursor_t.data_ptr(), records_t.data_ptr()

@@ -6,7 +6,10 @@
 
 namespace dbw {
 
-typedef LdsAgg<3, 9> TexAgg;      // 512 texels x (key + fp64 rgb) = 14 KB
+#ifndef DBW_TEX_LOG2
+#define DBW_TEX_LOG2 9
+#endif
+typedef LdsAgg<3, DBW_TEX_LOG2> TexAgg;      // 512 texels x (key + fp64 rgb) = 14 KB
 typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces x (key + fp64)       =  3 KB
 typedef LdsAgg<9, 7> FaceAgg;     // 128 faces x (key + fp64 3x3)   = 9.5 KB
 

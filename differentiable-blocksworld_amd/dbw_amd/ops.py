@@ -245,8 +245,7 @@ class _RenderScene(torch.autograd.Function):
             cap = 0
             if bins is not None and bins[2] > 0:
                 bin_base, bin_info, nbins = bins
-                # room for half of all fragment slots (the measured occupancy is ~20 %), spread evenly over the bins
-                cap = int(min(max(R.shape[0] * cfg.H * cfg.W * cfg.K // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+                cap = texbin_capacity(R.shape[0], cfg.H, cfg.W, cfg.K, nbins)
                 cursor = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
                 records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
@@ -272,6 +271,12 @@ class _RenderScene(torch.autograd.Function):
         elif need_geom:
             g_verts = torch.zeros_like(verts)
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
+
+
+def texbin_capacity(B, H, W, K, nbins):
+    """Records per texture bin: room for max(K/2, 2) fragments per pixel spread evenly over the bins (a soft K-layer render
+    fills ~20 % of its slots, a hard 1-layer render all of them; what does not fit falls back to atomics), at most 1 GiB."""
+    return int(min(max(B * H * W * max(K, 4) // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
 
 
 def render_scene(verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):

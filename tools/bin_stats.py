@@ -25,7 +25,7 @@ fvc = cl['face_verts'].view(-1, 3, 3)
 p2f, bary, dists, img = ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, 2)
 g_img = torch.rand_like(img); g_maps, g_fvc, g_alpha = torch.zeros_like(maps), torch.zeros_like(fvc), torch.zeros_like(alpha)
 bins = scene.texbins; nbins = bins[2]
-cap = int(min(max(B * H * W * K // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+cap = ops.texbin_capacity(B, H, W, K, nbins)
 cursor = torch.zeros(nbins, dtype=torch.int32, device=dev); records = torch.zeros(nbins * cap * 8, dtype=torch.int32, device=dev)
 _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
           cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
