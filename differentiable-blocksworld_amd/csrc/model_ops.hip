@@ -352,7 +352,69 @@ __global__ void overlap_finish_kernel(const float *sq_eps, const float *S, const
     if (g_alpha) g_alpha[j] += ws[j * NG + 17];
 }
 
+// ---- block opacities (dbw.py:297-311) and the parsimony regulariser (dbw.py:373-377) ------------------------------
+// One launch replaces the chain randn*s + logit -> sigmoid -> clone -> sigmoid(logit) > thresh -> mask multiply.
+__global__ void block_alpha_fwd_kernel(const float *logit, const float *noise, float noise_scale, float thresh, int Kb,
+                                       float *alpha, float *alpha_full, int *keep) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Kb) return;
+    const float x = logit[j] + (noise ? noise_scale * noise[j] : 0.f);
+    const float a = 1.f / (1.f + expf(-x));
+    alpha[j] = a;
+    int m = 1;
+    if (thresh >= 0.f) m = (1.f / (1.f + expf(-logit[j]))) > thresh ? 1 : 0;     // the mask looks at the noise-free opacity
+    alpha_full[j] = m ? a : 0.f;
+    if (keep) keep[j] = m;
+}
+
+__global__ void block_alpha_bwd_kernel(const float *alpha, const int *keep, const float *g_alpha, const float *g_alpha_full,
+                                       int Kb, float *g_logit) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Kb) return;
+    const float a = alpha[j];
+    float g = g_alpha ? g_alpha[j] : 0.f;
+    if (g_alpha_full && (!keep || keep[j])) g += g_alpha_full[j];
+    g_logit[j] = g * a * (1.f - a);
+}
+
+// loss += scale * mean(max(x, eps)^0.5); grad += scale * 0.5 / sqrt(x) / n where x > eps (clamp has no gradient below)
+__global__ void sqrt_mean_kernel(const float *x, int n, float eps, float scale, float *loss, float *grad) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = x[i], c = v > eps ? v : eps, r = sqrtf(c);
+        acc += r;
+        if (grad && v > eps) grad[i] += scale * 0.5f / r / (float)n;
+    }
+    acc = dbw::wave_sum(acc);
+    if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, scale * acc / (float)n);
+}
+
 }  // namespace
+
+extern "C" int dbw_block_alpha_fwd(const float *alpha_logit, const float *noise, float noise_scale, float mask_threshold, int Kb,
+                                   float *alpha, float *alpha_full, int32_t *keep, dbw_stream_t stream) {
+    DBW_REQUIRE(alpha_logit && alpha && alpha_full, "null pointer");
+    DBW_REQUIRE(Kb > 0, "bad size");
+    hipLaunchKernelGGL(block_alpha_fwd_kernel, dim3((Kb + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha_logit, noise, noise_scale,
+                       mask_threshold, Kb, alpha, alpha_full, keep);
+    return dbw_check_launch("block_alpha_fwd_kernel");
+}
+
+extern "C" int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, const float *g_alpha_full, int Kb,
+                                   float *g_logit, dbw_stream_t stream) {
+    DBW_REQUIRE(alpha && g_logit, "null pointer");
+    DBW_REQUIRE(Kb > 0, "bad size");
+    hipLaunchKernelGGL(block_alpha_bwd_kernel, dim3((Kb + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha, keep, g_alpha, g_alpha_full,
+                       Kb, g_logit);
+    return dbw_check_launch("block_alpha_bwd_kernel");
+}
+
+extern "C" int dbw_sqrt_mean(const float *x, int n, float eps, float scale, float *loss, float *grad, dbw_stream_t stream) {
+    DBW_REQUIRE(x && (loss || grad), "null pointer");
+    DBW_REQUIRE(n > 0, "bad size");
+    hipLaunchKernelGGL(sqrt_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, n, eps, scale, loss, grad);
+    return dbw_check_launch("sqrt_mean_kernel");
+}
 
 extern "C" int dbw_sq_blocks_fwd(const float *sq_eps, const float *S, const float *R6, const float *T, const float *trig,
                                  const int32_t *keep, int dense, int Kb, int nv, float ratio, float scale_min, float S_world,

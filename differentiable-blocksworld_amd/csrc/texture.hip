@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NT) void composite_mse_kernel(const float *__restri
     __shared__ float s_red[NT / DBW_WAVE];
     const long long total = (long long)N * plane;
     float part = 0.f;
+    const float loss_scale = scale;
     if (scale_dev) scale *= scale_dev[0];
     for (long long i0 = (long long)blockIdx.x * NT; i0 < total; i0 += (long long)gridDim.x * NT) {
         const long long i = i0 + threadIdx.x;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NT) void composite_mse_kernel(const float *__restri
         }
     }
     const float tot = block_sum(part, s_red);
-    if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, tot);
+    if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, tot * loss_scale);
 }
 
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,

@@ -30,6 +30,9 @@ OVERLAP_N_BLOCKS = 1.95        # dbw.py:34
 OVERLAP_TEMPERATURE = 0.005    # dbw.py:35
 
 
+_FUSED_SLOT = {'rgb': 0, 'parsimony': 1, 'tv': 2, 'overlap': 3}      # ops.fused_losses output layout
+
+
 def safe_pow(t, exponent, eps=1e-6):      # utils/pytorch.py:35-36
     return t.clamp(eps).pow(exponent)
 
@@ -294,24 +297,23 @@ class DifferentiableBlocksWorld(nn.Module):
         """build_blocks(filter_transparent, as_scene=True) (dbw.py:297-346) as a PackedScene, or None if no block is left.
         Sets self._alpha (live blocks), self._alpha_full, self._blocks_maps like the reference."""
         coarse = self.training and self.is_live('coarse_learning')
+        noise, noise_scale = None, 0.0
         if self.opacity_noise and coarse:
             noise = self._noise_override if self._noise_override is not None else self._shared_randn_like(self.alpha_logit)
-            alpha_logit = self.alpha_logit + self.opacity_noise * noise
-        else:
-            alpha_logit = self.alpha_logit
-        self._alpha = torch.sigmoid(alpha_logit)
-        self._alpha_full = self._alpha.clone()
+            noise_scale = float(self.opacity_noise)
+        masked = filter_transparent or self.kill_blocks
+        thresh = (0.5 if filter_transparent else 0.01) if masked else -1.0
+        # sigmoid(alpha_logit + noise), the transparency mask on the noise-free opacity and alpha * mask: one launch
+        self._alpha, self._alpha_full, mask_i32 = ops.block_alpha(self.alpha_logit, noise, noise_scale, thresh)
         keep, nb = None, self.n_blocks
-        if filter_transparent or self.kill_blocks:
-            mask = torch.sigmoid(self.alpha_logit) > (0.5 if filter_transparent else 0.01)
-            self._alpha_full = self._alpha_full * mask
+        if masked:
             if self.sync_free:
-                keep = mask.to(torch.int32)
+                keep = mask_i32
             else:
-                nb = int(mask.sum().item())                          # same host sync as dbw.py:322
+                nb = int(mask_i32.sum().item())                      # same host sync as dbw.py:322
                 if nb < self.n_blocks:
-                    keep = mask.to(torch.int32)
-                    self._alpha = self._alpha[mask]
+                    keep = mask_i32
+                    self._alpha = self._alpha[mask_i32.bool()]
         decim = self.decim_factor if (coarse and self.is_live('decimate_txt')) else 1
         maps_all, self._blocks_maps = ops.texture_prep(self.textures, decim)
         self._keep_mask = keep
@@ -325,10 +327,9 @@ class DifferentiableBlocksWorld(nn.Module):
         desc = (self._block_map_desc_all if decim == 1 else self._block_map_desc_dec)[:nb]
         self._blocks_decimated = decim > 1
         nbins = nb * self._bins_per_block
-        # binned texel-gradient reduction pays when the soft rasteriser produces dense fragments (coarse sigma) on full-resolution
-        # maps; decimated maps use the in-tile LDS hash, the fine phase (sigma 5e-6, ~1 fragment per pixel) plain atomics
-        fine = not self.is_live('coarse_learning')
-        texbins = None if (decim > 1 or fine) else (self._block_bin_base[:nb], self._block_bin_info[:nbins], nbins)
+        # full-resolution maps: texel gradients go through the texture-space bins (coarse phase 8.6 -> 4.2 ms/step, fine phase
+        # 3.1 -> 2.8 ms/step on the bench config); decimated maps use the in-tile LDS hash
+        texbins = None if decim > 1 else (self._block_bin_base[:nb], self._block_bin_info[:nbins], nbins)
         return PackedScene(verts.reshape(-1, 3), self._block_faces_all[:F_], self._block_face_uvs_all[:F_],
                            self._block_face_map_all[:F_], desc, maps.reshape(-1), texbins)
 
@@ -385,28 +386,54 @@ class DifferentiableBlocksWorld(nn.Module):
         return self.compute_losses(inp['imgs'], None, layers=(fg, env))
 
     # ------------------------------------------------------------------------------------------------ losses (dbw.py:361-408)
+    def _perceptual_term(self, imgs, rec, coarse):
+        if self.perceptual_fn is None:
+            raise RuntimeError('perceptual_weight > 0 needs model.set_perceptual(fn): lpips is a third-party network '
+                               'outside the HIP path (SURVEY.md 8a A10)')
+        return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * self.perceptual_fn(imgs, rec)
+
     def compute_losses(self, imgs, rec, layers=None):
         w = self.loss_weights
         dev = imgs.device
-        losses = {k: torch.zeros((), device=dev) for k in w}          # (fill kernel: hipGraph-capturable, unlike an H2D copy)
         coarse = self.is_live('coarse_learning')
         ws = self.world_size
-        if 'rgb' in losses:
-            if layers is not None:   # fused composite + MSE; count = elements of the GLOBAL batch under view sharding
-                count = imgs.numel() if getattr(self, '_global_count', None) is None else self._global_count
-                losses['rgb'] = w['rgb'] * ops.composite_mse(layers[0], layers[1], imgs, count)
-            else:
-                losses['rgb'] = w['rgb'] * F.mse_loss(imgs, rec)
-        if 'perceptual' in losses:
-            if self.perceptual_fn is None:
-                raise RuntimeError('perceptual_weight > 0 needs model.set_perceptual(fn): lpips is a third-party network '
-                                   'outside the HIP path (SURVEY.md 8a A10)')
-            if rec is None:
-                rec = ops.composite(*layers)
-            losses['perceptual'] = w['perceptual'] * (1 if coarse else 0.1) * self.perceptual_fn(imgs, rec)
         # view-independent regularisers: every rank computes them identically; scaled by 1/world_size so that the
         # sum all-reduce of gradients counts them once
         rs = 1.0 / ws
+        if layers is not None and 'rgb' in w:
+            # training path: composite + MSE and the regularisers as ONE autograd node (ops.fused_losses); factors of
+            # dbw.py:373-405: parsimony and overlap only act in the coarse phase, tv is scaled by 0.1 afterwards (and the
+            # ground map once more)
+            count = imgs.numel() if getattr(self, '_global_count', None) is None else self._global_count
+            tv_f = 1 if coarse else 0.1
+            cfg = {'rgb': float(w['rgb']), 'count': float(count),
+                   'parsimony': float(w['parsimony']) * rs if ('parsimony' in w and coarse) else None,
+                   'tv': float(w['tv']) * tv_f * rs if 'tv' in w else None, 'tv_ground_factor': tv_f,
+                   'overlap': float(w['overlap']) * rs if ('overlap' in w and coarse) else None,
+                   'overlap_consts': (float(self.ratio_block_scene), float(self.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS)}
+            u = None
+            if cfg['overlap']:
+                u = self._overlap_u_override
+                if u is None:
+                    u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev)
+            vals = ops.fused_losses(layers[0], layers[1], imgs, self._alpha_full, self._bkg_maps, self._blocks_maps, self._ground_maps,
+                                    self.sq_eps, self.S, self.R_6d, self.T, u, cfg)
+            losses = {}
+            for k in w:
+                if k in _FUSED_SLOT:
+                    losses[k] = vals[_FUSED_SLOT[k]]
+            total = vals.sum()
+            if 'perceptual' in w:
+                losses['perceptual'] = self._perceptual_term(imgs, ops.composite(*layers), coarse)
+                total = total + losses['perceptual']
+            losses = {k: losses[k] for k in w}
+            losses['total'] = total
+            return losses
+        losses = {k: torch.zeros((), device=dev) for k in w}          # (fill kernel: hipGraph-capturable, unlike an H2D copy)
+        if 'rgb' in losses:
+            losses['rgb'] = w['rgb'] * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
+        if 'perceptual' in losses:
+            losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse)
         if 'parsimony' in losses:
             factor = 1 if coarse else 0
             alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()

@@ -25,6 +25,49 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class ZeroArena:
+    """Per-step pool of zero-initialised scratch (gradient accumulators, cursors, workspaces).  An iteration used to issue ~30
+    `fill` launches of a few microseconds each for them; with the arena enabled they are carved out of one buffer that
+    `begin_step()` clears with a single launch.  Opt-in (ShardedTrainStep enables it): a tensor handed out is only valid until
+    the next begin_step(), which is safe when the parameters' .grad buffers are preallocated (gradients are accumulated into
+    them and nothing of the arena outlives the step) but not for callers that let autograd keep the returned gradient."""
+
+    def __init__(self):
+        self.enabled = False
+        self.buf, self.off, self.want = {}, {}, {}
+
+    def begin_step(self, device):
+        if not self.enabled:
+            return
+        used, want = self.off.get(device, 0), self.want.get(device, 0)
+        buf = self.buf.get(device)
+        if buf is None or want > buf.numel():
+            self.buf[device] = torch.zeros(max(int(want * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        elif used:
+            buf[:used].zero_()
+        self.off[device], self.want[device] = 0, 0
+
+    def zeros(self, shape, dtype, device):
+        device = torch.device(device)
+        if isinstance(shape, int):
+            shape = (shape,)
+        n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        n_al = (n + 255) & ~255
+        if self.enabled:
+            self.want[device] = self.want.get(device, 0) + n_al
+            buf, off = self.buf.get(device), self.off.get(device, 0)
+            if buf is not None and off + n_al <= buf.numel():
+                self.off[device] = off + n_al
+                return buf[off:off + n].view(dtype).view(shape)
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+    def zeros_like(self, t):
+        return self.zeros(tuple(t.shape), t.dtype, t.device)
+
+
+ARENA = ZeroArena()
+
+
 def _bg_ptr(bg):
     """background colour: HOST pointer to 3 floats (include/dbw_hip.h) -- a ctypes array kept alive by the caller."""
     return 0 if bg is None else ctypes.cast(bg, ctypes.c_void_p).value
@@ -127,7 +170,7 @@ def project_clip(verts, faces_i32, R, T, Kmat, eps=1e-8, z_clip=0.001, perspecti
 
 def project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_face_verts, eps=1e-8, z_clip=0.001, perspective_correct=True):
     B, V, F_ = R.shape[0], verts.shape[0], faces_i32.shape[0]
-    g = torch.zeros_like(verts)
+    g = ARENA.zeros_like(verts)
     _lib.call('dbw_project_clip_bwd', _ptr(verts), _ptr(faces_i32), _ptr(R), _ptr(T), _ptr(Kmat), B, V, F_, float(eps),
               float(z_clip or 0.0), int(perspective_correct), _ptr(cl['num_faces']), _ptr(cl['c2o']), _ptr(cl['clip_code']),
               _ptr(cl['clip_w']), _ptr(g_face_verts), _ptr(g), _stream(verts))
@@ -238,15 +281,15 @@ class _RenderScene(torch.autograd.Function):
         want_bary = need_geom and not cfg.detach_bary
         if FUSED_BACKWARD and (ctx.tiled or (need_geom and (want_dists or want_bary))):
             fvc = cl['face_verts'].view(-1, 3, 3)
-            g_maps, g_alpha = torch.zeros_like(maps), (torch.zeros_like(fa) if fa is not None else None)
-            g_fvc = torch.zeros_like(fvc)
+            g_maps, g_alpha = ARENA.zeros_like(maps), (ARENA.zeros_like(fa) if fa is not None else None)
+            g_fvc = ARENA.zeros_like(fvc)
             bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
             bin_base = cursor = records = None
             cap = 0
             if bins is not None and bins[2] > 0:
                 bin_base, bin_info, nbins = bins
                 cap = texbin_capacity(R.shape[0], cfg.H, cfg.W, cfg.K, nbins)
-                cursor = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
+                cursor = ARENA.zeros(nbins, torch.int32, fvc.device)
                 records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                            (R.shape[0], cfg.H, cfg.W, cfg.K)),
@@ -370,7 +413,7 @@ class _SqBlocks(torch.autograd.Function):
         ratio, scale_min, S_world, has_keep, dense = ctx.consts
         keep = keep if has_keep else None
         Kb, nv = trig.shape[1], trig.shape[2]
-        gs = [torch.zeros_like(t) for t in (sq_eps, S, R6, T)]
+        gs = [ARENA.zeros_like(t) for t in (sq_eps, S, R6, T)]
         _lib.call('dbw_sq_blocks_bwd', _ptr(sq_eps), _ptr(S), _ptr(R6), _ptr(T), _ptr(trig), _ptr(keep), int(dense), Kb, nv, ratio, scale_min,
                   S_world, _ptr(Rw), _ptr(g_verts.contiguous()), *[_ptr(g) for g in gs], _stream(trig))
         return gs[0], gs[1], gs[2], gs[3], None, None, None, None
@@ -390,7 +433,7 @@ class _PosedMesh(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         r6, t, base, Rw = ctx.saved_tensors
-        g6, gt = torch.zeros_like(r6), torch.zeros_like(t)
+        g6, gt = ARENA.zeros_like(r6), ARENA.zeros_like(t)
         _lib.call('dbw_posed_mesh_bwd', _ptr(base), base.shape[0], _ptr(r6), _ptr(t), ctx.S_world, _ptr(Rw), _ptr(g.contiguous()),
                   _ptr(g6), _ptr(gt), _stream(base))
         return g6, gt, None, None, None, None
@@ -414,7 +457,7 @@ class _CompositeMSE(torch.autograd.Function):
         _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, 1.0 / count, 0, 0, _ptr(loss), 0, 0, _stream(fg))
         ctx.save_for_backward(fg_c, env_c, imgs)
         ctx.count = count
-        return loss[0] / count
+        return loss[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -505,6 +548,117 @@ class _Overlap(torch.autograd.Function):
 def overlap_loss(sq_eps, S, R6, T, alpha, u, ratio, scale_min, temperature=0.005, n_blocks=1.95):
     """dbw.py:389-405.  u (Kb,npts,3) uniform samples in [0,1)."""
     return _Overlap.apply(sq_eps, S, R6, T, alpha, _chk(u, torch.float32, 'u'), (float(ratio), float(scale_min), float(temperature), float(n_blocks)))
+
+
+class _BlockAlpha(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, noise, noise_scale, thresh):
+        lg = _chk(logit.detach(), torch.float32, 'alpha_logit')
+        Kb = lg.numel()
+        alpha, alpha_full = torch.empty_like(lg), torch.empty_like(lg)
+        keep = torch.empty(Kb, dtype=torch.int32, device=lg.device)
+        nz = None if noise is None else _chk(noise, torch.float32, 'noise')
+        _lib.call('dbw_block_alpha_fwd', _ptr(lg), _ptr(nz), float(noise_scale), float(thresh), Kb, _ptr(alpha), _ptr(alpha_full),
+                  _ptr(keep), _stream(lg))
+        ctx.save_for_backward(alpha, keep)
+        ctx.mark_non_differentiable(keep)
+        return alpha, alpha_full, keep
+
+    @staticmethod
+    def backward(ctx, g_a, g_af, _):
+        alpha, keep = ctx.saved_tensors
+        g = torch.empty_like(alpha)
+        _lib.call('dbw_block_alpha_bwd', _ptr(alpha), _ptr(keep), _ptr(None if g_a is None else g_a.contiguous()),
+                  _ptr(None if g_af is None else g_af.contiguous()), alpha.numel(), _ptr(g), _stream(alpha))
+        return g, None, None, None
+
+
+def block_alpha(alpha_logit, noise=None, noise_scale=0.0, mask_threshold=-1.0):
+    """alpha = sigmoid(alpha_logit + noise_scale*noise); keep = sigmoid(alpha_logit) > mask_threshold (all ones when
+    mask_threshold < 0); alpha_full = alpha * keep  (dbw.py:297-311) -> (alpha, alpha_full, keep int32) in one launch."""
+    return _BlockAlpha.apply(alpha_logit, noise, float(noise_scale), float(mask_threshold))
+
+
+class _FusedLosses(torch.autograd.Function):
+    """[w_rgb * MSE(composite), parsimony, tv, overlap] as one autograd node: every term is a kernel that produces its value
+    and its gradient in the same pass, the weights are folded into the kernels' scale arguments and all four values land in
+    one 4-float tensor -- instead of ~45 scalar-sized torch launches (fills, weight multiplications, sums and their autograd
+    mirrors).  A term whose weight is None / 0 is skipped (its slot stays 0 and it sends no gradient)."""
+
+    @staticmethod
+    def forward(ctx, fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg):
+        dev = fg.device
+        out = torch.zeros(4, dtype=torch.float32, device=dev)
+        fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
+        imgs = _chk(imgs, torch.float32, 'imgs')
+        N, _, H, W = fg_c.shape
+        ctx.rgb_scale = cfg['rgb'] / cfg['count']
+        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, ctx.rgb_scale, 0, 0, _ptr(out), 0, 0, _stream(fg_c))
+        saved = [fg_c, env_c, imgs]
+        ctx.n_tv = 0
+        g_alpha_p = g_alpha_o = None
+        if cfg.get('parsimony') and alpha_full is not None:
+            a = _chk(alpha_full.detach(), torch.float32, 'alpha')
+            g_alpha_p = ARENA.zeros_like(a)
+            _lib.call('dbw_sqrt_mean', _ptr(a), a.numel(), 1e-6, float(cfg['parsimony']), _ptr(out) + 4, _ptr(g_alpha_p), _stream(a))
+        tv_grads = []
+        for maps, wrap, scale in ((bkg_maps, False, cfg.get('tv')), (blocks_maps, True, cfg.get('tv')),
+                                  (ground_maps, False, (cfg.get('tv') or 0.0) * cfg.get('tv_ground_factor', 1.0))):
+            if scale and maps is not None:
+                m = _chk(maps.detach(), torch.float32, 'maps')
+                n, h, w, _ = m.shape
+                g = torch.empty_like(m)
+                _lib.call('dbw_tv_l2sq', _ptr(m), n, h, w, int(wrap), float(scale), _ptr(out) + 8, _ptr(g), _stream(m))
+                tv_grads.append(g)
+            else:
+                tv_grads.append(None)
+        ov_grads = [None] * 4
+        if cfg.get('overlap') and u is not None:
+            ratio, scale_min, temp, thresh = cfg['overlap_consts']
+            args = [_chk(t.detach(), torch.float32, 'overlap param') for t in (sq_eps, S, R6, T, alpha_full)]
+            Kb, npts = u.shape[0], u.shape[1]
+            gs = [ARENA.zeros_like(t) for t in args]
+            ws = ARENA.zeros(Kb * 18, torch.float32, dev)
+            _lib.call('dbw_overlap_loss', _ptr(u), npts, *[_ptr(a) for a in args], Kb, ratio, scale_min, temp, thresh, float(cfg['overlap']),
+                      _ptr(out) + 12, *[_ptr(g) for g in gs], _ptr(ws), _stream(u))
+            ov_grads, g_alpha_o = gs[:4], gs[4]
+        ctx.save_for_backward(*saved)
+        ctx.grads = (g_alpha_p, tv_grads, ov_grads, g_alpha_o)
+        ctx.count = cfg['count']
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        fg, env, imgs = ctx.saved_tensors
+        g_alpha_p, tv_grads, ov_grads, g_alpha_o = ctx.grads
+        ctx.grads = None
+        go = go.detach().to(torch.float32).contiguous()
+        N, _, H, W = fg.shape
+        g_fg = g_env = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g_fg, g_env = torch.empty_like(fg), torch.empty_like(env)
+            _lib.call('dbw_composite_mse', _ptr(fg), _ptr(env), _ptr(imgs), N, H, W, ctx.rgb_scale, _ptr(go), 0, 0, _ptr(g_fg), _ptr(g_env),
+                      _stream(fg))
+        # the saved gradients assume an upstream gradient of 1 per slot: scale each group by its slot's gradient (one
+        # multi-tensor launch per group)
+        tv = [g for g in tv_grads if g is not None]
+        if tv:
+            torch._foreach_mul_(tv, go[2])
+        ov = [g for g in list(ov_grads) + [g_alpha_o] if g is not None]
+        if ov:
+            torch._foreach_mul_(ov, go[3])
+        g_alpha = g_alpha_o
+        if g_alpha_p is not None:
+            g_alpha = torch.addcmul(g_alpha_o, g_alpha_p, go[1]) if g_alpha_o is not None else g_alpha_p * go[1]
+        return (g_fg, g_env, None, g_alpha, tv_grads[0], tv_grads[1], tv_grads[2], ov_grads[0], ov_grads[1], ov_grads[2], ov_grads[3],
+                None, None)
+
+
+def fused_losses(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg):
+    """-> (4,) tensor [rgb, parsimony, tv, overlap], each already multiplied by its weight (dbw.py:361-408).
+    cfg: {'rgb': w, 'count': elements of the global batch, 'parsimony': w|None, 'tv': w|None, 'tv_ground_factor': f,
+          'overlap': w|None, 'overlap_consts': (ratio, scale_min, temperature, n_blocks)}."""
+    return _FusedLosses.apply(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg)
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):

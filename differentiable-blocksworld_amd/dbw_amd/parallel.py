@@ -94,9 +94,16 @@ class ShardedTrainStep:
         if self.use_graph and self.n_steps >= self.graph_warmup:
             losses = self._graph_iteration(inp)
         else:
-            self.params.zero_grad()
-            losses = self.model(inp, labels)
-            losses['total'].backward()
+            # gradients accumulate into the preallocated flat buffer, so nothing carved out of the zero arena outlives the
+            # iteration: all zero-initialised scratch of the step comes from one buffer cleared by one launch
+            ops.ARENA.enabled = True
+            try:
+                ops.ARENA.begin_step(self.params.flat.device)
+                self.params.zero_grad()
+                losses = self.model(inp, labels)
+                losses['total'].backward()
+            finally:
+                ops.ARENA.enabled = False
             losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
         if self.world_size > 1:
             dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)     # RCCL over xGMI, in place

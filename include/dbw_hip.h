@@ -194,8 +194,21 @@ int dbw_posed_mesh_bwd(const float *base, int nv, const float *R6, const float *
                        const float *R_world, const float *grad_verts, float *g_R6, float *g_T, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Block opacities (dbw.py:297-311): alpha = sigmoid(alpha_logit + noise_scale*noise) (noise may be NULL);
+ * keep = sigmoid(alpha_logit) > mask_threshold (the filter_transparent / kill_blocks mask; mask_threshold < 0: keep all);
+ * alpha_full = alpha * keep.  All (Kb).  keep may be NULL.
+ * bwd: g_logit = (g_alpha + keep * g_alpha_full) * alpha * (1 - alpha); g_alpha / g_alpha_full may be NULL. */
+int dbw_block_alpha_fwd(const float *alpha_logit, const float *noise, float noise_scale, float mask_threshold, int Kb,
+                        float *alpha, float *alpha_full, int32_t *keep, dbw_stream_t stream);
+int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, const float *g_alpha_full, int Kb,
+                        float *g_logit, dbw_stream_t stream);
+/* Parsimony (dbw.py:373-377, utils/pytorch.py:35 safe_pow): loss += scale * mean(clamp(x, eps)^0.5) over n values;
+ * grad (n, may be NULL) accumulates d loss / d x (zero where x <= eps). */
+int dbw_sqrt_mean(const float *x, int n, float eps, float scale, float *loss, float *grad, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Decoupled composite + MSE, forward and backward in one pass (dbw.py:223, 366-367):
- *   rec = fg_rgb*mask + (1-mask)*env_rgb ; loss_sum += sum((imgs-rec)^2)
+ *   rec = fg_rgb*mask + (1-mask)*env_rgb ; loss_sum += scale * sum((imgs-rec)^2)
  *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) are d(s*sum)/d(.) with s = scale * (scale_dev ? *scale_dev : 1)
  *   (scale = weight/count from the host, scale_dev = the upstream gradient scalar living on the device).
  * fg (N,4,H,W) premultiplied RGB + mask, env (N,4,H,W), imgs (N,3,H,W), rec (N,3,H,W) or NULL,

@@ -135,6 +135,63 @@ def test_composite_mse_and_composite():
     assert rel_err(ah.grad, a.grad) < REL
 
 
+def test_block_alpha_matches_torch():
+    torch.manual_seed(0)
+    logit, noise = torch.randn(12), torch.randn(12)
+    for thresh in (-1.0, 0.5, 0.01):
+        l_ref = logit.clone().requires_grad_(True)
+        a = torch.sigmoid(l_ref + 0.3 * noise)
+        mask = (torch.sigmoid(l_ref) > thresh) if thresh >= 0 else torch.ones(12, dtype=torch.bool)
+        af = a * mask
+        w1, w2 = torch.rand(12), torch.rand(12)
+        ((a * w1).sum() + (af * w2).sum()).backward()
+        l_h = logit.to(DEV).requires_grad_(True)
+        ah, afh, keep = ops.block_alpha(l_h, noise.to(DEV), 0.3, thresh)
+        ((ah * w1.to(DEV)).sum() + (afh * w2.to(DEV)).sum()).backward()
+        assert torch.equal(keep.cpu().bool(), mask)
+        assert rel_err(ah, a) < 1e-6 and rel_err(afh, af) < 1e-6 and rel_err(l_h.grad, l_ref.grad) < REL
+
+
+def test_fused_losses_equal_the_operator_level_losses():
+    """ops.fused_losses (one autograd node, weights folded into the kernels) against the separately tested operator-level
+    losses combined with torch arithmetic, values and every gradient, with a non-trivial upstream gradient per term."""
+    torch.manual_seed(1)
+    Kb = 4
+    mk = lambda *s: torch.rand(*s, device=DEV)
+    base = dict(fg=mk(2, 4, 9, 11), env=mk(2, 4, 9, 11), alpha=mk(Kb) * 0.9 + 0.05, bkg=mk(1, 16, 16, 3), blk=mk(Kb, 8, 12, 3),
+                gnd=mk(1, 16, 16, 3), sq_eps=mk(Kb, 2) * 0.5, S=mk(Kb, 3) * 0.2, R6=torch.randn(Kb, 6, device=DEV), T=mk(Kb, 3) * 0.4 - 0.2)
+    imgs, u = mk(2, 3, 9, 11), mk(Kb, 200, 3)
+    wts = dict(rgb=1.0, parsimony=0.01, tv=0.1, overlap=1.0)
+    consts = (0.5, 0.2, 0.005, 1.95)
+    up = torch.tensor([0.7, 1.3, 2.0, 0.5], device=DEV)
+
+    def leaves():
+        return {k: v.clone().requires_grad_(True) for k, v in base.items()}
+
+    a = leaves()
+    cfg = {'rgb': wts['rgb'], 'count': float(imgs.numel()), 'parsimony': wts['parsimony'], 'tv': wts['tv'] * 0.1, 'tv_ground_factor': 0.1,
+           'overlap': wts['overlap'], 'overlap_consts': consts}
+    vals = ops.fused_losses(a['fg'], a['env'], imgs, a['alpha'], a['bkg'], a['blk'], a['gnd'], a['sq_eps'], a['S'], a['R6'], a['T'], u, cfg)
+    (vals * up).sum().backward()
+    b = leaves()
+    ref = torch.stack([
+        wts['rgb'] * ops.composite_mse(b['fg'], b['env'], imgs),
+        wts['parsimony'] * b['alpha'].clamp(1e-6).pow(0.5).mean(),
+        wts['tv'] * 0.1 * (ops.tv_l2sq(b['bkg']) + ops.tv_l2sq(b['blk'], wrap_x=True) + ops.tv_l2sq(b['gnd']) * 0.1),
+        wts['overlap'] * ops.overlap_loss(b['sq_eps'], b['S'], b['R6'], b['T'], b['alpha'], u, *consts)])
+    (ref * up).sum().backward()
+    assert rel_err(vals, ref) < 1e-5
+    for k in base:
+        assert rel_err(a[k].grad, b[k].grad) < REL, k
+    # disabled terms: zero value, no gradient
+    c = leaves()
+    cfg2 = dict(cfg, parsimony=None, overlap=None)
+    v2 = ops.fused_losses(c['fg'], c['env'], imgs, c['alpha'], c['bkg'], c['blk'], c['gnd'], c['sq_eps'], c['S'], c['R6'], c['T'], None, cfg2)
+    v2.sum().backward()
+    assert v2[1].item() == 0 and v2[3].item() == 0 and c['alpha'].grad is None and c['S'].grad is None
+    assert rel_err(v2[[0, 2]], ref[[0, 2]]) < 1e-5
+
+
 def test_fused_adam_matches_torch():
     torch.manual_seed(0)
     p0 = torch.randn(1000)
