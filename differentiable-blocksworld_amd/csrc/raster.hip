@@ -49,15 +49,50 @@ __global__ void face_setup_kernel(const float *__restrict__ fv, long long F, flo
     bbox[i] = o;
 }
 
+// Coarse level of the two-level binning: one workgroup per (view, COARSE x COARSE pixel bin) compacts the indices of the faces
+// whose box touches the bin, in face order (wave ballots), so that tiles see the same candidate sequence as a full scan.
+__global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
+                                                         const int *__restrict__ num_faces, int H, int W, int nx, int ny,
+                                                         int *__restrict__ list, int *__restrict__ count) {
+    __shared__ int s_wcnt[4];
+    const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb;
+    const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
+    const int x1 = min(x0 + COARSE - 1, W - 1), y1 = min(y0 + COARSE - 1, H - 1);
+    const float bxmax = pix_to_ndc(W - 1 - x0, W, H), bxmin = pix_to_ndc(W - 1 - x1, W, H);
+    const float bymax = pix_to_ndc(H - 1 - y0, H, W), bymin = pix_to_ndc(H - 1 - y1, H, W);
+    const int f_begin = first_idx[n], nf = num_faces[n];
+    int *out = list + (long long)f_begin * nb + (long long)bin * nf;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int cnt = 0;
+    for (int base = 0; base < nf; base += 256) {
+        const int j = base + threadIdx.x;
+        bool hit = false;
+        if (j < nf) {
+            const float4 bb = bbox[f_begin + j];
+            hit = !(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+        if (hit) out[cnt + woff + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        cnt += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[n * nb + bin] = cnt;
+}
+
 template <int KMAX, int TW, int TH>
 __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void raster_fwd_kernel(
     const float *__restrict__ fv, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
     const int *__restrict__ num_faces, const int *__restrict__ neighbor, int N, int H, int W, int K, float blur,
-    int persp, int clipb, long long total_blocks, int *__restrict__ p2f, float *__restrict__ zbuf,
+    int persp, int clipb, long long total_blocks, CoarseBins cb, int *__restrict__ p2f, float *__restrict__ zbuf,
     float *__restrict__ bary, float *__restrict__ dists, int dbg) {
     int n, xi, yi;
     TopK<KMAX> q;
-    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, H, W, K, blur, persp, clipb, total_blocks, n, xi, yi, q)) return;
+    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, H, W, K, blur, persp, clipb, total_blocks, cb, n, xi, yi, q)) return;
     const bool in_img = xi < W && yi < H;
     if (!in_img) return;
     const long long o = (((long long)n * H + yi) * W + xi) * K;
@@ -133,23 +168,23 @@ int g_raster_dbg = 0;
 
 template <int KMAX, int TW, int TH>
 int launch_fwd_t(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
-                 int N, int H, int W, int K, float blur, int persp, int clipb, int *p2f, float *zbuf, float *bary,
-                 float *dists, hipStream_t s) {
+                 int N, int H, int W, int K, float blur, int persp, int clipb, const CoarseBins &cb, int *p2f, float *zbuf,
+                 float *bary, float *dists, hipStream_t s) {
     const long long total = (long long)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     hipLaunchKernelGGL((raster_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
-                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, p2f, zbuf, bary, dists, g_raster_dbg);
+                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, cb, p2f, zbuf, bary, dists, g_raster_dbg);
     return dbw_check_launch("raster_fwd_kernel");
 }
 
 template <int KMAX>
 int launch_fwd(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
-               int N, int H, int W, int K, float blur, int persp, int clipb, int *p2f, float *zbuf, float *bary,
-               float *dists, hipStream_t s) {
+               int N, int H, int W, int K, float blur, int persp, int clipb, const CoarseBins &cb, int *p2f, float *zbuf,
+               float *bary, float *dists, hipStream_t s) {
     const int shape = (g_raster_dbg >> 5) & 3;      // tile-shape experiment switch (tools/ablate_raster.py)
-    if (shape == 1) return launch_fwd_t<KMAX, 8, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
-    if (shape == 2) return launch_fwd_t<KMAX, 16, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
-    if (shape == 3) return launch_fwd_t<KMAX, 8, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
-    return launch_fwd_t<KMAX, 16, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, p2f, zbuf, bary, dists, s);
+    if (shape == 1) return launch_fwd_t<KMAX, 8, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
+    if (shape == 2) return launch_fwd_t<KMAX, 16, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
+    if (shape == 3) return launch_fwd_t<KMAX, 8, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
+    return launch_fwd_t<KMAX, 16, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
 }
 
 }  // namespace
@@ -161,6 +196,36 @@ int dbw_launch_face_setup(const float *face_verts, long long F_total, float marg
 }
 
 extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) { return (size_t)(F_total > 0 ? F_total : 1) * sizeof(float4); }
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
+    const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
+    return align256(dbw_rasterize_workspace_bytes(F_total)) + align256((size_t)(N > 0 ? N : 1) * nb * sizeof(int)) +
+           (size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int);
+}
+
+// Face boxes, then (when the workspace has room for it) the coarse bins.  bbox = workspace.
+int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s);
+int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, int N, long long F_total, int H, int W,
+                       float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s) {
+    cb.list = nullptr; cb.count = nullptr; cb.nx = cb.ny = 0;
+    if (F_total <= 0) return DBW_OK;
+    int rc = dbw_launch_face_setup(face_verts, F_total, margin, cull, workspace, s);
+    if (rc) return rc;
+    if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128)) {
+        const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
+        char *p = (char *)workspace + align256(dbw_rasterize_workspace_bytes(F_total));
+        int *count = (int *)p;
+        int *list = (int *)(p + align256((size_t)N * nx * ny * sizeof(int)));
+        hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
+                           num_faces, H, W, nx, ny, list, count);
+        rc = dbw_check_launch("coarse_bin_kernel");
+        if (rc) return rc;
+        cb.list = list; cb.count = count; cb.nx = nx; cb.ny = ny;
+    }
+    return DBW_OK;
+}
 
 extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_idx, const int32_t *num_faces,
                                  const int32_t *neighbor, int N, int64_t F_total, int H, int W, int K,
@@ -179,14 +244,11 @@ extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_i
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
     float4 *bbox = (float4 *)workspace;
-    if (F_total > 0) {
-        hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts,
-                           (long long)F_total, margin, cull_backfaces, bbox);
-        int rc = dbw_check_launch("face_setup_kernel");
-        if (rc) return rc;
-    }
+    CoarseBins cb;
+    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, N, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
+    if (rc) return rc;
 #define DBW_FWD(KM) launch_fwd<KM>(face_verts, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur_radius, \
-                                   perspective_correct, clip_barycentric_coords, pix_to_face, zbuf, bary, dists, s)
+                                   perspective_correct, clip_barycentric_coords, cb, pix_to_face, zbuf, bary, dists, s)
     if (K == 1) return DBW_FWD(1);
     if (K <= 4) return DBW_FWD(4);
     if (K <= 10) return DBW_FWD(10);

@@ -5,6 +5,15 @@
 namespace dbw {
 
 constexpr int LIST_CAP = 512;
+// Two-level binning: coarse_bin_kernel (raster.hip) first compacts, per view and per COARSE x COARSE pixel bin, the indices of
+// the faces whose blur-expanded box touches the bin (face order preserved); a tile then only scans the list of the bin it
+// lies in instead of every face of the view.  list == nullptr: single-level scan.
+constexpr int COARSE = 64;
+struct CoarseBins {
+    const int *list;    // view n, bin b: entries [first_idx[n] * nb + b * num_faces[n], +count[n * nb + b]), indices relative to first_idx[n]
+    const int *count;   // (N, nb)
+    int nx, ny;         // bins per row / column, nb = nx * ny
+};
 // minimum waves per SIMD the raster kernels are compiled for (caps the VGPR budget: the top-K list lives in registers)
 #define DBW_RASTER_WAVES(KMAX) ((KMAX) <= 4 ? 4 : (KMAX) <= 10 ? 2 : 1)
 
@@ -75,7 +84,9 @@ template <int KMAX, int TW, int TH, int GROUP = 2>
 __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces,
                                             const int *__restrict__ neighbor, int H, int W, int K, float blur, int persp,
-                                            int clipb, long long total_blocks, int &n, int &xi, int &yi, TopK<KMAX> &q) {
+                                            int clipb, long long total_blocks, const CoarseBins &cb, int &n, int &xi, int &yi,
+                                            TopK<KMAX> &q) {
+    static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
     constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = NT >= 256 ? LIST_CAP : 4 * NT;
     __shared__ FaceRec s_face[CAP];
     __shared__ int s_wcnt[NW];
@@ -101,7 +112,14 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
 
     q.init();
 
-    const int f_begin = first_idx[n], nf = num_faces[n];
+    const int f_begin = first_idx[n];
+    int nf = num_faces[n];
+    const int *lst = nullptr;
+    if (cb.list) {
+        const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
+        lst = cb.list + (long long)f_begin * nb + (long long)bin * nf;
+        nf = cb.count[n * nb + bin];
+    }
     int cnt = 0;
     // The face scan is latency bound (every tile walks the whole per-view bbox table): fetch the boxes of GROUP chunks with
     // independent loads before consuming them, so a tile pays nf / (GROUP * NT) memory round trips instead of nf / NT.
@@ -109,12 +127,19 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
     for (int base0 = 0; base0 < nf; base0 += GROUP * NT) {
         float4 bbs[GROUP];
         bool hits[GROUP];
+        int fjs[GROUP];
 #pragma unroll
         for (int g = 0; g < GROUP; ++g) {
             const int j = base0 + g * NT + tid;
             hits[g] = false;
+            fjs[g] = j;
+            if (j < nf && lst) fjs[g] = lst[j];
+        }
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            const int j = base0 + g * NT + tid;
             if (j < nf) {
-                bbs[g] = bbox[f_begin + j];
+                bbs[g] = bbox[f_begin + fjs[g]];
                 hits[g] = !(txmax < bbs[g].x || txmin > bbs[g].y || tymax < bbs[g].z || tymin > bbs[g].w);
             }
         }
@@ -122,7 +147,7 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
         for (int g = 0; g < GROUP; ++g) {
         const int base = base0 + g * NT;
         if (base >= nf) break;
-        const int j = base + tid;
+        const int j = fjs[g];
         const bool hit = hits[g];
         const float4 bb = bbs[g];
         const unsigned long long m = __ballot(hit);

@@ -11,7 +11,8 @@
 using namespace dbw;
 
 // implemented in raster.hip / shade_blend.hip
-int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s);
+int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, int N, long long F_total, int H, int W,
+                       float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s);
 int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                         const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
@@ -26,12 +27,12 @@ template <int KMAX, int TW, int TH, int GROUP>
 __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const float *__restrict__ fv, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
                                                              const int *__restrict__ neighbor, float blur, int persp,
-                                                             long long total_blocks, ShadeArgs A, int *__restrict__ p2f,
+                                                             long long total_blocks, ShadeArgs A, CoarseBins cb, int *__restrict__ p2f,
                                                              float *__restrict__ bary, float *__restrict__ dists,
                                                              float *__restrict__ image) {
     int n, xi, yi;
     TopK<KMAX> q;
-    if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, n, xi, yi, q)) return;
+    if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, n, xi, yi, q)) return;
     if (xi >= A.W || yi >= A.H) return;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
@@ -82,17 +83,17 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
 
 template <int KMAX, int TW, int TH, int GROUP>
 int launch_v(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
-             int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+             int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
     hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
-                       num_faces, neighbor, blur, persp, total, A, p2f, bary, dists, image);
+                       num_faces, neighbor, blur, persp, total, A, cb, p2f, bary, dists, image);
     return dbw_check_launch("render_fwd_kernel");
 }
 
 template <int KMAX>
 int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
-           int persp, ShadeArgs &A, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(fv, bbox, first_idx, num_faces, neighbor, blur, persp, A, p2f, bary, dists, image, s)
+           int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(fv, bbox, first_idx, num_faces, neighbor, blur, persp, A, cb, p2f, bary, dists, image, s)
     if (KMAX == 1) return DBW_V(16, 16, 4);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list
 #ifdef DBW_TUNE_VARIANTS
     switch (g_render_variant) {               // tile-shape / load-batching sweep (tools/sweep_render_fwd.py)
@@ -136,12 +137,11 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     if (N == 0) return DBW_OK;
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
-    if (F_total > 0) {
-        rc = dbw_launch_face_setup(face_verts_c, F_total, margin, 0, workspace, s);
-        if (rc) return rc;
-    }
+    CoarseBins cb;
+    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, N, F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
+    if (rc) return rc;
     const float4 *bbox = (const float4 *)workspace;
-#define DBW_RF(KM) launch<KM>(face_verts_c, bbox, first_idx, num_faces, neighbor, blur_radius, perspective_correct, A, pix_to_face, bary, dists, image, s)
+#define DBW_RF(KM) launch<KM>(face_verts_c, bbox, first_idx, num_faces, neighbor, blur_radius, perspective_correct, A, cb, pix_to_face, bary, dists, image, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);

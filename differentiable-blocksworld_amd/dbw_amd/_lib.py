@@ -69,6 +69,8 @@ def load():
     lib.dbw_abi_version.restype = c_i
     lib.dbw_rasterize_workspace_bytes.restype = c_sz
     lib.dbw_rasterize_workspace_bytes.argtypes = [c_i64]
+    lib.dbw_rasterize_workspace_bytes_binned.restype = c_sz
+    lib.dbw_rasterize_workspace_bytes_binned.argtypes = [c_i64, c_i, c_i, c_i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

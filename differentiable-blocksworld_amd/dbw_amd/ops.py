@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+COARSE_BINS = True        # two-level face binning in the rasteriser (64x64-pixel coarse bins); False: every tile scans every face
 TEXTURE_BINS = True       # full-resolution texel gradients: bin records by 32x32-texel tile and reduce in LDS (vs 12 atomics/fragment)
 UV_FRAGMENTS = True       # detach_bary passes: the forward stores resolved (u, v, face|map) per fragment for the backward
 TILED_FRAGMENTS = True    # fused path keeps its fragments in the 8x8-tile planar layout (coalesced); needs both FUSED_* = True
@@ -92,10 +93,15 @@ def _chk(t, dtype, name):
 # ---------------------------------------------------------------------------------------------------------------------
 # rasterize_meshes  (operator-level drop-in, int64 indices at the Python boundary like PyTorch3D)
 # ---------------------------------------------------------------------------------------------------------------------
+def _workspace_bytes(Ft, N, H, W):
+    lib = _lib.load()
+    return lib.dbw_rasterize_workspace_bytes_binned(Ft, N, H, W) if COARSE_BINS else lib.dbw_rasterize_workspace_bytes(Ft)
+
+
 def _raster_fwd(face_verts, first, num, neighbor, N, H, W, K, blur, pc, cb, cull, need_zbuf=True):
     dev = face_verts.device
     Ft = face_verts.shape[0]
-    ws_bytes = _lib.load().dbw_rasterize_workspace_bytes(Ft)
+    ws_bytes = _workspace_bytes(Ft, N, H, W)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     p2f = torch.empty(N, H, W, K, dtype=torch.int32, device=dev)
     zbuf = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if need_zbuf else None
@@ -227,7 +233,7 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
     TILED_FRAGMENTS = globals()['TILED_FRAGMENTS'] if tiled is None else tiled
     dev = fvc.device
     Ft = fvc.shape[0]
-    ws_bytes = _lib.load().dbw_rasterize_workspace_bytes(Ft)
+    ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     if TILED_FRAGMENTS:     # internal 8x8-tile planar layout (include/dbw_hip.h: frag_layout = 1)
         ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8

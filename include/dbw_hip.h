@@ -71,6 +71,10 @@ int dbw_project_clip_bwd(const float *verts_world, const int32_t *faces, const f
  *  workspace: dbw_rasterize_workspace_bytes(F_total) bytes of scratch.
  */
 size_t dbw_rasterize_workspace_bytes(int64_t F_total);
+/* Larger workspace that also holds the coarse bins of the two-level binning (per view and 64x64-pixel bin, the ordered list of
+ * faces touching it): when dbw_rasterize_fwd / dbw_render_fwd_fused are given at least this many bytes, tiles scan the list
+ * of their bin instead of every face of the view.  Results are identical either way. */
+size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W);
 int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_idx, const int32_t *num_faces,
                       const int32_t *neighbor, int N, int64_t F_total, int H, int W, int K, float blur_radius,
                       int perspective_correct, int clip_barycentric_coords, int cull_backfaces, int32_t *pix_to_face,

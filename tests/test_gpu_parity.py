@@ -54,6 +54,22 @@ def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb):
         assert torch.equal(a.cpu(), b), f'{name}: max abs diff {(a.cpu() - b).abs().max().item()}'
 
 
+def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
+    """Coarse 64x64-pixel bins (default) vs every tile scanning every face: same candidate order, so every output bit matches,
+    on an image spanning several bins with ragged borders and uneven meshes (one empty)."""
+    H, W, K = 150, 200, 10
+    fv = torch.cat([random_faces(900, seed=1, size=0.15), random_faces(300, seed=2, size=0.6)], 0).to(DEV)
+    first, num = torch.tensor([0, 900, 900]).to(DEV), torch.tensor([900, 0, 300]).to(DEV)
+    blur = math.log(1e4 - 1) * 1e-4
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, 'COARSE_BINS', on)
+        outs.append(ops.rasterize_meshes(fv, first, num, None, (H, W), blur, K, True, True, False))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert (outs[0][0] >= 0).sum() > 1000
+
+
 def test_rasterize_ties_and_degenerates():
     """Coincident faces (identical z everywhere: tie broken by face id), zero-area faces, faces behind the camera."""
     base = random_faces(8, seed=5)
