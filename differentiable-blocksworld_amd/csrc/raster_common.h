@@ -177,7 +177,17 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
                 if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
                     const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
                     const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
-                    const f3 bary0 = bary_fwd(p, a, b, c);
+                    // bary_fwd, opened up: for a hard pass (blur == 0) a pixel outside the triangle can never be kept, and
+                    // "outside" is decided exactly by the signs of the edge functions (b_i = e_i / area <= 0 for some i),
+                    // before paying the twelve IEEE divisions of the full evaluation
+                    const float area = edge_fn(c, a, b) + DBW_EPS;
+                    const float e0 = edge_fn(p, b, c), e1 = edge_fn(p, c, a), e2 = edge_fn(p, a, b);
+                    if (blur == 0.f) {
+                        const bool pos = area > 0.f;
+                        if (e0 == 0.f || e1 == 0.f || e2 == 0.f || (e0 > 0.f) != pos || (e1 > 0.f) != pos || (e2 > 0.f) != pos) continue;
+                    }
+                    f3 bary0;
+                    bary0.x = e0 / area; bary0.y = e1 / area; bary0.z = e2 / area;
                     const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
                     const f3 bc = clipb ? clip_fwd(bp) : bp;
                     const float pzv = bc.x * z0 + bc.y * z1 + bc.z * z2;
