@@ -93,19 +93,17 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     float *s_T = s_layers + threadIdx.x;
     TexAgg tex_agg;
     AlphaAgg alpha_agg;
-    const bool use_lds = A.agg != 0;
+    // A.agg bit 0: texel gradients through the LDS hash (magnified / decimated maps); bit 1: per-face opacity gradients through
+    // the LDS hash (always in the fused kernel: a wave sees one to three distinct opacities)
+    const bool use_lds = (A.agg & 1) != 0, lds_alpha = (A.agg & 2) != 0;
     FaceAgg face_agg;
     // BINNED: block-level slot reservation.  Pass 1 counts the block's records per bin in a small LDS hash table, one global
     // cursor atomic per (block, bin) reserves the range, pass 2 writes the records -- a single atomic round trip per block.
     int *s_key = nullptr, *s_cnt = nullptr, *s_base = nullptr, *s_ent = nullptr;
     {
         char *nxt = (char *)(s_layers + (long long)A.K * NT);
-        if (use_lds) {                             // block-uniform
-            tex_agg.bind(nxt); nxt += TexAgg::BYTES;
-            alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES;
-            tex_agg.clear(threadIdx.x, NT);
-            alpha_agg.clear(threadIdx.x, NT);
-        }
+        if (use_lds) { tex_agg.bind(nxt); nxt += TexAgg::BYTES; tex_agg.clear(threadIdx.x, NT); }          // block-uniform
+        if (lds_alpha) { alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES; alpha_agg.clear(threadIdx.x, NT); }
         if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); nxt += FaceAgg::BYTES; }
         if (BINNED) {
             s_key = (int *)nxt; s_cnt = s_key + BIN_SLOTS; s_base = s_cnt + BIN_SLOTS; s_ent = s_base + BIN_SLOTS + threadIdx.x;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     }
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
-    if (use_lds || FUSED) __syncthreads();
+    if (use_lds || lds_alpha || FUSED) __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
     f2 pndc;
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         if (!FUSED && gdists && in_img) gdists[pix * A.K + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
-            if (use_lds) { if (valid && gfa[0] != 0.f) alpha_agg.add(galpha, (int)fr.aidx, gfa); }
+            if (lds_alpha) { if (valid && gfa[0] != 0.f) alpha_agg.add(galpha, (int)fr.aidx, gfa); }
             else wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
         }
         // colour -> texels (and -> uv -> barycentrics)
@@ -342,11 +340,9 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             }
         }
     }
-    if (use_lds || FUSED) __syncthreads();
-    if (use_lds) {
-        tex_agg.flush(gmaps, threadIdx.x, NT);
-        if (galpha) alpha_agg.flush(galpha, threadIdx.x, NT);
-    }
+    if (use_lds || lds_alpha || FUSED) __syncthreads();
+    if (use_lds) tex_agg.flush(gmaps, threadIdx.x, NT);
+    if (lds_alpha && galpha) alpha_agg.flush(galpha, threadIdx.x, NT);
     if (FUSED) face_agg.flush(gfv, threadIdx.x, NT);
 }
 
@@ -475,9 +471,10 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     if (N == 0) return DBW_OK;
     const long long total = (long long)N * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     size_t lds = (size_t)K * NT * sizeof(float);
-    A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 1 : 0;
-    if (A.agg) lds += TexAgg::BYTES + AlphaAgg::BYTES;
     const bool fused = gfv != nullptr;
+    A.agg = (lds_aggregate && !(g_dbg_flags & 8)) ? 3 : ((fused && grad_faces_alpha && !(g_dbg_flags & 8)) ? 2 : 0);
+    if (A.agg & 1) lds += TexAgg::BYTES;
+    if (A.agg & 2) lds += AlphaAgg::BYTES;
     if (fused) lds += FaceAgg::BYTES;
     if (fused && A.bin_records) lds += (size_t)(3 * BIN_SLOTS + K * NT) * sizeof(int);
     static bool raised = false;
