@@ -189,6 +189,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Same sum on the VALU only (DPP row shifts + row broadcasts, the gfx9 reduction idiom): __shfl_xor lowers to ds_bpermute, i.e.
+// six LDS-pipe instructions per value, which is exactly the pipe the LDS tables of the backward are short of.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    const float t = v;
+    v += dpp_<0x111, 0xf, 0xf>(t);           // row_shr:1
+    v += dpp_<0x112, 0xf, 0xf>(t);           // row_shr:2
+    v += dpp_<0x113, 0xf, 0xf>(t);           // row_shr:3   -> every lane: itself + the 3 lanes below it in its row
+    v += dpp_<0x114, 0xf, 0xe>(v);           // row_shr:4
+    v += dpp_<0x118, 0xf, 0xc>(v);           // row_shr:8   -> lane 15 of every row: the row's sum
+    v += dpp_<0x142, 0xa, 0xf>(v);           // row_bcast:15
+    v += dpp_<0x143, 0xc, 0xf>(v);           // row_bcast:31 -> lane 63: the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Wave-aggregated atomic accumulation into base[idx*NC + c]: lanes of a wave that target the same index (neighbouring
 // pixels usually hit the same face / texel) are summed with a butterfly first, so memory sees ~1 atomic per
 // (wave, index) instead of one per lane.  Must be called by ALL lanes of the wave (inactive lanes pass active=false).
@@ -263,6 +281,23 @@ struct LdsAgg {
 #pragma unroll
         for (int c = 0; c < NV; ++c)
             if (v[c] != 0.f) unsafeAtomicAdd(gbase + (long long)key * NV + c, v[c]);
+    }
+    // Wave-collective add (every lane of the wave calls it; `active` marks the lanes with an update).  When all active lanes
+    // carry the same key -- a wave inside one large face, one block's opacity -- the values are summed across the wave first
+    // and one lane does the table update: 64 lanes hitting one slot would serialise at ~3 clk per lane and value.
+    __device__ __forceinline__ void add_wave(float *__restrict__ gbase, int key, const float (&v)[NV], bool active) {
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) return;
+        const int leader = __ffsll((long long)am) - 1;
+        const int k0 = __shfl(key, leader, 64);
+        if (__popcll(am) >= 8 && __ballot(active && key == k0) == am) {
+            float s[NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) s[c] = wave_sum_dpp(active ? v[c] : 0.f);
+            if ((int)(threadIdx.x & 63) == leader) add(gbase, k0, s);
+        } else if (active) {
+            add(gbase, key, v);
+        }
     }
     __device__ __forceinline__ void flush(float *__restrict__ gbase, int tid, int nthreads) {
         for (int i = tid; i < NSLOT; i += nthreads) {

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         if (!FUSED && gdists && in_img) gdists[pix * A.K + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
-            if (lds_alpha) { if (valid && gfa[0] != 0.f) alpha_agg.add(galpha, (int)fr.aidx, gfa); }
+            if (lds_alpha) alpha_agg.add_wave(galpha, valid ? (int)fr.aidx : 0, gfa, valid && gfa[0] != 0.f);
             else wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
         }
         // colour -> texels (and -> uv -> barycentrics)
@@ -290,6 +290,9 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 ++iter;
             }
         }
+        float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int fc = 0;
+        bool has_g9 = false;
         if ((FUSED ? (want_bary != 0) : (gbary != nullptr)) && in_img || (FUSED && in_img)) {
             float gb[3] = {0.f, 0.f, 0.f};
             if (FUSED ? (want_bary != 0) : true)
@@ -313,10 +316,10 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0; divisions by v_rcp_f32).
                 // d/d dist is non-zero only outside the triangle (fr.d >= 0), so its sign is +1 and the barycentrics are only
                 // recomputed when a barycentric gradient has to be propagated.
-                const int fc = A.p2f[fo.s];
+                fc = A.p2f[fo.s];
+                has_g9 = true;
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
-                float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (gd != 0.f) {
                     f2 d0, d1, d2;
                     point_tri_dist_bwd<true>(pndc, a, b, c, gd, d0, d1, d2);
@@ -336,8 +339,13 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                     g9[3] += e1.x; g9[4] += e1.y; g9[5] += pz1;
                     g9[6] += e2.x; g9[7] += e2.y; g9[8] += pz2;
                 }
-                if (!(A.dbg & 64)) face_agg.add(gfv, fc, g9);     // dbg 64: ablate the face-gradient aggregation (tools/ablate.py)
             }
+        }
+        if (FUSED && !(A.dbg & 64)) {           // dbg 64: ablate the aggregation (tools/ablate.py)
+            // hard single-layer passes rasterise few, large faces (a wave usually sits inside one): sum across the wave first;
+            // soft multi-layer passes see several small faces per wave and layer, where the uniformity test does not pay
+            if (A.K == 1) face_agg.add_wave(gfv, fc, g9, has_g9);
+            else if (has_g9) face_agg.add(gfv, fc, g9);
         }
     }
     if (use_lds || lds_alpha || FUSED) __syncthreads();
