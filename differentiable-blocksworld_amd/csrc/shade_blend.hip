@@ -207,21 +207,22 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
         if (use_lds && !(A.dbg & 1)) {
-            if (tex) {      // merge the footprint's texels that fall into the same stored cell, then one LDS insert per cell
-                float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
-                if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
-                if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
-                if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
-                else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
-                else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
-                const long long ad[4] = {s.a00, s.a01, s.a10, s.a11};
-                const float wt[4] = {w00, w01, w10, w11};
+            // merge the footprint's texels that fall into the same stored cell, then one LDS insert per cell
+            float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
+            if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
+            if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
+            if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
+            else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
+            else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
+            const long long ad[4] = {s.a00, s.a01, s.a10, s.a11};
+            const float wt[4] = {w00, w01, w10, w11};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (wt[q] != 0.f) {
-                        const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                        tex_agg.add(gmaps, (int)(ad[q] / 3), v);
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                const bool on = tex && wt[q] != 0.f;
+                // hard single-layer passes over magnified / decimated maps: a wave usually sits inside one cell
+                if (A.K == 1) tex_agg.add_wave(gmaps, (int)(ad[q] / 3), v, on);
+                else if (on) tex_agg.add(gmaps, (int)(ad[q] / 3), v);
             }
         } else if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
             bool pending = tex;
