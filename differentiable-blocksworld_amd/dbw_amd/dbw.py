@@ -333,6 +333,12 @@ class DifferentiableBlocksWorld(nn.Module):
         return PackedScene(verts.reshape(-1, 3), self._block_faces_all[:F_], self._block_face_uvs_all[:F_],
                            self._block_face_map_all[:F_], desc, maps.reshape(-1), texbins)
 
+    def build_scene(self, filter_transparent=False):
+        """Background + ground + blocks as ONE scene (dbw.py:250-266), for the non-decoupled hard / SSAA evaluation render."""
+        env = self.build_env_scene()
+        blocks = self.build_blocks_scene(filter_transparent=filter_transparent)
+        return env if blocks is None else PackedScene.join([env, blocks])
+
     def _shared_randn_like(self, t):
         """Opacity noise (and the overlap samples) must be identical on every data-parallel rank: they are
         drawn from the device's default generator, which ShardedTrainStep seeds identically on all ranks and which every
@@ -384,6 +390,39 @@ class DifferentiableBlocksWorld(nn.Module):
     def forward(self, inp, labels=None):
         fg, env = self.render_layers(inp)
         return self.compute_losses(inp['imgs'], None, layers=(fg, env))
+
+    # ------------------------------------------------------------------------------------------------ evaluation (dbw.py:464-493)
+    @torch.no_grad()
+    def quantitative_eval(self, loader, device, hard_inference=True):
+        """PSNR / SSIM (/ LPIPS when a perceptual network was supplied with set_perceptual) of the reconstruction over `loader`
+        (batches of (inp, labels) like the reference's datasets).  hard_inference: exact anti-aliased render of the joined scene
+        (4x resolution, sigma 0, one face per pixel, 4x4 average pooling; renderer.py:56-60,178-183), else the soft decoupled
+        prediction.  -> OrderedDict like the reference's; LPIPS is NaN when no network is installed."""
+        from collections import OrderedDict
+        from .metrics import AverageMeter, mse2psnr, ssim
+        was_training = self.training
+        self.eval()
+        opacities = self.get_opacities()
+        n_blocks = int((opacities > 0.5).sum().item())
+        meters = {k: AverageMeter() for k in ('L_tot', 'L_rec', 'PSNR', 'SSIM', 'LPIPS')}
+        scene = self.build_scene(filter_transparent=True) if hard_inference else None
+        for inp, labels in loader:
+            inp = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp.items()}
+            imgs, N = inp['imgs'], len(inp['imgs'])
+            if hard_inference:
+                self._ensure_cameras(inp)
+                rec = self.renderer.render_packed(scene, inp['R'], inp['T'], viz_purpose=True)[:, :3]
+            else:
+                rec = self.predict(inp, labels, filter_transparent=True)
+            losses = self.compute_losses(imgs, rec)
+            meters['L_tot'].update(losses['total'], N=N)
+            meters['L_rec'].update(sum(losses[k] for k in ('rgb', 'perceptual') if k in losses), N=N)
+            meters['PSNR'].update(mse2psnr(F.mse_loss(imgs, rec)), N=N)
+            meters['SSIM'].update(ssim(imgs, rec, padding=False).mean(), N=N)
+            meters['LPIPS'].update(self.perceptual_fn(imgs, rec) if self.perceptual_fn is not None else float('nan'), N=N)
+        self.train(was_training)
+        return OrderedDict([('n_blocks', n_blocks)] + [(k, m.avg) for k, m in meters.items()]
+                           + [(f'alpha{k}', a.item()) for k, a in enumerate(opacities)])
 
     # ------------------------------------------------------------------------------------------------ losses (dbw.py:361-408)
     def _perceptual_term(self, imgs, rec, coarse):

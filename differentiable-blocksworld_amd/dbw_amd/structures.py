@@ -129,6 +129,27 @@ class PackedScene:
         self.texbins = texbins      # optional (bin_base, bin_info, nbins) from describe_bins
 
     @staticmethod
+    def join(scenes):
+        """One scene out of several (join_meshes_as_scene on packed scenes): vertex, face and map tables concatenated, face and
+        map indices re-based; faces keep the order of `scenes`."""
+        verts, faces, uvs, fmap, desc, maps = [], [], [], [], [], []
+        v_off = m_off = f_off = 0
+        for s in scenes:
+            verts.append(s.verts)
+            faces.append(s.faces + v_off)
+            uvs.append(s.face_uvs)
+            fmap.append(s.face_map + m_off)
+            d = s.map_desc.clone()
+            d[:, 0] += f_off
+            desc.append(d)
+            maps.append(s.maps.reshape(-1))
+            v_off += s.verts.shape[0]
+            m_off += s.map_desc.shape[0]
+            f_off += s.maps.numel()
+        return PackedScene(torch.cat(verts, 0), torch.cat(faces, 0).to(torch.int32).contiguous(), torch.cat(uvs, 0).contiguous(),
+                           torch.cat(fmap, 0).to(torch.int32).contiguous(), torch.cat(desc, 0).contiguous(), torch.cat(maps))
+
+    @staticmethod
     def describe_maps(shapes, pads, device, shift=0):
         """shapes: full-resolution (h, w) of every map; shift: log2 of the decimation they are stored at."""
         rows, off = [], 0

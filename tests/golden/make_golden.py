@@ -13,6 +13,7 @@ SURVEY.md 8c):
   utils/pytorch.py:31-36      signed_pow / safe_pow
   model/loss.py:43-47         tv_norm_funcs['l2sq']
   model/tools.py:173-207      elev/azim/roll_to_rotation_matrix (R_world, dbw.py:59)
+  model/loss.py:28-29,124-156 mse2psnr, SSIMLoss (evaluation metrics)
   utils/mesh.py:78-89,127-169 point_to_uv_sphericalmap, get_icosphere_uvs post-processing
                               (fed an icosphere restated per SURVEY A.9 -- PyTorch3D's ico_sphere is absent)
 """
@@ -205,6 +206,22 @@ def main():
             lrs.append([g['lr'] for g in optimizer.param_groups])
         out[tag] = np.array(lrs, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, 'lr_schedule.npz'), **out)
+
+    # ---- 7. evaluation metrics of quantitative_eval (dbw.py:464-493): SSIMLoss (loss.py:124-156) with and without padding,
+    #         mse2psnr (loss.py:28-29)
+    loss = m['model.loss']
+    g = torch.Generator().manual_seed(7)
+    a = torch.rand(3, 3, 40, 52, generator=g)
+    b = (a + 0.1 * torch.randn(3, 3, 40, 52, generator=g)).clamp(0, 1)
+    out = {'img1': _np(a), 'img2': _np(b)}
+    for pad in (False, True):
+        f = loss.SSIMLoss(padding=pad)
+        out[f'one_minus_ssim_pad{int(pad)}'] = _np(f(a, b))          # per image: mean(1 - ssim_map)
+        out[f'ssim_map_pad{int(pad)}'] = _np(1 - f.ssim(a, b))
+    mse = torch.tensor([1e-4, 3.7e-3, 0.25])
+    out['mse'] = _np(mse)
+    out['psnr'] = _np(loss.mse2psnr(mse))
+    np.savez_compressed(os.path.join(HERE, 'ssim.npz'), **out)
     print('golden fixtures written to', HERE)
 
 

@@ -362,3 +362,48 @@ def test_trainer_driver_optimises_schedules_and_checkpoints():
     assert tr2.epoch == 5 and model2.cur_epoch == 4 and tr2.step_fn.lrs == pytest.approx(tr.step_fn.lrs)
     got_next = tr2.run_epoch(shuffle=False)
     assert abs(got_next['total'].item() - ref_next['total'].item()) < 1e-4 * abs(ref_next['total'].item())
+
+
+def test_quantitative_eval_hard_render_of_joined_scene_matches_oracle():
+    """quantitative_eval (dbw.py:464-493): the hard, 4x supersampled render of the JOINED scene (background + ground + opaque
+    blocks, one face per pixel) against the oracle rendering the same joined scene; PSNR / SSIM of that image against the
+    metrics module applied to the oracle's image."""
+    from dbw_amd import metrics
+    H, W, nb, ts = 40, 56, 4, 32
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, 6), (H, W))
+    orc = O.OracleDBW((H, W), n_blocks=nb, txt_size=ts, faces_per_pixel=6, seed=227391)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for name, scale in (('sq_eps', 1.0), ('alpha_logit', 2.0), ('textures', 1.0), ('texture_bkg', 1.0), ('texture_ground', 1.0)):
+            d = torch.randn(orc.p[name].shape, generator=g) * scale
+            orc.p[name].add_(d)
+            getattr(model, name).add_(d)
+        orc.p['alpha_logit'][1] = -3.0                                # transparent: filtered out of the evaluation scene
+        model.alpha_logit[1] = -3.0
+        orc.p['alpha_logit'][2] = 3.0
+        model.alpha_logit[2] = 3.0
+    model = model.to(DEV)
+    R, T, Km = O.synthetic_cameras(3, R_world=orc.R_world[0])
+    with torch.no_grad():
+        env, blk = orc.build_env(False, False), orc.build_blocks(False, False, False, None, filter_transparent=True)
+        nv, nm = env['verts'].shape[0], len(env['maps'])
+        joined = dict(verts=torch.cat([env['verts'], blk['verts']]), faces=torch.cat([env['faces'], blk['faces'] + nv]),
+                      face_uvs=torch.cat([env['face_uvs'], blk['face_uvs']]), face_map=torch.cat([env['face_map'], blk['face_map'] + nm]),
+                      maps=env['maps'] + blk['maps'])
+        ref = torch.nn.functional.avg_pool2d(O.render(joined, R, T, Km[0], (4 * H, 4 * W), 0.0, 1, False, None, 0.001, n_threads=8), 4, 4)[:, :3]
+    imgs = (ref + 0.05 * torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))).clamp(0, 1)
+    loader = [(dict(imgs=imgs[:2], R=R[:2], T=T[:2], K=Km[:2]), None), (dict(imgs=imgs[2:], R=R[2:], T=T[2:], K=Km[2:]), None)]
+    res = model.quantitative_eval(loader, DEV, hard_inference=True)
+    assert list(res)[:6] == ['n_blocks', 'L_tot', 'L_rec', 'PSNR', 'SSIM', 'LPIPS'] and f'alpha{nb - 1}' in res
+    assert res['n_blocks'] == int((torch.sigmoid(orc.p['alpha_logit']) > 0.5).sum())
+    psnr = [metrics.mse2psnr(F.mse_loss(imgs[s], ref[s])).item() for s in (slice(0, 2), slice(2, 3))]
+    ssim = [metrics.ssim(imgs[s], ref[s]).mean().item() for s in (slice(0, 2), slice(2, 3))]
+    assert abs(res['PSNR'] - (2 * psnr[0] + psnr[1]) / 3) < 2e-3 and abs(res['SSIM'] - (2 * ssim[0] + ssim[1]) / 3) < 1e-4
+    assert res['LPIPS'] != res['LPIPS'] and model.training              # no perceptual network: NaN; training mode restored
+    # and the image itself
+    model.eval()
+    with torch.no_grad():
+        scene = model.build_scene(filter_transparent=True)
+        img = model.renderer.render_packed(scene, R.to(DEV), T.to(DEV), viz_purpose=True)[:, :3]
+    assert rel_err(img, ref) < REL

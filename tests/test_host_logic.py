@@ -1,5 +1,6 @@
 """CPU: host-side logic of the product package (topology, containers, model construction, config handling) -- everything
 that does not launch a kernel.  The product's topology generators are checked against the oracle's independent ones."""
+import numpy as np
 import pytest
 import torch
 import yaml
@@ -164,3 +165,36 @@ def test_camera_ingest_round_trip_and_pixel_consistency():
         torch.testing.assert_close(W / 2 - ndc[:, 0] * s, u, rtol=1e-4, atol=5e-2)        # NDC +X points left, +Y up
         torch.testing.assert_close(H / 2 - ndc[:, 1] * s, v, rtol=1e-4, atol=5e-2)
         assert torch.all(ndc[:, 2] > 0)
+
+
+def test_eval_metrics_match_reference_ssim_and_psnr(golden_dir):
+    """metrics.ssim (separable 1-D Gaussian filtering) and mse2psnr against the reference's own SSIMLoss / mse2psnr outputs
+    (tests/golden/ssim.npz, generated by make_golden.py from src/model/loss.py)."""
+    import os
+    from dbw_amd import metrics
+    g = np.load(os.path.join(golden_dir, 'ssim.npz'))
+    a, b = torch.from_numpy(g['img1']), torch.from_numpy(g['img2'])
+    for pad in (0, 1):
+        m = metrics.ssim_map(a, b, padding=bool(pad))
+        assert m.shape == g[f'ssim_map_pad{pad}'].shape
+        assert np.abs(m.numpy() - g[f'ssim_map_pad{pad}']).max() < 2e-5
+        assert np.abs((1 - metrics.ssim(a, b, padding=bool(pad))).numpy() - g[f'one_minus_ssim_pad{pad}']).max() < 1e-6
+    assert np.allclose(metrics.mse2psnr(torch.from_numpy(g['mse'])).numpy(), g['psnr'], rtol=1e-6)
+    assert abs(metrics.ssim(a, a).mean().item() - 1.0) < 1e-6
+    meter = metrics.AverageMeter()
+    meter.update(torch.tensor(2.0), N=3); meter.update(4.0, N=1)
+    assert abs(meter.avg - 2.5) < 1e-12
+
+
+def test_packed_scene_join_rebases_faces_and_maps():
+    from dbw_amd.structures import PackedScene
+    d1, n1 = PackedScene.describe_maps([(4, 4)], [(0, 0)], 'cpu')
+    d2, n2 = PackedScene.describe_maps([(2, 2), (2, 4)], [(1, 1), (0, 0)], 'cpu')
+    s1 = PackedScene(torch.rand(5, 3), torch.tensor([[0, 1, 2], [2, 3, 4]], dtype=torch.int32), torch.rand(2, 3, 2),
+                     torch.zeros(2, dtype=torch.int32), d1, torch.rand(n1))
+    s2 = PackedScene(torch.rand(4, 3), torch.tensor([[0, 1, 3]], dtype=torch.int32), torch.rand(1, 3, 2), torch.ones(1, dtype=torch.int32),
+                     d2, torch.rand(n2))
+    j = PackedScene.join([s1, s2])
+    assert j.verts.shape == (9, 3) and j.faces.tolist() == [[0, 1, 2], [2, 3, 4], [5, 6, 8]] and j.face_map.tolist() == [0, 0, 2]
+    assert j.map_desc[:, 0].tolist() == [0, n1, n1 + 12] and j.map_desc[1, 3:5].tolist() == [1, 1]
+    assert torch.equal(j.maps, torch.cat([s1.maps, s2.maps])) and j.faces.dtype == torch.int32
