@@ -324,8 +324,9 @@ class _RenderScene(torch.autograd.Function):
 
 def texbin_capacity(B, H, W, K, nbins):
     """Records per texture bin: room for max(K/2, 2) fragments per pixel spread evenly over the bins (a soft K-layer render
-    fills ~20 % of its slots, a hard 1-layer render all of them; what does not fit falls back to atomics), at most 1 GiB."""
-    return int(min(max(B * H * W * max(K, 4) // (2 * nbins), 256), (1 << 30) // (32 * nbins)))
+    fills ~20 % of its slots, a hard 1-layer render all of them; what does not fit falls back to atomics), at most 16 GiB
+    of the 288 GB (config 5 -- 25 views of 1080x1920, K = 16 -- asks for 13 GB)."""
+    return int(min(max(B * H * W * max(K, 4) // (2 * nbins), 256), (16 << 30) // (32 * nbins)))
 
 
 def render_scene(verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):
