@@ -83,12 +83,15 @@ __device__ __forceinline__ bool bin_regular(const Sample &s) {
 
 // FUSED = true additionally runs the rasteriser backward on the fly: d/d dists and d/d barycentrics are
 // consumed in registers and only d/d face_verts leaves the kernel (pre-aggregated per face in LDS).
-template <bool FUSED, bool BINNED>
+// SINGLE = true: a hard single-layer pass (K == 1; the env pass) -- its own instantiation, so that the layer loops fold away and a
+// kernel trace tells the two passes of an iteration apart.
+template <bool FUSED, bool BINNED, bool SINGLE>
 __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
                                                              float *__restrict__ gbary, const float *__restrict__ fv,
                                                              float *__restrict__ gfv, int want_bary, int persp) {
+    const int KK = SINGLE ? 1 : A.K;
     extern __shared__ __attribute__((aligned(16))) float s_layers[];   // [K][NT]: transmittance T_k in front of layer k
     float *s_T = s_layers + threadIdx.x;
     TexAgg tex_agg;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     // cursor atomic per (block, bin) reserves the range, pass 2 writes the records -- a single atomic round trip per block.
     int *s_key = nullptr, *s_cnt = nullptr, *s_base = nullptr, *s_ent = nullptr;
     {
-        char *nxt = (char *)(s_layers + (long long)A.K * NT);
+        char *nxt = (char *)(s_layers + (long long)KK * NT);
         if (use_lds) { tex_agg.bind(nxt); nxt += TexAgg::BYTES; tex_agg.clear(threadIdx.x, NT); }          // block-uniform
         if (lds_alpha) { alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES; alpha_agg.clear(threadIdx.x, NT); }
         if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); nxt += FaceAgg::BYTES; }
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     // is a dependent load chain).  Exact for any input: no assumption that the occupied slots of a pixel form a prefix.
     int kmax = 0;
 #pragma unroll 5
-    for (int k = 0; k < A.K; ++k) {
+    for (int k = 0; k < KK; ++k) {
         const bool occ = in_img && A.p2f[frag_addr(A, n, yi, xi, k).s] >= 0;
         if (__ballot(occ) != 0ull) kmax = k + 1;
     }
-    if (!FUSED) kmax = A.K;                 // the unfused kernel writes d/d dists and d/d barycentrics of every slot
+    if (!FUSED) kmax = KK;                 // the unfused kernel writes d/d dists and d/d barycentrics of every slot
     // pass 1 (front to back): alpha and transmittance per layer; no texture access
     {
         float T = 1.f;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
         if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
-        if (!FUSED && gdists && in_img) gdists[pix * A.K + k] = gd;
+        if (!FUSED && gdists && in_img) gdists[pix * KK + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
             if (lds_alpha) alpha_agg.add_wave(galpha, valid ? (int)fr.aidx : 0, gfa, valid && gfa[0] != 0.f);
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
                 const bool on = tex && wt[q] != 0.f;
                 // hard single-layer passes over magnified / decimated maps: a wave usually sits inside one cell
-                if (A.K == 1) tex_agg.add_wave(gmaps, (int)(ad[q] / 3), v, on);
+                if (SINGLE) tex_agg.add_wave(gmaps, (int)(ad[q] / 3), v, on);
                 else if (on) tex_agg.add(gmaps, (int)(ad[q] / 3), v);
             }
         } else if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 convert_bary_bwd(fr.cd, fr.w2, fr.w3, go, gb);
             }
             if (!FUSED) {
-                const long long o = (pix * A.K + k) * 3;
+                const long long o = (pix * KK + k) * 3;
                 gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
             } else if (valid && (gd != 0.f || gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f)) {
                 // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0; divisions by v_rcp_f32).
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         if (FUSED && !(A.dbg & 64)) {           // dbg 64: ablate the aggregation (tools/ablate.py)
             // hard single-layer passes rasterise few, large faces (a wave usually sits inside one): sum across the wave first;
             // soft multi-layer passes see several small faces per wave and layer, where the uniformity test does not pay
-            if (A.K == 1) face_agg.add_wave(gfv, fc, g9, has_g9);
+            if (SINGLE) face_agg.add_wave(gfv, fc, g9, has_g9);
             else if (has_g9) face_agg.add(gfv, fc, g9);
         }
     }
@@ -488,22 +491,26 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     if (fused && A.bin_records) lds += (size_t)(3 * BIN_SLOTS + K * NT) * sizeof(int);
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             dbw_set_error("shade/blend backward: cannot raise the dynamic LDS limit");
             return DBW_ERR_LAUNCH;
         }
         raised = true;
     }
     if (fused && A.bin_records)
-        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, true>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, true, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+                           grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
+    else if (fused && K == 1)
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, false, true>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
                            grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
     else if (fused)
-        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<true, false, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
                            grad_faces_alpha, nullptr, nullptr, fv, gfv, want_bary, persp);
     else
-        hipLaunchKernelGGL((shade_blend_bwd_kernel<false, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
+        hipLaunchKernelGGL((shade_blend_bwd_kernel<false, false, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
                            grad_faces_alpha, grad_dists, grad_bary, nullptr, nullptr, 0, 1);
     return dbw_check_launch("shade_blend_bwd_kernel");
 }
