@@ -85,31 +85,29 @@ __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, in
     }
 }
 
-// one thread per (map, y, x, channel)
+// one thread per texel (its three channels); blockIdx.y = row (map * h + y): no integer division anywhere
 __global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m, int n, int h, int w, int wrap,
                                                      float scale, float *__restrict__ loss, float *__restrict__ gm) {
     __shared__ float s_red[NT / DBW_WAVE];
-    const long long total = (long long)n * h * w * 3;
     const float sx = 1.f / ((float)h * (float)(w - 1 + (wrap ? 1 : 0)));
     const float sy = 1.f / ((float)(h - 1) * (float)w);
     float part = 0.f;
-    for (long long i0 = (long long)blockIdx.x * NT; i0 < total; i0 += (long long)gridDim.x * NT) {
-        const long long i = i0 + threadIdx.x;
-        if (i < total) {
-            const int c = (int)(i % 3);
-            const long long t = i / 3;
-            const int x = (int)(t % w), y = (int)((t / w) % h);
-            (void)c;
-            const float v = m[i];
-            float g = 0.f;
-            // forward difference owned by this texel (x -> x+1, wrapping to column 0 when wrap)
-            if (x + 1 < w) { const float dxf = m[i + 3] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
-            else if (wrap) { const float dxf = m[i - (long long)(w - 1) * 3] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
-            if (x > 0) { const float dxb = v - m[i - 3]; g += 2.f * dxb * sx; }
-            else if (wrap) { const float dxb = v - m[i + (long long)(w - 1) * 3]; g += 2.f * dxb * sx; }
-            if (y + 1 < h) { const float dyf = m[i + (long long)w * 3] - v; part += dyf * dyf * sy; g -= 2.f * dyf * sy; }
-            if (y > 0) { const float dyb = v - m[i - (long long)w * 3]; g += 2.f * dyb * sy; }
-            if (gm) gm[i] = scale * g;
+    for (int row = blockIdx.y; row < n * h; row += gridDim.y) {
+        const int y = row % h;
+        const float *r = m + (long long)row * w * 3;
+        for (int x = blockIdx.x * NT + threadIdx.x; x < w; x += gridDim.x * NT) {
+            const int xr = x + 1 < w ? x + 1 : (wrap ? 0 : -1), xl = x > 0 ? x - 1 : (wrap ? w - 1 : -1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = r[x * 3 + c];
+                float g = 0.f;
+                // forward difference owned by this texel (x -> x+1, wrapping to column 0 when wrap)
+                if (xr >= 0) { const float dxf = r[xr * 3 + c] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
+                if (xl >= 0) { const float dxb = v - r[xl * 3 + c]; g += 2.f * dxb * sx; }
+                if (y + 1 < h) { const float dyf = r[(x + w) * 3 + c] - v; part += dyf * dyf * sy; g -= 2.f * dyf * sy; }
+                if (y > 0) { const float dyb = v - r[(x - w) * 3 + c]; g += 2.f * dyb * sy; }
+                if (gm) gm[((long long)row * w + x) * 3 + c] = scale * g;
+            }
         }
     }
     const float tot = block_sum(part, s_red);
@@ -203,8 +201,9 @@ extern "C" int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, f
                            float *grad_maps, dbw_stream_t stream) {
     DBW_REQUIRE(maps && loss, "null pointer");
     DBW_REQUIRE(n > 0 && h > 1 && w > 1, "bad size");
-    hipLaunchKernelGGL(tv_l2sq_kernel, dim3(grid_for((long long)n * h * w * 3)), dim3(NT), 0, (hipStream_t)stream, maps,
-                       n, h, w, wrap_x, scale, loss, grad_maps);
+    const long long rows = (long long)n * h;
+    hipLaunchKernelGGL(tv_l2sq_kernel, dim3((unsigned)((w + NT - 1) / NT), (unsigned)(rows < 512 ? rows : 512)), dim3(NT), 0,
+                       (hipStream_t)stream, maps, n, h, w, wrap_x, scale, loss, grad_maps);
     return dbw_check_launch("tv_l2sq_kernel");
 }
 
