@@ -462,3 +462,38 @@ def test_full_size_properties():
     c2o = cl['c2o'].view(-1).long()
     orig = torch.where(p2f[:1] >= 0, c2o[p2f[:1].clamp(min=0).long()], torch.full_like(p2f[:1], -1).long())
     assert torch.equal(orig.cpu(), ref['pix_to_face'])
+
+
+def test_full_size_gradient_paths_agree(monkeypatch):
+    """BASELINE config-2 geometry at full size (300x400, K = 10, 256^2 textures, 6 views): the alternative implementations of one
+    step must agree -- two-level binning vs full face scan (bit-identical image), texture-space bins vs atomic scatter of the
+    texel gradients (same sums up to the order of the fp32/fp64 additions), and the texel-gradient total equals the total
+    weight the blend assigns to the texture samples (bilinear weights sum to one: a conservation law of the scatter)."""
+    m = O.OracleDBW((300, 400), n_blocks=10, txt_size=256, faces_per_pixel=10, seed=227391)
+    R, T, Km = O.synthetic_cameras(6, R_world=m.R_world[0])
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    shapes = [tuple(t.shape[:2]) for t in scene['maps']]
+    F_ = scene['faces'].shape[0]
+    alpha = (torch.rand(10, generator=torch.Generator().manual_seed(3)) * 0.8 + 0.1).repeat_interleave(F_ // 10).to(DEV)
+    g_img = torch.rand(6, 4, 300, 400, generator=torch.Generator().manual_seed(4)).to(DEV)
+    g_img[:, 3] = 0                                    # colour gradients only: then sum(grad_maps[c]) = sum_pix g_c * sum_k T_k a_k
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    out = {}
+    for tag, coarse, bins in (('default', True, True), ('full_scan', False, True), ('atomics', True, False)):
+        monkeypatch.setattr(ops, 'COARSE_BINS', coarse)
+        ps = _packed(scene)
+        ps.maps.requires_grad_(True)
+        ps.verts.requires_grad_(True)
+        bb, bi, nb = PackedScene.describe_bins(shapes, DEV)
+        cfg = ops.RenderCfg(300, 400, 10, 1e-4, 0.001, True, True, F_, lds_aggregate=False, texbins=(bb, bi, nb) if bins else None)
+        img = ops.render_scene(ps.verts, ps.maps, alpha, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        (img * g_img).sum().backward()
+        out[tag] = (img.detach(), ps.maps.grad.clone(), ps.verts.grad.clone())
+    assert torch.equal(out['default'][0], out['full_scan'][0])
+    assert rel_err(out['default'][1], out['atomics'][1]) < 2e-5 and rel_err(out['default'][2], out['atomics'][2]) < 2e-5
+    # conservation: the colour part of the image is sum_k T_k a_k c_k; with unit textures it equals sum_k T_k a_k = 1 - T_K = alpha
+    # channel, so the texel gradients of channel c add up to sum_pix g_c * image_alpha
+    expect = (g_img[:, :3] * out['default'][0][:, 3:4]).sum(dim=(0, 2, 3)).double()
+    got = out['default'][1].view(-1, 3).double().sum(0)
+    assert torch.allclose(got, expect, rtol=2e-4), (got, expect)
