@@ -217,15 +217,15 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
             else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
             else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
-            const long long ad[4] = {s.a00, s.a01, s.a10, s.a11};
+            const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
             const float wt[4] = {w00, w01, w10, w11};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
                 const bool on = tex && wt[q] != 0.f;
                 // hard single-layer passes over magnified / decimated maps: a wave usually sits inside one cell
-                if (SINGLE) tex_agg.add_wave(gmaps, (int)(ad[q] / 3), v, on);
-                else if (on) tex_agg.add(gmaps, (int)(ad[q] / 3), v);
+                if (SINGLE) tex_agg.add_wave(gmaps, (int)((unsigned)ad[q] / 3u), v, on);
+                else if (on) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v);
             }
         } else if (__ballot(tex) != 0ull && !(A.dbg & 1)) {
             bool pending = tex;
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                     break;
                 }
                 const int leader = __ffsll((long long)rem) - 1;
-                const long long k00 = __shfl(s.a00, leader, 64), k11 = __shfl(s.a11, leader, 64);
+                const int k00 = __shfl(s.a00, leader, 64), k11 = __shfl(s.a11, leader, 64);
                 const bool match = pending && s.a00 == k00 && s.a11 == k11;
                 const unsigned long long mm = __ballot(match);
                 if (__popcll(mm) > 1) {
-                    const long long k01 = __shfl(s.a01, leader, 64), k10 = __shfl(s.a10, leader, 64);
+                    const int k01 = __shfl(s.a01, leader, 64), k10 = __shfl(s.a10, leader, 64);
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const float v00 = wave_sum(match ? gc[ch] * s.w00 : 0.f);

@@ -33,7 +33,7 @@ struct ShadeArgs {
 };
 
 struct Sample {   // bilinear footprint of one fragment
-    long long a00, a01, a10, a11;   // float offsets of the 4 texels (RGB triplets) in `maps`
+    int a00, a01, a10, a11;         // float offsets of the 4 texels (RGB triplets) in `maps` (map_desc offsets are int32: < 2^31 floats)
     float w00, w01, w10, w11;
     float dudx, dvdy;               // d(ix)/du, d(iy)/dv (0 when clamped at the border)
     float wx0, wx1, wy0, wy1;
@@ -172,7 +172,7 @@ __device__ __forceinline__ int wrap_col(int c, int w) {
 __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
     const float u = fr.u, v = fr.v;
     const int *md = A.map_desc + fr.map * 8;
-    const long long off = md[0];
+    const int off = md[0];
     const int h = md[1], w = md[2], pl = md[3], pr = md[4], sh = md[5];
     const int wp = w + pl + pr;
     float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
@@ -192,8 +192,8 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     // kept at cell resolution and the nearest upsampling is this shift
     const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;
     c0 >>= sh; c1 >>= sh;
-    s.a00 = off + ((long long)r0 * ws + c0) * 3; s.a01 = off + ((long long)r0 * ws + c1) * 3;
-    s.a10 = off + ((long long)r1 * ws + c0) * 3; s.a11 = off + ((long long)r1 * ws + c1) * 3;
+    s.a00 = off + (r0 * ws + c0) * 3; s.a01 = off + (r0 * ws + c1) * 3;
+    s.a10 = off + (r1 * ws + c0) * 3; s.a11 = off + (r1 * ws + c1) * 3;
     s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
     s.r0 = r0; s.c0 = c0; s.r1 = r1; s.c1 = c1; s.ws = ws;
 }

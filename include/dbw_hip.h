@@ -97,7 +97,8 @@ int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const
  *    faces (then pix_to_face = b*F + j).
  *  face_uvs (F,3,2)   face_map (F) -> row of map_desc
  *  map_desc (M,8) int32: {offset in floats into maps, height h, width w (unpadded), pad_left, pad_right, shift, 0, 0}
- *  maps: flat fp32 buffer of RGB maps in [0,1]; map m is STORED as (h>>shift, w>>shift, 3): shift > 0 is a decimated map
+ *  maps: flat fp32 buffer of RGB maps in [0,1], fewer than 2^31 floats in total (texels are addressed with the int32 offsets);
+ *    map m is STORED as (h>>shift, w>>shift, 3): shift > 0 is a decimated map
  *    (avg_pool2d(2^shift) kept at cell resolution; the nearest upsampling of dbw.py:278,334 is the shift)
  *  faces_alpha: NULL, or alpha_len floats with alpha_len == F (shared by all views) or N*F (packed per view).
  *  background3: HOST pointer to 3 floats (blend background colour, renderer.py:32), NULL = black.
