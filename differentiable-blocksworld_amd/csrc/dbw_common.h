@@ -195,6 +195,19 @@ template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, BANK_MASK, false));
 }
+// 2x2-pixel quad helpers (lanes 4i..4i+3 of the 8x8 patch are not a spatial quad, but they are 4 horizontally adjacent pixels):
+// broadcast of the quad's first lane, and the sum over the quad in every lane
+__device__ __forceinline__ int quad_first(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, false); }
+__device__ __forceinline__ int quad_and(int x) {
+    x &= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    x &= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_<0xB1, 0xf, 0xf>(v);
+    v += dpp_<0x4E, 0xf, 0xf>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     const float t = v;
     v += dpp_<0x111, 0xf, 0xf>(t);           // row_shr:1

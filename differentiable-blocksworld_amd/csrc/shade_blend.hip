@@ -219,11 +219,23 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
             const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
             const float wt[4] = {w00, w01, w10, w11};
+            // hard single-layer passes over magnified maps: 4 horizontally adjacent pixels usually share their footprint -- sum their
+            // contributions in registers (DPP) and let the first lane of the four update the table: 4x fewer lanes on one slot
+            bool lead = true;
+            int same4 = 0;
+            if (SINGLE) {
+                same4 = quad_and((tex && s.a00 == quad_first(s.a00) && s.a11 == quad_first(s.a11)) ? 1 : 0);
+                lead = !same4 || (lane & 3) == 0;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                const bool on = tex && wt[q] != 0.f;
-                // hard single-layer passes over magnified / decimated maps: a wave usually sits inside one cell
+                float v[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                if (SINGLE) {
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) { const float qs = quad_sum(tex ? v[c3] : 0.f); v[c3] = same4 ? qs : v[c3]; }
+                }
+                const bool on = tex && lead && (same4 ? (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f) : wt[q] != 0.f);
+                // ... and over decimated maps a whole wave usually sits inside one cell
                 if (SINGLE) tex_agg.add_wave(gmaps, (int)((unsigned)ad[q] / 3u), v, on);
                 else if (on) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v);
             }
