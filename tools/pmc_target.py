@@ -10,6 +10,7 @@ args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 30
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.sync_free = True
+model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
 step = ShardedTrainStep(model, seed=1)
 for _ in range(3):
     step(inp)
