@@ -115,7 +115,8 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
             c2o[o] = f; neighbor[o] = -1; code[o] = -1; cw[o * 2] = 0.f; cw[o * 2 + 1] = 0.f;
         } else if (emit == 1) {   // case 3: two behind, p1 = the vertex in front -> (p4, p5, p1)
             const int i1 = (behind_mask == 6) ? 0 : (behind_mask == 5 ? 1 : 2);
-            const f3 p1 = p[i1], p2 = p[(i1 + 1) % 3], p3 = p[(i1 + 2) % 3];
+            const f3 p1 = i1 == 0 ? p[0] : (i1 == 1 ? p[1] : p[2]), p2 = i1 == 0 ? p[1] : (i1 == 1 ? p[2] : p[0]),
+                     p3 = i1 == 0 ? p[2] : (i1 == 1 ? p[0] : p[1]);      // selects: runtime indexing would spill p[] to scratch
             float w2, w3;
             const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
             const long long o = base_out + slot;
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
             c2o[o] = f; neighbor[o] = -1; code[o] = i1 | (0 << 2); cw[o * 2] = w2; cw[o * 2 + 1] = w3;
         } else if (emit == 2) {   // case 4: one behind, p1 = the vertex behind -> t1 (p4,p2,p5), t2 (p5,p2,p3)
             const int i1 = (behind_mask == 1) ? 0 : (behind_mask == 2 ? 1 : 2);
-            const f3 p1 = p[i1], p2 = p[(i1 + 1) % 3], p3 = p[(i1 + 2) % 3];
+            const f3 p1 = i1 == 0 ? p[0] : (i1 == 1 ? p[1] : p[2]), p2 = i1 == 0 ? p[1] : (i1 == 1 ? p[2] : p[0]),
+                     p3 = i1 == 0 ? p[2] : (i1 == 1 ? p[0] : p[1]);      // selects: runtime indexing would spill p[] to scratch
             float w2, w3;
             const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
             const long long o = base_out + slot;
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
     if (tid == 0) { first_idx[b] = (int)base_out; num_faces[b] = running; }
 }
 
-// d(ndc vertex)/d(world vertex), accumulated atomically
-__device__ __forceinline__ void vertex_bwd(const float *verts, int vi, const Cam &c, float eps, f3 g, float *gverts) {
+// d(ndc vertex)/d(world vertex): the world-space gradient of one vertex of one view
+__device__ __forceinline__ f3 vertex_bwd(const float *verts, int vi, const Cam &c, float eps, f3 g) {
     const Proj pr = project(verts + (long long)vi * 3, c, eps);
     const float gpx = g.x / pr.denom, gpy = g.y / pr.denom;
     const float gden = -(g.x * pr.px + g.y * pr.py) / (pr.denom * pr.denom);
@@ -150,12 +152,11 @@ __device__ __forceinline__ void vertex_bwd(const float *verts, int vi, const Cam
     const float gvx = gpx * c.K[0] + gpy * c.K[4] + gpw * c.K[12];
     const float gvy = gpx * c.K[1] + gpy * c.K[5] + gpw * c.K[13];
     const float gvz = gpx * c.K[2] + gpy * c.K[6] + gpw * c.K[14] + g.z;
-    const float gx = gvx * c.R[0] + gvy * c.R[1] + gvz * c.R[2];
-    const float gy = gvx * c.R[3] + gvy * c.R[4] + gvz * c.R[5];
-    const float gz = gvx * c.R[6] + gvy * c.R[7] + gvz * c.R[8];
-    if (gx != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 0, gx);
-    if (gy != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 1, gy);
-    if (gz != 0.f) unsafeAtomicAdd(gverts + (long long)vi * 3 + 2, gz);
+    f3 o;
+    o.x = gvx * c.R[0] + gvy * c.R[1] + gvz * c.R[2];
+    o.y = gvx * c.R[3] + gvy * c.R[4] + gvz * c.R[5];
+    o.z = gvx * c.R[6] + gvy * c.R[7] + gvz * c.R[8];
+    return o;
 }
 
 // grads of q = clip_point(pa, pb) (w detached) pushed to ga, gb
@@ -173,53 +174,93 @@ __device__ __forceinline__ void clip_point_bwd(f3 pa, f3 pb, float c, int persp,
     }
 }
 
+// Backward of project + clip.  One WAVE per clipped-face slot j, one LANE per view: the B views push their gradient of slot j
+// onto the same three mesh vertices (unless clipping or culling shifted the slots of a view), so the wave sums the nine
+// world-space components over its lanes in registers (DPP) and one lane issues 9 atomics -- instead of B x 9 atomics per face
+// that all land on the same V x 3 addresses (measured: 68 us with them, 5 us without, at 49 views x 12.8 k slots).
 __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
     const float *__restrict__ T, const float *__restrict__ Kmat, int B, int V, int F, float eps, float zc, int persp,
     const int *__restrict__ num_faces, const int *__restrict__ c2o, const int *__restrict__ code,
     const float *__restrict__ cw, const float *__restrict__ gfvc, float *__restrict__ gverts) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * NT + threadIdx.x;
-    if (j >= num_faces[b]) return;
-    const long long o = (long long)b * 2 * F + j;
-    const float *g = gfvc + o * 9;
-    bool any = false;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (NT / DBW_WAVE) + (threadIdx.x >> 6);
+    if (j >= 2 * F) return;
+    for (int b0 = 0; b0 < B; b0 += DBW_WAVE) {
+        const int b = b0 + lane;
+        bool act = b < B && j < num_faces[b];
+        const long long o = (long long)(act ? b : 0) * 2 * F + j;
+        float g[9];
+        if (act) {
+            bool any = false;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) any |= (g[i] != 0.f);
-    if (!any) return;
-    Cam cam;
-    load_cam(R, T, Kmat, b, cam);
-    const int f = c2o[o], cd = code[o];
-    const int vi[3] = {faces[f * 3], faces[f * 3 + 1], faces[f * 3 + 2]};
-    f3 gv[3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    const f3 ga{g[0], g[1], g[2]}, gb{g[3], g[4], g[5]}, gc{g[6], g[7], g[8]};
-    if (cd < 0) {
-        gv[0] = ga; gv[1] = gb; gv[2] = gc;
-    } else {
-        const int i1 = cd & 3, kind = cd >> 2, i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
-        f3 p[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) p[i] = project(verts + (long long)vi[i] * 3, cam, eps).ndc;
-        const float w2 = cw[o * 2], w3 = cw[o * 2 + 1];
-        f3 g1{0.f, 0.f, 0.f}, g2{0.f, 0.f, 0.f}, g3{0.f, 0.f, 0.f};
-        if (kind == 0) {          // (p4, p5, p1)
-            clip_point_bwd(p[i1], p[i2], zc, persp, w2, ga, g1, g2);
-            clip_point_bwd(p[i1], p[i3], zc, persp, w3, gb, g1, g3);
-            g1.x += gc.x; g1.y += gc.y; g1.z += gc.z;
-        } else if (kind == 1) {   // (p4, p2, p5)
-            clip_point_bwd(p[i1], p[i2], zc, persp, w2, ga, g1, g2);
-            g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
-            clip_point_bwd(p[i1], p[i3], zc, persp, w3, gc, g1, g3);
-        } else {                  // (p5, p2, p3)
-            clip_point_bwd(p[i1], p[i3], zc, persp, w3, ga, g1, g3);
-            g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
-            g3.x += gc.x; g3.y += gc.y; g3.z += gc.z;
+            for (int i = 0; i < 9; ++i) { g[i] = gfvc[o * 9 + i]; any |= (g[i] != 0.f); }
+            act = any;
         }
-        gv[i1] = g1; gv[i2] = g2; gv[i3] = g3;
-    }
+        int f = -1, vi[3] = {0, 0, 0};
+        float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            Cam cam;
+            load_cam(R, T, Kmat, b, cam);
+            f = c2o[o];
+            const int cd = code[o];
+            vi[0] = faces[f * 3]; vi[1] = faces[f * 3 + 1]; vi[2] = faces[f * 3 + 2];
+            f3 gv[3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            const f3 ga{g[0], g[1], g[2]}, gb{g[3], g[4], g[5]}, gc{g[6], g[7], g[8]};
+            if (cd < 0) {
+                gv[0] = ga; gv[1] = gb; gv[2] = gc;
+            } else {
+                const int i1 = cd & 3, kind = cd >> 2;
+                // vertex roles rotated by i1 with selects (runtime indexing would put the arrays in scratch memory)
+                const f3 q0 = project(verts + (long long)vi[0] * 3, cam, eps).ndc, q1 = project(verts + (long long)vi[1] * 3, cam, eps).ndc,
+                         q2 = project(verts + (long long)vi[2] * 3, cam, eps).ndc;
+                const f3 P1 = i1 == 0 ? q0 : (i1 == 1 ? q1 : q2), P2 = i1 == 0 ? q1 : (i1 == 1 ? q2 : q0),
+                         P3 = i1 == 0 ? q2 : (i1 == 1 ? q0 : q1);
+                const float w2 = cw[o * 2], w3 = cw[o * 2 + 1];
+                f3 g1{0.f, 0.f, 0.f}, g2{0.f, 0.f, 0.f}, g3{0.f, 0.f, 0.f};
+                if (kind == 0) {          // (p4, p5, p1)
+                    clip_point_bwd(P1, P2, zc, persp, w2, ga, g1, g2);
+                    clip_point_bwd(P1, P3, zc, persp, w3, gb, g1, g3);
+                    g1.x += gc.x; g1.y += gc.y; g1.z += gc.z;
+                } else if (kind == 1) {   // (p4, p2, p5)
+                    clip_point_bwd(P1, P2, zc, persp, w2, ga, g1, g2);
+                    g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
+                    clip_point_bwd(P1, P3, zc, persp, w3, gc, g1, g3);
+                } else {                  // (p5, p2, p3)
+                    clip_point_bwd(P1, P3, zc, persp, w3, ga, g1, g3);
+                    g2.x += gb.x; g2.y += gb.y; g2.z += gb.z;
+                    g3.x += gc.x; g3.y += gc.y; g3.z += gc.z;
+                }
+                gv[0] = i1 == 0 ? g1 : (i1 == 1 ? g3 : g2);
+                gv[1] = i1 == 0 ? g2 : (i1 == 1 ? g1 : g3);
+                gv[2] = i1 == 0 ? g3 : (i1 == 1 ? g2 : g1);
+            }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (gv[i].x != 0.f || gv[i].y != 0.f || gv[i].z != 0.f) vertex_bwd(verts, vi[i], cam, eps, gv[i], gverts);
+            for (int i = 0; i < 3; ++i)
+                if (gv[i].x != 0.f || gv[i].y != 0.f || gv[i].z != 0.f) {
+                    const f3 w = vertex_bwd(verts, vi[i], cam, eps, gv[i]);
+                    gw[i * 3] = w.x; gw[i * 3 + 1] = w.y; gw[i * 3 + 2] = w.z;
+                }
+        }
+        const unsigned long long am = __ballot(act);
+        if (am == 0ull) continue;
+        const int leader = __ffsll((long long)am) - 1;
+        const int f0 = __shfl(f, leader, 64);
+        if (__popcll(am) >= 4 && __ballot(act && f == f0) == am) {      // every view maps slot j to the same mesh face
+            float s[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s[c] = wave_sum_dpp(gw[c]);       // inactive lanes hold zeros
+            if (lane == leader) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c)
+                    if (s[c] != 0.f) unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), s[c]);
+            }
+        } else if (act) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (gw[c] != 0.f) unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), gw[c]);
+        }
+    }
 }
 
 }  // namespace
@@ -250,7 +291,7 @@ extern "C" int dbw_project_clip_bwd(const float *verts_world, const int32_t *fac
                     grad_face_verts_c && grad_verts_world, "null pointer");
     DBW_REQUIRE(B >= 0 && V > 0 && F > 0, "bad size");
     if (B == 0) return DBW_OK;
-    hipLaunchKernelGGL(project_clip_bwd_kernel, dim3((2 * F + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(project_clip_bwd_kernel, dim3((2 * F + NT / DBW_WAVE - 1) / (NT / DBW_WAVE)), dim3(NT), 0, (hipStream_t)stream,
                        verts_world, faces, R, T, Kmat, B, V, F, eps, z_clip, perspective_correct, num_faces, c2o,
                        clip_code, clip_w, grad_face_verts_c, grad_verts_world);
     return dbw_check_launch("project_clip_bwd_kernel");
