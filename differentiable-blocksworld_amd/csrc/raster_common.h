@@ -4,7 +4,7 @@
 
 namespace dbw {
 
-constexpr int LIST_CAP = 512;
+constexpr int LIST_CAP = 384;      // 16x16 tiles: 24 KB of face records per block -> 5 resident blocks/CU (the VGPR limit) instead of 4
 // Two-level binning: coarse_bin_kernel (raster.hip) first compacts, per view and per COARSE x COARSE pixel bin, the indices of
 // the faces whose blur-expanded box touches the bin (face order preserved); a tile then only scans the list of the bin it
 // lies in instead of every face of the view.  list == nullptr: single-level scan.
