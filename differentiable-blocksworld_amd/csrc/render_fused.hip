@@ -94,7 +94,8 @@ template <int KMAX>
 int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
 #define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(fv, bbox, first_idx, num_faces, neighbor, blur, persp, A, cb, p2f, bary, dists, image, s)
-    if (KMAX == 1) return DBW_V(16, 16, 4);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list
+    if (KMAX == 1) return DBW_V(16, 16, 2);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list; 2 bbox
+                                              // loads in flight keep it at 80 VGPRs = 6 resident blocks per CU (it is latency bound)
 #ifdef DBW_TUNE_VARIANTS
     switch (g_render_variant) {               // tile-shape / load-batching sweep (tools/sweep_render_fwd.py)
         case 1: return DBW_V(8, 8, 1);
