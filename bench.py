@@ -232,6 +232,9 @@ def main():
     assert total_loss == total_loss, 'loss is NaN'
 
     if rank == 0:
+        phase = ('coarse phase (sigma=1e-4, opacity noise, decimated textures)' if model.is_live('decimate_txt') else
+                 'coarse phase (sigma=1e-4, opacity noise, full-resolution textures)' if model.is_live('coarse_learning') else
+                 'fine phase (sigma=5e-6, transparent blocks filtered, full-resolution textures)')
         views_per_s = world * args.views * args.steps / dt
         P = args.H * args.W
         bytes_per_view = 64 * P * args.fpp + 140 * P                      # whole-path algorithmic bytes
@@ -251,8 +254,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'DTU-scan24-like synthetic: {args.views} views/GPU/step, {args.W}x{args.H}, {args.blocks} superquadric '
-                                   f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, coarse phase '
-                                   f'(sigma=1e-4, opacity noise, decimated textures), MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
+                                   f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, {phase}, '
+                                   f'MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
                        'views_per_gpu': args.views, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks, 'faces_per_pixel': args.fpp,
                        'txt_size': args.txt, 'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
                                  ('' if args.no_overlap else ', env pass on a side stream'),
@@ -260,7 +263,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
-                         'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS},
+                         'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS,
+                         'limiter': 'instruction issue, not HBM: SQ counters show the fused forward ~70 % VALU-active and the fused backward '
+                                    'waiting on dependent loads / LDS at 3.5 waves per SIMD (DESIGN.md section 4); frac is the share of '
+                                    'the HBM roofline the algorithmic bytes reach'},
             'final_loss': total_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
