@@ -41,6 +41,7 @@ struct Sample {   // bilinear footprint of one fragment
 };
 
 struct Frag {
+    int fc;           // clipped face id of the slot (index into face_verts_c)
     int j;            // local original face id
     int cd;           // clip code
     float w2, w3;
@@ -142,6 +143,7 @@ template <bool FAST = false>
 __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragAddr &o, Frag &fr) {
     const int fc = A.p2f[o.s];
     if (fc < 0) return false;
+    fr.fc = fc;
     if (A.tiled == 2) {   // shading inputs were resolved by the forward pass: no table gathers, the dependent-load chain is
                           // fragment -> {opacity, map descriptor} -> texels
         fr.u = A.bary[o.b];
