@@ -72,6 +72,15 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     o[3 * plane] = 1.f - T;
 }
 
+#ifdef DBW_PROFILE_BWD
+// cycle accounting of the fused backward (tools/bwd_cycles.py only): per-wave s_memtime deltas of the phases, summed in g_prof
+__device__ unsigned long long g_prof[8];
+#define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define PROF_ADD(i, a, b) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], (b) - (a))
+#else
+#define PROF_T(x)
+#define PROF_ADD(i, a, b)
+#endif
 constexpr int BIN_LOG2 = 7, BIN_SLOTS = 1 << BIN_LOG2;   // per-block hash table of touched texture bins
 constexpr int BIN_CHUNK = 8192;                           // records one texbin_reduce workgroup accumulates
 
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
     // backward 0.73 -> 0.67 ms).  For fragments of unknown origin (layout 0) a pass 0 looks at every slot first -- exact without
     // that assumption; the binned and single-layer instantiations keep pass 0 too (two more live registers cost the binned one
     // a wave per SIMD, and one layer has nothing to skip).
+    PROF_T(t_begin);
     const bool prefix = FUSED && !BINNED && !SINGLE && A.tiled != 0;
     int kmax = 0;
     if (!prefix) {
@@ -145,6 +155,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         }
         if (!FUSED) kmax = KK;             // the unfused kernel writes d/d dists and d/d barycentrics of every slot
     }
+    PROF_T(t_p0);
+    PROF_ADD(0, t_begin, t_p0);
     // pass 1 (front to back): alpha and transmittance per layer; no texture access
     {
         float T = 1.f;
@@ -188,10 +200,13 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             s_base[threadIdx.x] = atomicAdd(A.bin_cursor + s_key[threadIdx.x], s_cnt[threadIdx.x]);
         __syncthreads();
     }
+    PROF_T(t_p1);
+    PROF_ADD(1, t_p0, t_p1);
     // pass 2 (back to front)
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
 #pragma unroll DBW_BWD_UNROLL
     for (int k = kmax - 1; k >= 0; --k) {    // unrolled by 2: the gather chains of two layers overlap
+        PROF_T(t_it);
         Frag fr;
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
@@ -210,6 +225,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         U1 = ak * c[1] + (1.f - ak) * U1;
         U2 = ak * c[2] + (1.f - ak) * U2;
         Vb = (1.f - ak) * Vb;
+        PROF_T(t_a);
+        PROF_ADD(2, t_it, t_a);
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
         if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
@@ -219,6 +236,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
             if (lds_alpha) alpha_agg.add_wave(galpha, valid ? (int)fr.aidx : 0, gfa, valid && gfa[0] != 0.f);
             else wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
         }
+        PROF_T(t_b);
+        PROF_ADD(3, t_a, t_b);
         // colour -> texels (and -> uv -> barycentrics)
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
@@ -319,6 +338,8 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 ++iter;
             }
         }
+        PROF_T(t_c);
+        PROF_ADD(4, t_b, t_c);
         float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int fc = 0;
         bool has_g9 = false;
@@ -370,13 +391,19 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 }
             }
         }
+        PROF_T(t_d);
+        PROF_ADD(5, t_c, t_d);
         if (FUSED && !(A.dbg & 64)) {           // dbg 64: ablate the aggregation (tools/ablate.py)
             // hard single-layer passes rasterise few, large faces (a wave usually sits inside one): sum across the wave first;
             // soft multi-layer passes see several small faces per wave and layer, where the uniformity test does not pay
             if (SINGLE) face_agg.add_wave(gfv, fc, g9, has_g9);
             else if (has_g9) face_agg.add(gfv, fc, g9);
         }
+        PROF_T(t_e);
+        PROF_ADD(6, t_d, t_e);
     }
+    PROF_T(t_end);
+    PROF_ADD(7, t_begin, t_end);
     if (use_lds || lds_alpha || FUSED) __syncthreads();
     if (use_lds) tex_agg.flush(gmaps, threadIdx.x, NT);
     if (lds_alpha && galpha) alpha_agg.flush(galpha, threadIdx.x, NT);
@@ -450,6 +477,12 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
 }
 
 int g_dbg_flags = 0;
+#ifdef DBW_PROFILE_BWD
+extern "C" void dbw_debug_read_profile(unsigned long long *out8, int reset) {
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), 64);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, 64); }
+}
+#endif
 
 int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
               const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
