@@ -61,6 +61,7 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
                     bary[o.b + 2 * o.bstride] = __int_as_float(fr.j | (fr.map << 20));
                 }
                 const float a = fr.e * fr.fa;
+                if (A.tiled == 2) bary[o.b + 3 * o.bstride] = a;      // the blend opacity: all pass 1 of the backward needs
                 if (a != 0.f) {
                     Sample s;
                     footprint(A, fr, s);

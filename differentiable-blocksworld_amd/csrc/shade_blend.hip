@@ -165,7 +165,16 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         for (int k = 0; k < klimit; ++k) {  // unrolled: the fragment loads of several layers are in flight together
             float ak = 0.f;
             Frag fr;
-            const bool valid = in_img && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
+            bool valid;
+            if (FUSED && !BINNED && A.tiled == 2) {
+                // uv-fragments carry the blend opacity the forward used: two coalesced loads per layer instead of the whole
+                // payload + the opacity gather + an exponential (pass 1 was 20 % of the wave time)
+                const FragAddr o = frag_addr(A, n, yi, xi, k);
+                valid = in_img && A.p2f[o.s] >= 0;
+                if (valid) { fr.e = A.bary[o.b + 3 * o.bstride]; fr.fa = 1.f; }
+            } else {
+                valid = in_img && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
+            }
             if (prefix) {
                 const bool anyv = __ballot(valid) != 0ull;
                 if (anyv) kmax = k + 1;

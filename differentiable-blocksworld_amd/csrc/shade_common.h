@@ -128,7 +128,7 @@ __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi,
         const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
         const int lane = ((yi & 7) << 3) | (xi & 7);
         a.s = ((tile * A.K + k) << 6) + lane;
-        a.b = (((tile * A.K + k) * 3) << 6) + lane;
+        a.b = (((tile * A.K + k) * (A.tiled == 2 ? 4 : 3)) << 6) + lane;      // layout 2 has a fourth plane: the blend opacity
         a.bstride = 64;
     } else {
         a.s = (((long long)n * A.H + yi) * A.W + xi) * A.K + k;
