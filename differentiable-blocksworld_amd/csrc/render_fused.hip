@@ -61,14 +61,17 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
                     bary[o.b + 2 * o.bstride] = __int_as_float(fr.j | (fr.map << 20));
                 }
                 const float a = fr.e * fr.fa;
-                if (A.tiled == 2) bary[o.b + 3 * o.bstride] = a;      // the blend opacity: all pass 1 of the backward needs
+                float c[3] = {0.f, 0.f, 0.f};
                 if (a != 0.f) {
                     Sample s;
                     footprint(A, fr, s);
-                    float c[3];
                     fetch(A.maps, s, c);
                     const float wgt = T * a;
                     r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+                }
+                if (A.tiled == 2) {       // ... together with the blend opacity and the sampled colour (0 where the opacity is 0)
+                    bary[o.b + 3 * o.bstride] = a;
+                    bary[o.b + 4 * o.bstride] = c[0]; bary[o.b + 5 * o.bstride] = c[1]; bary[o.b + 6 * o.bstride] = c[2];
                 }
                 T *= (1.f - a);
             }

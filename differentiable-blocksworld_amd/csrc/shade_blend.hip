@@ -95,7 +95,7 @@ __device__ __forceinline__ bool bin_regular(const Sample &s) {
 // SINGLE = true: a hard single-layer pass (K == 1; the env pass) -- its own instantiation, so that the layer loops fold away and a
 // kernel trace tells the two passes of an iteration apart.
 template <bool FUSED, bool BINNED, bool SINGLE>
-__global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
+__global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
                                                              float *__restrict__ gbary, const float *__restrict__ fv,
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 // payload + the opacity gather + an exponential (pass 1 was 20 % of the wave time)
                 const FragAddr o = frag_addr(A, n, yi, xi, k);
                 valid = in_img && A.p2f[o.s] >= 0;
-                if (valid) { fr.e = A.bary[o.b + 3 * o.bstride]; fr.fa = 1.f; }
+                if (valid) fr.a = A.bary[o.b + 3 * o.bstride];
             } else {
                 valid = in_img && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
             }
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
                 if (anyv) kmax = k + 1;
                 else if (k % 5 == 4) break;     // (the stores below of an all-empty layer are never read: pass 2 stops at kmax)
             }
-            if (valid) ak = fr.e * fr.fa;
+            if (valid) ak = fr.a;
             s_T[k * NT] = T;
             if (BINNED) {
                 int ent = -1;
@@ -220,13 +220,14 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
         if (in_img) valid = load_frag<FUSED>(A, n, fo, fr);
-        const float ak = valid ? fr.e * fr.fa : 0.f, Tk = s_T[k * NT];
+        const float ak = valid ? fr.a : 0.f, Tk = s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
         float c[3] = {0.f, 0.f, 0.f};
         if (valid) {
             footprint(A, fr, s);
-            if (ak != 0.f) fetch(A.maps, s, c);
+            if (A.tiled == 2) { c[0] = fr.col[0]; c[1] = fr.col[1]; c[2] = fr.col[2]; }     // sampled by the forward (0 where ak == 0)
+            else if (ak != 0.f) fetch(A.maps, s, c);
         }
         const float ga = valid ? Tk * (gr * (c[0] - U0) + gg * (c[1] - U1) + gbl * (c[2] - U2) + gA * Vb) : 0.f;
         const float wgt = valid ? Tk * ak : 0.f;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NT) void shade_blend_bwd_kernel(ShadeArgs A, long l
         PROF_ADD(2, t_it, t_a);
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
-        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.fa * fr.e * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
+        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.a * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
         if (!FUSED && gdists && in_img) gdists[pix * KK + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};

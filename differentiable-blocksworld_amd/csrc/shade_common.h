@@ -48,6 +48,8 @@ struct Frag {
     float bo[3];      // barycentrics w.r.t. the original face
     float e;          // geometric alpha exp(-max(d,0)/sigma) or hard indicator
     float fa;         // learned face opacity (1 if none)
+    float a;          // blend opacity e * fa
+    float col[3];     // frag_layout 2 only: the texture colour the forward sampled for this fragment
     long long aidx;   // index into faces_alpha
     float d;
     float u, v;       // texture coordinates
@@ -91,6 +93,7 @@ __device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) 
         fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
         fr.fa = A.faces_alpha[fr.aidx];
     }
+    fr.a = fr.e * fr.fa;
 }
 
 // decode one fragment (clipped face id fc >= 0, clipped barycentrics b, signed distance d)
@@ -128,7 +131,7 @@ __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi,
         const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
         const int lane = ((yi & 7) << 3) | (xi & 7);
         a.s = ((tile * A.K + k) << 6) + lane;
-        a.b = (((tile * A.K + k) * (A.tiled == 2 ? 4 : 3)) << 6) + lane;      // layout 2 has a fourth plane: the blend opacity
+        a.b = (((tile * A.K + k) * (A.tiled == 2 ? 7 : 3)) << 6) + lane;      // layout 2: u, v, face|map, blend opacity, r, g, b
         a.bstride = 64;
     } else {
         a.s = (((long long)n * A.H + yi) * A.W + xi) * A.K + k;
@@ -144,16 +147,22 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
     const int fc = A.p2f[o.s];
     if (fc < 0) return false;
     fr.fc = fc;
-    if (A.tiled == 2) {   // shading inputs were resolved by the forward pass: no table gathers, the dependent-load chain is
-                          // fragment -> {opacity, map descriptor} -> texels
+    if (A.tiled == 2) {   // shading inputs, blend opacity and sampled colour were resolved by the forward pass: one hop of
+                          // coalesced loads, no table gathers, no texel fetch (the footprint is only needed for the scatter)
         fr.u = A.bary[o.b];
         fr.v = A.bary[o.b + o.bstride];
         const int jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
+        fr.a = A.bary[o.b + 3 * o.bstride];
+        fr.col[0] = A.bary[o.b + 4 * o.bstride]; fr.col[1] = A.bary[o.b + 5 * o.bstride]; fr.col[2] = A.bary[o.b + 6 * o.bstride];
         fr.j = jm & 0xfffff;
         fr.map = jm >> 20;
         fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
         fr.d = A.dists[o.s];
-        frag_alpha<FAST>(A, n, fr);
+        if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+        else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
+        else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
+        fr.fa = 1.f;      // not needed: a = e * fa is stored
+        fr.aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j) : 0;
         return true;
     }
     const float b[3] = {A.bary[o.b], A.bary[o.b + o.bstride], A.bary[o.b + 2 * o.bstride]};
