@@ -142,10 +142,8 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     // dbw_render_fwd_fused (tiled layouts) fill the slots of a pixel front to back, so pass 1 finds the bound on its way: it stops
     // after the first batch of 5 layers whose last layer is empty everywhere (measured: pass 0 was 17 % of the wave time; fg
     // backward 0.73 -> 0.67 ms).  For fragments of unknown origin (layout 0) a pass 0 looks at every slot first -- exact without
-    // that assumption; the binned and single-layer instantiations keep pass 0 too (two more live registers cost the binned one
-    // a wave per SIMD, and one layer has nothing to skip).
-    PROF_T(t_begin);
-    const bool prefix = FUSED && !BINNED && !SINGLE && A.tiled != 0;
+    // that assumption; the single-layer instantiation keeps pass 0 as well (one layer has nothing to skip).
+    const bool prefix = FUSED && !SINGLE && A.tiled != 0;
     int kmax = 0;
     if (!prefix) {
 #pragma unroll 5
