@@ -35,12 +35,16 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, n, xi, yi, q)) return;
     if (xi >= A.W || yi >= A.H) return;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    int cnt = 0;                             // fragments of this pixel (the list is filled front to back)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) cnt += (k < A.K && q.fi[k] != 0x7fffffff) ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < A.K) {
             const bool valid = q.fi[k] != 0x7fffffff;
             const FragAddr o = frag_addr(A, n, yi, xi, k);
-            p2f[o.s] = valid ? q.fi[k] : -1;
+            // layout 2: the first layer's id carries the fragment count, so that the backward knows how deep to go from one load
+            p2f[o.s] = valid ? ((A.tiled == 2 && k == 0) ? (q.fi[k] | (cnt << FRAG_COUNT_SHIFT)) : q.fi[k]) : -1;
             // internal layouts: empty slots carry only the -1 face id (the backward never reads the rest; a wave whose 64
             // pixels are all empty at this depth issues no store at all); the PyTorch3D-shaped layout 0 is filled with -1
             if (valid || A.tiled == 0) {
@@ -69,7 +73,9 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
                     const float wgt = T * a;
                     r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
                 }
-                if (A.tiled == 2) {       // ... together with the blend opacity and the sampled colour (0 where the opacity is 0)
+                if (A.tiled == 2) {       // ... together with the blend opacity, the sampled colour (0 where the opacity is 0) and
+                                          // the transmittance in front of the fragment
+                    bary[o.b + 7 * o.bstride] = T;
                     bary[o.b + 3 * o.bstride] = a;
                     bary[o.b + 4 * o.bstride] = c[0]; bary[o.b + 5 * o.bstride] = c[1]; bary[o.b + 6 * o.bstride] = c[2];
                 }
@@ -134,6 +140,7 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     if (rc) return rc;
     DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
     DBW_REQUIRE(frag_layout != 2 || F < (1 << 20), "frag_layout 2 packs the face id in 20 bits");
+    DBW_REQUIRE(frag_layout != 2 || F_total < (1LL << FRAG_COUNT_SHIFT), "frag_layout 2 packs the clipped face id in 26 bits");
     A.tiled = frag_layout;
     if (K > DBW_MAX_FACES_PER_PIXEL) {
         dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);

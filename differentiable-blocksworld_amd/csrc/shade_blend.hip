@@ -144,8 +144,18 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     // backward 0.73 -> 0.67 ms).  For fragments of unknown origin (layout 0) a pass 0 looks at every slot first -- exact without
     // that assumption; the single-layer instantiation keeps pass 0 as well (one layer has nothing to skip).
     const bool prefix = FUSED && !SINGLE && A.tiled != 0;
+    // uv-fragments (layout 2): the first layer's id carries the pixel's fragment count and every fragment its transmittance, so
+    // the unbinned kernel needs no pass 1 at all: one load gives the bound, pass 2 reads T_k with the rest of the payload
+    const bool stored_T = FUSED && !BINNED && A.tiled == 2;
     int kmax = 0;
-    if (!prefix) {
+    if (stored_T) {
+        const int raw0 = in_img ? A.p2f[frag_addr(A, n, yi, xi, 0).s] : -1;
+        const int cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
+        for (int k = 0; k < KK; ++k) {
+            if (__ballot(cnt > k) == 0ull) break;
+            kmax = k + 1;
+        }
+    } else if (!prefix) {
 #pragma unroll 5
         for (int k = 0; k < KK; ++k) {
             const bool occ = in_img && A.p2f[frag_addr(A, n, yi, xi, k).s] >= 0;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     PROF_T(t_p0);
     PROF_ADD(0, t_begin, t_p0);
     // pass 1 (front to back): alpha and transmittance per layer; no texture access
-    {
+    if (!stored_T) {
         float T = 1.f;
         const int klimit = prefix ? KK : kmax;
 #pragma unroll 5
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
         if (in_img) valid = load_frag<FUSED>(A, n, fo, fr);
-        const float ak = valid ? fr.a : 0.f, Tk = s_T[k * NT];
+        const float ak = valid ? fr.a : 0.f, Tk = stored_T ? (valid ? fr.T : 1.f) : s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
         float c[3] = {0.f, 0.f, 0.f};
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
                 // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0; divisions by v_rcp_f32).
                 // d/d dist is non-zero only outside the triangle (fr.d >= 0), so its sign is +1 and the barycentrics are only
                 // recomputed when a barycentric gradient has to be propagated.
-                fc = BINNED ? A.p2f[fo.s] : fr.fc;      // (the binned instantiation re-reads the id: one live register less, it sits at the 128-VGPR edge)
+                fc = BINNED ? (A.tiled == 2 ? (A.p2f[fo.s] & FRAG_FACE_MASK) : A.p2f[fo.s]) : fr.fc;      // (the binned instantiation re-reads the id: one live register less, it sits at the 128-VGPR edge)
                 has_g9 = true;
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};

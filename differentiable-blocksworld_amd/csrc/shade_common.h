@@ -50,6 +50,7 @@ struct Frag {
     float fa;         // learned face opacity (1 if none)
     float a;          // blend opacity e * fa
     float col[3];     // frag_layout 2 only: the texture colour the forward sampled for this fragment
+    float T;          // frag_layout 2 only: transmittance in front of this fragment, as blended by the forward
     long long aidx;   // index into faces_alpha
     float d;
     float u, v;       // texture coordinates
@@ -119,6 +120,9 @@ __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, c
 }
 
 // Addressing of fragment slot k of pixel (n, yi, xi): `s` indexes pix_to_face / dists, `b + c * bstride` the barycentric c.
+// frag_layout 2: pix_to_face of a pixel's FIRST layer = clipped face id | fragment count << 26 (ids < 2^26, K <= 25)
+constexpr int FRAG_COUNT_SHIFT = 26, FRAG_FACE_MASK = (1 << FRAG_COUNT_SHIFT) - 1;
+
 struct FragAddr {
     long long s, b;
     int bstride;
@@ -131,7 +135,7 @@ __device__ __forceinline__ FragAddr frag_addr(const ShadeArgs &A, int n, int yi,
         const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
         const int lane = ((yi & 7) << 3) | (xi & 7);
         a.s = ((tile * A.K + k) << 6) + lane;
-        a.b = (((tile * A.K + k) * (A.tiled == 2 ? 7 : 3)) << 6) + lane;      // layout 2: u, v, face|map, blend opacity, r, g, b
+        a.b = (((tile * A.K + k) * (A.tiled == 2 ? 8 : 3)) << 6) + lane;      // layout 2: u, v, face|map, blend opacity, r, g, b, T
         a.bstride = 64;
     } else {
         a.s = (((long long)n * A.H + yi) * A.W + xi) * A.K + k;
@@ -146,7 +150,7 @@ template <bool FAST = false>
 __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragAddr &o, Frag &fr) {
     const int fc = A.p2f[o.s];
     if (fc < 0) return false;
-    fr.fc = fc;
+    fr.fc = A.tiled == 2 ? (fc & FRAG_FACE_MASK) : fc;       // layout 2: the first layer's id also carries the pixel's fragment count
     if (A.tiled == 2) {   // shading inputs, blend opacity and sampled colour were resolved by the forward pass: one hop of
                           // coalesced loads, no table gathers, no texel fetch (the footprint is only needed for the scatter)
         fr.u = A.bary[o.b];
@@ -154,6 +158,7 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
         const int jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
         fr.a = A.bary[o.b + 3 * o.bstride];
         fr.col[0] = A.bary[o.b + 4 * o.bstride]; fr.col[1] = A.bary[o.b + 5 * o.bstride]; fr.col[2] = A.bary[o.b + 6 * o.bstride];
+        fr.T = A.bary[o.b + 7 * o.bstride];
         fr.j = jm & 0xfffff;
         fr.map = jm >> 20;
         fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;

@@ -128,10 +128,12 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
  * Arguments as in those two entry points.  frag_layout selects how the fragments are stored: 0 = (N,H,W,K[,3]) like
  * dbw_rasterize_fwd; 1 = internal 8x8-tile planar layout [N][ceil(H/8)][ceil(W/8)][K][64] (bary [..][K][3][64]), in which
  * every wave access is fully coalesced -- buffers must then hold N*ceil(H/8)*ceil(W/8)*K*64 (x3) elements and can only be
- * consumed by dbw_render_bwd_fused with the same frag_layout; 2 = layout 1 with SEVEN `bary` planes ([..][K][7][64]: the
- * buffer holds N*ceil(H/8)*ceil(W/8)*K*64*7 floats) holding (u, v, bitcast(face | map << 20), blend opacity, r, g, b of
- * the sampled texture colour) -- everything the blend needs already resolved, for passes whose barycentrics carry no
- * gradient (detach_bary): the backward then needs no per-face table gathers and no texel fetch (F < 2^20, maps < 2^11). */
+ * consumed by dbw_render_bwd_fused with the same frag_layout; 2 = layout 1 with EIGHT `bary` planes ([..][K][8][64]: the
+ * buffer holds N*ceil(H/8)*ceil(W/8)*K*64*8 floats) holding (u, v, bitcast(face | map << 20), blend opacity, r, g, b of
+ * the sampled texture colour, transmittance in front of the fragment) -- everything the blend needs already resolved --,
+ * and the pix_to_face entry of a pixel's first layer = id | fragment count << 26; for passes whose barycentrics carry no
+ * gradient (detach_bary): the backward then needs no per-face table gathers, no texel fetch and no front-to-back pass
+ * (F < 2^20, F_total < 2^26, maps < 2^11). */
 int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                          const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
                          int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
