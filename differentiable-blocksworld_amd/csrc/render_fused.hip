@@ -44,7 +44,9 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
             const bool valid = q.fi[k] != 0x7fffffff;
             const FragAddr o = frag_addr(A, n, yi, xi, k);
             // layout 2: the first layer's id carries the fragment count, so that the backward knows how deep to go from one load
-            p2f[o.s] = valid ? ((A.tiled == 2 && k == 0) ? (q.fi[k] | (cnt << FRAG_COUNT_SHIFT)) : q.fi[k]) : -1;
+            // (and which slots exist at all: the -1 of an empty slot below the first layer is not even stored)
+            if (valid || k == 0 || A.tiled != 2)
+                p2f[o.s] = valid ? ((A.tiled == 2 && k == 0) ? (q.fi[k] | (cnt << FRAG_COUNT_SHIFT)) : q.fi[k]) : -1;
             // internal layouts: empty slots carry only the -1 face id (the backward never reads the rest; a wave whose 64
             // pixels are all empty at this depth issues no store at all); the PyTorch3D-shaped layout 0 is filled with -1
             if (valid || A.tiled == 0) {

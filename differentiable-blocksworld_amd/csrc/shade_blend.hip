@@ -148,9 +148,12 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     // the unbinned kernel needs no pass 1 at all: one load gives the bound, pass 2 reads T_k with the rest of the payload
     const bool stored_T = FUSED && !BINNED && A.tiled == 2;
     int kmax = 0;
-    if (stored_T) {
+    int cnt = KK;                            // layout 2: slots [0, cnt) of this pixel exist, the rest was never written
+    if (FUSED && A.tiled == 2) {
         const int raw0 = in_img ? A.p2f[frag_addr(A, n, yi, xi, 0).s] : -1;
-        const int cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
+        cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
+    }
+    if (stored_T) {
         for (int k = 0; k < KK; ++k) {
             if (__ballot(cnt > k) == 0ull) break;
             kmax = k + 1;
@@ -178,10 +181,10 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
                 // uv-fragments carry the blend opacity the forward used: two coalesced loads per layer instead of the whole
                 // payload + the opacity gather + an exponential (pass 1 was 20 % of the wave time)
                 const FragAddr o = frag_addr(A, n, yi, xi, k);
-                valid = in_img && A.p2f[o.s] >= 0;
+                valid = in_img && k < cnt && A.p2f[o.s] >= 0;
                 if (valid) fr.a = A.bary[o.b + 3 * o.bstride];
             } else {
-                valid = in_img && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
+                valid = in_img && k < cnt && load_frag<FUSED>(A, n, frag_addr(A, n, yi, xi, k), fr);
             }
             if (prefix) {
                 const bool anyv = __ballot(valid) != 0ull;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
         Frag fr;
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
-        if (in_img) valid = load_frag<FUSED>(A, n, fo, fr);
+        if (in_img && k < cnt) valid = load_frag<FUSED>(A, n, fo, fr);
         const float ak = valid ? fr.a : 0.f, Tk = stored_T ? (valid ? fr.T : 1.f) : s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;
