@@ -8,6 +8,19 @@ constexpr int LIST_CAP = 384;      // 16x16 tiles: 24 KB of face records per blo
 // Two-level binning: coarse_bin_kernel (raster.hip) first compacts, per view and per COARSE x COARSE pixel bin, the indices of
 // the faces whose blur-expanded box touches the bin (face order preserved); a tile then only scans the list of the bin it
 // lies in instead of every face of the view.  list == nullptr: single-level scan.
+#ifdef DBW_PROFILE_FWD
+// cycle accounting of the fused forward (tools/fwd_cycles.py only): per-wave s_memtime deltas, summed in g_fprof
+// 0 binning (list walk + LDS fill), 1 per-pixel evaluation of the staged faces, 2 shading + stores, 3 whole kernel, 4 staged faces,
+// 5 (pixel, face) evaluations that passed the box test, 6 accepted inserts
+__device__ unsigned long long g_fprof[8];
+#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define FPROF_ADD(i, v) if (KMAX > 1 && (threadIdx.x & 63) == 0) atomicAdd(&g_fprof[i], (unsigned long long)(v))      // soft passes only
+#define FPROF_CNT(i, pred) { const unsigned long long m_ = __ballot(pred); if (KMAX > 1 && (threadIdx.x & 63) == 0 && m_) atomicAdd(&g_fprof[i], (unsigned long long)__popcll(m_)); }
+#else
+#define FPROF_T(x)
+#define FPROF_ADD(i, v)
+#define FPROF_CNT(i, pred)
+#endif
 constexpr int COARSE = 64;
 struct CoarseBins {
     const int *list;    // view n, bin b: entries [first_idx[n] * nb + b * num_faces[n], +count[n * nb + b]), indices relative to first_idx[n]
@@ -111,6 +124,10 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
     const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
 
     q.init();
+#ifdef DBW_PROFILE_FWD
+    unsigned long long t_bin = __builtin_readcyclecounter();
+    int n_ins_ = 0;
+#endif
 
     const int f_begin = first_idx[n];
     int nf = num_faces[n];
@@ -169,12 +186,17 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
         cnt += tot;
         __syncthreads();
         if (cnt > CAP - NT || base + NT >= nf) {
+            FPROF_T(t_ev0);
+            FPROF_ADD(0, t_ev0 - t_bin);
+            FPROF_ADD(4, cnt);
             FaceRec nxt = s_face[0];          // software pipeline: the next record's LDS read overlaps this face's arithmetic
 #pragma unroll 1
             for (int i = 0; i < cnt; ++i) {
                 const FaceRec r = nxt;
                 nxt = s_face[i + 1 < cnt ? i + 1 : i];
-                if (in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi)) {
+                const bool inbox_ = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
+                FPROF_CNT(5, inbox_);
+                if (inbox_) {
                     const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
                     const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
                     // bary_fwd, opened up: for a hard pass (blur == 0) a pixel outside the triangle can never be kept, and
@@ -199,15 +221,24 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
                             bool done = false;
                             if (r.nb != -1) done = q.sibling(K, r.nb, dist, pzv, r.id, sd, bc.x, bc.y, bc.z);
                             if (!done) q.insert(K, pzv, r.id, sd, bc.x, bc.y, bc.z);
+#ifdef DBW_PROFILE_FWD
+                            ++n_ins_;
+#endif
                         }
                     }
                 }
             }
             cnt = 0;
             __syncthreads();
+#ifdef DBW_PROFILE_FWD
+            { const unsigned long long t_ev1 = __builtin_readcyclecounter(); FPROF_ADD(1, t_ev1 - t_ev0); t_bin = t_ev1; }
+#endif
         }
         }
     }
+#ifdef DBW_PROFILE_FWD
+    if (KMAX > 1 && n_ins_) atomicAdd(&g_fprof[6], (unsigned long long)n_ins_);
+#endif
     return true;
 }
 

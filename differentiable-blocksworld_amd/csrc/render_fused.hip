@@ -19,6 +19,12 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
 
 int g_render_variant = 0;
+#ifdef DBW_PROFILE_FWD
+extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out8, int reset) {
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(dbw::g_fprof), 64);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dbw::g_fprof), z, 64); }
+}
+#endif
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
 
 namespace {
@@ -32,7 +38,9 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
                                                              float *__restrict__ image) {
     int n, xi, yi;
     TopK<KMAX> q;
+    FPROF_T(t_k0);
     if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, n, xi, yi, q)) return;
+    FPROF_T(t_k1);
     if (xi >= A.W || yi >= A.H) return;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
     int cnt = 0;                             // fragments of this pixel (the list is filled front to back)
@@ -91,6 +99,8 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     out[plane] = g + T * A.bg[1];
     out[2 * plane] = b + T * A.bg[2];
     out[3 * plane] = 1.f - T;
+    FPROF_T(t_k2);
+    if (KMAX > 1) { FPROF_ADD(2, t_k2 - t_k1); FPROF_ADD(3, t_k2 - t_k0); }
 }
 
 template <int KMAX, int TW, int TH, int GROUP>
