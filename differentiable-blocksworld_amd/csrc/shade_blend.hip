@@ -143,6 +143,7 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     // after the first batch of 5 layers whose last layer is empty everywhere (measured: pass 0 was 17 % of the wave time; fg
     // backward 0.73 -> 0.67 ms).  For fragments of unknown origin (layout 0) a pass 0 looks at every slot first -- exact without
     // that assumption; the single-layer instantiation keeps pass 0 as well (one layer has nothing to skip).
+    PROF_T(t_begin);
     const bool prefix = FUSED && !SINGLE && A.tiled != 0;
     // uv-fragments (layout 2): the first layer's id carries the pixel's fragment count and every fragment its transmittance, so
     // the unbinned kernel needs no pass 1 at all: one load gives the bound, pass 2 reads T_k with the rest of the payload
