@@ -95,7 +95,7 @@ __device__ __forceinline__ bool bin_regular(const Sample &s) {
 // SINGLE = true: a hard single-layer pass (K == 1; the env pass) -- its own instantiation, so that the layer loops fold away and a
 // kernel trace tells the two passes of an iteration apart.
 template <bool FUSED, bool BINNED, bool SINGLE>
-__global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
+__global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bwd_kernel(ShadeArgs A, long long total_blocks,
                                                              const float *__restrict__ gimg, float *__restrict__ gmaps,
                                                              float *__restrict__ galpha, float *__restrict__ gdists,
                                                              float *__restrict__ gbary, const float *__restrict__ fv,
@@ -225,13 +225,23 @@ __global__ __launch_bounds__(NT, (BINNED ? 4 : 1)) void shade_blend_bwd_kernel(S
     PROF_ADD(1, t_p0, t_p1);
     // pass 2 (back to front)
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
+    // uv-fragments without pass 1: the payload of layer k - 1 is requested while layer k is being processed (the only unhidden
+    // latency of the loop is the single hop of coalesced loads at the top of each iteration)
+    RawUV nxt;
+    nxt.ok = false;
+    if (stored_T && kmax > 0) nxt = load_raw_uv(A, frag_addr(A, n, yi, xi, kmax - 1), in_img && kmax - 1 < cnt);
 #pragma unroll DBW_BWD_UNROLL
     for (int k = kmax - 1; k >= 0; --k) {    // unrolled by 2: the gather chains of two layers overlap
         PROF_T(t_it);
         Frag fr;
         bool valid = false;
         const FragAddr fo = frag_addr(A, n, yi, xi, k);
-        if (in_img && k < cnt) valid = load_frag<FUSED>(A, n, fo, fr);
+        if (stored_T) {
+            const RawUV cur = nxt;
+            if (k > 0) nxt = load_raw_uv(A, frag_addr(A, n, yi, xi, k - 1), in_img && k - 1 < cnt);
+            valid = cur.ok;
+            if (valid) frag_from_raw_uv<FUSED>(A, n, cur, fr);
+        } else if (in_img && k < cnt) valid = load_frag<FUSED>(A, n, fo, fr);
         const float ak = valid ? fr.a : 0.f, Tk = stored_T ? (valid ? fr.T : 1.f) : s_T[k * NT];
         Sample s;
         s.a00 = s.a01 = s.a10 = s.a11 = 0;

@@ -184,6 +184,43 @@ __device__ __forceinline__ int wrap_col(int c, int w) {
     return c;
 }
 
+// frag_layout 2: the ten raw words of one slot, requested without looking at them, so that the backward can ask for the next layer
+// while it works on the current one (`ok` = the slot exists)
+struct RawUV { int fc; float u, v, jm, a, c0, c1, c2, T, d; bool ok; };
+
+__device__ __forceinline__ RawUV load_raw_uv(const ShadeArgs &A, const FragAddr &o, bool ok) {
+    RawUV r;
+    r.ok = ok;
+    r.fc = -1; r.u = r.v = r.jm = r.a = r.c0 = r.c1 = r.c2 = r.d = 0.f; r.T = 1.f;
+    if (ok) {
+        r.fc = A.p2f[o.s] & FRAG_FACE_MASK;
+        r.u = A.bary[o.b]; r.v = A.bary[o.b + o.bstride]; r.jm = A.bary[o.b + 2 * o.bstride]; r.a = A.bary[o.b + 3 * o.bstride];
+        r.c0 = A.bary[o.b + 4 * o.bstride]; r.c1 = A.bary[o.b + 5 * o.bstride]; r.c2 = A.bary[o.b + 6 * o.bstride];
+        r.T = A.bary[o.b + 7 * o.bstride];
+        r.d = A.dists[o.s];
+    }
+    return r;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void frag_from_raw_uv(const ShadeArgs &A, int n, const RawUV &r, Frag &fr) {
+    fr.fc = r.fc;
+    fr.u = r.u; fr.v = r.v;
+    const int jm = __float_as_int(r.jm);
+    fr.a = r.a;
+    fr.col[0] = r.c0; fr.col[1] = r.c1; fr.col[2] = r.c2;
+    fr.T = r.T;
+    fr.j = jm & 0xfffff;
+    fr.map = jm >> 20;
+    fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
+    fr.d = r.d;
+    if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
+    else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
+    fr.fa = 1.f;
+    fr.aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j) : 0;
+}
+
 // grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
 __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
     const float u = fr.u, v = fr.v;
