@@ -8,27 +8,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "raster_math.h"      // f2 / f3, pix_to_ndc, edge_fn, FaceRec, eval_pair, TopK (host + device)
+
 #pragma clang fp contract(off)
 
-#define DBW_EPS 1e-8f
 #define DBW_WAVE 64
 
 namespace dbw {
-
-struct f2 { float x, y; };
-struct f3 { float x, y, z; };
-
-// SURVEY A.1 NonSquarePixToNdc
-__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
-    float range = 2.0f;
-    if (S1 > S2) range = ((float)S1 * range) / (float)S2;
-    const float offset = range / 2.0f;
-    return -offset + (range * (float)i + offset) / (float)S1;
-}
-
-__device__ __forceinline__ float edge_fn(f2 p, f2 a, f2 b) {
-    return (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
-}
 
 __device__ __forceinline__ void edge_fn_bwd(f2 p, f2 a, f2 b, float g, f2 &gp, f2 &ga, f2 &gb) {
     gp.x = g * (b.y - a.y); gp.y = g * (a.x - b.x);

@@ -6,15 +6,16 @@
 // oracle/raster_ref.c given the same fp32 face_verts.
 //
 // Design (MI355X-first, not a translation of PyTorch3D's coarse/fine CUDA pair):
-//  * one 256-thread workgroup = one 16x16 pixel tile of one view; a wave64 owns a 16x4 pixel strip;
-//  * the workgroup bins the view's faces against the tile with a wave-ballot ORDERED compaction (face order must
-//    be preserved: the sibling de-duplication rule is order dependent) and stages the surviving faces
-//    (9 coords + margin-expanded bbox + sibling id = 64 B) in LDS; the per-pixel loop then reads them with
-//    wave-uniform (broadcast, conflict-free) ds_read_b128;
-//  * each lane keeps its top-K list entirely in VGPRs (template on K, fully unrolled bubble insert);
+//  * face_setup_kernel turns every face into a 128 B record of its pixel-independent arithmetic (raster_math.h: FaceRec) and a
+//    blur-expanded box; coarse_bin_kernel compacts, per 64x64-pixel bin, the ordered list of faces touching it;
+//  * one workgroup = one pixel tile of one view (8x8 = one wave64 for the soft K-layer passes, 16x16 for the hard 1-layer pass
+//    whose faces are huge); it bins the faces of its coarse bin against the tile with a wave-ballot ORDERED compaction (face
+//    order must be preserved: the sibling de-duplication rule is order dependent) and stages their indices in LDS; its waves
+//    then read each staged record with wave-uniform scalar loads and evaluate it for their 64 pixels;
+//  * each lane keeps the sorted 64-bit keys of its top-K list in VGPRs and the payloads in an LDS home array (raster_common.h);
 //  * blockIdx -> tile mapping is XCD-aware: all tiles of a view run on one XCD so its face table and its output
 //    rows stay in that XCD's L2;
-//  * the kernel is HBM-write bound: 24*K bytes of fragments per pixel, compute is ~1% of the time.
+//  * measured (profiles/): the kernel is instruction-issue bound, not HBM bound -- see DESIGN.md section 4.
 #include "raster_common.h"
 #include "../../include/dbw_hip.h"
 
@@ -27,26 +28,17 @@ namespace {
 constexpr int TILE = 16;
 constexpr int NT = 256;
 
-// Per-face screen bbox expanded by sqrt(blur_radius); faces that can never be hit (touching/behind the camera plane,
+// Per-face record + screen box expanded by sqrt(blur_radius); faces that can never be hit (touching/behind the camera plane,
 // zero area, culled) get an empty box.  One rounding per value, same as the oracle's per-pixel expression.
-__global__ void face_setup_kernel(const float *__restrict__ fv, long long F, float margin, int cull,
-                                  float4 *__restrict__ bbox) {
+__global__ void face_setup_kernel(const float *__restrict__ fv, const int *__restrict__ neighbor, long long F, float margin, int cull,
+                                  float4 *__restrict__ bbox, FaceRec *__restrict__ recs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
-    const float *p = fv + i * 9;
-    f2 a{p[0], p[1]}, b{p[3], p[4]}, c{p[6], p[7]};
-    const float z0 = p[2], z1 = p[5], z2 = p[8];
-    float xmin = a.x < b.x ? a.x : b.x; xmin = xmin < c.x ? xmin : c.x;
-    float xmax = a.x > b.x ? a.x : b.x; xmax = xmax > c.x ? xmax : c.x;
-    float ymin = a.y < b.y ? a.y : b.y; ymin = ymin < c.y ? ymin : c.y;
-    float ymax = a.y > b.y ? a.y : b.y; ymax = ymax > c.y ? ymax : c.y;
-    float zmin = z0 < z1 ? z0 : z1; zmin = zmin < z2 ? zmin : z2;
-    const float area = edge_fn(a, b, c);
-    const bool dead = (zmin < DBW_EPS) || (area <= DBW_EPS && area >= -DBW_EPS) || (cull && area < 0.f);
-    float4 o;
-    if (dead) { o.x = INFINITY; o.y = -INFINITY; o.z = INFINITY; o.w = -INFINITY; }
-    else { o.x = xmin - margin; o.y = xmax + margin; o.z = ymin - margin; o.w = ymax + margin; }
-    bbox[i] = o;
+    FaceRec r;
+    float box[4];
+    make_face_rec(fv + i * 9, margin, cull, neighbor ? neighbor[i] : -1, r, box);
+    bbox[i] = make_float4(box[0], box[1], box[2], box[3]);
+    recs[i] = r;
 }
 
 // Coarse level of the two-level binning: one workgroup per (view, COARSE x COARSE pixel bin) compacts the indices of the faces
@@ -86,26 +78,30 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
 
 template <int KMAX, int TW, int TH>
 __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void raster_fwd_kernel(
-    const float *__restrict__ fv, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
-    const int *__restrict__ num_faces, const int *__restrict__ neighbor, int N, int H, int W, int K, float blur,
+    const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
+    const int *__restrict__ num_faces, int N, int H, int W, int K, float blur,
     int persp, int clipb, long long total_blocks, CoarseBins cb, int *__restrict__ p2f, float *__restrict__ zbuf,
     float *__restrict__ bary, float *__restrict__ dists, int dbg) {
     int n, xi, yi;
     TopK<KMAX> q;
-    if (!raster_tile<KMAX, TW, TH>(fv, bbox, first_idx, num_faces, neighbor, H, W, K, blur, persp, clipb, total_blocks, cb, n, xi, yi, q)) return;
+    pay4 *home;
+    if (!raster_tile<KMAX, TW, TH>(recs, bbox, first_idx, num_faces, H, W, K, blur, persp, clipb, total_blocks, cb, dbg >> 8, n, xi, yi, q, home)) return;
     const bool in_img = xi < W && yi < H;
     if (!in_img) return;
     const long long o = (((long long)n * H + yi) * W + xi) * K;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        if (k < K && !((dbg & 16) && q.pz[k] != 12345.678f)) {     // dbg 16: ablate the stores (tools/ablate.py)
-            const bool valid = q.fi[k] != 0x7fffffff;
-            p2f[o + k] = valid ? q.fi[k] : -1;
-            if (zbuf) zbuf[o + k] = valid ? q.pz[k] : -1.f;
-            dists[o + k] = q.ds[k];
-            bary[(o + k) * 3 + 0] = q.b0[k];
-            bary[(o + k) * 3 + 1] = q.b1[k];
-            bary[(o + k) * 3 + 2] = q.b2[k];
+        if (k < K && !(dbg & 16)) {     // dbg 16: ablate the stores (tools/ablate.py)
+            float pz = -1.f;
+            int fi = -1;
+            pay4 v{-1.f, -1.f, -1.f, -1.f};
+            q.get(k, home, TW * TH, threadIdx.x, pz, fi, v);
+            p2f[o + k] = fi;
+            if (zbuf) zbuf[o + k] = pz;
+            dists[o + k] = v.x;
+            bary[(o + k) * 3 + 0] = v.y;
+            bary[(o + k) * 3 + 1] = v.z;
+            bary[(o + k) * 3 + 2] = v.w;
         }
     }
 }
@@ -167,55 +163,65 @@ __global__ __launch_bounds__(NT) void raster_bwd_kernel(
 int g_raster_dbg = 0;
 
 template <int KMAX, int TW, int TH>
-int launch_fwd_t(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
+int launch_fwd_t(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces,
                  int N, int H, int W, int K, float blur, int persp, int clipb, const CoarseBins &cb, int *p2f, float *zbuf,
                  float *bary, float *dists, hipStream_t s) {
     const long long total = (long long)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    hipLaunchKernelGGL((raster_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
-                       num_faces, neighbor, N, H, W, K, blur, persp, clipb, total, cb, p2f, zbuf, bary, dists, g_raster_dbg);
+    hipLaunchKernelGGL((raster_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
+                       num_faces, N, H, W, K, blur, persp, clipb, total, cb, p2f, zbuf, bary, dists, g_raster_dbg);
     return dbw_check_launch("raster_fwd_kernel");
 }
 
 template <int KMAX>
-int launch_fwd(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor,
+int launch_fwd(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces,
                int N, int H, int W, int K, float blur, int persp, int clipb, const CoarseBins &cb, int *p2f, float *zbuf,
                float *bary, float *dists, hipStream_t s) {
-    const int shape = (g_raster_dbg >> 5) & 3;      // tile-shape experiment switch (tools/ablate_raster.py)
-    if (shape == 1) return launch_fwd_t<KMAX, 8, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
-    if (shape == 2) return launch_fwd_t<KMAX, 16, 8>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
-    if (shape == 3) return launch_fwd_t<KMAX, 8, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
-    return launch_fwd_t<KMAX, 16, 16>(fv, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
+    // hard single-layer passes rasterise few, huge faces: 16x16 tiles (fewer tiles re-scan the face list, the payload stays in
+    // registers); soft K-layer passes: one wave64 per 8x8 tile (the LDS home array is KMAX * 16 B per pixel)
+    if constexpr (KMAX == 1) return launch_fwd_t<KMAX, 16, 16>(recs, bbox, first_idx, num_faces, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
+    else return launch_fwd_t<KMAX, 8, 8>(recs, bbox, first_idx, num_faces, N, H, W, K, blur, persp, clipb, cb, p2f, zbuf, bary, dists, s);
 }
 
 }  // namespace
 
-int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s) {
-    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, F_total, margin, cull,
-                       (float4 *)bbox);
-    return dbw_check_launch("face_setup_kernel");
-}
-
-extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) { return (size_t)(F_total > 0 ? F_total : 1) * sizeof(float4); }
-
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace = [boxes: F x 16 B][records: F x 128 B][coarse-bin counts][coarse-bin lists]
+extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) {
+    const size_t F = (size_t)(F_total > 0 ? F_total : 1);
+    return align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec));
+}
 
 extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
     const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
-    return align256(dbw_rasterize_workspace_bytes(F_total)) + align256((size_t)(N > 0 ? N : 1) * nb * sizeof(int)) +
+    return dbw_rasterize_workspace_bytes(F_total) + align256((size_t)(N > 0 ? N : 1) * nb * sizeof(int)) +
            (size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int);
 }
 
-// Face boxes, then (when the workspace has room for it) the coarse bins.  bbox = workspace.
-int dbw_launch_face_setup(const float *face_verts, long long F_total, float margin, int cull, void *bbox, hipStream_t s);
-int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, int N, long long F_total, int H, int W,
-                       float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s) {
+const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
+    return (const FaceRec *)((const char *)workspace + align256((size_t)(F_total > 0 ? F_total : 1) * sizeof(float4)));
+}
+
+// Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
+int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
+                       int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s) {
     cb.list = nullptr; cb.count = nullptr; cb.nx = cb.ny = 0;
     if (F_total <= 0) return DBW_OK;
-    int rc = dbw_launch_face_setup(face_verts, F_total, margin, cull, workspace, s);
+    if (F_total >= (1LL << TOPK_ID_BITS) - 1) {
+        dbw_set_error("rasteriser: %lld packed faces, the per-pixel list keys hold face ids below 2^%d - 1", F_total, TOPK_ID_BITS);
+        return DBW_ERR_UNSUPPORTED;
+    }
+    if (((uintptr_t)workspace & 127) != 0) {
+        dbw_set_error("rasteriser: the workspace must be 128-byte aligned");
+        return DBW_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
+                       (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total));
+    int rc = dbw_check_launch("face_setup_kernel");
     if (rc) return rc;
     if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128)) {
         const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
-        char *p = (char *)workspace + align256(dbw_rasterize_workspace_bytes(F_total));
+        char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
         int *count = (int *)p;
         int *list = (int *)(p + align256((size_t)N * nx * ny * sizeof(int)));
         hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
@@ -244,10 +250,11 @@ extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_i
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
     float4 *bbox = (float4 *)workspace;
+    const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
     CoarseBins cb;
-    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, N, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
+    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
     if (rc) return rc;
-#define DBW_FWD(KM) launch_fwd<KM>(face_verts, bbox, first_idx, num_faces, neighbor, N, H, W, K, blur_radius, \
+#define DBW_FWD(KM) launch_fwd<KM>(recs, bbox, first_idx, num_faces, N, H, W, K, blur_radius, \
                                    perspective_correct, clip_barycentric_coords, cb, pix_to_face, zbuf, bary, dists, s)
     if (K == 1) return DBW_FWD(1);
     if (K <= 4) return DBW_FWD(4);
@@ -272,3 +279,18 @@ extern "C" int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_
 }
 
 extern "C" void dbw_debug_set_raster_flags(int flags) { g_raster_dbg = flags; }
+
+// Test hook: div_fast (shared-reciprocal division of the rasteriser, raster_math.h) against the IEEE quotient on the real v_rcp_f32,
+// for caller-supplied operands; *mismatches (device, zeroed by the caller) counts the lanes whose bits differ (NaN == NaN).
+__global__ void divcheck_kernel(const float *__restrict__ n, const float *__restrict__ d, long long count, unsigned long long *__restrict__ bad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float q = div_fast(n[i], d[i], rcp_refined(d[i])), e = n[i] / d[i];
+    if (__float_as_uint(q) != __float_as_uint(e) && !(q != q && e != e)) atomicAdd(bad, 1ull);
+}
+extern "C" int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream) {
+    DBW_REQUIRE(n && d && mismatches && count >= 0, "bad argument");
+    if (count == 0) return DBW_OK;
+    hipLaunchKernelGGL(divcheck_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d, (long long)count, mismatches);
+    return dbw_check_launch("divcheck_kernel");
+}

@@ -1,108 +1,73 @@
 // Tile rasterisation shared by raster_fwd_kernel (raster.hip) and the fused render kernel (render_fused.hip).
+//
+// Round-2 design (the round-1 kernel spent ~70 % of its issued VALU lane-slots on masked-off work and on moving six-register list
+// entries around; profiles/r01_*):
+//  * face_setup_kernel evaluates everything pixel-independent once per (view, face) into a 128 B FaceRec (raster_math.h); a tile
+//    stages only the INDICES of the faces that touch it (4 B each, wave-ballot ordered compaction as before) and its waves then
+//    read each staged record with wave-uniform SCALAR loads (s_load_dwordx16: the record lives in SGPRs, costs no VGPRs and no
+//    LDS, and every VALU instruction takes its face operand straight from an SGPR);
+//  * besides the box test, binning applies a conservative tile-vs-edge-line test (tile_culled) so that faces whose blur-expanded box
+//    touches the tile but whose blur-expanded triangle does not are never staged;
+//  * the per-pair arithmetic shares one reciprocal per division stage (div_fast, bit-identical to the IEEE quotient inside its
+//    guarded operand range, IEEE `/` outside);
+//  * the per-pixel top-K list is a register array of 64-bit keys updated by a branch-free compare-exchange chain (5 VALU per
+//    slot); payloads are written once to a fixed slot of an LDS home array and fetched back only when the tile is shaded / stored.
 #pragma once
 #include "dbw_common.h"
 
 namespace dbw {
 
-constexpr int LIST_CAP = 384;      // 16x16 tiles: 24 KB of face records per block -> 5 resident blocks/CU (the VGPR limit) instead of 4
 // Two-level binning: coarse_bin_kernel (raster.hip) first compacts, per view and per COARSE x COARSE pixel bin, the indices of
 // the faces whose blur-expanded box touches the bin (face order preserved); a tile then only scans the list of the bin it
 // lies in instead of every face of the view.  list == nullptr: single-level scan.
-#ifdef DBW_PROFILE_FWD
-// cycle accounting of the fused forward (tools/fwd_cycles.py only): per-wave s_memtime deltas, summed in g_fprof
-// 0 binning (list walk + LDS fill), 1 per-pixel evaluation of the staged faces, 2 shading + stores, 3 whole kernel, 4 staged faces,
-// 5 (pixel, face) evaluations that passed the box test, 6 accepted inserts
-__device__ unsigned long long g_fprof[8];
-#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#define FPROF_ADD(i, v) if (KMAX > 1 && (threadIdx.x & 63) == 0) atomicAdd(&g_fprof[i], (unsigned long long)(v))      // soft passes only
-#define FPROF_CNT(i, pred) { const unsigned long long m_ = __ballot(pred); if (KMAX > 1 && (threadIdx.x & 63) == 0 && m_) atomicAdd(&g_fprof[i], (unsigned long long)__popcll(m_)); }
-#else
-#define FPROF_T(x)
-#define FPROF_ADD(i, v)
-#define FPROF_CNT(i, pred)
-#endif
 constexpr int COARSE = 64;
 struct CoarseBins {
     const int *list;    // view n, bin b: entries [first_idx[n] * nb + b * num_faces[n], +count[n * nb + b]), indices relative to first_idx[n]
     const int *count;   // (N, nb)
     int nx, ny;         // bins per row / column, nb = nx * ny
 };
-// minimum waves per SIMD the raster kernels are compiled for (caps the VGPR budget: the top-K list lives in registers)
-#define DBW_RASTER_WAVES(KMAX) ((KMAX) <= 4 ? 4 : (KMAX) <= 10 ? 2 : 1)
+// minimum waves per SIMD the raster kernels are compiled for (the LDS home array of the payloads bounds the residency anyway:
+// KMAX * 16 B per pixel)
+#define DBW_RASTER_WAVES(KMAX) ((KMAX) <= 4 ? 4 : (KMAX) <= 10 ? 3 : (KMAX) <= 16 ? 2 : 1)
 
-struct __attribute__((aligned(16))) FaceRec {
-    float v[9];
-    float xlo, xhi, ylo, yhi;
-    int nb;
-    int id;
-    int pad;
-};
-static_assert(sizeof(FaceRec) == 64, "FaceRec must be 64 B");
+// One staged record -> SGPRs: two s_load_dwordx16 issued together at the top of the iteration (field-by-field scalar loads would
+// each be sunk next to their first use and put a scalar-cache round trip in front of every stage of the evaluation).
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec *__restrict__ rp) {
+    const v16f *vp = (const v16f *)rp;
+    union { v16f v[2]; FaceRec r; } u;
+    u.v[0] = vp[0];
+    u.v[1] = vp[1];
+    // both halves are requested before anything looks at the box in the second one (otherwise the first half is only asked for
+    // after the box test: two scalar-cache round trips per face instead of one)
+    float pin = u.v[0][0];
+    asm volatile("" : "+s"(pin));
+    u.v[0][0] = pin;
+    return u.r;
+}
 
-template <int KMAX>
-struct TopK {
-    float pz[KMAX], ds[KMAX], b0[KMAX], b1[KMAX], b2[KMAX];
-    int fi[KMAX];
+#ifndef DBW_RASTER_FASTDIV
+#define DBW_RASTER_FASTDIV 1
+#endif
+#ifndef DBW_RASTER_TILECULL
+#define DBW_RASTER_TILECULL 1
+#endif
 
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) { pz[i] = INFINITY; fi[i] = 0x7fffffff; ds[i] = b0[i] = b1[i] = b2[i] = -1.f; }
-    }
-    __device__ __forceinline__ static bool less(float pa, int fa, float pb, int fb) {
-        return (pa < pb) || (!(pb < pa) && fa < fb);
-    }
-    __device__ __forceinline__ void swap_with(int i, float &cp, int &cf, float &cd, float &c0, float &c1, float &c2) {
-        float t;
-        int ti;
-        t = pz[i]; pz[i] = cp; cp = t;
-        ti = fi[i]; fi[i] = cf; cf = ti;
-        t = ds[i]; ds[i] = cd; cd = t;
-        t = b0[i]; b0[i] = c0; c0 = t;
-        t = b1[i]; b1[i] = c1; c1 = t;
-        t = b2[i]; b2[i] = c2; c2 = t;
-    }
-    // sorted insert; the displaced largest entry falls off the end (== emplace_back, sort, pop_back if size > K)
-    __device__ __forceinline__ void insert(int K, float cp, int cf, float cd, float c0, float c1, float c2) {
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i)
-            if (i < K && less(cp, cf, pz[i], fi[i])) swap_with(i, cp, cf, cd, c0, c1, c2);
-    }
-    __device__ __forceinline__ void cswap(int i) {  // order entries i, i+1
-        if (less(pz[i + 1], fi[i + 1], pz[i], fi[i])) swap_with(i, pz[i + 1], fi[i + 1], ds[i + 1], b0[i + 1], b1[i + 1], b2[i + 1]);
-    }
-    // sibling rule: returns true if `nb` was found (entry possibly replaced, list re-sorted)
-    __device__ __forceinline__ bool sibling(int K, int nb, float dist, float cp, int cf, float cd, float c0, float c1, float c2) {
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) {
-            if (i < K && !found && fi[i] == nb) {
-                found = true;
-                const float nd = ds[i] < 0.f ? -ds[i] : ds[i];
-                if (dist < nd) { pz[i] = cp; fi[i] = cf; ds[i] = cd; b0[i] = c0; b1[i] = c1; b2[i] = c2; }
-            }
-        }
-        if (found) {  // one entry may be out of place: one forward + one backward adjacent pass restores the order
-#pragma unroll
-            for (int i = 0; i < KMAX - 1; ++i) if (i + 1 < K) cswap(i);
-#pragma unroll
-            for (int i = KMAX - 2; i >= 0; --i) if (i + 1 < K) cswap(i);
-        }
-        return found;
-    }
-};
-
-// Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n.
-// Returns false for the padding blocks of the XCD-aware grid.  All threads of the block must call it.
+// Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n
+// (keys in `q`, payloads in the LDS array `home`, stride TW * TH, lane threadIdx.x).  Returns false for the padding blocks of the
+// XCD-aware grid.  All threads of the block must call it.  dbg: bit 0 = plain IEEE divisions, bit 1 = no tile culling (parity tests
+// run every variant against the oracle).
 template <int KMAX, int TW, int TH, int GROUP = 2>
-__device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const float4 *__restrict__ bbox,
-                                            const int *__restrict__ first_idx, const int *__restrict__ num_faces,
-                                            const int *__restrict__ neighbor, int H, int W, int K, float blur, int persp,
-                                            int clipb, long long total_blocks, const CoarseBins &cb, int &n, int &xi, int &yi,
-                                            TopK<KMAX> &q) {
+__device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
+                                            const int *__restrict__ first_idx, const int *__restrict__ num_faces, int H, int W, int K,
+                                            float blur, int persp, int clipb, long long total_blocks, const CoarseBins &cb, int dbg,
+                                            int &n, int &xi, int &yi, TopK<KMAX> &q, pay4 *&home) {
     static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
-    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = NT >= 256 ? LIST_CAP : 4 * NT;
-    __shared__ FaceRec s_face[CAP];
+    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = 2 * GROUP * NT;      // staged face indices: flushed when more than half full
+    __shared__ int s_list[CAP];
     __shared__ int s_wcnt[NW];
+    __shared__ pay4 s_home[KMAX == 1 ? 1 : KMAX * NT];
+    home = s_home;
 
     const long long logical = xcd_remap(blockIdx.x, total_blocks);
     if (logical < 0) return false;
@@ -124,10 +89,6 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
     const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
 
     q.init();
-#ifdef DBW_PROFILE_FWD
-    unsigned long long t_bin = __builtin_readcyclecounter();
-    int n_ins_ = 0;
-#endif
 
     const int f_begin = first_idx[n];
     int nf = num_faces[n];
@@ -137,9 +98,10 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
         lst = cb.list + (long long)f_begin * nb + (long long)bin * nf;
         nf = cb.count[n * nb + bin];
     }
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2);
     int cnt = 0;
-    // The face scan is latency bound (every tile walks the whole per-view bbox table): fetch the boxes of GROUP chunks with
-    // independent loads before consuming them, so a tile pays nf / (GROUP * NT) memory round trips instead of nf / NT.
+    // The face scan is latency bound: fetch the boxes of GROUP chunks with independent loads before consuming them, so a tile
+    // pays nf / (GROUP * NT) memory round trips instead of nf / NT.
 #pragma unroll 1
     for (int base0 = 0; base0 < nf; base0 += GROUP * NT) {
         float4 bbs[GROUP];
@@ -160,85 +122,68 @@ __device__ __forceinline__ bool raster_tile(const float *__restrict__ fv, const 
                 hits[g] = !(txmax < bbs[g].x || txmin > bbs[g].y || tymax < bbs[g].z || tymin > bbs[g].w);
             }
         }
+        if (tilecull) {
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g)
+                if (hits[g] && tile_culled(recs[f_begin + fjs[g]], txmin, txmax, tymin, tymax)) hits[g] = false;
+        }
 #pragma unroll
         for (int g = 0; g < GROUP; ++g) {
-        const int base = base0 + g * NT;
-        if (base >= nf) break;
-        const int j = fjs[g];
-        const bool hit = hits[g];
-        const float4 bb = bbs[g];
-        const unsigned long long m = __ballot(hit);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
+            const int base = base0 + g * NT;
+            if (base >= nf) break;
+            const bool hit = hits[g];
+            const unsigned long long m = __ballot(hit);
+            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+            int woff = 0, tot = __popcll(m);
+            if (NW > 1) {
+                if (lane == 0) s_wcnt[wv] = tot;
+                __syncthreads();
+                tot = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
-        if (hit) {
-            FaceRec &r = s_face[cnt + woff + prefix];
-            const float *src = fv + (long long)(f_begin + j) * 9;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) r.v[i] = src[i];
-            r.xlo = bb.x; r.xhi = bb.y; r.ylo = bb.z; r.yhi = bb.w;
-            r.nb = neighbor ? neighbor[f_begin + j] : -1;
-            r.id = f_begin + j;
+                for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+            }
+            if (hit) s_list[cnt + woff + prefix] = fjs[g];
+            cnt += tot;
+            if (NW > 1) __syncthreads();         // s_wcnt is rewritten by the next chunk
         }
-        cnt += tot;
         __syncthreads();
-        if (cnt > CAP - NT || base + NT >= nf) {
-            FPROF_T(t_ev0);
-            FPROF_ADD(0, t_ev0 - t_bin);
-            FPROF_ADD(4, cnt);
-            FaceRec nxt = s_face[0];          // software pipeline: the next record's LDS read overlaps this face's arithmetic
+        if (cnt > CAP - GROUP * NT || base0 + GROUP * NT >= nf) {
+            // every wave walks the staged faces: records arrive in SGPRs, lanes are pixels
 #pragma unroll 1
-            for (int i = 0; i < cnt; ++i) {
-                const FaceRec r = nxt;
-                nxt = s_face[i + 1 < cnt ? i + 1 : i];
-                const bool inbox_ = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
-                FPROF_CNT(5, inbox_);
-                if (inbox_) {
-                    const f2 a{r.v[0], r.v[1]}, b{r.v[3], r.v[4]}, c{r.v[6], r.v[7]};
-                    const float z0 = r.v[2], z1 = r.v[5], z2 = r.v[8];
-                    // bary_fwd, opened up: for a hard pass (blur == 0) a pixel outside the triangle can never be kept, and
-                    // "outside" is decided exactly by the signs of the edge functions (b_i = e_i / area <= 0 for some i),
-                    // before paying the twelve IEEE divisions of the full evaluation
-                    const float area = edge_fn(c, a, b) + DBW_EPS;
-                    const float e0 = edge_fn(p, b, c), e1 = edge_fn(p, c, a), e2 = edge_fn(p, a, b);
-                    if (blur == 0.f) {
-                        const bool pos = area > 0.f;
-                        if (e0 == 0.f || e1 == 0.f || e2 == 0.f || (e0 > 0.f) != pos || (e1 > 0.f) != pos || (e2 > 0.f) != pos) continue;
+            for (int cb0 = 0; cb0 < cnt; cb0 += DBW_WAVE) {
+                const int jl = cb0 + lane < cnt ? s_list[cb0 + lane] : 0;
+                const int mcnt = min(DBW_WAVE, cnt - cb0);
+#pragma unroll 1
+                for (int i = 0; i < mcnt; ++i) {
+                    const int j = __builtin_amdgcn_readlane(jl, i);
+                    const FaceRec r = load_rec_uniform(recs + f_begin + j);
+                    const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
+                    if (__ballot(inbox) == 0ull) continue;
+                    float pz = 0.f, sd = 0.f;
+                    f3 bc{0.f, 0.f, 0.f};
+                    bool keep = false;
+                    bool redo = !(fastdiv && (r.flags & REC_FAST));
+                    if (!redo) {
+                        bool unsafe = false;
+                        if (inbox) keep = eval_pair<true>(r, p, blur, persp, clipb, pz, sd, bc, unsafe);
+                        redo = __ballot(inbox && unsafe) != 0ull;
                     }
-                    f3 bary0;
-                    bary0.x = e0 / area; bary0.y = e1 / area; bary0.z = e2 / area;
-                    const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
-                    const f3 bc = clipb ? clip_fwd(bp) : bp;
-                    const float pzv = bc.x * z0 + bc.y * z1 + bc.z * z2;
-                    if (!(pzv < 0.f)) {
-                        const float dist = point_tri_dist(p, a, b, c);
-                        const bool inside = bp.x > 0.f && bp.y > 0.f && bp.z > 0.f;
-                        if (inside || !(dist >= blur)) {
-                            const float sd = inside ? -dist : dist;
-                            bool done = false;
-                            if (r.nb != -1) done = q.sibling(K, r.nb, dist, pzv, r.id, sd, bc.x, bc.y, bc.z);
-                            if (!done) q.insert(K, pzv, r.id, sd, bc.x, bc.y, bc.z);
-#ifdef DBW_PROFILE_FWD
-                            ++n_ins_;
-#endif
-                        }
+                    if (redo) {
+                        bool unused;
+                        keep = false;
+                        if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused);
                     }
+                    if (__ballot(keep) == 0ull) continue;
+                    const pay4 v{sd, bc.x, bc.y, bc.z};
+                    bool done = false;
+                    if (r.nb != -1) done = q.sibling(K, keep, r.nb, sd < 0.f ? -sd : sd, pz, f_begin + j, v, home, NT, tid);
+                    q.insert(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
                 }
             }
             cnt = 0;
-            __syncthreads();
-#ifdef DBW_PROFILE_FWD
-            { const unsigned long long t_ev1 = __builtin_readcyclecounter(); FPROF_ADD(1, t_ev1 - t_ev0); t_bin = t_ev1; }
-#endif
-        }
+            if (NW > 1) __syncthreads();
         }
     }
-#ifdef DBW_PROFILE_FWD
-    if (KMAX > 1 && n_ins_) atomicAdd(&g_fprof[6], (unsigned long long)n_ins_);
-#endif
     return true;
 }
 

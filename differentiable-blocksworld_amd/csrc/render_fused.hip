@@ -11,64 +11,64 @@
 using namespace dbw;
 
 // implemented in raster.hip / shade_blend.hip
-int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, int N, long long F_total, int H, int W,
-                       float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s);
+int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
+                       int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s);
+const dbw::FaceRec *dbw_workspace_recs(const void *workspace, long long F_total);
 int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                         const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
 
 int g_render_variant = 0;
-#ifdef DBW_PROFILE_FWD
-extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out8, int reset) {
-    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(dbw::g_fprof), 64);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dbw::g_fprof), z, 64); }
-}
-#endif
+int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
+void dbw_set_render_dbg(int v) { g_render_dbg = v; }
 
 namespace {
 
 template <int KMAX, int TW, int TH, int GROUP>
-__global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const float *__restrict__ fv, const float4 *__restrict__ bbox,
+__global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
-                                                             const int *__restrict__ neighbor, float blur, int persp,
+                                                             float blur, int persp, int dbg,
                                                              long long total_blocks, ShadeArgs A, CoarseBins cb, int *__restrict__ p2f,
                                                              float *__restrict__ bary, float *__restrict__ dists,
                                                              float *__restrict__ image) {
     int n, xi, yi;
     TopK<KMAX> q;
-    FPROF_T(t_k0);
-    if (!raster_tile<KMAX, TW, TH, GROUP>(fv, bbox, first_idx, num_faces, neighbor, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, n, xi, yi, q)) return;
-    FPROF_T(t_k1);
+    pay4 *home;
+    if (!raster_tile<KMAX, TW, TH, GROUP>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, dbg, n, xi, yi, q, home)) return;
     if (xi >= A.W || yi >= A.H) return;
+    constexpr int NT = TW * TH;
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
     int cnt = 0;                             // fragments of this pixel (the list is filled front to back)
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) cnt += (k < A.K && q.fi[k] != 0x7fffffff) ? 1 : 0;
+    for (int k = 0; k < KMAX; ++k) cnt += (k < A.K && q.valid(k)) ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < A.K) {
-            const bool valid = q.fi[k] != 0x7fffffff;
+            float pzk = -1.f;
+            int fik = -1;
+            pay4 v{-1.f, -1.f, -1.f, -1.f};
+            const bool valid = q.get(k, home, NT, threadIdx.x, pzk, fik, v);
             const FragAddr o = frag_addr(A, n, yi, xi, k);
             // layout 2: the first layer's id carries the fragment count, so that the backward knows how deep to go from one load
             // (and which slots exist at all: the -1 of an empty slot below the first layer is not even stored)
             if (valid || k == 0 || A.tiled != 2)
-                p2f[o.s] = valid ? ((A.tiled == 2 && k == 0) ? (q.fi[k] | (cnt << FRAG_COUNT_SHIFT)) : q.fi[k]) : -1;
+                p2f[o.s] = valid ? ((A.tiled == 2 && k == 0) ? (fik | (cnt << FRAG_COUNT_SHIFT)) : fik) : -1;
             // internal layouts: empty slots carry only the -1 face id (the backward never reads the rest; a wave whose 64
             // pixels are all empty at this depth issues no store at all); the PyTorch3D-shaped layout 0 is filled with -1
             if (valid || A.tiled == 0) {
-                dists[o.s] = q.ds[k];
+                dists[o.s] = v.x;
                 if (A.tiled != 2) {
-                    bary[o.b] = q.b0[k];
-                    bary[o.b + o.bstride] = q.b1[k];
-                    bary[o.b + 2 * o.bstride] = q.b2[k];
+                    bary[o.b] = v.y;
+                    bary[o.b + o.bstride] = v.z;
+                    bary[o.b + 2 * o.bstride] = v.w;
                 }
             }
             if (valid) {
                 Frag fr;
-                const float bc[3] = {q.b0[k], q.b1[k], q.b2[k]};
-                decode_frag(A, n, q.fi[k], bc, q.ds[k], fr);
+                const float bc[3] = {v.y, v.z, v.w};
+                decode_frag(A, n, fik, bc, v.x, fr);
                 if (A.tiled == 2) {       // hand the resolved shading inputs to the backward pass
                     bary[o.b] = fr.u;
                     bary[o.b + o.bstride] = fr.v;
@@ -99,37 +99,35 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     out[plane] = g + T * A.bg[1];
     out[2 * plane] = b + T * A.bg[2];
     out[3 * plane] = 1.f - T;
-    FPROF_T(t_k2);
-    if (KMAX > 1) { FPROF_ADD(2, t_k2 - t_k1); FPROF_ADD(3, t_k2 - t_k0); }
 }
 
 template <int KMAX, int TW, int TH, int GROUP>
-int launch_v(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
+int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
              int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
-    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, fv, bbox, first_idx,
-                       num_faces, neighbor, blur, persp, total, A, cb, p2f, bary, dists, image);
+    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
+                       num_faces, blur, persp, g_render_dbg, total, A, cb, p2f, bary, dists, image);
     return dbw_check_launch("render_fwd_kernel");
 }
 
 template <int KMAX>
-int launch(const float *fv, const float4 *bbox, const int *first_idx, const int *num_faces, const int *neighbor, float blur,
+int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(fv, bbox, first_idx, num_faces, neighbor, blur, persp, A, cb, p2f, bary, dists, image, s)
-    if (KMAX == 1) return DBW_V(16, 16, 2);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list; 2 bbox
-                                              // loads in flight keep it at 80 VGPRs = 6 resident blocks per CU (it is latency bound)
+#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, p2f, bary, dists, image, s)
+    if constexpr (KMAX == 1) return DBW_V(16, 16, 2);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list; the
+                                              // single payload stays in registers
+    else {
 #ifdef DBW_TUNE_VARIANTS
     switch (g_render_variant) {               // tile-shape / load-batching sweep (tools/sweep_render_fwd.py)
         case 1: return DBW_V(8, 8, 1);
         case 2: return DBW_V(8, 8, 2);
-        case 3: return DBW_V(16, 16, 1);
-        case 4: return DBW_V(16, 16, 4);
-        case 5: return DBW_V(16, 8, 2);
-        case 6: return DBW_V(8, 16, 2);
+        case 3: return DBW_V(16, 8, 2);
+        case 4: return DBW_V(16, 16, 2);
         default: break;
     }
 #endif
-    return DBW_V(8, 8, 4);
+    return DBW_V(8, 8, 4);                    // soft K-layer passes: one wave64 per 8x8 tile
+    }
 #undef DBW_V
 }
 
@@ -162,10 +160,11 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
     CoarseBins cb;
-    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, N, F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
+    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
     if (rc) return rc;
     const float4 *bbox = (const float4 *)workspace;
-#define DBW_RF(KM) launch<KM>(face_verts_c, bbox, first_idx, num_faces, neighbor, blur_radius, perspective_correct, A, cb, pix_to_face, bary, dists, image, s)
+    const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
+#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, pix_to_face, bary, dists, image, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);

@@ -660,4 +660,7 @@ extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cur
 
 // Ablation hook for profiling scripts (tools/): not part of the rendering contract.
 extern "C" void dbw_debug_set_raster_flags(int flags);
-extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags; dbw_debug_set_raster_flags(flags); }
+void dbw_set_render_dbg(int v);
+// bits 0-7: shading/blend ablations (ShadeArgs::dbg) and rasteriser ablations (16, 128); bit 8: plain IEEE divisions in the
+// rasteriser, bit 9: no tile culling in the binning (the parity tests run these variants against the oracle too)
+extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags & 0xff; dbw_debug_set_raster_flags(flags); dbw_set_render_dbg(flags >> 8); }

@@ -34,8 +34,13 @@ typedef void *dbw_stream_t;
 
 int dbw_abi_version(void);
 const char *dbw_last_error(void);
-/* profiling/ablation switches used by tools/ (0 = product behaviour) */
+/* profiling/ablation switches used by tools/ and by the parity tests (0 = product behaviour); bits 0-7: shading ablations,
+ * 16: no fragment stores, 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal
+ * div_fast, which is bit-identical inside its guards), 512: no conservative tile-vs-edge culling in the binning */
 void dbw_debug_set_flags(int flags);
+/* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
+ * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */
+int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Camera transform + z-clipping of one scene seen from B cameras.
@@ -68,7 +73,9 @@ int dbw_project_clip_bwd(const float *verts_world, const int32_t *faces, const f
  * canonical semantics = the CPU naive path, list kept sorted by (z, face index).
  *  face_verts (F_total,3,3)   first_idx/num_faces (N)   neighbor (F_total) or NULL
  *  pix_to_face i32 (N,H,W,K)  zbuf (N,H,W,K)  bary (N,H,W,K,3)  dists (N,H,W,K); zbuf may be NULL (not stored).
- *  workspace: dbw_rasterize_workspace_bytes(F_total) bytes of scratch.
+ *  workspace: dbw_rasterize_workspace_bytes(F_total) bytes of scratch, 128-byte aligned (per face a 16 B screen box and a 128 B
+ *    record of the pixel-independent arithmetic, csrc/raster_math.h: FaceRec).  F_total must be below 2^27 - 1 (the per-pixel list
+ *    packs depth | face id | payload slot into 64-bit keys).
  */
 size_t dbw_rasterize_workspace_bytes(int64_t F_total);
 /* Larger workspace that also holds the coarse bins of the two-level binning (per view and 64x64-pixel bin, the ordered list of

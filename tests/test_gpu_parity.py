@@ -31,9 +31,41 @@ def random_faces(n_faces, seed, zmin=0.5, zmax=5.0, spread=1.2, size=0.5):
     return torch.cat([xy, z], -1).contiguous()
 
 
+@pytest.fixture
+def raster_flags():
+    """Sets the library's debug switches for one test (include/dbw_hip.h: dbw_debug_set_flags) and restores the product setting."""
+    from dbw_amd import _lib
+    lib = _lib.load()
+    yield lib.dbw_debug_set_flags
+    lib.dbw_debug_set_flags(0)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # rasteriser: operator-level drop-in
 # ---------------------------------------------------------------------------------------------------------------------
+def test_shared_reciprocal_division_equals_ieee_division_on_this_gpu():
+    """div_fast (raster_math.h) against `/` with the real v_rcp_f32: 64 M operand pairs spanning the guarded range (numerators 0 or
+    2^-60..2^62 of either sign, denominators 2^-27..2^40 of either sign), plus quotients that sit next to a rounding boundary."""
+    from dbw_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n_ = 1 << 26
+    def spread(lo, hi):
+        e = torch.rand(n_, device=DEV, generator=g) * (hi - lo) + lo
+        m = torch.rand(n_, device=DEV, generator=g) + 1.0
+        sgn = (torch.rand(n_, device=DEV, generator=g) < 0.5).float() * 2 - 1
+        return (sgn * m * torch.exp2(e)).float()
+    num, den = spread(-60, 62), spread(-27, 40)
+    num[:4096] = 0.0
+    q = torch.rand(1 << 22, device=DEV, generator=g) * 1.5 + 0.5
+    d2 = torch.rand(1 << 22, device=DEV, generator=g) * 7.5 + 0.5
+    n2 = (d2.double() * q.double()).float()
+    n2 = torch.nextafter(n2, torch.where(torch.rand(1 << 22, device=DEV, generator=g) < 0.5, n2 * 2, n2 * 0))
+    num, den = torch.cat([num, n2]).contiguous(), torch.cat([den, d2]).contiguous()
+    bad = torch.zeros(1, dtype=torch.int64, device=DEV)
+    _lib.call('dbw_debug_divcheck', num.data_ptr(), den.data_ptr(), num.numel(), bad.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(bad.item()) == 0
+
+
 @pytest.mark.parametrize('H,W,K,nf,blur,persp,clipb', [
     (33, 47, 4, 60, 1e-3, True, True),        # ragged image size (partial tiles)
     (64, 48, 10, 300, math.log(1e4 - 1) * 1e-4, True, True),   # the coarse renderer's setting, H > W
@@ -41,7 +73,9 @@ def random_faces(n_faces, seed, zmin=0.5, zmax=5.0, spread=1.2, size=0.5):
     (32, 64, 16, 20, 5e-3, False, False),     # K > faces hit, no perspective correction / clipping
     (48, 80, 25, 700, 2e-4, True, True),      # > LIST_CAP faces per tile flush path, max K
 ])
-def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb):
+@pytest.mark.parametrize('flags', [0, 256, 512, 768])     # product / IEEE divisions / no tile culling / neither (include/dbw_hip.h)
+def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb, flags, raster_flags):
+    raster_flags(flags)
     fv = random_faces(nf, seed=nf + K)
     # two meshes packed back to back, the second one a shifted copy
     fv = torch.cat([fv, fv * torch.tensor([0.9, -1.1, 1.0])], 0)
