@@ -41,17 +41,30 @@ __global__ void face_setup_kernel(const float *__restrict__ fv, const int *__res
     recs[i] = r;
 }
 
-// Coarse level of the two-level binning: one workgroup per (view, COARSE x COARSE pixel bin) compacts the indices of the faces
-// whose box touches the bin, in face order (wave ballots), so that tiles see the same candidate sequence as a full scan.
+// Coarse level of the two-level binning: one workgroup per (view, COARSE x COARSE pixel bin) compacts the faces whose box touches the
+// bin, in face order (wave ballots), so that tiles see the same candidate sequence as a full scan.  An entry packs the face index
+// with the range of 8x8-pixel cells of the bin the box reaches (pixel-centre extents, the same comparisons a tile would make),
+// so that a tile decides from the entry alone -- no second, dependent load of the box -- and the bin also gets a 64-bit mask of its
+// occupied cells: a tile none of whose cells is occupied exits before its prologue.
 __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
                                                          const int *__restrict__ num_faces, int H, int W, int nx, int ny,
-                                                         int *__restrict__ list, int *__restrict__ count) {
+                                                         int *__restrict__ list, int *__restrict__ count, unsigned *__restrict__ mask) {
     __shared__ int s_wcnt[4];
+    __shared__ float s_cmin[2][8], s_cmax[2][8];
+    __shared__ unsigned s_mask[2];
     const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb;
     const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
     const int x1 = min(x0 + COARSE - 1, W - 1), y1 = min(y0 + COARSE - 1, H - 1);
     const float bxmax = pix_to_ndc(W - 1 - x0, W, H), bxmin = pix_to_ndc(W - 1 - x1, W, H);
     const float bymax = pix_to_ndc(H - 1 - y0, H, W), bymin = pix_to_ndc(H - 1 - y1, H, W);
+    if (threadIdx.x < 16) {          // NDC extents of the pixel centres of cell column / row c (empty beyond the image)
+        const int axis = threadIdx.x >> 3, c = threadIdx.x & 7;
+        const int S1 = axis ? H : W, S2 = axis ? W : H, p0 = (axis ? y0 : x0) + 8 * c, p1 = min(p0 + 7, S1 - 1);
+        s_cmax[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p0, S1, S2) : -INFINITY;
+        s_cmin[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p1, S1, S2) : INFINITY;
+    }
+    if (threadIdx.x < 2) s_mask[threadIdx.x] = 0u;
+    __syncthreads();
     const int f_begin = first_idx[n], nf = num_faces[n];
     int *out = list + (long long)f_begin * nb + (long long)bin * nf;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -59,9 +72,30 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
     for (int base = 0; base < nf; base += 256) {
         const int j = base + threadIdx.x;
         bool hit = false;
+        int entry = 0;
         if (j < nf) {
             const float4 bb = bbox[f_begin + j];
-            hit = !(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w);
+            if (!(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w)) {
+                int cx0 = 8, cx1 = -1, cy0 = 8, cy1 = -1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (!(s_cmax[0][c] < bb.x || s_cmin[0][c] > bb.y)) { cx0 = min(cx0, c); cx1 = c; }
+                    if (!(s_cmax[1][c] < bb.z || s_cmin[1][c] > bb.w)) { cy0 = min(cy0, c); cy1 = c; }
+                }
+                hit = cx1 >= 0 && cy1 >= 0;        // a box that slips between the pixel centres of two cells touches no pixel at all
+                if (hit) {
+                    entry = j | (cx0 << 20) | (cx1 << 23) | (cy0 << 26) | (cy1 << 29);
+                    const unsigned row = ((1u << (cx1 - cx0 + 1)) - 1u) << cx0;
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r >= cy0 && r <= cy1) lo |= row << (8 * r);
+                        if (r + 4 >= cy0 && r + 4 <= cy1) hi |= row << (8 * r);
+                    }
+                    if (lo) atomicOr(&s_mask[0], lo);
+                    if (hi) atomicOr(&s_mask[1], hi);
+                }
+            }
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0) s_wcnt[wv] = __popcll(m);
@@ -69,11 +103,12 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
         int woff = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
-        if (hit) out[cnt + woff + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        if (hit) out[cnt + woff + __popcll(m & ((1ull << lane) - 1ull))] = entry;
         cnt += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) count[n * nb + bin] = cnt;
+    if (threadIdx.x < 2) mask[(n * nb + bin) * 2 + threadIdx.x] = s_mask[threadIdx.x];
 }
 
 template <int KMAX, int TW, int TH>
@@ -167,6 +202,7 @@ int launch_fwd_t(const FaceRec *recs, const float4 *bbox, const int *first_idx, 
                  int N, int H, int W, int K, float blur, int persp, int clipb, const CoarseBins &cb, int *p2f, float *zbuf,
                  float *bary, float *dists, hipStream_t s) {
     const long long total = (long long)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    DBW_REQUIRE(total < (1LL << 31) - 8, "more than 2^31 tiles in one pass");
     hipLaunchKernelGGL((raster_fwd_kernel<KMAX, TW, TH>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
                        num_faces, N, H, W, K, blur, persp, clipb, total, cb, p2f, zbuf, bary, dists, g_raster_dbg);
     return dbw_check_launch("raster_fwd_kernel");
@@ -186,15 +222,15 @@ int launch_fwd(const FaceRec *recs, const float4 *bbox, const int *first_idx, co
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// workspace = [boxes: F x 16 B][records: F x 128 B][coarse-bin counts][coarse-bin lists]
+// workspace = [boxes: F x 16 B][records: F x 128 B][shading records of the fused forward: F x 64 B][coarse-bin counts][coarse-bin lists]
 extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) {
     const size_t F = (size_t)(F_total > 0 ? F_total : 1);
-    return align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec));
+    return align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec)) + align256(F * 64);
 }
 
 extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
     const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
-    return dbw_rasterize_workspace_bytes(F_total) + align256((size_t)(N > 0 ? N : 1) * nb * sizeof(int)) +
+    return dbw_rasterize_workspace_bytes(F_total) + align256((size_t)(N > 0 ? N : 1) * nb * 3 * sizeof(int)) +
            (size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int);
 }
 
@@ -202,10 +238,16 @@ const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
     return (const FaceRec *)((const char *)workspace + align256((size_t)(F_total > 0 ? F_total : 1) * sizeof(float4)));
 }
 
+void *dbw_workspace_shade_recs(void *workspace, long long F_total) {
+    const size_t F = (size_t)(F_total > 0 ? F_total : 1);
+    return (char *)workspace + align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec));
+}
+
 // Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
-                       int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s) {
-    cb.list = nullptr; cb.count = nullptr; cb.nx = cb.ny = 0;
+                       long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
+                       dbw::CoarseBins &cb, hipStream_t s) {
+    cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
     if (F_total <= 0) return DBW_OK;
     if (F_total >= (1LL << TOPK_ID_BITS) - 1) {
         dbw_set_error("rasteriser: %lld packed faces, the per-pixel list keys hold face ids below 2^%d - 1", F_total, TOPK_ID_BITS);
@@ -219,16 +261,18 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
                        (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total));
     int rc = dbw_check_launch("face_setup_kernel");
     if (rc) return rc;
-    if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128)) {
+    // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
+    if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20)) {
         const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
         char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
         int *count = (int *)p;
-        int *list = (int *)(p + align256((size_t)N * nx * ny * sizeof(int)));
+        unsigned *mask = (unsigned *)(count + (size_t)N * nx * ny);
+        int *list = (int *)(p + align256((size_t)N * nx * ny * 3 * sizeof(int)));
         hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
-                           num_faces, H, W, nx, ny, list, count);
+                           num_faces, H, W, nx, ny, list, count, mask);
         rc = dbw_check_launch("coarse_bin_kernel");
         if (rc) return rc;
-        cb.list = list; cb.count = count; cb.nx = nx; cb.ny = ny;
+        cb.list = list; cb.count = count; cb.mask = mask; cb.nx = nx; cb.ny = ny;
     }
     return DBW_OK;
 }
@@ -252,7 +296,7 @@ extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_i
     float4 *bbox = (float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
     CoarseBins cb;
-    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
+    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
     if (rc) return rc;
 #define DBW_FWD(KM) launch_fwd<KM>(recs, bbox, first_idx, num_faces, N, H, W, K, blur_radius, \
                                    perspective_correct, clip_barycentric_coords, cb, pix_to_face, zbuf, bary, dists, s)

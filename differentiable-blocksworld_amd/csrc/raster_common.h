@@ -22,8 +22,11 @@ namespace dbw {
 // lies in instead of every face of the view.  list == nullptr: single-level scan.
 constexpr int COARSE = 64;
 struct CoarseBins {
-    const int *list;    // view n, bin b: entries [first_idx[n] * nb + b * num_faces[n], +count[n * nb + b]), indices relative to first_idx[n]
+    const int *list;    // view n, bin b: entries [first_idx[n] * nb + b * num_faces[n], +count[n * nb + b]); an entry = face index relative
+                        // to first_idx[n] (20 bits) | first / last cell column (3 + 3 bits) | first / last cell row (3 + 3 bits) the
+                        // face's box reaches, cells = the 8x8-pixel squares of the bin
     const int *count;   // (N, nb)
+    const unsigned *mask;   // (N, nb, 2): bit (8 * row + column) = some entry reaches that cell
     int nx, ny;         // bins per row / column, nb = nx * ny
 };
 // minimum waves per SIMD the raster kernels are compiled for (the LDS home array of the payloads bounds the residency anyway:
@@ -46,6 +49,23 @@ __device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec *__restrict__ 
     return u.r;
 }
 
+#ifdef DBW_PROFILE_FWD
+// cycle / event accounting of the soft (K > 1) forward passes (tools/fwd_cycles.py only): per-wave s_memtime deltas and counts, kept
+// per workgroup (no cross-workgroup contention: a shared counter would serialise 10^6 atomics and distort what it measures) and
+// summed on the host: 0 binning, 1 staged-face loop, 2 shading + stores, 3 whole kernel, 4 staged (tile, face) pairs, 5 of those with
+// a pixel in the box, 6 (pixel, face) evaluations, 7 kept, 8 wave re-evaluations with IEEE divisions, 9 tiles, 10 tiles with staged
+// faces, 11 candidates culled by the tile-vs-edge test, 12 prologue (index arithmetic + the scalar loads of the view's face range)
+constexpr int FPROF_BLOCKS = 1 << 17;
+__device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
+#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define FPROF_ADD(i, v) { if (KMAX > 1 && (threadIdx.x & 63) == 0 && blockIdx.x < FPROF_BLOCKS) atomicAdd(&g_fprof[(size_t)blockIdx.x * 16 + (i)], (unsigned long long)(v)); }
+#define FPROF_CNT(i, pred) { const unsigned long long m_ = __ballot(pred); if (m_) FPROF_ADD(i, __popcll(m_)); }
+#else
+#define FPROF_T(x)
+#define FPROF_ADD(i, v)
+#define FPROF_CNT(i, pred)
+#endif
+
 #ifndef DBW_RASTER_FASTDIV
 #define DBW_RASTER_FASTDIV 1
 #endif
@@ -57,75 +77,113 @@ __device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec *__restrict__ 
 // (keys in `q`, payloads in the LDS array `home`, stride TW * TH, lane threadIdx.x).  Returns false for the padding blocks of the
 // XCD-aware grid.  All threads of the block must call it.  dbg: bit 0 = plain IEEE divisions, bit 1 = no tile culling (parity tests
 // run every variant against the oracle).
-template <int KMAX, int TW, int TH, int GROUP = 2>
+template <int KMAX, int TW, int TH, int GROUP = 2, bool PAY3 = false>
 __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces, int H, int W, int K,
                                             float blur, int persp, int clipb, long long total_blocks, const CoarseBins &cb, int dbg,
-                                            int &n, int &xi, int &yi, TopK<KMAX> &q, pay4 *&home) {
+                                            int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home) {
     static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
     constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = 2 * GROUP * NT;      // staged face indices: flushed when more than half full
     __shared__ int s_list[CAP];
     __shared__ int s_wcnt[NW];
-    __shared__ pay4 s_home[KMAX == 1 ? 1 : KMAX * NT];
+    __shared__ pay4 s_home[KMAX == 1 ? 1 : (PAY3 ? (KMAX * NT * 3 + 3) / 4 : KMAX * NT)];
     home = s_home;
+#ifdef DBW_LDS_PAD      // occupancy experiments (tools/variants.sh): extra LDS per workgroup
+    __shared__ int s_pad[DBW_LDS_PAD / 4];
+    if (blur < 0.f) s_pad[threadIdx.x] = 1;
+#endif
 
+    FPROF_T(t_pro);
     const long long logical = xcd_remap(blockIdx.x, total_blocks);
     if (logical < 0) return false;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    n = (int)(logical / (tiles_x * tiles_y));
-    const int t = (int)(logical % (tiles_x * tiles_y));
-    const int ty = t / tiles_x, tx = t % tiles_x;
+    const unsigned per_view = (unsigned)(tiles_x * tiles_y), lg = (unsigned)logical;      // total_blocks < 2^31 (checked by the host side)
+    n = (int)(lg / per_view);
+    const int t = (int)(lg - (unsigned)n * per_view);
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // a wave always owns an 8-aligned compact footprint: lanes 0..63 -> 8x8 (TW == 8) or 16x4 (TW == 16) pixels
     xi = tx * TW + (tid % TW);
     yi = ty * TH + (tid / TW);
     const bool in_img = xi < W && yi < H;
-    f2 p;
-    p.x = pix_to_ndc(W - 1 - xi, W, H);
-    p.y = pix_to_ndc(H - 1 - yi, H, W);
     const int x0 = tx * TW, y0 = ty * TH;
     const int x1 = min(x0 + TW - 1, W - 1), y1 = min(y0 + TH - 1, H - 1);
-    const float txmax = pix_to_ndc(W - 1 - x0, W, H), txmin = pix_to_ndc(W - 1 - x1, W, H);
-    const float tymax = pix_to_ndc(H - 1 - y0, H, W), tymin = pix_to_ndc(H - 1 - y1, H, W);
 
     q.init();
 
-    const int f_begin = first_idx[n];
-    int nf = num_faces[n];
+    int f_begin = 0, nf;
     const int *lst = nullptr;
+    // cells (8x8-pixel squares of the coarse bin) this tile covers
+    const int ccx0 = (x0 & (COARSE - 1)) >> 3, ccx1 = (x1 & (COARSE - 1)) >> 3, ccy0 = (y0 & (COARSE - 1)) >> 3, ccy1 = (y1 & (COARSE - 1)) >> 3;
     if (cb.list) {
         const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
-        lst = cb.list + (long long)f_begin * nb + (long long)bin * nf;
         nf = cb.count[n * nb + bin];
+        // occupied cells of the bin: a tile that covers none of them has nothing to rasterise (two of three tiles of a sparse soft
+        // pass) and skips the whole prologue below
+        const unsigned mlo = cb.mask[(n * nb + bin) * 2], mhi = cb.mask[(n * nb + bin) * 2 + 1];
+        const unsigned long long occ = ((unsigned long long)mhi << 32) | mlo;
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int cy = 0; cy < TH / 8; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < TW / 8; ++cx) mine |= 1ull << (8 * min(ccy0 + cy, 7) + min(ccx0 + cx, 7));
+        if (!(occ & mine)) nf = 0;
+        if (nf > 0) {
+            f_begin = first_idx[n];
+            lst = cb.list + (long long)f_begin * nb + (long long)bin * num_faces[n];
+        }
+    } else {
+        f_begin = first_idx[n];
+        nf = num_faces[n];
+    }
+    f2 p{0.f, 0.f};
+    float txmax = 0.f, txmin = 0.f, tymax = 0.f, tymin = 0.f;
+    if (nf > 0) {
+        const NdcAxis ax = ndc_axis(W, H), ay = ndc_axis(H, W);
+        p.x = pix_to_ndc_fast(W - 1 - xi, ax);
+        p.y = pix_to_ndc_fast(H - 1 - yi, ay);
+        txmax = pix_to_ndc_fast(W - 1 - x0, ax); txmin = pix_to_ndc_fast(W - 1 - x1, ax);
+        tymax = pix_to_ndc_fast(H - 1 - y0, ay); tymin = pix_to_ndc_fast(H - 1 - y1, ay);
     }
     const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2);
     int cnt = 0;
+    FPROF_T(t_begin);
+    FPROF_ADD(9, 1);
+    FPROF_ADD(12, t_begin - t_pro);
+#ifdef DBW_PROFILE_FWD
+    unsigned long long t_evsum = 0;
+    bool any_staged = false;
+#endif
     // The face scan is latency bound: fetch the boxes of GROUP chunks with independent loads before consuming them, so a tile
     // pays nf / (GROUP * NT) memory round trips instead of nf / NT.
 #pragma unroll 1
     for (int base0 = 0; base0 < nf; base0 += GROUP * NT) {
-        float4 bbs[GROUP];
         bool hits[GROUP];
         int fjs[GROUP];
+        if (lst) {      // coarse-bin entries carry the cell range of the face's box: one load decides
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            const int j = base0 + g * NT + tid;
-            hits[g] = false;
-            fjs[g] = j;
-            if (j < nf && lst) fjs[g] = lst[j];
-        }
+            for (int g = 0; g < GROUP; ++g) {
+                const int j = base0 + g * NT + tid;
+                const int e = j < nf ? lst[j] : 0;
+                fjs[g] = e & 0xfffff;
+                hits[g] = j < nf && !(ccx1 < ((e >> 20) & 7) || ccx0 > ((e >> 23) & 7) || ccy1 < ((e >> 26) & 7) || ccy0 > ((e >> 29) & 7));
+            }
+        } else {
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            const int j = base0 + g * NT + tid;
-            if (j < nf) {
-                bbs[g] = bbox[f_begin + fjs[g]];
-                hits[g] = !(txmax < bbs[g].x || txmin > bbs[g].y || tymax < bbs[g].z || tymin > bbs[g].w);
+            for (int g = 0; g < GROUP; ++g) {
+                const int j = base0 + g * NT + tid;
+                fjs[g] = j;
+                hits[g] = false;
+                if (j < nf) {
+                    const float4 bb = bbox[f_begin + j];
+                    hits[g] = !(txmax < bb.x || txmin > bb.y || tymax < bb.z || tymin > bb.w);
+                }
             }
         }
         if (tilecull) {
 #pragma unroll
             for (int g = 0; g < GROUP; ++g)
-                if (hits[g] && tile_culled(recs[f_begin + fjs[g]], txmin, txmax, tymin, tymax)) hits[g] = false;
+                if (hits[g] && tile_culled(recs[f_begin + fjs[g]], txmin, txmax, tymin, tymax)) { hits[g] = false; FPROF_CNT(11, true); }
         }
 #pragma unroll
         for (int g = 0; g < GROUP; ++g) {
@@ -149,6 +207,11 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
         __syncthreads();
         if (cnt > CAP - GROUP * NT || base0 + GROUP * NT >= nf) {
             // every wave walks the staged faces: records arrive in SGPRs, lanes are pixels
+            FPROF_T(t_ev0);
+            FPROF_ADD(4, cnt);
+#ifdef DBW_PROFILE_FWD
+            any_staged = any_staged || cnt > 0;
+#endif
 #pragma unroll 1
             for (int cb0 = 0; cb0 < cnt; cb0 += DBW_WAVE) {
                 const int jl = cb0 + lane < cnt ? s_list[cb0 + lane] : 0;
@@ -159,6 +222,8 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
                     const FaceRec r = load_rec_uniform(recs + f_begin + j);
                     const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
                     if (__ballot(inbox) == 0ull) continue;
+                    FPROF_ADD(5, 1);
+                    FPROF_CNT(6, inbox);
                     float pz = 0.f, sd = 0.f;
                     f3 bc{0.f, 0.f, 0.f};
                     bool keep = false;
@@ -169,11 +234,13 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
                         redo = __ballot(inbox && unsafe) != 0ull;
                     }
                     if (redo) {
+                        FPROF_ADD(8, 1);
                         bool unused;
                         keep = false;
                         if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused);
                     }
                     if (__ballot(keep) == 0ull) continue;
+                    FPROF_CNT(7, keep);
                     const pay4 v{sd, bc.x, bc.y, bc.z};
                     bool done = false;
                     if (r.nb != -1) done = q.sibling(K, keep, r.nb, sd < 0.f ? -sd : sd, pz, f_begin + j, v, home, NT, tid);
@@ -182,8 +249,14 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
             }
             cnt = 0;
             if (NW > 1) __syncthreads();
+#ifdef DBW_PROFILE_FWD
+            t_evsum += __builtin_readcyclecounter() - t_ev0;
+#endif
         }
     }
+#ifdef DBW_PROFILE_FWD
+    { const unsigned long long t_end = __builtin_readcyclecounter(); FPROF_ADD(1, t_evsum); FPROF_ADD(0, t_end - t_begin - t_evsum); if (any_staged) FPROF_ADD(10, 1); }
+#endif
     return true;
 }
 

@@ -88,6 +88,20 @@ DBW_HD bool guard3(float n0, float n1, float n2) { return umin3(guard_key(n0), g
 // positive denominator in [2^-27, 2^40)  (the eps clamp of the perspective denominator, 1e-8, lies inside)
 DBW_HD bool guard_den(float d) { return (f2u(d) - ((127u - 27u) << 23)) < (67u << 23); }
 
+// pix_to_ndc with the division by S1 done by div_fast on a reciprocal shared by all pixels of an axis: the numerator
+// |range * i + offset| >= range / 2 >= 1 and the denominator S1 >= 1 are always inside the guarded range, so the bits are pix_to_ndc's
+struct NdcAxis { float range, offset, s1, r; };
+DBW_HD NdcAxis ndc_axis(int S1, int S2) {
+    NdcAxis a;
+    a.range = 2.0f;
+    if (S1 > S2) a.range = ((float)S1 * a.range) / (float)S2;
+    a.offset = a.range / 2.0f;
+    a.s1 = (float)S1;
+    a.r = rcp_refined(a.s1);
+    return a;
+}
+DBW_HD float pix_to_ndc_fast(int i, const NdcAxis &a) { return -a.offset + div_fast(a.range * (float)i + a.offset, a.s1, a.r); }
+
 // ---- per-face record -----------------------------------------------------------------------------------------------------------
 enum { REC_FAST = 1, REC_AREA_POS = 2, REC_DEG_AB = 4, REC_DEG_AC = 8, REC_DEG_BC = 16, REC_CULL = 32 };
 
@@ -254,7 +268,11 @@ constexpr int TOPK_ID_BITS = 27;
 constexpr uint32_t TOPK_ID_MASK = (1u << TOPK_ID_BITS) - 1u;
 constexpr uint64_t TOPK_EMPTY = 0xffffffffffffffe0ull;
 
-template <int KMAX>
+// PAY3: the payload home keeps (signed distance, b0, b1) only, 12 B per entry in planes of `stride` floats, and b2 comes back as
+// (1 - b0) - b1.  Only for consumers that resolve the barycentrics into texture coordinates and never output them (the fused
+// forward's uv-fragment path: clipped barycentrics sum to 1 within 2 ulp, far inside its 1e-4 bar); it cuts the LDS per pixel by a
+// quarter, which is what bounds the number of resident waves.
+template <int KMAX, bool PAY3 = false>
 struct TopK {
     // the two halves of the keys are kept as separate 32-bit arrays: every select below is then a plain v_cndmask on the mask of ONE
     // 64-bit compare (selects of whole 64-bit values are canonicalised into umin / umax, each lowered with a compare of its own)
@@ -279,7 +297,21 @@ struct TopK {
     // entry i of `home` for this pixel: home[slot * stride + lane]
     DBW_HD void store(pay4 *home, int stride, int lane, uint32_t slot, const pay4 &v, bool on) {
         if (KMAX == 1) { if (on) pay1 = v; }
-        else if (on) home[slot * stride + lane] = v;
+        else if (PAY3) {
+            float *h = (float *)home + slot * 3 * stride + lane;
+            if (on) { h[0] = v.x; h[stride] = v.y; h[2 * stride] = v.z; }
+        } else if (on) home[slot * stride + lane] = v;
+    }
+    DBW_HD pay4 load(const pay4 *home, int stride, int lane, uint32_t slot) const {
+        if (KMAX == 1) return pay1;
+        if (PAY3) {
+            const float *h = (const float *)home + slot * 3 * stride + lane;
+            pay4 v;
+            v.x = h[0]; v.y = h[stride]; v.z = h[2 * stride];
+            v.w = (1.f - v.y) - v.z;
+            return v;
+        }
+        return home[slot * stride + lane];
     }
     // sorted insert; the displaced largest entry falls off the end (== emplace_back, sort, pop_back if size > K).  Rank-and-shift:
     // m_i = [cand < key_i] is monotone in i because the list is sorted, so key_i' = m_i ? (m_{i-1} ? key_{i-1} : cand) : key_i --
@@ -322,7 +354,7 @@ struct TopK {
                 if (m) {
                     found = true;
                     const uint32_t slot = klo[i] & 31u;
-                    const float od = KMAX == 1 ? pay1.x : home[slot * stride + lane].x;
+                    const float od = load(home, stride, lane, slot).x;
                     const float nd = od < 0.f ? -od : od;
                     if (dist < nd) {
                         khi[i] = key_hi(pz); klo[i] = key_lo(id, slot);
@@ -343,7 +375,7 @@ struct TopK {
         if (khi[k] == 0xffffffffu) return false;
         pz = u2f(khi[k]);
         fi = (int)((klo[k] >> 5) & TOPK_ID_MASK);
-        v = KMAX == 1 ? pay1 : home[(klo[k] & 31u) * stride + lane];
+        v = load(home, stride, lane, klo[k] & 31u);
         return true;
     }
     DBW_HD bool valid(int k) const { return khi[k] != 0xffffffffu; }

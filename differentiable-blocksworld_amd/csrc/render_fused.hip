@@ -7,18 +7,36 @@
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 using namespace dbw;
 
 // implemented in raster.hip / shade_blend.hip
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
-                       int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes, dbw::CoarseBins &cb, hipStream_t s);
+                       long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
+                       dbw::CoarseBins &cb, hipStream_t s);
 const dbw::FaceRec *dbw_workspace_recs(const void *workspace, long long F_total);
+void *dbw_workspace_shade_recs(void *workspace, long long F_total);
 int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                         const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
 
+#ifdef DBW_PROFILE_FWD
+// sums the per-workgroup records into out16 (host) and optionally clears them
+extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out16, int reset) {
+    static unsigned long long *host = nullptr;
+    const size_t bytes = (size_t)dbw::FPROF_BLOCKS * 16 * sizeof(unsigned long long);
+    if (!host) host = (unsigned long long *)malloc(bytes);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(dbw::g_fprof), bytes);
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (size_t b = 0; b < (size_t)dbw::FPROF_BLOCKS; ++b)
+        for (int i = 0; i < 16; ++i) out16[i] += host[b * 16 + i];
+    if (reset) { memset(host, 0, bytes); (void)hipMemcpyToSymbol(HIP_SYMBOL(dbw::g_fprof), host, bytes); }
+}
+#endif
 int g_render_variant = 0;
 int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
@@ -26,19 +44,38 @@ void dbw_set_render_dbg(int v) { g_render_dbg = v; }
 
 namespace {
 
-template <int KMAX, int TW, int TH, int GROUP>
-__global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
-                                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces,
-                                                             float blur, int persp, int dbg,
-                                                             long long total_blocks, ShadeArgs A, CoarseBins cb, int *__restrict__ p2f,
-                                                             float *__restrict__ bary, float *__restrict__ dists,
-                                                             float *__restrict__ image) {
-    int n, xi, yi;
-    TopK<KMAX> q;
-    pay4 *home;
-    if (!raster_tile<KMAX, TW, TH, GROUP>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, dbg, n, xi, yi, q, home)) return;
-    if (xi >= A.W || yi >= A.H) return;
-    constexpr int NT = TW * TH;
+// One record per clipped face slot of the pass (ShadeRec, shade_common.h).  Slots beyond a view's face count get a benign record
+// (1x1 map at offset 0, opacity 0), so that the branch-free shading loop may fetch through ANY record without a validity test.
+__global__ void shade_setup_kernel(ShadeArgs A, const int *__restrict__ first_idx, const int *__restrict__ num_faces, long long F_total,
+                                   ShadeRec *__restrict__ out) {
+    const long long fc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fc >= F_total) return;
+    ShadeRec r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.uv[i] = 0.f;
+    r.j = 0; r.cd = -1; r.w2 = r.w3 = 0.f; r.map = 0; r.fa = 0.f; r.off = 0; r.hw = (1 << 16) | 1; r.pads = 0; r.sh = 0;
+    const int stride = A.c2o ? A.Fc_stride : A.F;
+    const int n = (int)(fc / stride);
+    const long long local = fc - first_idx[n];
+    if (n < A.N && local >= 0 && local < num_faces[n]) {
+        if (A.c2o) { r.j = A.c2o[fc]; r.cd = A.code[fc]; r.w2 = A.cw[fc * 2]; r.w3 = A.cw[fc * 2 + 1]; }
+        else r.j = (int)(fc - (long long)n * A.F);
+        const float *uv = A.face_uvs + (long long)r.j * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r.uv[i] = uv[i];
+        r.map = A.face_map[r.j];
+        r.fa = A.faces_alpha ? A.faces_alpha[(A.alpha_len == A.F) ? (long long)r.j : (long long)n * A.F + r.j] : 1.f;
+        const int *md = A.map_desc + r.map * 8;
+        r.off = md[0]; r.hw = (md[1] << 16) | md[2]; r.pads = (md[3] << 16) | md[4]; r.sh = md[5];
+    }
+    out[fc] = r;
+}
+
+// ---- shading + blend + fragment stores: generic form (any tile shape, any fragment layout) -------------------------------------------
+template <int KMAX, int NT>
+__device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMAX> &q, const pay4 *home, int n, int xi, int yi,
+                                              int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
+                                              float *__restrict__ image) {
     float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
     int cnt = 0;                             // fragments of this pixel (the list is filled front to back)
 #pragma unroll
@@ -101,32 +138,141 @@ __global__ __launch_bounds__(TW * TH, DBW_RASTER_WAVES(KMAX)) void render_fwd_ke
     out[3 * plane] = 1.f - T;
 }
 
-template <int KMAX, int TW, int TH, int GROUP>
+// ---- the same for the training path's soft pass: 8x8 tile = one wave, uv-fragments (layout 2) --------------------------------------------
+// Same arithmetic, organised for throughput: the tile index is wave-uniform, so every fragment plane is addressed as a scalar base +
+// a constant + lane * 4; each layer's inputs come from the payload home (LDS) and ONE ShadeRec gather, requested a layer ahead; the
+// per-layer arithmetic is branch-free (texels are fetched through the record of an empty slot too -- slot validity only masks the
+// result and the stores) and the unrolled layer loop ends at the deepest layer any pixel of the wave holds.
+struct UvSlot { bool valid; int fik; pay4 v; ShadeRec sr; };
+
+template <int KMAX>
+__device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 *home, const ShadeRec *__restrict__ srec, int k, bool in_img) {
+    UvSlot s;
+    float pz = 0.f;
+    s.fik = 0;
+    s.v = pay4{0.f, 0.f, 0.f, 0.f};
+    s.valid = q.get(k, home, 64, threadIdx.x, pz, s.fik, s.v) && in_img;
+    if (!s.valid) s.fik = 0;
+    s.sr = srec[s.fik];
+    return s;
+}
+
+template <int KMAX>
+__device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
+                                          int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
+                                          float *__restrict__ image) {
+    const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
+    const bool in_img = xi < A.W && yi < A.H;
+    const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
+    const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
+    const long long tb = ((long long)tile * A.K) << 6;
+    int *__restrict__ p2f_t = p2f + tb;
+    float *__restrict__ dists_t = dists + tb;
+    float *__restrict__ bary_t = bary + tb * 8;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) cnt += (in_img && k < A.K && q.valid(k)) ? 1 : 0;
+    if (in_img && cnt == 0) p2f_t[lane] = -1;         // an empty pixel still tells the backward its fragment count (0)
+    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    UvSlot cur = uv_slot(q, home, srec, 0, in_img), nxt = cur;
+    bool more = true;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        more = more && k < A.K && __ballot(cnt > k) != 0ull;               // wave-uniform: lists are filled front to back
+        if (!more) continue;
+        if (k + 1 < KMAX) nxt = uv_slot(q, home, srec, k + 1, in_img);
+        const ShadeRec &sr = cur.sr;
+        const float bc[3] = {cur.v.y, cur.v.z, cur.v.w};
+        float bo[3];
+        convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
+        const float u = bo[0] * sr.uv[0] + bo[1] * sr.uv[2] + bo[2] * sr.uv[4];
+        const float v = bo[0] * sr.uv[1] + bo[1] * sr.uv[3] + bo[2] * sr.uv[5];
+        const float d = cur.v.x;
+        float e;
+        if (A.sigma == 0.f) e = d <= 0.f ? 1.f : 0.f;
+        else e = expf(-(d > 0.f ? d : 0.f) / A.sigma);
+        const float a = cur.valid ? e * sr.fa : 0.f;
+        Sample s;
+        footprint_desc(u, v, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+        float c[3];
+        fetch(A.maps, s, c);
+        if (!(a != 0.f)) c[0] = c[1] = c[2] = 0.f;
+        const float wgt = T * a;
+        r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+        if (cur.valid) {
+            const int o = (k << 6) + lane;
+            p2f_t[o] = k == 0 ? (cur.fik | (cnt << FRAG_COUNT_SHIFT)) : cur.fik;
+            dists_t[o] = d;
+            float *bp = bary_t + (k << 9) + lane;                          // 8 planes of 64 lanes per layer
+            bp[0] = u;
+            bp[64] = v;
+            bp[128] = __int_as_float(sr.j | (sr.map << 20));
+            bp[192] = a;
+            bp[256] = c[0]; bp[320] = c[1]; bp[384] = c[2];
+            bp[448] = T;
+        }
+        T *= (1.f - a);
+        cur = nxt;
+    }
+    if (in_img) {
+        const long long plane = (long long)A.H * A.W;
+        float *out = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        out[0] = r + T * A.bg[0];
+        out[plane] = g + T * A.bg[1];
+        out[2 * plane] = b + T * A.bg[2];
+        out[3 * plane] = 1.f - T;
+    }
+}
+
+// UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
+#define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
+template <int KMAX, int TW, int TH, int GROUP, bool UV>
+__global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
+                                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces,
+                                                             float blur, int persp, int dbg,
+                                                             long long total_blocks, ShadeArgs A, CoarseBins cb, const ShadeRec *__restrict__ srec,
+                                                             int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
+                                                             float *__restrict__ image) {
+    static_assert(!UV || (TW == 8 && TH == 8), "shade_uv8 needs one wave per 8x8 tile");
+    int n, xi, yi;
+    TopK<KMAX, UV> q;
+    pay4 *home;
+    FPROF_T(t_k0);
+    if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, dbg, n, xi, yi, q, home)) return;
+    FPROF_T(t_k1);
+    if constexpr (UV) shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image);
+    else {
+        if (xi >= A.W || yi >= A.H) return;
+        shade_generic<KMAX, TW * TH>(A, q, home, n, xi, yi, p2f, bary, dists, image);
+    }
+    FPROF_T(t_k2);
+    FPROF_ADD(2, t_k2 - t_k1);
+    FPROF_ADD(3, t_k2 - t_k0);
+}
+
+template <int KMAX, int TW, int TH, int GROUP, bool UV>
 int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
-             int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+             int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
-    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
-                       num_faces, blur, persp, g_render_dbg, total, A, cb, p2f, bary, dists, image);
+    DBW_REQUIRE(total < (1LL << 31) - 8, "more than 2^31 tiles in one pass");
+    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP, UV>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
+                       num_faces, blur, persp, g_render_dbg, total, A, cb, srec, p2f, bary, dists, image);
     return dbw_check_launch("render_fwd_kernel");
 }
 
 template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
-           int persp, ShadeArgs &A, const CoarseBins &cb, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-#define DBW_V(TW, TH, G) launch_v<KMAX, TW, TH, G>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, p2f, bary, dists, image, s)
-    if constexpr (KMAX == 1) return DBW_V(16, 16, 2);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face list; the
-                                              // single payload stays in registers
+           int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+#define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, s)
+    if constexpr (KMAX == 1) return DBW_V(16, 16, 2, false);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face
+                                                               // list; the single payload stays in registers
     else {
-#ifdef DBW_TUNE_VARIANTS
-    switch (g_render_variant) {               // tile-shape / load-batching sweep (tools/sweep_render_fwd.py)
-        case 1: return DBW_V(8, 8, 1);
-        case 2: return DBW_V(8, 8, 2);
-        case 3: return DBW_V(16, 8, 2);
-        case 4: return DBW_V(16, 16, 2);
-        default: break;
-    }
+        // soft K-layer passes: one wave64 per 8x8 tile; uv-fragments (the training path) take the specialised shading
+#ifndef DBW_FWD_GROUP
+#define DBW_FWD_GROUP 2
 #endif
-    return DBW_V(8, 8, 4);                    // soft K-layer passes: one wave64 per 8x8 tile
+        if (A.tiled == 2 && !(g_render_dbg & 4)) return DBW_V(8, 8, DBW_FWD_GROUP, true);
+        return DBW_V(8, 8, DBW_FWD_GROUP, false);
     }
 #undef DBW_V
 }
@@ -160,11 +306,18 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
     CoarseBins cb;
-    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
+    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, c2o ? (long long)Fc_stride : F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
     if (rc) return rc;
     const float4 *bbox = (const float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
-#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, pix_to_face, bary, dists, image, s)
+    ShadeRec *srec = nullptr;
+    if (frag_layout == 2 && K > 1 && F_total > 0) {
+        srec = (ShadeRec *)dbw_workspace_shade_recs(workspace, F_total);
+        hipLaunchKernelGGL(shade_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, A, first_idx, num_faces, (long long)F_total, srec);
+        rc = dbw_check_launch("shade_setup_kernel");
+        if (rc) return rc;
+    }
+#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);

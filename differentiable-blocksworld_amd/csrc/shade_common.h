@@ -221,12 +221,9 @@ __device__ __forceinline__ void frag_from_raw_uv(const ShadeArgs &A, int n, cons
     fr.aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j) : 0;
 }
 
-// grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map
-__device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
-    const float u = fr.u, v = fr.v;
-    const int *md = A.map_desc + fr.map * 8;
-    const int off = md[0];
-    const int h = md[1], w = md[2], pl = md[3], pr = md[4], sh = md[5];
+// grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map whose descriptor is
+// (off, h, w, pl, pr, sh)
+__device__ __forceinline__ void footprint_desc(float u, float v, int off, int h, int w, int pl, int pr, int sh, Sample &s) {
     const int wp = w + pl + pr;
     float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
     float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
@@ -250,6 +247,24 @@ __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sa
     s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
     s.r0 = r0; s.c0 = c0; s.r1 = r1; s.c1 = c1; s.ws = ws;
 }
+
+__device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
+    const int *md = A.map_desc + fr.map * 8;
+    footprint_desc(fr.u, fr.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
+}
+
+// Per-clipped-face shading record of the fused forward (built once per pass by shade_setup_kernel, render_fused.hip): everything
+// decode_frag + footprint gather through the c2o -> {uv, map, opacity} -> map descriptor table chain, in ONE 64 B record, so that a
+// fragment is two dependent loads (record, texels) away from its colour instead of four.
+struct __attribute__((aligned(16))) ShadeRec {
+    float uv[6];        // texture coordinates of the ORIGINAL face's vertices
+    int j, cd;          // local original face id, clip code
+    float w2, w3;       // clip interpolation weights
+    int map;            // row of map_desc
+    float fa;           // learned face opacity (1 if none)
+    int off, hw, pads, sh;   // map descriptor: float offset, h << 16 | w, pad_left << 16 | pad_right, decimation shift
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec must be 64 B");
 
 __device__ __forceinline__ void fetch(const float *maps, const Sample &s, float c[3]) {
 #pragma unroll

@@ -97,6 +97,15 @@ extern "C" int host_rasterize(const float *fv, const int64_t *first, const int64
     return 0;
 }
 
+// pix_to_ndc_fast against pix_to_ndc for every pixel index of an axis (and a few beyond it); returns the number of mismatches
+extern "C" long long host_ndccheck(int S1, int S2, int rcp_perturb) {
+    g_host_rcp_perturb = rcp_perturb;
+    const NdcAxis a = ndc_axis(S1, S2);
+    long long bad = 0;
+    for (int i = -16; i < S1 + 16; ++i) bad += f2u(pix_to_ndc_fast(i, a)) != f2u(pix_to_ndc(i, S1, S2));
+    return bad;
+}
+
 // div_fast against the IEEE quotient on caller-supplied operands; returns the number of mismatches (bit compare, NaN == NaN)
 extern "C" long long host_divcheck(const float *n, const float *d, long long count, int rcp_perturb) {
     g_host_rcp_perturb = rcp_perturb;

@@ -353,7 +353,8 @@ def test_decimated_maps_at_cell_resolution_match_upsampled_copy(agg):
 @pytest.mark.parametrize('which', ['fg', 'env'])
 def test_operator_level_kernels_equal_fused_path(which, monkeypatch):
     """The stand-alone rasterise / shade-blend / raster-backward kernels (operator-level ABI, (N,H,W,K) fragments) and the
-    fused forward/backward kernels (8x8-tile planar fragments) produce the same image (bit-equal) and gradients."""
+    fused forward/backward kernels (8x8-tile planar fragments) produce the same image and gradients.  The hard pass is bit-equal;
+    the soft uv-fragment pass keeps 12 B payloads (b2 = 1 - b0 - b1, raster_math.h: PAY3), i.e. agrees to a few fp32 ulp."""
     m, R, T, Km = _model(seed=21, ts=16)
     with torch.no_grad():
         scene = m.build_blocks(False, True, False, None, kill_blocks=False) if which == 'fg' else m.build_env(False, False)
@@ -371,7 +372,9 @@ def test_operator_level_kernels_equal_fused_path(which, monkeypatch):
         img = ops.render_scene(ps.verts, ps.maps, fa_, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
         (img * torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)).sum().backward()
         outs.append((img.detach(), ps.maps.grad, ps.verts.grad, None if fa_ is None else fa_.grad))
-    assert torch.equal(outs[0][0], outs[1][0])
+    if which == 'env':
+        assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[0][0], outs[1][0]) < 2e-6
     for a, b in zip(outs[0][1:], outs[1][1:]):
         if a is not None:
             assert rel_err(a, b) < 1e-5

@@ -125,6 +125,14 @@ def test_large_faces_with_near_plane_coordinates():
         assert_same(out, ref)
 
 
+def test_pix_to_ndc_with_shared_reciprocal_is_bit_exact():
+    lib().host_ndccheck.restype = ctypes.c_longlong
+    for S1, S2 in ((300, 400), (400, 300), (75, 100), (100, 75), (576, 768), (768, 576), (1080, 1920), (1920, 1080), (33, 47), (1, 7),
+                   (4096, 4096), (8191, 17)):
+        for perturb in (0, 1, -1):
+            assert lib().host_ndccheck(S1, S2, perturb) == 0, (S1, S2, perturb)
+
+
 def test_div_fast_equals_ieee_division_inside_the_guarded_range():
     """div_fast == `/` bit for bit for operands inside the guards (|n| in {0} U [2^-60, 2^69], d in [2^-27, 2^40]) whatever the last
     bit of the reciprocal seed; the device-side twin of this test runs the real v_rcp_f32 (tests/test_gpu_parity.py)."""
