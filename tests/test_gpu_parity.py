@@ -279,7 +279,7 @@ def test_render_env_hard_pass_with_clipping_matches_oracle():
         scene = m.build_env(True, False)
     res = _render_both(scene, R, T, Km[0], 48, 64, 0.0, 1, False, None, bg=(0.1, 0.2, 0.3))
     for k, (a, b) in res.items():
-        assert rel_err(a, b) < (REL if k != 'g_verts' else 5e-4), f'{k}: rel err {rel_err(a, b)}'
+        assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
     assert res['g_verts'][1].abs().max() > 0
 
 
@@ -374,7 +374,7 @@ def test_operator_level_kernels_equal_fused_path(which, monkeypatch):
         outs.append((img.detach(), ps.maps.grad, ps.verts.grad, None if fa_ is None else fa_.grad))
     if which == 'env':
         assert torch.equal(outs[0][0], outs[1][0])
-    assert rel_err(outs[0][0], outs[1][0]) < 2e-6
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5
     for a, b in zip(outs[0][1:], outs[1][1:]):
         if a is not None:
             assert rel_err(a, b) < 1e-5
