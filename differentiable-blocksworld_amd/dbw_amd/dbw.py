@@ -382,10 +382,55 @@ class DifferentiableBlocksWorld(nn.Module):
         return fg, env
 
     def predict(self, inp, labels=None, w_edges=False, filter_transparent=False):
-        if w_edges:
-            raise NotImplementedError('edge overlays are visualisation-only (SURVEY.md 8f N4)')
         fg, env = self.render_layers(inp, filter_transparent)
-        return ops.composite(fg, env)                                  # rec = rec_fg*mask + (1-mask)*rec_env (dbw.py:223)
+        rec = ops.composite(fg, env)                                   # rec = rec_fg*mask + (1-mask)*rec_env (dbw.py:223)
+        if w_edges:                                                    # dbw.py:234-238: wireframe of the joined scene, coloured per block
+            fine = not self.is_live('coarse_learning')
+            filter_tsp = filter_transparent or fine
+            with torch.no_grad():
+                scene = self.build_scene(filter_transparent=filter_tsp)
+                colors = self.get_scene_face_colors(filter_transparent=filter_tsp).repeat(len(inp['R']), 1)
+                renderer = self.renderer_fine if fine else self.renderer
+                rec = renderer.draw_edges(rec, scene, inp['R'], inp['T'], colors=colors)
+        return rec
+
+    @torch.no_grad()
+    def predict_synthetic(self, inp, labels=None):
+        """Blocks alone in their synthetic colours (dbw.py:240-248), exact 4x anti-aliased hard render.  The reference shades them
+        with a directional light (`renderer_light`: phong shading, visualisation-only); here the colours are flat."""
+        self._ensure_cameras(inp)
+        was_training = self.training
+        self.eval()
+        blocks = self.build_blocks_scene(filter_transparent=True)
+        self.train(was_training)
+        if blocks is None:
+            return torch.ones_like(inp['imgs'])
+        keep = (self.get_opacities() > 0.5).nonzero().flatten()
+        values = torch.linspace(0, 1, self.n_blocks + 1)[1:][keep.cpu()]
+        colors = torch.from_numpy(M.get_fancy_cmap()(values.numpy())).float().to(blocks.verts.device)
+        desc = PackedScene.describe_maps([(1, 1)] * len(colors), [(0, 0)] * len(colors), blocks.verts.device)[0]
+        flat = PackedScene(blocks.verts, blocks.faces, blocks.face_uvs, blocks.face_map, desc, colors.reshape(-1).contiguous())
+        bg_renderer = Renderer(self.img_size, **{**self.renderer.init_kwargs, 'background_color': (1, 1, 1)})
+        bg_renderer.update_cameras(device=blocks.verts.device, K=self.renderer.cameras.K)
+        return bg_renderer.render_packed(flat, inp['R'], inp['T'], viz_purpose=True)[:, :3]
+
+    @torch.no_grad()
+    def get_scene_face_colors(self, filter_transparent=False, w_env=True):       # dbw.py:420-431
+        val_blocks = torch.linspace(0, 1, self.n_blocks + 1)[1:]
+        if filter_transparent:
+            val_blocks = val_blocks[self.get_opacities().cpu() > 0.5]
+        elif self.kill_blocks:
+            val_blocks = val_blocks[self.get_opacities().cpu() > 0.01]
+        NFE = self.env_n_faces if w_env else 0
+        values = torch.cat([torch.zeros(NFE), val_blocks.repeat_interleave(self.BNF)])
+        return torch.from_numpy(M.get_fancy_cmap()(values.numpy())).float().to(self.sq_eps.device)
+
+    @torch.no_grad()
+    def get_arranged_block_txt(self):                                            # dbw.py:433-438
+        maps = torch.sigmoid(self.textures).permute(0, 3, 1, 2)
+        ncol, nrow = 5, len(maps) // 5
+        rows = [torch.cat([maps[k] for k in range(ncol * i, ncol * (i + 1))], dim=2) for i in range(nrow)]
+        return torch.cat(rows, dim=1)[None]
 
     def forward(self, inp, labels=None):
         fg, env = self.render_layers(inp)

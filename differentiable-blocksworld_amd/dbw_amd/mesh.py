@@ -169,3 +169,27 @@ def synthetic_cameras(n_views, R_world=None, dist=2.8, f_ndc=4.82, elev_deg=30.0
     R, T = look_at_view_transform(C, up=tuple(up[0].tolist()))
     K = torch.tensor([[f_ndc, 0, 0, 0], [0, f_ndc, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=torch.float32)
     return R, T, K[None].repeat(n_views, 1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# colour map of the visualisations (utils/plot.py:77-87: seaborn 'hls' palette of 21 colours behind gold, as a matplotlib
+# LinearSegmentedColormap) restated with colorsys / numpy -- neither seaborn nor matplotlib is a dependency of the render path
+# ---------------------------------------------------------------------------------------------------------------------
+def get_fancy_cmap():
+    import colorsys
+    import numpy as np
+    hues = np.linspace(0, 1, 22)[:-1] + 0.01                                  # seaborn.hls_palette(21, h=.01, l=.6, s=.65)
+    hues = hues % 1
+    hls = [colorsys.hls_to_rgb(float(h), 0.6, 0.65) for h in hues]
+    colors = np.array([(1.0, 0.8431372549019608, 0.0)] + hls[3:] + hls[:2])    # gold first
+    x = np.linspace(0, 1, len(colors))
+    lut = np.stack([np.interp(np.linspace(0, 1, 256), x, colors[:, c]) for c in range(3)], -1)   # matplotlib's 256-entry table
+
+    def cmap(values):
+        if isinstance(values, torch.Tensor):
+            values = values.detach().cpu().numpy()
+        v = np.asarray(values, dtype=np.float64)
+        idx = np.clip((v * 256).astype(np.int64), 0, 255)
+        idx[v == 1.0] = 255
+        return lut[idx]
+    return cmap

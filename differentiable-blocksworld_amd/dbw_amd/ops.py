@@ -138,14 +138,23 @@ class _RasterizeMeshes(torch.autograd.Function):
         return g, None, None, None, None, None, None, None, None, None
 
 
-def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
-                     blur_radius=0.0, faces_per_pixel=8, perspective_correct=False, clip_barycentric_coords=False,
+def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size, blur_radius,
+                     faces_per_pixel, bin_size=0, max_faces_per_bin=0, perspective_correct=False, clip_barycentric_coords=False,
                      cull_backfaces=False):
-    """face_verts (F,3,3) packed NDC faces of N meshes -> (pix_to_face int64, zbuf, bary_coords, dists), each
-    (N,H,W,K[,3]), -1 where empty.  Same contract as PyTorch3D's `_C.rasterize_meshes`; gradients flow to face_verts
-    through zbuf, bary_coords and dists."""
+    """Positional drop-in for PyTorch3D 0.7.1's `_C.rasterize_meshes` (pytorch3d/renderer/mesh/rasterize_meshes.py; reached by the
+    reference through src/model/renderer.py:53-54,92-94): the same twelve arguments in the same order.
+    face_verts (F,3,3) packed NDC faces of N meshes -> (pix_to_face int64, zbuf, bary_coords, dists), each (N,H,W,K[,3]), -1 where
+    empty; gradients flow to face_verts through zbuf, bary_coords and dists (autograd calls the backward kernel; the stand-alone
+    `rasterize_meshes_backward` below is the `_C.rasterize_meshes_backward` twin).
+    bin_size / max_faces_per_bin select PyTorch3D's coarse-to-fine CUDA path and size its bins; they never change its result unless a
+    bin overflows (which PyTorch3D reports as an error).  This rasteriser has its own two-level binning without capacity limits, so
+    both are accepted (None or any int >= 0) and ignored: the result is always the naive rasterisation (bin_size = 0)."""
     if isinstance(image_size, int):
         image_size = (image_size, image_size)
+    if bin_size is not None and bin_size < 0:
+        raise ValueError('bin_size must be >= 0')
+    if max_faces_per_bin is not None and max_faces_per_bin < 0:
+        raise ValueError('max_faces_per_bin must be >= 0')
     if faces_per_pixel > MAX_FACES_PER_PIXEL:
         raise ValueError(f'faces_per_pixel={faces_per_pixel} > {MAX_FACES_PER_PIXEL}')
     first = _chk(mesh_to_face_first_idx.to(torch.int32), torch.int32, 'mesh_to_face_first_idx')
@@ -153,6 +162,21 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
     nb = None if clipped_faces_neighbor_idx is None else _chk(clipped_faces_neighbor_idx.to(torch.int32), torch.int32, 'neighbor')
     return _RasterizeMeshes.apply(face_verts, first, num, nb, tuple(image_size), float(blur_radius), int(faces_per_pixel),
                                   bool(perspective_correct), bool(clip_barycentric_coords), bool(cull_backfaces))
+
+
+def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct, clip_barycentric_coords):
+    """Positional drop-in for PyTorch3D 0.7.1's `_C.rasterize_meshes_backward`: face_verts (F,3,3), pix_to_face (N,H,W,K) int64 (or
+    int32), grad_zbuf / grad_dists (N,H,W,K), grad_bary (N,H,W,K,3) -> grad_face_verts (F,3,3)."""
+    fv = _chk(face_verts.detach(), torch.float32, 'face_verts')
+    p2f = _chk(pix_to_face.to(torch.int32), torch.int32, 'pix_to_face')
+    N, H, W, K = p2f.shape
+    gz, gb, gd = [_chk(t.detach(), torch.float32, n) for t, n in ((grad_zbuf, 'grad_zbuf'), (grad_bary, 'grad_bary'), (grad_dists, 'grad_dists'))]
+    if gz.shape != p2f.shape or gd.shape != p2f.shape or gb.shape != p2f.shape + (3,):
+        raise ValueError('gradient shapes must be (N,H,W,K), (N,H,W,K,3), (N,H,W,K)')
+    g = torch.zeros_like(fv)
+    _lib.call('dbw_rasterize_bwd', _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), N, fv.shape[0], H, W, K, int(bool(perspective_correct)),
+              int(bool(clip_barycentric_coords)), _ptr(g), _stream(fv))
+    return g
 
 
 # ---------------------------------------------------------------------------------------------------------------------

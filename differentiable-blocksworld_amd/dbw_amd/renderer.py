@@ -119,6 +119,55 @@ class Renderer(nn.Module):
         return ops.render_scene(scene.verts, scene.maps, faces_alpha, scene.faces, R, T, Kmat, scene.face_uvs, scene.face_map,
                                 scene.map_desc, self._bg, cfg)
 
+    # -- renderer.py:134-175: wireframe overlays (visualisation) on the same rasteriser kernels
+    def _as_scene(self, meshes):
+        return PackedScene.from_meshes(meshes) if isinstance(meshes, Meshes) else meshes
+
+    @torch.no_grad()
+    def render_edges(self, meshes, R, T, image_size=None, linewidth=1, return_pix2face=False, faces_per_pixel=1):
+        """(B,1,H,W) mask of the pixels that lie inside a face and closer than `linewidth` pixels to one of its edges
+        (renderer.py:134-147): a hard rasterisation whose signed squared NDC distances are thresholded at
+        (linewidth * 2 / min(image_size))^2; with return_pix2face also the (B,H,W) int64 packed face id of the nearest face."""
+        if self.cam_name != 'perspective' or self.cameras.K is None:
+            raise NotImplementedError('the HIP path needs perspective cameras with an explicit NDC K (dbw.py:204-208)')
+        scene = self._as_scene(meshes)
+        H, W = image_size or self.img_size
+        cfg = ops.RenderCfg(H, W, int(faces_per_pixel), 0.0, self.z_clip, self.perspective_correct, False, scene.faces.shape[0], EPS)
+        Kmat = self.cameras.K[0].to(R.device).contiguous()
+        cl, p2f, _, _, dists = ops.render_fragments(scene.verts.detach(), scene.faces, R.float().contiguous(), T.float().contiguous(), Kmat, cfg)
+        mask = (-dists < (linewidth * 2 / min(H, W)) ** 2).float()[:, None]       # B1HWK; empty slots hold -1: never an edge
+        mask = mask.max(-1)[0]
+        if not return_pix2face:
+            return mask
+        first = p2f[..., 0]
+        B, F_ = R.shape[0], scene.faces.shape[0]
+        orig = cl['c2o'].view(-1).long()[first.clamp(min=0).long()] + torch.arange(B, device=first.device).view(B, 1, 1) * F_
+        return mask, torch.where(first >= 0, orig, torch.full_like(orig, -1))
+
+    @torch.no_grad()
+    def draw_edges(self, img, meshes, R=None, T=None, colors=None, linewidth=1, antialias=True):
+        """img (B,3,H,W) with the wireframe of `meshes` painted on it (renderer.py:149-175); colors: one RGB triple, or one per
+        packed face (B*F,3).  antialias: the mask is rasterised at 4x the resolution and average-pooled."""
+        scene = self._as_scene(meshes)
+        B = img.shape[0]
+        dev = img.device
+        if R is None:
+            R = torch.eye(3, device=dev)[None].expand(B, -1, -1)
+        if T is None:
+            T = torch.zeros(1, 3, device=dev).expand(B, -1)
+        colors = torch.as_tensor((1., 0., 0.) if colors is None else colors, dtype=torch.float32, device=dev)
+        size = tuple(img.shape[-2:])
+        if antialias:
+            size, linewidth = (size[0] * 4, size[1] * 4), linewidth * 4
+        mask, pix2face = self.render_edges(scene, R, T, image_size=size, linewidth=linewidth, return_pix2face=True)
+        if colors.dim() == 2:
+            face_img = colors[pix2face].permute(0, 3, 1, 2)                       # one colour per face (empty pixels: last row, masked)
+        else:
+            face_img = colors[None, :, None, None].expand(B, -1, *size)
+        if antialias:
+            mask, face_img = [F.avg_pool2d(t, kernel_size=4, stride=4) for t in (mask, face_img)]
+        return img * (1 - mask) + mask * face_img
+
     def forward(self, meshes, R, T, viz_purpose=False, **kwargs):
         faces_alpha = kwargs.pop('faces_alpha', None)
         assert len(kwargs) == 0, kwargs

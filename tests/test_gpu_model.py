@@ -406,3 +406,59 @@ def test_quantitative_eval_hard_render_of_joined_scene_matches_oracle():
         scene = model.build_scene(filter_transparent=True)
         img = model.renderer.render_packed(scene, R.to(DEV), T.to(DEV), viz_purpose=True)[:, :3]
     assert rel_err(img, ref) < REL
+
+
+def test_edge_overlays_and_log_tick_members():
+    """N4: Renderer.render_edges / draw_edges (renderer.py:134-175) on the HIP rasteriser against the oracle's
+    fragments, and the model members src/trainer.py's log tick calls (trainer.py:181-198): predict(w_edges=True),
+    predict(filter_transparent=True), predict_synthetic, get_arranged_block_txt."""
+    import torch.nn.functional as Fn
+    from dbw_amd.structures import PackedScene
+    H, W, nb, ts = 40, 56, 5, 16
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, 6), (H, W))
+    orc = O.OracleDBW((H, W), n_blocks=nb, txt_size=ts, faces_per_pixel=6, seed=227391)
+    with torch.no_grad():
+        orc.p['alpha_logit'][1] = -3.0
+        model.alpha_logit[1] = -3.0
+    model = model.to(DEV).eval()
+    R, T, Km = O.synthetic_cameras(2, R_world=orc.R_world[0])
+    inp = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(2, 3, H, W), R=R, T=T, K=Km).items()}
+    model._ensure_cameras(inp)
+    # ---- render_edges of the env scene at 4x: mask and nearest-face ids against the oracle's clip + rasterise ----
+    with torch.no_grad():
+        env_o = orc.build_env(False, False)
+        scene = model.build_env_scene()
+        mask, p2f = model.renderer.render_edges(scene, inp['R'], inp['T'], image_size=(4 * H, 4 * W), linewidth=4, return_pix2face=True)
+        Fs = env_o['faces'].shape[0]
+        ndc = O.transform_to_ndc(env_o['verts'], R, T, Km[0], eps=1e-8)
+        fv = ndc[:, env_o['faces']].reshape(2 * Fs, 3, 3)
+        cl = O.clip_faces(fv, torch.arange(2) * Fs, torch.full((2,), Fs), 0.001, True)
+        p2f_c, _, bary_c, dists = O.rasterize(cl['face_verts'], cl['first_idx'], cl['num_faces'], cl['neighbor'], (4 * H, 4 * W), 0.0, 1, True, True, 8)
+        p2f_o, _ = O.convert_clipped_to_original(p2f_c, bary_c, cl)
+    ref_mask = (-dists < (4 * 2 / min(4 * H, 4 * W)) ** 2).float()[:, None].max(-1)[0]
+    # vertices come from two libms (device / host): allow the handful of pixels an ulp moves across a threshold
+    assert (mask.cpu() != ref_mask).float().mean() < 1e-4 and (p2f.cpu() != p2f_o[..., 0]).float().mean() < 1e-4
+    assert 0.01 < mask.mean() < 0.6
+    # ---- draw_edges = img * (1 - mask) + mask * colour, with the 4x mask average-pooled ----
+    img = torch.rand(2, 3, H, W, device=DEV)
+    colors = torch.rand(2 * scene.faces.shape[0], 3, device=DEV)
+    out = model.renderer.draw_edges(img, scene, inp['R'], inp['T'], colors=colors)
+    m4, c4 = Fn.avg_pool2d(mask, 4, 4), Fn.avg_pool2d(colors[p2f].permute(0, 3, 1, 2), 4, 4)
+    assert torch.allclose(out, img * (1 - m4) + m4 * c4, atol=1e-6)
+    red = model.renderer.draw_edges(img, scene, inp['R'], inp['T'], antialias=False)
+    m1 = model.renderer.render_edges(scene, inp['R'], inp['T'])
+    assert torch.allclose(red, img * (1 - m1) + m1 * torch.tensor([1., 0., 0.], device=DEV).view(1, 3, 1, 1))
+    # ---- the log tick ----
+    rec = model.predict(inp, None)
+    rec_e = model.predict(inp, None, w_edges=True)
+    assert rec_e.shape == rec.shape == (2, 3, H, W) and torch.isfinite(rec_e).all() and (rec_e != rec).any()
+    assert rec_e.min() >= 0 and rec_e.max() <= 1 + 1e-5
+    hard = model.predict(inp, None, filter_transparent=True)
+    assert hard.shape == (2, 3, H, W)
+    syn = model.predict_synthetic(inp, None)
+    assert syn.shape == (2, 3, H, W) and syn.min() >= 0 and syn.max() <= 1 + 1e-5 and (syn == 1).float().mean() > 0.2
+    txt = model.get_arranged_block_txt()
+    assert txt.shape == (1, 3, ts * (nb // 5), ts * 5)
+    cols = model.get_scene_face_colors(filter_transparent=True)
+    assert cols.shape == (model.env_n_faces + (nb - 1) * model.BNF, 3)

@@ -81,7 +81,7 @@ def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb, flags, ras
     fv = torch.cat([fv, fv * torch.tensor([0.9, -1.1, 1.0])], 0)
     first, num = torch.tensor([0, nf]), torch.tensor([nf, nf])
     ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), blur, K, persp, clipb, n_threads=8)
-    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (H, W), blur, K, persp, clipb, False)
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (H, W), blur, K, 0, 0, persp, clipb, False)
     assert out[0].dtype == torch.int64
     assert torch.equal(out[0].cpu(), ref[0]), f'pix_to_face mismatch on {(out[0].cpu() != ref[0]).sum().item()} slots'
     for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
@@ -98,7 +98,7 @@ def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
     outs = []
     for on in (True, False):
         monkeypatch.setattr(ops, 'COARSE_BINS', on)
-        outs.append(ops.rasterize_meshes(fv, first, num, None, (H, W), blur, K, True, True, False))
+        outs.append(ops.rasterize_meshes(fv, first, num, None, (H, W), blur, K, 0, 0, True, True, False))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert (outs[0][0] >= 0).sum() > 1000
@@ -111,7 +111,7 @@ def test_rasterize_ties_and_degenerates():
     fv[3, 2] = fv[3, 1]                                          # zero-area face
     first, num = torch.tensor([0]), torch.tensor([fv.shape[0]])
     ref = O.rasterize_fwd_raw(fv, first, num, None, (37, 29), 1e-3, 6)
-    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (37, 29), 1e-3, 6, True, True, False)
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (37, 29), 1e-3, 6, 0, 0, True, True, False)
     assert torch.equal(out[0].cpu(), ref[0])
     assert torch.equal(out[3].cpu(), ref[3])
     p = ref[0]
@@ -122,7 +122,7 @@ def test_rasterize_ties_and_degenerates():
 def test_rasterize_empty_and_errors():
     fv = random_faces(4, seed=1).to(DEV)
     first, num = torch.tensor([0, 4], device=DEV), torch.tensor([4, 0], device=DEV)      # second mesh is empty
-    p2f, zbuf, bary, dists = ops.rasterize_meshes(fv, first, num, None, (16, 16), 1e-3, 3, True, True)
+    p2f, zbuf, bary, dists = ops.rasterize_meshes(fv, first, num, None, (16, 16), 1e-3, 3, 0, 0, True, True)
     assert torch.all(p2f[1] == -1) and torch.all(zbuf[1] == -1) and torch.all(bary[1] == -1) and torch.all(dists[1] == -1)
     with pytest.raises(ValueError):
         ops.rasterize_meshes(fv, first, num, None, (16, 16), 1e-3, 26)
@@ -130,6 +130,32 @@ def test_rasterize_empty_and_errors():
         ops.rasterize_meshes(fv.cpu(), first, num, None, (16, 16), 1e-3, 3)       # no CPU fallback
     with pytest.raises(RuntimeError):
         ops.rasterize_meshes(fv, first, num, None, (16, 16), -1.0, 3)             # C ABI rejects blur < 0
+
+
+def test_rasterize_operators_take_pytorch3d_positional_signatures():
+    """`_C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+    blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)` and
+    `_C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct,
+    clip_barycentric_coords)` (PyTorch3D 0.7.1; SURVEY.md 8b), called positionally in exactly that order, against the oracle;
+    bin_size / max_faces_per_bin take PyTorch3D's values (None, 0, heuristics) without changing a bit."""
+    H, W, K, nf = 40, 56, 5, 80
+    fv = random_faces(nf, seed=11)
+    first, num = torch.tensor([0]), torch.tensor([nf])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), 2e-3, K)
+    fvd, firstd, numd = fv.to(DEV), first.to(DEV), num.to(DEV)
+    for bin_size, max_faces_per_bin in ((0, 0), (None, None), (16, 10000), (32, 18)):
+        out = ops.rasterize_meshes(fvd, firstd, numd, None, (H, W), 2e-3, K, bin_size, max_faces_per_bin, True, True, False)
+        assert len(out) == 4 and out[0].dtype == torch.int64
+        for a, b in zip(out, ref):
+            assert torch.equal(a.cpu(), b)
+    g = torch.Generator().manual_seed(3)
+    gz, gb, gd = torch.randn(ref[1].shape, generator=g), torch.randn(ref[2].shape, generator=g), torch.randn(ref[3].shape, generator=g)
+    grad = ops.rasterize_meshes_backward(fvd, out[0], gz.to(DEV), gb.to(DEV), gd.to(DEV), True, True)
+    assert grad.shape == fv.shape and rel_err(grad, O.rasterize_bwd_raw(fv, ref[0], gz, gb, gd)) < REL
+    with pytest.raises(ValueError):
+        ops.rasterize_meshes(fvd, firstd, numd, None, (H, W), 2e-3, K, -1, 0, True, True, False)
+    with pytest.raises(ValueError):
+        ops.rasterize_meshes_backward(fvd, out[0], gz.to(DEV), gd.to(DEV), gd.to(DEV), True, True)
 
 
 def test_rasterize_backward_matches_oracle():
@@ -141,13 +167,13 @@ def test_rasterize_backward_matches_oracle():
     gz, gb, gd = torch.randn(ref[1].shape, generator=g), torch.randn(ref[2].shape, generator=g), torch.randn(ref[3].shape, generator=g)
     g_ref = O.rasterize_bwd_raw(fv, ref[0], gz, gb, gd)
     fvd = fv.to(DEV).requires_grad_(True)
-    out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, True, True, False)
+    out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, 0, 0, True, True, False)
     (out[1] * gz.to(DEV) + (out[2] * gb.to(DEV)).sum(-1) + out[3] * gd.to(DEV)).sum().backward()
     assert rel_err(fvd.grad, g_ref) < REL
     # each gradient stream alone (NULL pointers for the others)
     for sel in range(3):
         fvd.grad = None
-        out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, True, True, False)
+        out = ops.rasterize_meshes(fvd, first.to(DEV), num.to(DEV), None, (H, W), 2e-3, K, 0, 0, True, True, False)
         z = torch.zeros
         parts = [gz, gb, gd]
         (out[1 + sel] * parts[sel].to(DEV)).sum().backward()

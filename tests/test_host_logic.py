@@ -198,3 +198,17 @@ def test_packed_scene_join_rebases_faces_and_maps():
     assert j.verts.shape == (9, 3) and j.faces.tolist() == [[0, 1, 2], [2, 3, 4], [5, 6, 8]] and j.face_map.tolist() == [0, 0, 2]
     assert j.map_desc[:, 0].tolist() == [0, n1, n1 + 12] and j.map_desc[1, 3:5].tolist() == [1, 1]
     assert torch.equal(j.maps, torch.cat([s1.maps, s2.maps])) and j.faces.dtype == torch.int32
+
+
+def test_fancy_cmap_structure():
+    """utils/plot.py:77-87 restated without seaborn / matplotlib: gold at 0, a 256-entry table, hues in palette order."""
+    import numpy as np
+    from dbw_amd import mesh as M
+    cmap = M.get_fancy_cmap()
+    c = cmap(np.array([0.0, 1.0, 0.5, 1.0 / 3]))
+    assert c.shape == (4, 3) and np.allclose(c[0], (1.0, 0.8431372549, 0.0)) and (c >= 0).all() and (c <= 1).all()
+    fine = cmap(np.linspace(0, 1, 1000))
+    assert len(np.unique(fine.round(6), axis=0)) == 256                      # matplotlib's default quantisation
+    assert np.abs(np.diff(fine, axis=0)).max() < 0.12                        # piecewise-linear, no jumps
+    import torch
+    assert np.allclose(cmap(torch.tensor([0.25, 0.75])), cmap(np.array([0.25, 0.75])))
