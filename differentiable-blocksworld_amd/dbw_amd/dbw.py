@@ -271,9 +271,13 @@ class DifferentiableBlocksWorld(nn.Module):
     def build_env_scene(self):
         """join(build_bkg(world_coord=True), build_ground(world_coord=True))  (dbw.py:214,267-295) as a PackedScene."""
         S_w, R_w, T_w = self._world_consts()
-        bkg_v = getattr(self, '_bkg_world', None)                         # constant geometry (no parameter involved): cached
-        if bkg_v is None or bkg_v.device != self._bkg_verts.device:
-            bkg_v = self._bkg_world = ((self._bkg_verts * S_w) @ R_w + T_w).detach()
+        # constant geometry (no parameter involved): cached until the world transform changes (load_state_dict copies into the
+        # R_world / T_world buffers in place -> their version counters move; S_world is a plain attribute) or the model moves
+        key = (float(S_w), self.R_world._version, self.T_world._version, self.R_world.data_ptr(), self._bkg_verts.device)
+        if getattr(self, '_bkg_world_key', None) != key:
+            self._bkg_world = ((self._bkg_verts * S_w) @ R_w + T_w).detach()
+            self._bkg_world_key = key
+        bkg_v = self._bkg_world
         ground_v = ops.posed_mesh(self.R_6d_ground, self.T_ground, self._ground_base, S_w, R_w, T_w)
         decim = self.decim_factor if (self.training and self.is_live('decimate_txt')) else 1
         bkg_maps, self._bkg_maps = ops.texture_prep(self.texture_bkg, decim)
@@ -433,6 +437,12 @@ class DifferentiableBlocksWorld(nn.Module):
         return torch.cat(rows, dim=1)[None]
 
     def forward(self, inp, labels=None):
+        if inp['imgs'].shape[0] == 0:
+            # a data-parallel rank whose shard is exhausted (parallel.py / trainer.py: uneven shards): nothing to render, the step
+            # only carries this rank's share of the view-independent regularisers
+            self.build_env_scene()
+            self.build_blocks_scene(filter_transparent=not self.is_live('coarse_learning'))
+            return self.compute_losses(inp['imgs'], None, layers=None)
         fg, env = self.render_layers(inp)
         return self.compute_losses(inp['imgs'], None, layers=(fg, env))
 
@@ -474,7 +484,13 @@ class DifferentiableBlocksWorld(nn.Module):
         if self.perceptual_fn is None:
             raise RuntimeError('perceptual_weight > 0 needs model.set_perceptual(fn): lpips is a third-party network '
                                'outside the HIP path (SURVEY.md 8a A10)')
-        return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * self.perceptual_fn(imgs, rec)
+        # the perceptual criterion is a mean over the views it is given: under view-sharded data parallelism the gradients of all ranks
+        # are SUMMED, so a rank's term is weighted by its share of the global batch (like the MSE, which is normalised by the
+        # global element count) -- the sum over ranks is then the reference's mean over the whole batch
+        share = 1.0
+        if self.world_size > 1 and getattr(self, '_global_count', None):
+            share = imgs.numel() / float(self._global_count)
+        return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * share * self.perceptual_fn(imgs, rec)
 
     def compute_losses(self, imgs, rec, layers=None):
         w = self.loss_weights
@@ -514,9 +530,10 @@ class DifferentiableBlocksWorld(nn.Module):
             losses['total'] = total
             return losses
         losses = {k: torch.zeros((), device=dev) for k in w}          # (fill kernel: hipGraph-capturable, unlike an H2D copy)
-        if 'rgb' in losses:
+        empty = imgs.shape[0] == 0                                     # no views on this rank in this step: regularisers only
+        if 'rgb' in losses and not empty:
             losses['rgb'] = w['rgb'] * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
-        if 'perceptual' in losses:
+        if 'perceptual' in losses and not empty:
             losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse)
         if 'parsimony' in losses:
             factor = 1 if coarse else 0

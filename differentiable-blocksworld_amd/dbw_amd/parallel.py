@@ -66,7 +66,6 @@ class ShardedTrainStep:
         self.exp_avg_sq = torch.zeros_like(self.params.flat)
         self.n_steps = 0
         self.adam_fn = adam_fn or ops.adam_step_
-        self._count_cache = {}
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
             s = torch.tensor([seed if seed is not None else 0], dtype=torch.int64)
@@ -77,20 +76,24 @@ class ShardedTrainStep:
                 dist.broadcast(s, src=0, group=process_group)
             torch.manual_seed(int(s.item()))
 
-    def _global_count(self, imgs):
-        """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367)."""
+    def _global_count(self, imgs, global_count):
+        """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367).  Callers that
+        know how the batch is split pass it (Trainer: from shard_views and the batch index, identical on every rank; bench: local x
+        world_size) -- no collective, no host sync.  Without it the local counts are all-reduced on EVERY call: nothing is cached,
+        because ranks whose shards differ in size must issue the same sequence of collectives."""
+        if global_count is not None:
+            return float(global_count)
         if self.world_size == 1:
-            return imgs.numel()
-        key = imgs.numel()
-        if key not in self._count_cache:
-            t = torch.tensor([float(key)], device=imgs.device)
-            dist.all_reduce(t, group=self.pg)
-            self._count_cache[key] = t.item()
-        return self._count_cache[key]
+            return float(imgs.numel())
+        gloo = dist.get_backend(self.pg) != 'nccl'
+        t = torch.tensor([float(imgs.numel())], device='cpu' if gloo else imgs.device)
+        dist.all_reduce(t, group=self.pg)
+        return float(t.item())
 
-    def __call__(self, inp, labels=None):
-        """One optimisation step on this rank's shard of views; returns the (local) loss dict (device tensors, no sync)."""
-        self.model._global_count = self._global_count(inp['imgs'])
+    def __call__(self, inp, labels=None, global_count=None):
+        """One optimisation step on this rank's shard of views (possibly EMPTY: the rank then only contributes its share of the
+        view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
+        self.model._global_count = self._global_count(inp['imgs'], global_count)
         if self.use_graph and self.n_steps >= self.graph_warmup:
             losses = self._graph_iteration(inp)
         else:
@@ -106,13 +109,23 @@ class ShardedTrainStep:
                 ops.ARENA.enabled = False
             losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
         if self.world_size > 1:
-            dist.all_reduce(self.params.grad, op=dist.ReduceOp.SUM, group=self.pg)     # RCCL over xGMI, in place
+            self.allreduce_gradients()
         self.n_steps += 1
         for (a, b), lr in zip(self.params.bounds, self.lrs):
             if b > a:
                 self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,
                              self.betas, self.eps)
         return losses
+
+    def allreduce_gradients(self):
+        """ONE in-place sum all-reduce of the flat gradient buffer (RCCL over xGMI; gloo on CPU tensors in the tests)."""
+        g = self.params.grad
+        if g.is_cuda and dist.get_backend(self.pg) != 'nccl':      # ranks sharing one GPU over gloo (tests, bench's debug mode)
+            h = g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            g.copy_(h)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _graph_iteration(self, inp):
         if self._graph is None:

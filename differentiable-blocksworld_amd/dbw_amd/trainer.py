@@ -60,9 +60,9 @@ class Trainer:
         opt = dict(tr.get('optimizer') or {})
         if opt.pop('name', 'adam') != 'adam':
             raise NotImplementedError('only Adam (the optimiser of every shipped config, default.yml:31) is fused')
-        txt = opt.pop('texture', {})
+        txt = dict(opt.pop('texture', {}) or {})
         lr = opt.pop('lr', 1e-3)
-        lr_txt = txt.get('lr', lr)
+        lr_txt = txt.pop('lr', lr)
         sch = dict(tr.get('scheduler') or {})
         if sch.pop('name', 'multi_step') != 'multi_step':
             raise NotImplementedError('only the multi_step scheduler')
@@ -70,22 +70,33 @@ class Trainer:
         model.sync_free = sync_free
         self.step_fn = ShardedTrainStep(model, lr=lr, lr_texture=lr_txt, betas=opt.pop('betas', (0.9, 0.999)), eps=opt.pop('eps', 1e-8),
                                         process_group=process_group, seed=tr.get('seed'))
+        if opt or txt:       # the reference forwards these to torch.optim.Adam (optimizer.py:9-18); the fused kernel implements plain Adam
+            raise NotImplementedError(f'optimizer options not supported by the fused Adam: {sorted(opt) + ["texture." + k for k in sorted(txt)]}')
         self.scheduler = MultiStepLR([lr, lr_txt], **sch)
         self.step_fn.lrs = tuple(self.scheduler.get_last_lr())
         self.batch_size = tr.get('batch_size', 4)
         self.n_epoches = tr.get('n_epoches', 1)
         self.epoch, self.n_iters, self.time_per_img = 1, 0, 0.0
-        a, b = shard_views(views['imgs'].shape[0], self.step_fn.world_size, self.step_fn.rank)
+        V, ws = views['imgs'].shape[0], self.step_fn.world_size
+        a, b = shard_views(V, ws, self.step_fn.rank)
         self.local = {k: v[a:b] for k, v in views.items()}
+        self.shard_sizes = [shard_views(V, ws, r)[1] - shard_views(V, ws, r)[0] for r in range(ws)]
+        self.n_batches = -(-max(self.shard_sizes) // self.batch_size)          # every rank runs this many steps per epoch
+        self.per_view = views['imgs'][0].numel() if V else 0
         self._perm_gen = torch.Generator().manual_seed(int(tr.get('seed') or 0))
 
     # trainer.py:137-147
-    def run_single_batch_train(self, inp):
+    def run_single_batch_train(self, inp, global_count=None):
         t0 = time.time()
         self.model.train()
-        losses = self.step_fn(inp)
+        losses = self.step_fn(inp, global_count=global_count)
         self.n_iters += 1
         return losses, t0
+
+    def global_count(self, batch):
+        """Image elements of mini-batch `batch` over ALL ranks -- every rank derives it from the shard sizes, no collective."""
+        bs = self.batch_size
+        return self.per_view * sum(min(bs, max(0, v - batch * bs)) for v in self.shard_sizes)
 
     def run_epoch(self, shuffle=True):
         """One pass over this rank's views in mini-batches (DataLoader(shuffle=True) equivalent), then the per-epoch
@@ -94,11 +105,15 @@ class Trainer:
         order = torch.randperm(V, generator=self._perm_gen) if shuffle else torch.arange(V)
         last = None
         t_start, n_img = time.time(), 0
-        for s in range(0, V, self.batch_size):
-            idx = order[s:s + self.batch_size].to(self.local['imgs'].device)
-            last, _ = self.run_single_batch_train({k: v[idx] for k, v in self.local.items()})
+        # Uneven shards (49 views over 8 ranks: 7,6,...,6; batch 4 -> two steps everywhere, the second of sizes 3,2,...,2): all ranks
+        # run n_batches steps -- a rank that has run out of views steps on an EMPTY batch (regularisers only) -- so that the
+        # sequence of collectives is the same everywhere, and the MSE normalisation of a step is the size of its global batch
+        for b in range(self.n_batches):
+            idx = order[b * self.batch_size:(b + 1) * self.batch_size].to(self.local['imgs'].device)
+            last, _ = self.run_single_batch_train({k: v[idx] for k, v in self.local.items()}, self.global_count(b))
             n_img += idx.numel()
-        torch.cuda.synchronize()
+        if self.local['imgs'].is_cuda:
+            torch.cuda.synchronize()
         self.time_per_img = (time.time() - t_start) / max(n_img, 1)
         self.step_fn.lrs = tuple(self.scheduler.step())
         self.model.step()
@@ -116,7 +131,11 @@ class Trainer:
 
     # trainer.py:201-209 / 84-107
     def state_dict(self):
-        return {'epoch': self.epoch, 'batch': 1, 'model_name': self.model.name, 'model_kwargs': self.model.init_kwargs,
+        """Same keys as trainer.py:201-209.  'epoch' / 'batch' = the last COMPLETED epoch and its number of batches, like the
+        reference's end-of-epoch save, so either trainer resumes the other's checkpoint at the same epoch; 'model_state' and
+        'scheduler_state' interchange.  'optimizer_state' does NOT: it holds the fused Adam's flat moment buffers
+        ({'exp_avg', 'exp_avg_sq', 'n_steps'} in FlatParams order), not a torch.optim.Adam state_dict."""
+        return {'epoch': self.epoch - 1, 'batch': self.n_batches, 'model_name': self.model.name, 'model_kwargs': self.model.init_kwargs,
                 'model_state': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
                 'optimizer_state': {'exp_avg': self.step_fn.exp_avg.clone(), 'exp_avg_sq': self.step_fn.exp_avg_sq.clone(),
                                     'n_steps': self.step_fn.n_steps},
@@ -125,10 +144,13 @@ class Trainer:
     def load_state_dict(self, ckpt):
         self.model.load_state_dict(ckpt['model_state'])
         o = ckpt['optimizer_state']
+        if 'exp_avg' not in o:
+            raise KeyError("optimizer_state is not a fused-Adam state ({'exp_avg', 'exp_avg_sq', 'n_steps'}): a reference checkpoint's "
+                           'torch.optim.Adam state_dict cannot be loaded; load its model_state / scheduler_state and restart the moments')
         self.step_fn.exp_avg.copy_(o['exp_avg'])
         self.step_fn.exp_avg_sq.copy_(o['exp_avg_sq'])
         self.step_fn.n_steps = o['n_steps']
         self.scheduler.load_state_dict(ckpt['scheduler_state'])
         self.step_fn.lrs = tuple(self.scheduler.get_last_lr())
-        self.epoch = ckpt['epoch']
-        self.model.set_cur_epoch(self.epoch - 1)
+        self.epoch = ckpt['epoch'] + 1                         # trainer.py:94-97: resume with the epoch after the saved one
+        self.model.set_cur_epoch(ckpt['epoch'])

@@ -1,0 +1,75 @@
+"""Multi-GPU readiness on a one-GPU box (`-m gpu`): two ranks of the REAL model (HIP kernels, opacity noise and overlap sampling
+on) share cuda:0 and all-reduce over gloo -- the same ShardedTrainStep code path a node runs with one rank per GPU over RCCL
+(backend 'nccl'); only the transport differs.  The driver measures the 8-GPU scaling itself (bench.py --gpus N)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+H, W, NB, TS, FPP, V = 48, 64, 4, 32, 6, 5
+
+
+def _cfg():
+    return {'model': {'name': 'dbw', 'mesh': {'n_blocks': NB, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': TS},
+                      'renderer': {'faces_per_pixel': FPP, 'cameras': {'name': 'perspective'}, 'detach_bary': True, 'z_clip': 0.001},
+                      'rend_optim': {'coarse_learning': 1500, 'decimate_txt': 750, 'decimate_factor': 8, 'kill_blocks': True,
+                                     'decouple_rendering': True, 'opacity_noise': True},
+                      'loss': {'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1, 'overlap_weight': 1}}}
+
+
+def _views():
+    import oracle as O                                          # camera rig + targets only (checker-side helper)
+    R, T, Km = O.synthetic_cameras(V, R_world=O.world_rotation(115, 0, 0))
+    imgs = torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(2))
+    return dict(imgs=imgs, R=R, T=T, K=Km)
+
+
+def _run(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, 'differentiable-blocksworld_amd'), os.path.join(root, 'oracle')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dbw_amd
+    from dbw_amd.parallel import ShardedTrainStep, shard_views
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_cfg(), (H, W)).to(dev).train()
+    model.sync_free = True
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+    views = {k: v.to(dev) for k, v in _views().items()}
+    a, b = shard_views(V, world, rank)
+    local = {k: v[a:b] for k, v in views.items()}
+    count = views['imgs'].numel()                              # the global batch of every step: all V views
+    grads, params = [], []
+    for _ in range(3):
+        step(local, global_count=count)
+        grads.append(step.params.grad.detach().cpu().clone())   # after the all-reduce: the gradient of the global batch
+        params.append(step.params.flat.detach().cpu().clone())
+    out[rank] = (grads, params, step.params.names)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_one_gpu_reproduce_the_full_batch_step():
+    mgr = mp.Manager()
+    ref, out = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, ref), nprocs=1, join=True)                     # single process, all 5 views (its own CUDA context)
+    mp.spawn(_run, args=(2, 29517, out), nprocs=2, join=True)                 # shards of 3 and 2 views
+    g_ref, p_ref, names = ref[0]
+    for s in range(3):
+        assert torch.equal(out[0][1][s], out[1][1][s]), f'replicas diverged at step {s}'           # (i) bit-identical replicas
+        assert torch.equal(out[0][0][s], out[1][0][s])
+    for n, off, k in names:                                                                        # (ii) == the full-batch gradient
+        a, b = out[0][0][0][off:off + k], g_ref[0][off:off + k]
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
+        assert err < 1e-5, (n, err)
+    assert float((out[0][1][2] - p_ref[2]).abs().max()) < 1e-4                                     # and the same parameters after 3 steps

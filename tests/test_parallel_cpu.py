@@ -30,6 +30,18 @@ class ToyModel(nn.Module):
         self.texture_bkg = nn.Parameter(torch.randn(2, 5))
         self.world_size, self._global_count = 1, None
 
+    # the few members of DifferentiableBlocksWorld that Trainer touches
+    name, init_kwargs, sync_free, cur_epoch = 'toy', {}, True, 0
+
+    def step(self):
+        self.cur_epoch += 1
+
+    def set_cur_epoch(self, e):
+        self.cur_epoch = e
+
+    def get_opacities(self):
+        return torch.ones(1)
+
     def forward(self, inp, labels=None):
         pred = (inp['imgs'] * self.S.sum() + self.texture_bkg.sum())
         count = self._global_count or inp['imgs'].numel()
@@ -78,3 +90,59 @@ def test_flat_params_bind_grads_in_place_and_group_textures_last():
     assert fp.grad.abs().sum() > 0 and m.S.grad.data_ptr() == fp.grad.data_ptr()
     fp.zero_grad()
     assert m.S.grad.abs().sum() == 0
+
+
+def _trainer_worker(rank, world, port, views, out):
+    from dbw_amd.trainer import Trainer
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = {'training': {'batch_size': 2, 'n_epoches': 2, 'seed': 7, 'optimizer': {'name': 'adam', 'lr': 1e-2, 'texture': {'lr': 3e-2}},
+                        'scheduler': {'name': 'multi_step', 'gamma': [0.1, 0.1], 'milestones': [50]}}}
+    tr = Trainer(cfg, ToyModel(), {'imgs': views})
+    tr.step_fn.adam_fn = torch_adam
+    steps = 0
+    for _ in range(2):
+        tr.run_epoch(shuffle=False)
+        steps += tr.n_batches
+    out[rank] = (tr.step_fn.params.flat.clone(), tr.n_iters, tr.shard_sizes, steps)
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_every_rank_runs_the_same_steps_and_matches_the_union_batches():
+    """5 views on 2 ranks, batch 2: shards 3 / 2 -> both ranks run 2 steps per epoch, the second one on batches of 1 and 0 views (the
+    empty one only carries its share of the regulariser).  Must not hang (same collectives everywhere: the advisor's finding on
+    the cached element count) and must equal a single process stepping on the union of the ranks' batches, whose MSE is normalised
+    by the size of THAT global batch."""
+    views = torch.rand(5, 3, 4, 4, generator=torch.Generator().manual_seed(3))
+    ref = ShardedTrainStep(ToyModel(), lr=1e-2, lr_texture=3e-2, adam_fn=torch_adam)
+    for _ in range(2):
+        ref({'imgs': views[[0, 1, 3, 4]]})           # step 1: rank 0 holds views 0-2, rank 1 views 3-4
+        ref({'imgs': views[[2]]})                    # step 2: rank 0's last view, rank 1 idle
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, 29513, views, out), nprocs=2, join=True)
+    assert out[0][2] == [3, 2] and out[0][1] == out[1][1] == 4 and out[0][3] == 4
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.allclose(out[0][0], ref.params.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_global_count_is_never_cached_across_differently_sized_batches():
+    step = ShardedTrainStep(ToyModel(), adam_fn=torch_adam)
+    a, b = torch.rand(4, 3, 2, 2), torch.rand(3, 3, 2, 2)
+    assert step._global_count(a, None) == a.numel() and step._global_count(b, None) == b.numel()
+    assert step._global_count(b, 123) == 123.0
+
+
+def test_perceptual_term_is_weighted_by_the_rank_share_of_the_global_batch():
+    """Advisor finding: rgb uses the global count, the regularisers 1/world_size -- the perceptual mean must be weighted by
+    local / global views, otherwise the summed gradient counts it world_size times."""
+    import dbw_amd
+    cfg = {'model': {'name': 'dbw', 'mesh': {'n_blocks': 2, 'txt_size': 8}, 'renderer': {'cameras': {'name': 'perspective'}},
+                     'rend_optim': {'decouple_rendering': True}, 'loss': {'rgb_weight': 1, 'perceptual_weight': 0.1}}}
+    m = dbw_amd.create_model(cfg, (8, 8))
+    m.set_perceptual(lambda a, b: ((a - b) ** 2).mean())
+    imgs, rec = torch.rand(3, 3, 8, 8), torch.rand(3, 3, 8, 8)
+    single = m._perceptual_term(imgs, rec, True)
+    m.world_size, m._global_count = 2, float(5 * 3 * 8 * 8)          # this rank holds 3 of the 5 views of the step
+    assert torch.allclose(m._perceptual_term(imgs, rec, True), single * 3 / 5)
+    assert torch.allclose(m._perceptual_term(imgs, rec, False), single * 0.1 * 3 / 5)
