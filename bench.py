@@ -9,8 +9,10 @@ BASELINE.json: V=49 views per GPU, 300x400 (HxW), 10 superquadric blocks + groun
 textures, coarse phase at epoch 0: sigma=1e-4, opacity noise, decimated textures): param -> mesh, env pass + fg pass
 (project/clip, raster, shade+blend), composite + MSE, parsimony/TV/overlap regularisers, backward to all 10 parameter
 tensors, [RCCL all-reduce of the flat gradient buffer when N > 1], fused Adam on both lr groups.  LPIPS is excluded
-(SURVEY.md 8a A10).  Inputs are resident in HBM before the timed region.  Weak scaling: every rank renders V views per
-step; value = N * V * steps / max-over-ranks time.
+(SURVEY.md 8a A10).  Inputs are resident in HBM before the timed region.  Weak scaling (default): every rank renders V views per
+step; value = N * V * steps / max-over-ranks time.  `--scaling strong` is BASELINE config 3 as written: the SAME 49 views split over
+the ranks (7,6,...,6), value = V * steps / time.  The line also carries, measured in the same run after the timed region: the two
+other training phases of the config (`phases`), the per-step all-reduce time (`allreduce_ms`, N > 1), and at N = 1 the CPU baselines.
 
 Rank 0 prints ONE JSON line, with `roofline` for the dominant kernel (HIP-event timed on the launch stream) and, at N=1,
 `cpu_baseline` (the CPU oracle -- a port, the reference's PyTorch3D path cannot run here -- on a bounded sample)."""
@@ -153,15 +155,29 @@ def cpu_baseline(args):
         loss = m.forward(inp, training=True, coarse=True, decimate=True, opacity_noise=torch.randn(args.blocks, generator=g),
                          overlap_points=torch.rand(args.blocks, 1000, 3, generator=g), n_threads=cores)
         loss['total'].backward()
+    # (`inp`, `cores`, `nv` are rebound below for the single-thread variant: `it` reads them at call time)
     it()
     t0, n = time.time(), 0
     while n < 3 or (time.time() - t0 < 10 and n < 20):
         it()
         n += 1
     dt = (time.time() - t0) / n
-    return {'value': nv / dt, 'unit': 'views/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} fwd+bwd iterations of {nv} views of the same config (oracle/: OpenMP C rasteriser on {cores} threads + '
-                      f'torch-CPU sampling/blend/losses/autograd), {dt:.2f} s/iter'}
+    out = {'value': nv / dt, 'unit': 'views/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{n} fwd+bwd iterations of {nv} views of the same config (oracle/: OpenMP C rasteriser on {cores} threads + '
+                     f'torch-CPU sampling/blend/losses/autograd), {dt:.2f} s/iter'}
+    # the "PyTorch3D-faithful" variant -- the naive CPU rasteriser is single-threaded per image in PyTorch3D, so
+    # the same iteration on ONE thread, one view (bounded: one warm-up + one timed iteration)
+    torch.set_num_threads(1)
+    inp = {k: v[:1] for k, v in inp.items()}
+    cores, nv = 1, 1
+    it()
+    t0 = time.time()
+    it()
+    dt1 = time.time() - t0
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    out['single_thread'] = {'value': 1 / dt1, 'unit': 'views/s', 'cores': 1,
+                            'sample': f'1 fwd+bwd iteration of 1 view, 1 thread (naive rasteriser as PyTorch3D runs it on CPU), {dt1:.2f} s'}
+    return out
 
 
 def main():
@@ -177,6 +193,9 @@ def main():
     ap.add_argument('--txt', type=int, default=256)
     ap.add_argument('--epoch', type=int, default=0, help='training phase to measure: 0 = coarse+decimated textures (default, the '
                     'configuration at the start of training), 800 = coarse, 1600 = fine (dbw.py:210-219, default.yml:15-16)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak', help='weak: --views per GPU (default); strong: --views in total, '
+                    'sharded over the ranks (BASELINE config 3: 49 views -> 7,6,...,6)')
+    ap.add_argument('--no-phases', action='store_true', help='skip the measurement of the two other training phases')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
                     'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
@@ -204,11 +223,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from dbw_amd.parallel import ShardedTrainStep
+    from dbw_amd.parallel import ShardedTrainStep, shard_views
     model, inp = build_workload(args, dev)
     model.set_cur_epoch(args.epoch)
     model.sync_free = True
     model.overlap_passes = not args.no_overlap
+    if args.scaling == 'strong':            # BASELINE config 3: the SAME views, split 7,6,...,6 over the ranks
+        a, b = shard_views(args.views, world, rank)
+        global_count = inp['imgs'].numel()
+        inp = {k: v[a:b].contiguous() for k, v in inp.items()}
+        views_total = args.views
+    else:
+        global_count = inp['imgs'].numel() * world
+        views_total = args.views * world
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
 
     def sync():
@@ -216,57 +243,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        """n steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step(inp, global_count=global_count)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, out
+
     for _ in range(max(args.warmup, 2 if args.graph else 0)):     # graph capture happens in the second iteration
-        step(inp)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step(inp)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        step(inp, global_count=global_count)
+    dt, losses = timed(args.steps)
     total_loss = losses['total'].item()
     assert total_loss == total_loss, 'loss is NaN'
+
+    # ---- outside the timed region: the other two training phases of the same config, the all-reduce alone ----
+    PHASES = (('epoch0', 0, 'coarse, decimated textures', 750), ('epoch800', 800, 'coarse, full-resolution textures', 750),
+              ('epoch1600', 1600, 'fine', 300))          # default.yml:15-16,39: decimation until 750, coarse until 1500, 1800 epochs
+    phases = None
+    if not args.no_phases and not args.graph:
+        phases = {}
+        for name, epoch, what, n_ep in PHASES:
+            if epoch == args.epoch:
+                d, k = dt, args.steps
+            else:
+                model.set_cur_epoch(epoch)
+                for _ in range(3):
+                    step(inp, global_count=global_count)
+                k = max(5, min(args.steps, 10))
+                d, _ = timed(k)
+            phases[name] = {'what': what, 'epochs': n_ep, 'ms_per_step': d / k * 1e3, 'views_per_s': views_total * k / d}
+        model.set_cur_epoch(args.epoch)
+        step(inp, global_count=global_count)
+        mean_ms = sum(p['ms_per_step'] * p['epochs'] for p in phases.values()) / sum(p['epochs'] for p in phases.values())
+        phases['schedule_weighted'] = {'ms_per_step': mean_ms, 'views_per_s': views_total / mean_ms * 1e3,
+                                       'what': 'mean over the 1800-epoch schedule (750 / 750 / 300 epochs)'}
+    allreduce_ms = None
+    if world > 1:
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            step.allreduce_gradients()
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 5
+        step.params.zero_grad()
 
     if rank == 0:
         phase = ('coarse phase (sigma=1e-4, opacity noise, decimated textures)' if model.is_live('decimate_txt') else
                  'coarse phase (sigma=1e-4, opacity noise, full-resolution textures)' if model.is_live('coarse_learning') else
                  'fine phase (sigma=5e-6, transparent blocks filtered, full-resolution textures)')
-        views_per_s = world * args.views * args.steps / dt
+        views_per_s = views_total * args.steps / dt
         P = args.H * args.W
         bytes_per_view = 64 * P * args.fpp + 140 * P                      # SURVEY.md 8(d): whole-path algorithmic bytes
         kb = kernel_breakdown(model, inp)
         dom = max(kb, key=lambda k: kb[k][0])
         ms, nbytes = kb[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9
-        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, see its _how)
+        # counter evidence for the dominant kernel from the rocprofv3 PMC passes of this same workload (profiles/, see its _how):
+        # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE with the gfx950 correction) and the SQ issue counters
+        traffic, counters = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))
-            if args.views == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt) == (300, 400, 10, 10, 256) and dom in pmc:
-                traffic = pmc[dom]['hbm_bytes']
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_counters.json')))
+            if inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0) and dom in pmc:
+                traffic, counters = pmc[dom].get('hbm_bytes'), {k: v for k, v in pmc[dom].items() if k != 'hbm_bytes'}
         except (OSError, ValueError, KeyError):
             pass
+        local_views = inp['R'].shape[0]
         out = {
             'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'DTU-scan24-like synthetic: {args.views} views/GPU/step, {args.W}x{args.H}, {args.blocks} superquadric '
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DTU-scan24-like synthetic: ' + (f'{args.views} views/GPU/step' if args.scaling == 'weak' else
+                                   f'{args.views} views/step sharded over {world} ranks ({local_views} on rank 0)') +
+                                   f', {args.W}x{args.H}, {args.blocks} superquadric '
                                    f'blocks + ground + sky dome, faces_per_pixel={args.fpp}, {args.txt}^2 textures, {phase}, '
                                    f'MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
-                       'views_per_gpu': args.views, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks, 'faces_per_pixel': args.fpp,
-                       'txt_size': args.txt, 'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
+                       'views_per_gpu': local_views, 'views_per_step': views_total, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks,
+                       'faces_per_pixel': args.fpp, 'txt_size': args.txt,
+                       'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
                                  ('' if args.no_overlap else ', env pass on a side stream'),
-                       'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step'},
+                       'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step',
+                       'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
+                         'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS,
-                         'limiter': 'instruction issue, not HBM: SQ counters show the fused forward ~70 % VALU-active and the fused backward '
-                                    'waiting on dependent loads / LDS at 3.5 waves per SIMD (DESIGN.md section 4); frac is the share of '
-                                    'the HBM roofline the algorithmic bytes reach'},
+                         'counters': counters,
+                         'limiter': 'instruction issue and latency, not HBM: see `counters` (share of the SIMD time the VALU is busy, lane '
+                                    'utilisation, HBM traffic per launch; profiles/r02_pmc_counters.json) and DESIGN.md section 4; frac is the '
+                                    'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
+            'phases': phases, 'allreduce_ms': allreduce_ms,
             'final_loss': total_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
