@@ -16,6 +16,9 @@
 #include "shade_common.h"
 #include "../../include/dbw_hip.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 using namespace dbw;
 
 namespace {
@@ -73,10 +76,12 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
 }
 
 #ifdef DBW_PROFILE_BWD
-// cycle accounting of the fused backward (tools/bwd_cycles.py only): per-wave s_memtime deltas of the phases, summed in g_prof
-__device__ unsigned long long g_prof[8];
+// cycle accounting of the fused backward (tools/bwd_cycles.py only): per-wave s_memtime deltas of the phases, kept per workgroup (a
+// shared counter would serialise the atomics of 10^5 waves and distort what it measures) and summed on the host
+constexpr int PROF_BLOCKS = 1 << 16;
+__device__ unsigned long long g_prof[PROF_BLOCKS * 8];
 #define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#define PROF_ADD(i, a, b) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], (b) - (a))
+#define PROF_ADD(i, a, b) if (!SINGLE && (threadIdx.x & 63) == 0 && blockIdx.x < PROF_BLOCKS) atomicAdd(&g_prof[(size_t)blockIdx.x * 8 + (i)], (b) - (a))
 #else
 #define PROF_T(x)
 #define PROF_ADD(i, a, b)
@@ -511,8 +516,15 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
 int g_dbg_flags = 0;
 #ifdef DBW_PROFILE_BWD
 extern "C" void dbw_debug_read_profile(unsigned long long *out8, int reset) {
-    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), 64);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, 64); }
+    static unsigned long long *host = nullptr;
+    const size_t bytes = (size_t)PROF_BLOCKS * 8 * sizeof(unsigned long long);
+    if (!host) host = (unsigned long long *)malloc(bytes);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), bytes);
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (size_t b = 0; b < (size_t)PROF_BLOCKS; ++b)
+        for (int i = 0; i < 8; ++i) out8[i] += host[b * 8 + i];
+    if (reset) { memset(host, 0, bytes); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, bytes); }
 }
 #endif
 
@@ -663,4 +675,5 @@ extern "C" void dbw_debug_set_raster_flags(int flags);
 void dbw_set_render_dbg(int v);
 // bits 0-7: shading/blend ablations (ShadeArgs::dbg) and rasteriser ablations (16, 128); bit 8: plain IEEE divisions in the
 // rasteriser, bit 9: no tile culling in the binning (the parity tests run these variants against the oracle too)
-extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = flags & 0xff; dbw_debug_set_raster_flags(flags); dbw_set_render_dbg(flags >> 8); }
+extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = (flags & 0xff) | (flags & ~0xffff);   // bits 16+: backward experiments (ShadeArgs::dbg)
+    dbw_debug_set_raster_flags(flags); dbw_set_render_dbg(flags >> 8); }
