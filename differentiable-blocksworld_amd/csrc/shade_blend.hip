@@ -447,6 +447,195 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     if (FUSED) face_agg.flush(gfv, threadIdx.x, NT);
 }
 
+// ---- the training path's soft pass, specialised: uv-fragments (layout 2), detached barycentrics, texel gradients through the LDS
+// hash (decimated maps) ----------------------------------------------------------------------------------------------------------
+// Same mathematics as shade_blend_bwd_kernel<true, false, false> on those inputs, organised for residency and issue rate (the
+// generic kernel sits at 127 VGPRs / 36.5 KB of LDS = 4 waves per SIMD and spends 60 % of its wave time waiting):
+//  * every run-time switch of the generic kernel is resolved, the per-layer transmittance array in LDS is gone (the fragments
+//    carry T), the opacity and face-vertex tables are ONE table keyed by the clipped face (one claiming ds_cmpst per fragment
+//    instead of two) -> 22 KB of LDS per 256 threads;
+//  * the tile index is wave-uniform: fragment planes are addressed as scalar base + lane;
+//  * the distance backward picks the closest edge with selects and differentiates that one edge (the generic form runs the three
+//    candidate branches under divergence).
+struct FaceAlphaAgg {      // key = clipped face id -> 6 vertex xy-gradients + 1 opacity gradient (destination index in `aux`)
+    static constexpr int LOG2 = 7, NSLOT = 1 << LOG2, NV = 7;
+    static constexpr size_t BYTES = (size_t)NSLOT * (NV * 8 + 8);
+    int *keys, *aux;
+    double *vals;
+    __device__ __forceinline__ void bind(void *lds) { keys = (int *)lds; aux = keys + NSLOT; vals = (double *)(aux + NSLOT); }
+    __device__ __forceinline__ void clear(int tid, int nthreads) {
+        for (int i = tid; i < NSLOT; i += nthreads) keys[i] = -1;
+        for (int i = tid; i < NSLOT * NV; i += nthreads) vals[i] = 0.0;
+    }
+    __device__ __forceinline__ void add(float *__restrict__ gfv, float *__restrict__ galpha, int key, int aidx, const float (&v)[NV]) {
+        unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2);
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            const int old = atomicCAS(&keys[h], -1, key);
+            if (old == -1 || old == key) {
+                aux[h] = aidx;                      // every lane of a face writes the same opacity index
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
+                return;
+            }
+            h = (h + 1) & (NSLOT - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (v[c] != 0.f) unsafeAtomicAdd(gfv + (long long)key * 9 + (c >> 1) * 3 + (c & 1), v[c]);
+        if (v[6] != 0.f && galpha) unsafeAtomicAdd(galpha + aidx, v[6]);
+    }
+    __device__ __forceinline__ void flush(float *__restrict__ gfv, float *__restrict__ galpha, int tid, int nthreads) {
+        for (int i = tid; i < NSLOT; i += nthreads) {
+            const int k = keys[i];
+            if (k >= 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float x = (float)vals[i * NV + c];
+                    if (x != 0.f) unsafeAtomicAdd(gfv + (long long)k * 9 + (c >> 1) * 3 + (c & 1), x);
+                }
+                const float x = (float)vals[i * NV + 6];
+                if (x != 0.f && galpha) unsafeAtomicAdd(galpha + aux[i], x);
+            }
+        }
+    }
+};
+
+// squared distance to segment a -> b and the clamped parameter of the closest point (point_line_dist_t<true> + its t)
+__device__ __forceinline__ float seg_dist_t(f2 p, f2 a, f2 b, float &tt) {
+    const float dx = b.x - a.x, dy = b.y - a.y;
+    const float l2 = dx * dx + dy * dy;
+    tt = 1.f;
+    if (l2 <= DBW_EPS) return (p.x - b.x) * (p.x - b.x) + (p.y - b.y) * (p.y - b.y);
+    const float t = (dx * (p.x - a.x) + dy * (p.y - a.y)) * __builtin_amdgcn_rcpf(l2);
+    tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = a.x + tt * dx, qy = a.y + tt * dy;
+    return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
+}
+
+__global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
+                                                              float *__restrict__ gmaps, float *__restrict__ galpha,
+                                                              const float *__restrict__ fv, float *__restrict__ gfv) {
+    extern __shared__ __attribute__((aligned(16))) float s_uvbwd[];
+    TexAgg tex_agg;
+    FaceAlphaAgg fa_agg;
+    tex_agg.bind(s_uvbwd);
+    fa_agg.bind((char *)s_uvbwd + TexAgg::BYTES);
+    tex_agg.clear(threadIdx.x, NT);
+    fa_agg.clear(threadIdx.x, NT);
+    int n, xi, yi;
+    if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    __syncthreads();
+    const bool in_img = xi < A.W && yi < A.H;
+    const int lane = threadIdx.x & 63;
+    f2 pndc;
+    pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
+    pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
+    const long long plane = (long long)A.H * A.W;
+    float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
+    if (in_img) {
+        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        gr = gi[0]; gg = gi[plane]; gbl = gi[2 * plane]; gA = gi[3 * plane];
+    }
+    // wave-uniform tile of the 8x8-tile planar fragment layout
+    const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
+    const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
+    const long long tb = ((long long)tile * A.K) << 6;
+    const int *__restrict__ p2f_t = A.p2f + tb + lane;
+    const float *__restrict__ dists_t = A.dists + tb + lane;
+    const float *__restrict__ bary_t = A.bary + tb * 8 + lane;
+    int cnt = 0;
+    if (in_img && (yi >> 3) < tiles_y && (xi >> 3) < tiles_x) {
+        const int raw0 = p2f_t[0];
+        cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
+    }
+    int kmax = 0;
+    for (int k = 0; k < A.K; ++k) {
+        if (__ballot(cnt > k) == 0ull) break;
+        kmax = k + 1;
+    }
+    float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
+    struct Raw { int fc; float u, v, jm, a, c0, c1, c2, T, d; };
+    auto load = [&](int k, bool ok) {
+        Raw r;
+        r.fc = 0; r.u = r.v = r.jm = r.a = r.c0 = r.c1 = r.c2 = r.d = 0.f; r.T = 1.f;
+        if (ok) {
+            r.fc = p2f_t[k << 6] & FRAG_FACE_MASK;
+            const float *b = bary_t + (k << 9);
+            r.u = b[0]; r.v = b[64]; r.jm = b[128]; r.a = b[192]; r.c0 = b[256]; r.c1 = b[320]; r.c2 = b[384]; r.T = b[448];
+            r.d = dists_t[k << 6];
+        }
+        return r;
+    };
+    Raw nxt = load(kmax > 0 ? kmax - 1 : 0, kmax > 0 && kmax - 1 < cnt);
+#pragma unroll 1
+    for (int k = kmax - 1; k >= 0; --k) {
+        const Raw cur = nxt;
+        const bool valid = k < cnt;
+        if (k > 0) nxt = load(k - 1, k - 1 < cnt);
+        const float ak = valid ? cur.a : 0.f, Tk = valid ? cur.T : 1.f;
+        const float ga = valid ? Tk * (gr * (cur.c0 - U0) + gg * (cur.c1 - U1) + gbl * (cur.c2 - U2) + gA * Vb) : 0.f;
+        const float wgt = Tk * ak;
+        U0 = ak * cur.c0 + (1.f - ak) * U0;
+        U1 = ak * cur.c1 + (1.f - ak) * U1;
+        U2 = ak * cur.c2 + (1.f - ak) * U2;
+        Vb = (1.f - ak) * Vb;
+        const int jm = __float_as_int(cur.jm);
+        const int j = jm & 0xfffff, map = jm >> 20;
+        // geometric alpha e = exp(-max(d, 0) / sigma) (the opacity gradient is ga * e), d/d dist of the blend opacity for d >= 0
+        const float e = A.sigma == 0.f ? (cur.d <= 0.f ? 1.f : 0.f) : __expf(-(cur.d > 0.f ? cur.d : 0.f) * A.inv_sigma);
+        const float gd = (valid && A.sigma != 0.f && cur.d >= 0.f) ? ga * ak * -A.inv_sigma : 0.f;
+        // colour -> texels of the decimated map: the bilinear footprint's texels that fall into the same stored cell are merged
+        const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
+        const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
+        if (__ballot(tex) != 0ull) {
+            const int *md = A.map_desc + (valid ? map : 0) * 8;
+            Sample s;
+            footprint_desc(cur.u, cur.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
+            float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
+            if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
+            if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
+            if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
+            else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
+            else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
+            const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
+            const float wt[4] = {w00, w01, w10, w11};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                if (tex && wt[q] != 0.f) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);
+            }
+        }
+        // distance -> the two vertices of the closest edge; opacity; one table update per fragment
+        float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
+        if (__ballot(gd != 0.f) != 0ull) {
+            const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
+            const f2 v0{q[0], q[1]}, v1{q[3], q[4]}, v2{q[6], q[7]};
+            float t01, t02, t12;
+            const float e01 = seg_dist_t(pndc, v0, v1, t01), e02 = seg_dist_t(pndc, v0, v2, t02), e12 = seg_dist_t(pndc, v1, v2, t12);
+            const int sel = (e01 <= e02 && e01 <= e12) ? 0 : ((e02 <= e01 && e02 <= e12) ? 1 : ((e12 <= e01 && e12 <= e02) ? 2 : 3));
+            const f2 ea = sel == 2 ? v1 : v0, eb = sel == 0 ? v1 : v2;
+            const float tt = sel == 0 ? t01 : (sel == 1 ? t02 : t12);
+            const float qx = (1.f - tt) * ea.x + tt * eb.x, qy = (1.f - tt) * ea.y + tt * eb.y;
+            const float g = sel == 3 ? 0.f : gd;
+            const float gax = g * (1.f - tt) * 2.f * (qx - pndc.x), gay = g * (1.f - tt) * 2.f * (qy - pndc.y);
+            const float gbx = g * tt * 2.f * (qx - pndc.x), gby = g * tt * 2.f * (qy - pndc.y);
+            // sel 0: (v0, v1), 1: (v0, v2), 2: (v1, v2)
+            g7[0] = sel <= 1 ? gax : 0.f; g7[1] = sel <= 1 ? gay : 0.f;
+            g7[2] = sel == 0 ? gbx : (sel == 2 ? gax : 0.f); g7[3] = sel == 0 ? gby : (sel == 2 ? gay : 0.f);
+            g7[4] = sel >= 1 ? gbx : 0.f; g7[5] = sel >= 1 ? gby : 0.f;
+        }
+        if (valid && (gd != 0.f || g7[6] != 0.f)) {
+            const int aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? j : n * A.F + j) : 0;
+            fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
+        }
+    }
+    __syncthreads();
+    tex_agg.flush(gmaps, threadIdx.x, NT);
+    fa_agg.flush(gfv, galpha, threadIdx.x, NT);
+}
+
 // One workgroup per (texture bin, chunk of BIN_CHUNK records): accumulate the records into a (32+1)x(32+1) texel LDS tile
 // (1-texel halo: row -1, column +32), then add the tile to the gradient map.  bin_info (nbins,4) = {offset of the map in floats,
 // stored width ws, stored height hs, tile_y << 16 | tile_x}.
@@ -601,6 +790,20 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
             return DBW_ERR_LAUNCH;
         }
         raised = true;
+    }
+    // the training path's soft pass on decimated maps: uv-fragments, detached barycentrics, LDS aggregation -> the specialised kernel
+    if (fused && !A.bin_records && K > 1 && A.tiled == 2 && !want_bary && (A.agg & 1) && !(g_dbg_flags & (1 << 16))) {
+        static bool raised_uv = false;
+        const size_t lds_uv = TexAgg::BYTES + FaceAlphaAgg::BYTES;
+        if (!raised_uv) {
+            if (hipFuncSetAttribute((const void *)render_bwd_uv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
+                dbw_set_error("shade/blend backward: cannot raise the dynamic LDS limit");
+                return DBW_ERR_LAUNCH;
+            }
+            raised_uv = true;
+        }
+        hipLaunchKernelGGL(render_bwd_uv_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds_uv, s, A, total, grad_image, grad_maps, grad_faces_alpha, fv, gfv);
+        return dbw_check_launch("render_bwd_uv_kernel");
     }
     if (fused && A.bin_records)
         hipLaunchKernelGGL((shade_blend_bwd_kernel<true, true, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
