@@ -214,13 +214,34 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         T *= (1.f - a);
         cur = nxt;
     }
-    if (in_img) {
-        const long long plane = (long long)A.H * A.W;
-        float *out = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-        out[0] = r + T * A.bg[0];
-        out[plane] = g + T * A.bg[1];
-        out[2 * plane] = b + T * A.bg[2];
-        out[3 * plane] = 1.f - T;
+    const long long plane = (long long)A.H * A.W;
+    const long long pix = (long long)yi * A.W + xi;
+    const float f0 = r + T * A.bg[0], f1 = g + T * A.bg[1], f2 = b + T * A.bg[2], m = 1.f - T;
+    if (A.target) {
+        // decoupled composite + MSE on registers (dbw.py:223,366-367): rec = fg_rgb * mask + (1 - mask) * env_rgb (the fg colour is
+        // premultiplied AND multiplied by the mask again); the loss gradient is local to the pixel, so the pass hands
+        // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
+        float sq = 0.f;
+        if (in_img) {
+            const float *ev = A.env_img + (long long)n * 4 * plane + pix, *tg = A.target + (long long)n * 3 * plane + pix;
+            const float e0 = ev[0], e1 = ev[plane], e2 = ev[2 * plane];
+            const float d0 = tg[0] - (f0 * m + (1.f - m) * e0), d1 = tg[plane] - (f1 * m + (1.f - m) * e1), d2 = tg[2 * plane] - (f2 * m + (1.f - m) * e2);
+            sq = d0 * d0 + d1 * d1 + d2 * d2;
+            const float s2 = -2.f * A.mse_scale;
+            const float q0 = s2 * d0, q1 = s2 * d1, q2 = s2 * d2;                 // d loss / d rec
+            float *gf = A.g_fg + (long long)n * 4 * plane + pix, *ge = A.g_env + (long long)n * 4 * plane + pix;
+            gf[0] = q0 * m; gf[plane] = q1 * m; gf[2 * plane] = q2 * m;
+            gf[3 * plane] = q0 * (f0 - e0) + q1 * (f1 - e1) + q2 * (f2 - e2);
+            ge[0] = q0 * (1.f - m); ge[plane] = q1 * (1.f - m); ge[2 * plane] = q2 * (1.f - m); ge[3 * plane] = 0.f;
+        }
+        const float tot = wave_sum_dpp(sq);
+        if (lane == 0) A.loss_part[tile] = tot;
+    } else if (in_img) {
+        float *out = image + (long long)n * 4 * plane + pix;
+        out[0] = f0;
+        out[plane] = f1;
+        out[2 * plane] = f2;
+        out[3 * plane] = m;
     }
 }
 
@@ -271,7 +292,7 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
 #ifndef DBW_FWD_GROUP
 #define DBW_FWD_GROUP 2
 #endif
-        if (A.tiled == 2 && !(g_render_dbg & 4)) return DBW_V(8, 8, DBW_FWD_GROUP, true);
+        if (A.tiled == 2 && (A.target || !(g_render_dbg & 4))) return DBW_V(8, 8, DBW_FWD_GROUP, true);
         return DBW_V(8, 8, DBW_FWD_GROUP, false);
     }
 #undef DBW_V
@@ -279,15 +300,17 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
 
 }  // namespace
 
-extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+struct MseArgs { const float *env_img, *target; float scale; float *loss_part, *g_fg, *g_env; };
+
+static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                                     const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code,
                                     const float *clip_w, int Fc_stride, const float *face_uvs, const int32_t *face_map,
                                     const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len,
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, dbw_stream_t stream) {
-    DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && image && workspace, "null pointer");
+                                    int frag_layout, const MseArgs *mse, dbw_stream_t stream) {
+    DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
     DBW_REQUIRE(blur_radius >= 0.f && F_total >= 0, "bad blur_radius / F_total");
     ShadeArgs A;
@@ -298,6 +321,11 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     DBW_REQUIRE(frag_layout != 2 || F < (1 << 20), "frag_layout 2 packs the face id in 20 bits");
     DBW_REQUIRE(frag_layout != 2 || F_total < (1LL << FRAG_COUNT_SHIFT), "frag_layout 2 packs the clipped face id in 26 bits");
     A.tiled = frag_layout;
+    if (mse) {
+        DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
+        DBW_REQUIRE(mse->env_img && mse->target && mse->loss_part && mse->g_fg && mse->g_env, "null pointer");
+        A.env_img = mse->env_img; A.target = mse->target; A.mse_scale = mse->scale; A.loss_part = mse->loss_part; A.g_fg = mse->g_fg; A.g_env = mse->g_env;
+    }
     if (K > DBW_MAX_FACES_PER_PIXEL) {
         dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
         return DBW_ERR_UNSUPPORTED;
@@ -324,4 +352,32 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
     if (K <= 16) return DBW_RF(16);
     return DBW_RF(25);
 #undef DBW_RF
+}
+
+extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+                                    const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code,
+                                    const float *clip_w, int Fc_stride, const float *face_uvs, const int32_t *face_map,
+                                    const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len,
+                                    int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
+                                    int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
+                                    float *dists, float *image, void *workspace, size_t workspace_bytes,
+                                    int frag_layout, dbw_stream_t stream) {
+    return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
+                           faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
+                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, stream);
+}
+
+extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+                                        const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code,
+                                        const float *clip_w, int Fc_stride, const float *face_uvs, const int32_t *face_map,
+                                        const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len,
+                                        int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
+                                        int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
+                                        float *dists, void *workspace, size_t workspace_bytes, const float *env_image,
+                                        const float *target, float mse_scale, float *loss_partial, float *grad_fg,
+                                        float *grad_env, dbw_stream_t stream) {
+    const MseArgs mse{env_image, target, mse_scale, loss_partial, grad_fg, grad_env};
+    return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
+                           faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stream);
 }

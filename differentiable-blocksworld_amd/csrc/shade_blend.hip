@@ -140,7 +140,8 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
     if (in_img) {
         const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-        gr = gi[0]; gg = gi[plane]; gbl = gi[2 * plane]; gA = gi[3 * plane];
+        const float gs = A.gscale ? *A.gscale : 1.f;
+        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs; gA = gi[3 * plane] * gs;
     }
     // The deepest layer in which any pixel of this wave holds a fragment: only ~20 % of the slots of a soft render are occupied
     // and most waves see few layers, so both passes stop there instead of walking all K layers.  Fragments written by
@@ -536,7 +537,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
     if (in_img) {
         const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-        gr = gi[0]; gg = gi[plane]; gbl = gi[2 * plane]; gA = gi[3 * plane];
+        const float gs = A.gscale ? *A.gscale : 1.f;
+        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs; gA = gi[3 * plane] * gs;
     }
     // wave-uniform tile of the 8x8-tile planar fragment layout
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
@@ -734,6 +736,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.agg = 0;
     A.tiled = 0;
     A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0;
+    A.gscale = nullptr; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
     return DBW_OK;
 }
 
@@ -845,7 +848,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     const float *face_verts_c, int perspective_correct, int detach_bary,
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
                                     int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
-                                    void *bin_records, int bin_cap, dbw_stream_t stream) {
+                                    void *bin_records, int bin_cap, const float *grad_scale, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -855,6 +858,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
     DBW_REQUIRE(frag_layout != 2 || detach_bary, "frag_layout 2 carries no barycentrics: only valid with detach_bary");
     A.tiled = frag_layout;
+    A.gscale = grad_scale;
     DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap > 0) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none");
     if (bin_records && !lds_aggregate) {
         A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap;

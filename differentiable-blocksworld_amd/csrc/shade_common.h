@@ -30,6 +30,14 @@ struct ShadeArgs {
     int4 *bin_records;     // (nbins, bin_cap, 2)
     int bin_cap;
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
+    // backward: device scalar every incoming image gradient is multiplied by (the upstream gradient of the loss node), NULL = 1
+    const float *gscale;
+    // forward, decoupled composite + MSE epilogue (dbw_render_fwd_fused_mse; all NULL otherwise): instead of storing its image the
+    // pass composites it over env_img, compares with target and stores d(mse_scale * sum of squares) / d(fg image), d / d(env image)
+    // and the tile's sum of squares
+    const float *env_img, *target;
+    float mse_scale;
+    float *loss_part, *g_fg, *g_env;
 };
 
 struct Sample {   // bilinear footprint of one fragment

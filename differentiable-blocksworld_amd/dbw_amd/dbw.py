@@ -58,7 +58,8 @@ class DifferentiableBlocksWorld(nn.Module):
         # kernel instead of being packed away on the host -> no device->host sync per iteration (dbw.py:322 `.item()`), same
         # images/losses/gradients, and the whole iteration becomes hipGraph-capturable.
         self.sync_free = False
-        self.overlap_passes = False   # render the env pass on a side stream, concurrently with the fg pass
+        self.overlap_passes = False   # render the env pass on a side stream, concurrently with the fg pass (layered path only)
+        self.fused_loss_epilogue = True   # training forward: composite + MSE as the epilogue of the fg pass (ops.render_decoupled_mse)
 
     @property
     def init_kwargs(self):
@@ -443,8 +444,40 @@ class DifferentiableBlocksWorld(nn.Module):
             self.build_env_scene()
             self.build_blocks_scene(filter_transparent=not self.is_live('coarse_learning'))
             return self.compute_losses(inp['imgs'], None, layers=None)
+        fused = self._forward_fused(inp) if self.fused_loss_epilogue else None
+        if fused is not None:
+            return fused
         fg, env = self.render_layers(inp)
         return self.compute_losses(inp['imgs'], None, layers=(fg, env))
+
+    def _forward_fused(self, inp):
+        """The training iteration with the reconstruction loss as the epilogue of the fg pass (ops.render_decoupled_mse): env pass,
+        then fg pass + decoupled composite + MSE in one kernel -- no fg image, no composite kernel, no image-sized gradient round
+        trips.  Returns None when the configuration needs the general path (non-decoupled, perceptual term, no block left, layered
+        fallbacks switched off)."""
+        w = self.loss_weights
+        if (not self.decouple_rendering or 'rgb' not in w or 'perceptual' in w
+                or not (ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS)):
+            return None
+        self._ensure_cameras(inp)
+        fine = not self.is_live('coarse_learning')
+        renderer = self.renderer_fine if fine else self.renderer
+        if not renderer.detach_bary or renderer.faces_per_pixel < 2 or renderer.cam_name != 'perspective' or renderer.cameras.K is None:
+            return None
+        blocks = self.build_blocks_scene(filter_transparent=fine)
+        if blocks is None or blocks.faces.shape[0] >= (1 << 20) or blocks.map_desc.shape[0] >= (1 << 11):
+            return None
+        env = self.build_env_scene()
+        R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
+        Kmat = renderer.cameras.K[0].to(R.device).contiguous()
+        alpha = None if fine else self._alpha.repeat_interleave(self.BNF)
+        cfg_e = self.renderer_env._cfg(env.faces.shape[0], lds_aggregate=True)
+        cfg_f = renderer._cfg(blocks.faces.shape[0], lds_aggregate=self._blocks_decimated, texbins=blocks.texbins)
+        imgs = inp['imgs']
+        count = imgs.numel() if getattr(self, '_global_count', None) is None else self._global_count
+        rgb = ops.render_decoupled_mse(env, blocks, alpha, imgs, float(w['rgb']) / float(count), R, T, Kmat, cfg_e, cfg_f,
+                                       self.renderer_env._bg, renderer._bg)
+        return self.compute_losses(imgs, None, layers=None, rgb_value=rgb)
 
     # ------------------------------------------------------------------------------------------------ evaluation (dbw.py:464-493)
     @torch.no_grad()
@@ -492,7 +525,7 @@ class DifferentiableBlocksWorld(nn.Module):
             share = imgs.numel() / float(self._global_count)
         return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * share * self.perceptual_fn(imgs, rec)
 
-    def compute_losses(self, imgs, rec, layers=None):
+    def compute_losses(self, imgs, rec, layers=None, rgb_value=None):
         w = self.loss_weights
         dev = imgs.device
         coarse = self.is_live('coarse_learning')
@@ -500,7 +533,7 @@ class DifferentiableBlocksWorld(nn.Module):
         # view-independent regularisers: every rank computes them identically; scaled by 1/world_size so that the
         # sum all-reduce of gradients counts them once
         rs = 1.0 / ws
-        if layers is not None and 'rgb' in w:
+        if (layers is not None or rgb_value is not None) and 'rgb' in w:
             # training path: composite + MSE and the regularisers as ONE autograd node (ops.fused_losses); factors of
             # dbw.py:373-405: parsimony and overlap only act in the coarse phase, tv is scaled by 0.1 afterwards (and the
             # ground map once more)
@@ -516,13 +549,17 @@ class DifferentiableBlocksWorld(nn.Module):
                 u = self._overlap_u_override
                 if u is None:
                     u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev)
-            vals = ops.fused_losses(layers[0], layers[1], imgs, self._alpha_full, self._bkg_maps, self._blocks_maps, self._ground_maps,
+            fg_l, env_l = layers if layers is not None else (None, None)
+            vals = ops.fused_losses(fg_l, env_l, imgs, self._alpha_full, self._bkg_maps, self._blocks_maps, self._ground_maps,
                                     self.sq_eps, self.S, self.R_6d, self.T, u, cfg)
             losses = {}
             for k in w:
                 if k in _FUSED_SLOT:
                     losses[k] = vals[_FUSED_SLOT[k]]
             total = vals.sum()
+            if rgb_value is not None:       # reconstruction term already reduced by the fg pass's epilogue (slot 0 of vals is 0)
+                losses['rgb'] = rgb_value
+                total = total + rgb_value
             if 'perceptual' in w:
                 losses['perceptual'] = self._perceptual_term(imgs, ops.composite(*layers), coarse)
                 total = total + losses['perceptual']

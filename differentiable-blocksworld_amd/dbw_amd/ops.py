@@ -310,23 +310,8 @@ class _RenderScene(torch.autograd.Function):
         want_dists = need_geom and cfg.sigma > 0
         want_bary = need_geom and not cfg.detach_bary
         if FUSED_BACKWARD and (ctx.tiled or (need_geom and (want_dists or want_bary))):
-            fvc = cl['face_verts'].view(-1, 3, 3)
-            g_maps, g_alpha = ARENA.zeros_like(maps), (ARENA.zeros_like(fa) if fa is not None else None)
-            g_fvc = ARENA.zeros_like(fvc)
-            bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
-            bin_base = cursor = records = None
-            cap = 0
-            if bins is not None and bins[2] > 0:
-                bin_base, bin_info, nbins = bins
-                cap = texbin_capacity(R.shape[0], cfg.H, cfg.W, cfg.K, nbins)
-                cursor = ARENA.zeros(nbins, torch.int32, fvc.device)
-                records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
-            _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
-                                                           (R.shape[0], cfg.H, cfg.W, cfg.K)),
-                      _ptr(g_img.contiguous()), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
-                      int(cfg.lds_aggregate), int(ctx.tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, _stream(fvc))
-            if records is not None:
-                _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
+            g_maps, g_alpha, g_fvc = _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, ctx.tiled, g_img.contiguous(),
+                                                R.shape[0], None)
             g_verts = project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_fvc, cfg.eps, cfg.z_clip, cfg.persp) if need_geom else None
             return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
         if ctx.tiled:
@@ -344,6 +329,97 @@ class _RenderScene(torch.autograd.Function):
         elif need_geom:
             g_verts = torch.zeros_like(verts)
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
+
+
+def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale):
+    """dbw_render_bwd_fused (+ dbw_texbin_reduce when the texel gradients go through texture-space bins) of one pass.
+    gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c."""
+    fvc = cl['face_verts'].view(-1, 3, 3)
+    g_maps, g_alpha = ARENA.zeros_like(maps), (ARENA.zeros_like(fa) if fa is not None else None)
+    g_fvc = ARENA.zeros_like(fvc)
+    bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
+    bin_base = cursor = records = None
+    cap = 0
+    if bins is not None and bins[2] > 0:
+        bin_base, bin_info, nbins = bins
+        cap = texbin_capacity(B, cfg.H, cfg.W, cfg.K, nbins)
+        cursor = ARENA.zeros(nbins, torch.int32, fvc.device)
+        records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
+    _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
+                                                   (B, cfg.H, cfg.W, cfg.K)),
+              _ptr(g_img), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
+              int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, _ptr(gscale), _stream(fvc))
+    if records is not None:
+        _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
+    return g_maps, g_alpha, g_fvc
+
+
+class _DecoupledRenderMSE(torch.autograd.Function):
+    """The whole decoupled training render + reconstruction loss (dbw.py:213-223,366-367) as ONE autograd node:
+    env pass (sky + ground, hard, 1 face per pixel) -> fg pass (blocks, soft, K faces per pixel) whose epilogue composites over the
+    env image and takes the MSE against the targets on registers (dbw_render_fwd_fused_mse) -> scalar loss.  Neither the fg image
+    nor the composite ever exists in memory; the two backward passes read the per-pixel loss gradients the forward left behind,
+    scaled inside the kernels by the upstream gradient (a device scalar: no host sync, no elementwise pass)."""
+
+    @staticmethod
+    def forward(ctx, verts_e, maps_e, verts_f, maps_f, alpha, imgs, scale, R, T, Kmat, env_tab, fg_tab, cfg_e, cfg_f, bg_e, bg_f):
+        ve, me = _chk(verts_e.detach(), torch.float32, 'env verts'), _chk(maps_e.detach(), torch.float32, 'env maps')
+        vf, mf = _chk(verts_f.detach(), torch.float32, 'fg verts'), _chk(maps_f.detach(), torch.float32, 'fg maps')
+        fa = None if alpha is None else _chk(alpha.detach(), torch.float32, 'faces_alpha')
+        imgs = _chk(imgs, torch.float32, 'imgs')
+        faces_e, uv_e, fmap_e, desc_e = env_tab
+        faces_f, uv_f, fmap_f, desc_f = fg_tab
+        B, dev = R.shape[0], ve.device
+        # env pass: barycentric fragments (layout 1), image kept (the fg epilogue reads it)
+        cl_e = project_clip(ve, faces_e, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        p2f_e, bary_e, dists_e, img_e = _render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, uv_e, fmap_e, desc_e, me, None, bg_e, 1)
+        # fg pass with the composite + MSE epilogue
+        cl_f = project_clip(vf, faces_f, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+        fvc = cl_f['face_verts'].view(-1, 3, 3)
+        Ft = fvc.shape[0]
+        ws_bytes = _workspace_bytes(Ft, B, cfg_f.H, cfg_f.W)
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        ty, tx = (cfg_f.H + 7) // 8, (cfg_f.W + 7) // 8
+        p2f = torch.empty(B, ty, tx, cfg_f.K, 64, dtype=torch.int32, device=dev)
+        bary = torch.empty(B, ty, tx, cfg_f.K, 8, 64, dtype=torch.float32, device=dev)
+        dists = torch.empty(B, ty, tx, cfg_f.K, 64, dtype=torch.float32, device=dev)
+        part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
+        g_fg = torch.empty(B, 4, cfg_f.H, cfg_f.W, dtype=torch.float32, device=dev)
+        g_env = torch.empty_like(g_fg)
+        _lib.call('dbw_render_fwd_fused_mse', _ptr(fvc), _ptr(cl_f['first_idx']), _ptr(cl_f['num_faces']), _ptr(cl_f['neighbor']), _ptr(cl_f['c2o']),
+                  _ptr(cl_f['clip_code']), _ptr(cl_f['clip_w']), 2 * cfg_f.F, _ptr(uv_f), _ptr(fmap_f), _ptr(desc_f), _ptr(mf), _ptr(fa),
+                  0 if fa is None else fa.numel(), B, Ft, cfg_f.H, cfg_f.W, cfg_f.K, cfg_f.F, float(cfg_f.sigma), float(cfg_f.blur), int(cfg_f.persp),
+                  _bg_ptr(bg_f), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _ptr(img_e), _ptr(imgs), float(scale), _ptr(part),
+                  _ptr(g_fg), _ptr(g_env), _stream(fvc))
+        ctx.save_for_backward(ve, me, vf, mf, fa if fa is not None else ve.new_empty(0), R, T, Kmat, p2f_e, bary_e, dists_e, p2f, bary, dists, g_fg, g_env)
+        ctx.misc = (env_tab, fg_tab, cfg_e, cfg_f, bg_e, bg_f, cl_e, cl_f, fa is not None)
+        return part.sum() * float(scale)
+
+    @staticmethod
+    def backward(ctx, go):
+        ve, me, vf, mf, fa, R, T, Kmat, p2f_e, bary_e, dists_e, p2f, bary, dists, g_fg, g_env = ctx.saved_tensors
+        env_tab, fg_tab, cfg_e, cfg_f, bg_e, bg_f, cl_e, cl_f, has_alpha = ctx.misc
+        ctx.misc = None
+        fa = fa if has_alpha else None
+        faces_e, uv_e, fmap_e, desc_e = env_tab
+        faces_f, uv_f, fmap_f, desc_f = fg_tab
+        B = R.shape[0]
+        gs = go.detach().to(torch.float32).reshape(1).contiguous()
+        gm_f, ga, g_fvc_f = _fused_bwd(p2f, bary, dists, cl_f, uv_f, fmap_f, desc_f, mf, fa, cfg_f, bg_f, 2, g_fg, B, gs)
+        gv_f = project_clip_bwd(vf, faces_f, R, T, Kmat, cl_f, g_fvc_f, cfg_f.eps, cfg_f.z_clip, cfg_f.persp) if ctx.needs_input_grad[2] else None
+        gm_e, _, g_fvc_e = _fused_bwd(p2f_e, bary_e, dists_e, cl_e, uv_e, fmap_e, desc_e, me, None, cfg_e, bg_e, 1, g_env, B, gs)
+        gv_e = project_clip_bwd(ve, faces_e, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp) if ctx.needs_input_grad[0] else None
+        return (gv_e, gm_e, gv_f, gm_f, ga) + (None,) * 11
+
+
+def render_decoupled_mse(env, fg, alpha, imgs, scale, R, T, Kmat, cfg_e, cfg_f, bg_e, bg_f):
+    """env / fg: PackedScene-like (verts, maps, faces, face_uvs, face_map, map_desc); alpha: per-face opacities of fg or None;
+    -> scale * sum((imgs - (fg_rgb * mask + (1 - mask) * env_rgb))^2) as a scalar tensor (scale = weight / element count)."""
+    if cfg_f.K < 2 or not cfg_f.detach_bary or cfg_e.K != 1:
+        raise ValueError('render_decoupled_mse: soft detach_bary fg pass over a hard single-layer env pass')
+    return _DecoupledRenderMSE.apply(env.verts, env.maps, fg.verts, fg.maps, alpha, imgs, float(scale), R, T, Kmat,
+                                     (env.faces, env.face_uvs, env.face_map, env.map_desc), (fg.faces, fg.face_uvs, fg.face_map, fg.map_desc),
+                                     cfg_e, cfg_f, bg_e, bg_f)
 
 
 def texbin_capacity(B, H, W, K, nbins):
@@ -618,14 +694,17 @@ class _FusedLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg):
-        dev = fg.device
+        dev = imgs.device
         out = torch.zeros(4, dtype=torch.float32, device=dev)
-        fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
-        imgs = _chk(imgs, torch.float32, 'imgs')
-        N, _, H, W = fg_c.shape
-        ctx.rgb_scale = cfg['rgb'] / cfg['count']
-        _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, ctx.rgb_scale, 0, 0, _ptr(out), 0, 0, _stream(fg_c))
-        saved = [fg_c, env_c, imgs]
+        ctx.has_rgb = fg is not None        # None: the reconstruction term comes from render_decoupled_mse, only the regularisers here
+        saved = []
+        if ctx.has_rgb:
+            fg_c, env_c = _chk(fg.detach(), torch.float32, 'fg'), _chk(env.detach(), torch.float32, 'env')
+            imgs = _chk(imgs, torch.float32, 'imgs')
+            N, _, H, W = fg_c.shape
+            ctx.rgb_scale = cfg['rgb'] / cfg['count']
+            _lib.call('dbw_composite_mse', _ptr(fg_c), _ptr(env_c), _ptr(imgs), N, H, W, ctx.rgb_scale, 0, 0, _ptr(out), 0, 0, _stream(fg_c))
+            saved = [fg_c, env_c, imgs]
         ctx.n_tv = 0
         g_alpha_p = g_alpha_o = None
         if cfg.get('parsimony') and alpha_full is not None:
@@ -660,13 +739,14 @@ class _FusedLosses(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        fg, env, imgs = ctx.saved_tensors
         g_alpha_p, tv_grads, ov_grads, g_alpha_o = ctx.grads
         ctx.grads = None
         go = go.detach().to(torch.float32).contiguous()
-        N, _, H, W = fg.shape
         g_fg = g_env = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if ctx.has_rgb:
+            fg, env, imgs = ctx.saved_tensors
+            N, _, H, W = fg.shape
+        if ctx.has_rgb and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             g_fg, g_env = torch.empty_like(fg), torch.empty_like(env)
             _lib.call('dbw_composite_mse', _ptr(fg), _ptr(env), _ptr(imgs), N, H, W, ctx.rgb_scale, _ptr(go), 0, 0, _ptr(g_fg), _ptr(g_env),
                       _stream(fg))

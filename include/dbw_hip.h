@@ -149,6 +149,21 @@ int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, co
                          int32_t *pix_to_face, float *bary, float *dists, float *image, void *workspace,
                          size_t workspace_bytes, int frag_layout, dbw_stream_t stream);
 
+/* The same forward for the training path's soft pass (uv-fragments, frag_layout 2, K > 1) with the decoupled composite and the MSE
+ * (dbw.py:223,366-367) as its epilogue: instead of storing its image the pass composites it in registers over env_image (N,4,H,W:
+ * the already rendered sky + ground pass), rec = fg_rgb * mask + (1 - mask) * env_rgb, compares with target (N,3,H,W) and stores
+ *   loss_partial (N * ceil(H/8) * ceil(W/8)): the sum of squared differences of each 8x8 tile (loss = mse_scale * their sum),
+ *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) = d(mse_scale * sum of squares) / d(fg image), / d(env image)
+ * -- the gradients dbw_composite_mse would produce, without the composite kernel's two round trips of both images through HBM. */
+int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
+                             const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
+                             int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                             const float *maps, const float *faces_alpha, int alpha_len, int N, int64_t F_total, int H, int W,
+                             int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
+                             int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
+                             const float *env_image, const float *target, float mse_scale, float *loss_partial,
+                             float *grad_fg, float *grad_env, dbw_stream_t stream);
+
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
  * face_verts_c (the rasteriser's input).  detach_bary != 0 reproduces renderer.py:222-223 (geometry gradient through
@@ -158,7 +173,9 @@ int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, co
  * fragment, each fragment appends one 32 B record to the bin of the 32x32-texel tile its footprint starts in
  * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins) zeroed by the caller; bin_records
  * nbins*bin_cap*32 bytes); dbw_texbin_reduce then sums every bin in LDS and adds it to grad_maps.  Records that do not fit
- * (bin overflow, circular-wrap footprints) fall back to atomics, so the result is exact either way.  All NULL / 0 = off. */
+ * (bin overflow, circular-wrap footprints) fall back to atomics, so the result is exact either way.  All NULL / 0 = off.
+ * grad_scale: DEVICE scalar every value of grad_image is multiplied by (the upstream gradient of a loss node, so that no
+ * elementwise pass over the image-sized gradient is needed), NULL = 1. */
 int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
                          const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
                          const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
@@ -166,7 +183,7 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
                          int frag_layout, const int32_t *bin_base, int32_t *bin_cursor, void *bin_records, int bin_cap,
-                         dbw_stream_t stream);
+                         const float *grad_scale, dbw_stream_t stream);
 /* bin_info (nbins,4) int32 = {offset of the bin's map in floats, stored width, stored height, tile_y << 16 | tile_x}. */
 int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap, int nbins,
                       float *grad_maps, dbw_stream_t stream);

@@ -462,3 +462,34 @@ def test_edge_overlays_and_log_tick_members():
     assert txt.shape == (1, 3, ts * (nb // 5), ts * 5)
     cols = model.get_scene_face_colors(filter_transparent=True)
     assert cols.shape == (model.env_n_faces + (nb - 1) * model.BNF, 3)
+
+
+@pytest.mark.parametrize('epoch', [0, 800, 1600])
+def test_loss_epilogue_path_equals_layered_path(epoch):
+    """The training forward with composite + MSE as the epilogue of the fg pass (ops.render_decoupled_mse: no fg image, no composite
+    kernel, upstream gradient applied inside the backward kernels) against the layered path (two render nodes + dbw_composite_mse):
+    same losses, same gradients for all 10 parameter tensors, also under a non-unit upstream gradient."""
+    H, W, nb, ts, fpp = 48, 64, 4, 32, 6
+    R, T, Km = O.synthetic_cameras(3, R_world=O.world_rotation(115, 0, 0))
+    imgs = torch.rand(3, 3, H, W, generator=torch.Generator().manual_seed(2))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=imgs, R=R, T=T, K=Km).items()}
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(227391)
+        model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, fpp), (H, W)).to(DEV).train()
+        with torch.no_grad():
+            model.T.mul_(0.5)
+            model.alpha_logit.add_(torch.tensor([1.0, -0.5, 0.3, 2.0], device=DEV))
+        model.set_cur_epoch(epoch)
+        model.fused_loss_epilogue = fused
+        model._noise_override, model._overlap_u_override = noise, u
+        out = model(inp, None)
+        (out['total'] * 1.7).backward()
+        res.append(({k: v.item() for k, v in out.items()}, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert set(res[0][0]) == set(res[1][0]) and set(res[0][1]) == set(res[1][1])
+    for k in res[0][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) <= 2e-6 * max(abs(res[1][0][k]), 1e-3), (k, res[0][0][k], res[1][0][k])
+    for n in res[0][1]:
+        assert rel_err(res[0][1][n], res[1][1][n]) < 1e-5, (n, rel_err(res[0][1][n], res[1][1][n]))
