@@ -367,12 +367,14 @@ __global__ void block_alpha_fwd_kernel(const float *logit, const float *noise, f
     if (keep) keep[j] = m;
 }
 
-__global__ void block_alpha_bwd_kernel(const float *alpha, const int *keep, const float *g_alpha, const float *g_alpha_full,
+__global__ void block_alpha_bwd_kernel(const float *alpha, const int *keep, const float *g_alpha, int parts, const float *g_alpha_full,
                                        int Kb, float *g_logit) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Kb) return;
     const float a = alpha[j];
-    float g = g_alpha ? g_alpha[j] : 0.f;
+    float g = 0.f;
+    if (g_alpha)
+        for (int i = 0; i < parts; ++i) g += g_alpha[j * parts + i];
     if (g_alpha_full && (!keep || keep[j])) g += g_alpha_full[j];
     g_logit[j] = g * a * (1.f - a);
 }
@@ -400,12 +402,12 @@ extern "C" int dbw_block_alpha_fwd(const float *alpha_logit, const float *noise,
     return dbw_check_launch("block_alpha_fwd_kernel");
 }
 
-extern "C" int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, const float *g_alpha_full, int Kb,
-                                   float *g_logit, dbw_stream_t stream) {
+extern "C" int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, int g_alpha_parts,
+                                   const float *g_alpha_full, int Kb, float *g_logit, dbw_stream_t stream) {
     DBW_REQUIRE(alpha && g_logit, "null pointer");
-    DBW_REQUIRE(Kb > 0, "bad size");
-    hipLaunchKernelGGL(block_alpha_bwd_kernel, dim3((Kb + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha, keep, g_alpha, g_alpha_full,
-                       Kb, g_logit);
+    DBW_REQUIRE(Kb > 0 && g_alpha_parts >= 1, "bad size");
+    hipLaunchKernelGGL(block_alpha_bwd_kernel, dim3((Kb + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha, keep, g_alpha, g_alpha_parts,
+                       g_alpha_full, Kb, g_logit);
     return dbw_check_launch("block_alpha_bwd_kernel");
 }
 

@@ -64,7 +64,7 @@ __global__ void shade_setup_kernel(ShadeArgs A, const int *__restrict__ first_id
 #pragma unroll
         for (int i = 0; i < 6; ++i) r.uv[i] = uv[i];
         r.map = A.face_map[r.j];
-        r.fa = A.faces_alpha ? A.faces_alpha[(A.alpha_len == A.F) ? (long long)r.j : (long long)n * A.F + r.j] : 1.f;
+        r.fa = A.faces_alpha ? A.faces_alpha[alpha_index(A, n, r.j, r.map)] : 1.f;
         const int *md = A.map_desc + r.map * 8;
         r.off = md[0]; r.hw = (md[1] << 16) | md[2]; r.pads = (md[3] << 16) | md[4]; r.sh = md[5];
     }

@@ -271,8 +271,9 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
         if (!FUSED && gdists && in_img) gdists[pix * KK + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
-            if (lds_alpha) alpha_agg.add_wave(galpha, valid ? (int)fr.aidx : 0, gfa, valid && gfa[0] != 0.f);
-            else wave_agg_atomic<1>(galpha, valid ? fr.aidx : 0, valid && gfa[0] != 0.f, gfa, lane);
+            const long long gidx = valid ? alpha_grad_index(A, n, fr.j, fr.map) : 0;
+            if (lds_alpha) alpha_agg.add_wave(galpha, (int)gidx, gfa, valid && gfa[0] != 0.f);
+            else wave_agg_atomic<1>(galpha, gidx, valid && gfa[0] != 0.f, gfa, lane);
         }
         PROF_T(t_b);
         PROF_ADD(3, t_a, t_b);
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             g7[4] = sel >= 1 ? gbx : 0.f; g7[5] = sel >= 1 ? gby : 0.f;
         }
         if (valid && (gd != 0.f || g7[6] != 0.f)) {
-            const int aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? j : n * A.F + j) : 0;
+            const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
         }
     }
@@ -726,7 +727,8 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     DBW_REQUIRE(pix_to_face && bary && dists && face_uvs && face_map && map_desc && maps, "null pointer");
     DBW_REQUIRE((c2o && clip_code && clip_w) || (!c2o && !clip_code && !clip_w), "c2o/clip_code/clip_w: all or none");
     DBW_REQUIRE(N >= 0 && H > 0 && W > 0 && K > 0 && F > 0, "bad size");
-    DBW_REQUIRE(!faces_alpha || alpha_len == F || (long long)alpha_len == (long long)N * F, "faces_alpha length must be F or N*F");
+    DBW_REQUIRE(!faces_alpha || alpha_len == F || (long long)alpha_len == (long long)N * F || alpha_len < 0,
+                "faces_alpha length must be F, N*F, or -(number of maps) for one opacity per texture map");
     DBW_REQUIRE(sigma >= 0.f, "sigma < 0");
     A.p2f = pix_to_face; A.bary = bary; A.dists = dists; A.c2o = c2o; A.code = clip_code; A.cw = clip_w;
     A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;

@@ -89,6 +89,20 @@ __device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, con
     else { gb[0] = g1 * (1.f - w3) + g3 * w3; gb[1] = g2; gb[2] = g3; }
 }
 
+// index of a fragment's learned opacity: per face shared by the views (alpha_len == F), per face and view (N * F), or -- alpha_len < 0
+// -- per texture map (one opacity per mesh of the scene: dbw.py:219 repeats each block's opacity over its faces)
+__device__ __forceinline__ long long alpha_index(const ShadeArgs &A, int n, int j, int map) {
+    return A.alpha_len < 0 ? (long long)map : ((A.alpha_len == A.F) ? (long long)j : (long long)n * A.F + j);
+}
+
+// ... and of its gradient: per-map opacities spread their gradient over DBW_ALPHA_SPREAD partial sums (by face), which the caller
+// adds up -- every fragment of a mesh in every view otherwise lands on ONE address (measured: the fused backward of the bench
+// config went from 0.37 to 1.78 ms on ten addresses)
+#define DBW_ALPHA_SPREAD 64
+__device__ __forceinline__ long long alpha_grad_index(const ShadeArgs &A, int n, int j, int map) {
+    return A.alpha_len < 0 ? (long long)map * DBW_ALPHA_SPREAD + (j & (DBW_ALPHA_SPREAD - 1)) : alpha_index(A, n, j, map);
+}
+
 // geometric alpha from the signed distance + learned per-face opacity (renderer.py:252-260)
 // FAST (fused backward only, gradients are compared at 1e-4): v_exp_f32 and a multiplication by 1/sigma
 template <bool FAST = false>
@@ -99,7 +113,7 @@ __device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) 
     fr.fa = 1.f;
     fr.aidx = 0;
     if (A.faces_alpha) {
-        fr.aidx = (A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j;
+        fr.aidx = alpha_index(A, n, fr.j, fr.map);
         fr.fa = A.faces_alpha[fr.aidx];
     }
     fr.a = fr.e * fr.fa;
@@ -175,7 +189,7 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
         else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
         else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
         fr.fa = 1.f;      // not needed: a = e * fa is stored
-        fr.aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j) : 0;
+        fr.aidx = A.faces_alpha ? alpha_index(A, n, fr.j, fr.map) : 0;
         return true;
     }
     const float b[3] = {A.bary[o.b], A.bary[o.b + o.bstride], A.bary[o.b + 2 * o.bstride]};
@@ -226,7 +240,7 @@ __device__ __forceinline__ void frag_from_raw_uv(const ShadeArgs &A, int n, cons
     else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
     else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
     fr.fa = 1.f;
-    fr.aidx = A.faces_alpha ? ((A.alpha_len == A.F) ? (long long)fr.j : (long long)n * A.F + fr.j) : 0;
+    fr.aidx = A.faces_alpha ? alpha_index(A, n, fr.j, fr.map) : 0;
 }
 
 // grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map whose descriptor is

@@ -41,7 +41,7 @@ SIGNATURES = {
     'dbw_tv_l2sq': [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     'dbw_overlap_loss': [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'dbw_block_alpha_fwd': [c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p],
-    'dbw_block_alpha_bwd': [c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    'dbw_block_alpha_bwd': [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     'dbw_sqrt_mean': [c_p, c_i, c_f, c_f, c_p, c_p, c_p],
     'dbw_adam_step': [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i, c_p],
     'dbw_debug_divcheck': [c_p, c_p, c_i64, c_p, c_p],

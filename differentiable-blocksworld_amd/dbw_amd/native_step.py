@@ -1,0 +1,200 @@
+"""One optimisation iteration of the training path WITHOUT autograd: the forward kernels, then the backward kernels in a fixed order,
+every parameter gradient accumulated straight into the flat gradient buffer (parallel.FlatParams) that the all-reduce and the fused
+Adam consume.
+
+Why: `model(inp); loss.backward()` drives the same kernels through ~25 autograd nodes.  Each node costs Python time, and wherever two
+nodes feed one parameter (pose: blocks + overlap; textures: render + TV; opacities: render + parsimony + overlap) autograd inserts an
+elementwise add, plus one more per parameter to accumulate into the preallocated `.grad` -- 18 five-microsecond launches per step, next
+to `cat`s, fills, a `repeat_interleave` pair and three reductions that only exist because tensors travel between nodes
+(profiles/r02_step_sequence_autograd.txt: 66 launches).  Here every kernel writes where its result is needed: 30 launches.
+
+Same mathematics as DifferentiableBlocksWorld.forward (src/model/dbw.py:198-408) + backward, checked against it
+(tests/test_gpu_model.py::test_native_step_equals_autograd_step).  Scope: the decoupled training render with MSE + parsimony + TV +
+overlap (every shipped config minus LPIPS); anything else -> `supported()` is False and the caller uses the autograd path."""
+import torch
+
+from . import _lib, ops
+from .dbw import OVERLAP_N_BLOCKS, OVERLAP_N_POINTS, OVERLAP_TEMPERATURE
+
+_p = ops._ptr
+
+
+class NativeStep:
+    def __init__(self, model, params):
+        self.m, self.params = model, params
+        self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
+        self._env_verts = None
+
+    def supported(self):
+        m, w = self.m, self.m.loss_weights
+        r = self.m.renderer
+        return (m.decouple_rendering and m.sync_free and 'rgb' in w and 'perceptual' not in w and r.detach_bary and r.faces_per_pixel > 1
+                and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11)
+                and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS)
+
+    def __call__(self, inp, global_count=None):
+        """Forward + backward of one iteration on this rank's views.  The caller has zeroed the flat gradient buffer and opened the
+        zero arena (ops.ARENA.begin_step).  -> {'rgb', 'parsimony', 'tv', 'overlap', 'total'} as 0-dim device tensors."""
+        m, g = self.m, self.grad
+        w = m.loss_weights
+        imgs = inp['imgs']
+        dev = imgs.device
+        st = ops._stream(imgs)
+        m._ensure_cameras(inp)
+        B = imgs.shape[0]
+        coarse = m.is_live('coarse_learning')              # (training mode)
+        fine = not coarse
+        decim = int(m.decim_factor) if m.is_live('decimate_txt') else 1
+        decim_blocks = decim if coarse else 1              # dbw.py:329-334: blocks are only decimated in the coarse phase
+        rs = 1.0 / m.world_size
+        S_w, R_w, T_w = m._world_consts()
+        nb, nv, TS, u_ = m.n_blocks, m._block_nv, m.txt_size, m.txt_bkg_upscale
+        vals = ops.ARENA.zeros(8, torch.float32, dev)      # 0 rgb (filled below), 1 parsimony, 2 tv, 3 overlap
+        # ---- opacities (dbw.py:297-311) ----
+        noise, noise_scale = None, 0.0
+        if m.opacity_noise and coarse:
+            noise = m._noise_override if m._noise_override is not None else m._shared_randn_like(m.alpha_logit)
+            noise_scale = float(m.opacity_noise)
+        masked = fine or m.kill_blocks
+        thresh = (0.5 if fine else 0.01) if masked else -1.0
+        alpha, alpha_full = torch.empty(nb, device=dev), torch.empty(nb, device=dev)
+        keep = torch.empty(nb, dtype=torch.int32, device=dev)
+        _lib.call('dbw_block_alpha_fwd', _p(m.alpha_logit), _p(noise), noise_scale, thresh, nb, _p(alpha), _p(alpha_full), _p(keep), st)
+        keep_p = _p(keep) if masked else 0
+        # ---- textures: sigmoid (+ decimation to cell resolution); `sig` = the undecimated maps of the TV term ----
+        def prep(tex, d, out):
+            n, h, ww, _ = tex.shape
+            sig = torch.empty_like(tex) if d > 1 else None
+            _lib.call('dbw_texture_prep_fwd', _p(tex), n, h, ww, d, _p(out), _p(sig), st)
+            return sig
+        Te = TS * u_
+        ce = (Te // decim) ** 2 * 3
+        env_maps = torch.empty(2 * ce, device=dev)                    # [sky | ground]
+        sig_bkg = prep(m.texture_bkg, decim, env_maps[:ce])
+        sig_gnd = prep(m.texture_ground, decim, env_maps[ce:])
+        blk_maps = torch.empty(nb * (TS // decim_blocks) ** 2 * 3, device=dev)
+        sig_blk = prep(m.textures, decim_blocks, blk_maps)
+        sig_bkg = env_maps[:ce].view(1, Te, Te, 3) if sig_bkg is None else sig_bkg
+        sig_gnd = env_maps[ce:].view(1, Te, Te, 3) if sig_gnd is None else sig_gnd
+        sig_blk = blk_maps.view(nb, TS, TS, 3) if sig_blk is None else sig_blk
+        # ---- vertices ----
+        nbv = m._bkg_verts.shape[0]
+        ngv = m._ground_base.shape[0]
+        key = (float(S_w), m.R_world._version, m.T_world._version, m.R_world.data_ptr())
+        if self._env_verts is None or self._env_key != key:          # the sky dome is constant: written once
+            self._env_verts = torch.empty(nbv + ngv, 3, device=dev)
+            self._env_verts[:nbv] = ((m._bkg_verts * S_w) @ R_w + T_w)
+            self._env_key = key
+        env_verts = self._env_verts
+        _lib.call('dbw_posed_mesh_fwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w), _p(T_w),
+                  env_verts.data_ptr() + nbv * 12, st)
+        blk_verts = torch.empty(nb * nv, 3, device=dev)
+        _lib.call('dbw_sq_blocks_fwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
+                  float(m.scale_min), float(S_w), _p(R_w), _p(T_w), _p(blk_verts), st)
+        # ---- the two render passes; the fg pass ends in the composite + MSE ----
+        renderer = m.renderer_fine if fine else m.renderer
+        R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
+        Kmat = renderer.cameras.K[0].to(dev).contiguous()
+        Fe, Ff = m._env_faces.shape[0], nb * m.BNF
+        cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True)
+        desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
+        cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
+                                                              desc_e, env_maps, None, m.renderer_env._bg, 1)
+        desc_f = m._block_map_desc_all if decim_blocks == 1 else m._block_map_desc_dec
+        texbins = None if decim_blocks > 1 else (m._block_bin_base, m._block_bin_info, nb * m._bins_per_block)
+        cfg_f = renderer._cfg(Ff, lds_aggregate=decim_blocks > 1, texbins=texbins)
+        fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
+        count = float(imgs.numel() if global_count is None else global_count)
+        scale = float(w['rgb']) / count
+        cl_f = ops.project_clip(blk_verts, m._block_faces_all, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
+                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale)
+        # ---- regularisers: value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405) ----
+        g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
+        if 'parsimony' in w and coarse:
+            _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
+        g_sig = [None, None, None]
+        if 'tv' in w:
+            tv_f = 1.0 if coarse else 0.1
+            tv = float(w['tv']) * tv_f * rs
+            for i, (mp, wrap, sc) in enumerate(((sig_bkg, 0, tv), (sig_blk, 1, tv), (sig_gnd, 0, tv * tv_f))):
+                n, h, ww, _ = mp.shape
+                g_sig[i] = torch.empty_like(mp)
+                _lib.call('dbw_tv_l2sq', _p(mp), n, h, ww, wrap, sc, vals.data_ptr() + 8, _p(g_sig[i]), st)
+        if 'overlap' in w and coarse:
+            u = m._overlap_u_override if m._overlap_u_override is not None else torch.rand(nb, OVERLAP_N_POINTS, 3, device=dev)
+            ws = ops.ARENA.zeros(nb * 18, torch.float32, dev)
+            _lib.call('dbw_overlap_loss', _p(u), u.shape[1], _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(alpha_full), nb,
+                      float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
+                      vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
+        # ---- backward of the two passes (upstream gradient 1: nothing sits above this step) ----
+        g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, cfg_f,
+                                                 renderer._bg, 2, g_fg, B, None)
+        g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+        g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
+                                                m.renderer_env._bg, 1, g_env, B, None)
+        g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        # ---- meshes / textures / opacities -> parameters, written straight into the flat gradient buffer ----
+        _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
+                  g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)
+        _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
+                  float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
+        for tex, d, gm, gs_, name in ((m.texture_bkg, decim, g_env_maps[:ce], g_sig[0], 'texture_bkg'),
+                                      (m.texture_ground, decim, g_env_maps[ce:], g_sig[2], 'texture_ground'),
+                                      (m.textures, decim_blocks, g_blk_maps, g_sig[1], 'textures')):
+            n, h, ww, _ = tex.shape
+            _lib.call('dbw_texture_prep_bwd', _p(tex), n, h, ww, d, _p(gm), _p(gs_), _p(g[name]), st)
+        _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+        m._alpha, m._alpha_full = alpha, alpha_full
+        return LazyLosses(vals, part, scale, [k for k in w if k in _SLOT])
+
+
+_SLOT = {'rgb': 0, 'parsimony': 1, 'tv': 2, 'overlap': 3}
+
+
+class LazyLosses(dict):
+    """The loss values of a native step.  Nothing is differentiated through them, so the reductions that produce them (the sum of the
+    per-tile squared differences, the total) are only launched when somebody reads a value -- a logging tick, not every step."""
+
+    def __init__(self, vals, part, scale, names):
+        super().__init__()
+        self._vals, self._part, self._scale, self._names, self._done = vals.clone(), part, scale, names, False
+
+    def _finish(self):
+        if not self._done:
+            v = self._vals
+            v[0] = self._part.sum() * self._scale
+            v[4] = v[:4].sum()
+            for k in self._names:
+                dict.__setitem__(self, k, v[_SLOT[k]])
+            dict.__setitem__(self, 'total', v[4])
+            self._part, self._done = None, True
+
+    def __getitem__(self, k):
+        self._finish()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._finish()
+        return dict.items(self)
+
+    def keys(self):
+        self._finish()
+        return dict.keys(self)
+
+    def values(self):
+        self._finish()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._finish()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._finish()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._finish()
+        return dict.__contains__(self, k)

@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
+ALPHA_SPREAD = 64          # partial sums per per-map opacity gradient (csrc/shade_common.h: DBW_ALPHA_SPREAD)
 COARSE_BINS = True        # two-level face binning in the rasteriser (64x64-pixel coarse bins); False: every tile scans every face
 TEXTURE_BINS = True       # full-resolution texel gradients: bin records by 32x32-texel tile and reduce in LDS (vs 12 atomics/fragment)
 UV_FRAGMENTS = True       # detach_bary passes: the forward stores resolved (u, v, face|map) per fragment for the backward
@@ -210,11 +211,19 @@ def project_clip_bwd(verts, faces_i32, R, T, Kmat, cl, g_face_verts, eps=1e-8, z
 # ---------------------------------------------------------------------------------------------------------------------
 # shade + blend on given fragments
 # ---------------------------------------------------------------------------------------------------------------------
+def _alpha_len(faces_alpha, map_desc, F_):
+    """alpha_len of the C ABI: F or N*F for per-face opacities, -M for one opacity per texture map (include/dbw_hip.h)."""
+    if faces_alpha is None:
+        return 0
+    n = faces_alpha.numel()
+    return -n if (n == map_desc.shape[0] and n != F_) else n
+
+
 def _shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, faces_alpha, F_, sigma, bg, dims=None):
     N, H, W, K = p2f.shape if dims is None else dims      # dims: explicit (N,H,W,K) when the fragments use the tiled layout
     c2o, code, cw = (cl['c2o'], cl['clip_code'], cl['clip_w']) if cl is not None else (None, None, None)
     return (_ptr(p2f), _ptr(bary), _ptr(dists), _ptr(c2o), _ptr(code), _ptr(cw), 2 * F_, _ptr(face_uvs), _ptr(face_map),
-            _ptr(map_desc), _ptr(maps), _ptr(faces_alpha), 0 if faces_alpha is None else faces_alpha.numel(), N, H, W, K, F_,
+            _ptr(map_desc), _ptr(maps), _ptr(faces_alpha), _alpha_len(faces_alpha, map_desc, F_), N, H, W, K, F_,
             float(sigma), _bg_ptr(bg))
 
 
@@ -271,7 +280,7 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
     img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
-              0 if fa is None else fa.numel(), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
+              _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
               _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), _stream(fvc))   # 0 / 1 / 2
     return p2f, bary, dists, img
 
@@ -335,7 +344,9 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     """dbw_render_bwd_fused (+ dbw_texbin_reduce when the texel gradients go through texture-space bins) of one pass.
     gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c."""
     fvc = cl['face_verts'].view(-1, 3, 3)
-    g_maps, g_alpha = ARENA.zeros_like(maps), (ARENA.zeros_like(fa) if fa is not None else None)
+    per_map = fa is not None and _alpha_len(fa, map_desc, cfg.F) < 0        # then 64 partial sums per opacity (include/dbw_hip.h)
+    g_maps = ARENA.zeros_like(maps)
+    g_alpha = None if fa is None else (ARENA.zeros(fa.numel() * ALPHA_SPREAD, torch.float32, fa.device) if per_map else ARENA.zeros_like(fa))
     g_fvc = ARENA.zeros_like(fvc)
     bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
     bin_base = cursor = records = None
@@ -352,6 +363,28 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     if records is not None:
         _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
     return g_maps, g_alpha, g_fvc
+
+
+def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, env_img, imgs, scale):
+    """dbw_render_fwd_fused_mse on the clipped faces `cl` of the fg scene (no grad bookkeeping): uv-fragments + per-tile sums of
+    squared differences + d loss / d fg image, d loss / d env image.  -> p2f, bary, dists, part, g_fg, g_env."""
+    fvc = cl['face_verts'].view(-1, 3, 3)
+    dev, Ft = fvc.device, fvc.shape[0]
+    ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
+    p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, ty, tx, cfg.K, 8, 64, dtype=torch.float32, device=dev)
+    dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
+    part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
+    g_fg = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+    g_env = torch.empty_like(g_fg)
+    _lib.call('dbw_render_fwd_fused_mse', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
+              _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
+              _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
+              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _ptr(env_img), _ptr(imgs), float(scale), _ptr(part),
+              _ptr(g_fg), _ptr(g_env), _stream(fvc))
+    return p2f, bary, dists, part, g_fg, g_env
 
 
 class _DecoupledRenderMSE(torch.autograd.Function):
@@ -375,22 +408,7 @@ class _DecoupledRenderMSE(torch.autograd.Function):
         p2f_e, bary_e, dists_e, img_e = _render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, uv_e, fmap_e, desc_e, me, None, bg_e, 1)
         # fg pass with the composite + MSE epilogue
         cl_f = project_clip(vf, faces_f, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
-        fvc = cl_f['face_verts'].view(-1, 3, 3)
-        Ft = fvc.shape[0]
-        ws_bytes = _workspace_bytes(Ft, B, cfg_f.H, cfg_f.W)
-        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-        ty, tx = (cfg_f.H + 7) // 8, (cfg_f.W + 7) // 8
-        p2f = torch.empty(B, ty, tx, cfg_f.K, 64, dtype=torch.int32, device=dev)
-        bary = torch.empty(B, ty, tx, cfg_f.K, 8, 64, dtype=torch.float32, device=dev)
-        dists = torch.empty(B, ty, tx, cfg_f.K, 64, dtype=torch.float32, device=dev)
-        part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
-        g_fg = torch.empty(B, 4, cfg_f.H, cfg_f.W, dtype=torch.float32, device=dev)
-        g_env = torch.empty_like(g_fg)
-        _lib.call('dbw_render_fwd_fused_mse', _ptr(fvc), _ptr(cl_f['first_idx']), _ptr(cl_f['num_faces']), _ptr(cl_f['neighbor']), _ptr(cl_f['c2o']),
-                  _ptr(cl_f['clip_code']), _ptr(cl_f['clip_w']), 2 * cfg_f.F, _ptr(uv_f), _ptr(fmap_f), _ptr(desc_f), _ptr(mf), _ptr(fa),
-                  0 if fa is None else fa.numel(), B, Ft, cfg_f.H, cfg_f.W, cfg_f.K, cfg_f.F, float(cfg_f.sigma), float(cfg_f.blur), int(cfg_f.persp),
-                  _bg_ptr(bg_f), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _ptr(img_e), _ptr(imgs), float(scale), _ptr(part),
-                  _ptr(g_fg), _ptr(g_env), _stream(fvc))
+        p2f, bary, dists, part, g_fg, g_env = render_fwd_fused_mse(cl_f, B, cfg_f, uv_f, fmap_f, desc_f, mf, fa, bg_f, img_e, imgs, scale)
         ctx.save_for_backward(ve, me, vf, mf, fa if fa is not None else ve.new_empty(0), R, T, Kmat, p2f_e, bary_e, dists_e, p2f, bary, dists, g_fg, g_env)
         ctx.misc = (env_tab, fg_tab, cfg_e, cfg_f, bg_e, bg_f, cl_e, cl_f, fa is not None)
         return part.sum() * float(scale)
@@ -675,7 +693,7 @@ class _BlockAlpha(torch.autograd.Function):
     def backward(ctx, g_a, g_af, _):
         alpha, keep = ctx.saved_tensors
         g = torch.empty_like(alpha)
-        _lib.call('dbw_block_alpha_bwd', _ptr(alpha), _ptr(keep), _ptr(None if g_a is None else g_a.contiguous()),
+        _lib.call('dbw_block_alpha_bwd', _ptr(alpha), _ptr(keep), _ptr(None if g_a is None else g_a.contiguous()), 1,
                   _ptr(None if g_af is None else g_af.contiguous()), alpha.numel(), _ptr(g), _stream(alpha))
         return g, None, None, None
 

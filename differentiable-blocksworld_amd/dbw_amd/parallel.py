@@ -52,7 +52,7 @@ class ShardedTrainStep:
     of constant shape.  The gradient all-reduce and the two Adam launches stay outside the graph."""
 
     def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
-                 use_graph=False, graph_warmup=3, seed=None):
+                 use_graph=False, graph_warmup=3, seed=None, use_native=True):
         self.model, self.pg = model, process_group
         self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
         if use_graph and not getattr(model, 'sync_free', False):
@@ -66,6 +66,12 @@ class ShardedTrainStep:
         self.exp_avg_sq = torch.zeros_like(self.params.flat)
         self.n_steps = 0
         self.adam_fn = adam_fn or ops.adam_step_
+        # the iteration without autograd (native_step.py: same kernels, 30 launches instead of 66) whenever the model is the HIP
+        # DifferentiableBlocksWorld in a configuration it covers; the autograd path otherwise
+        self.native = None
+        if use_native and hasattr(model, 'loss_weights') and hasattr(model, 'renderer_env'):
+            from .native_step import NativeStep
+            self.native = NativeStep(model, self.params)
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
             s = torch.tensor([seed if seed is not None else 0], dtype=torch.int64)
@@ -103,11 +109,17 @@ class ShardedTrainStep:
             try:
                 ops.ARENA.begin_step(self.params.flat.device)
                 self.params.zero_grad()
-                losses = self.model(inp, labels)
-                losses['total'].backward()
+                native = self.native is not None and self.model.training and inp['imgs'].shape[0] > 0 and self.native.supported()
+                if native:
+                    with torch.no_grad():
+                        losses = self.native(inp, self.model._global_count)
+                else:
+                    losses = self.model(inp, labels)
+                    losses['total'].backward()
             finally:
                 ops.ARENA.enabled = False
-            losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
+            if not native:
+                losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
         if self.world_size > 1:
             self.allreduce_gradients()
         self.n_steps += 1

@@ -107,7 +107,11 @@ int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const
  *  maps: flat fp32 buffer of RGB maps in [0,1], fewer than 2^31 floats in total (texels are addressed with the int32 offsets);
  *    map m is STORED as (h>>shift, w>>shift, 3): shift > 0 is a decimated map
  *    (avg_pool2d(2^shift) kept at cell resolution; the nearest upsampling of dbw.py:278,334 is the shift)
- *  faces_alpha: NULL, or alpha_len floats with alpha_len == F (shared by all views) or N*F (packed per view).
+ *  faces_alpha: NULL, or |alpha_len| floats: alpha_len == F (per face, shared by all views), N*F (packed per view), or
+ *    alpha_len = -M < 0: one opacity per texture map / mesh (indexed by face_map; the reference repeats each block's opacity over
+ *    its faces, dbw.py:219 -- this form needs no repeated copy).  Its gradient buffer grad_faces_alpha then holds 64 partial
+ *    sums per opacity (M x 64 floats, spread by face index so that a mesh's fragments do not all hit one address), to be added
+ *    by the caller (dbw_block_alpha_bwd does, g_alpha_parts = 64).
  *  background3: HOST pointer to 3 floats (blend background colour, renderer.py:32), NULL = black.
  *  image (N,4,H,W): premultiplied RGB + alpha (BCHW).
  */
@@ -229,11 +233,13 @@ int dbw_posed_mesh_bwd(const float *base, int nv, const float *R6, const float *
  * Block opacities (dbw.py:297-311): alpha = sigmoid(alpha_logit + noise_scale*noise) (noise may be NULL);
  * keep = sigmoid(alpha_logit) > mask_threshold (the filter_transparent / kill_blocks mask; mask_threshold < 0: keep all);
  * alpha_full = alpha * keep.  All (Kb).  keep may be NULL.
- * bwd: g_logit = (g_alpha + keep * g_alpha_full) * alpha * (1 - alpha); g_alpha / g_alpha_full may be NULL. */
+ * bwd: g_logit = (g_alpha + keep * g_alpha_full) * alpha * (1 - alpha); g_alpha / g_alpha_full may be NULL.
+ * g_alpha holds g_alpha_parts partial sums per block (Kb x g_alpha_parts; 1 = plain; 64 for the per-map opacity gradients of
+ * dbw_render_bwd_fused, see faces_alpha). */
 int dbw_block_alpha_fwd(const float *alpha_logit, const float *noise, float noise_scale, float mask_threshold, int Kb,
                         float *alpha, float *alpha_full, int32_t *keep, dbw_stream_t stream);
-int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, const float *g_alpha_full, int Kb,
-                        float *g_logit, dbw_stream_t stream);
+int dbw_block_alpha_bwd(const float *alpha, const int32_t *keep, const float *g_alpha, int g_alpha_parts,
+                        const float *g_alpha_full, int Kb, float *g_logit, dbw_stream_t stream);
 /* Parsimony (dbw.py:373-377, utils/pytorch.py:35 safe_pow): loss += scale * mean(clamp(x, eps)^0.5) over n values;
  * grad (n, may be NULL) accumulates d loss / d x (zero where x <= eps). */
 int dbw_sqrt_mean(const float *x, int n, float eps, float scale, float *loss, float *grad, dbw_stream_t stream);

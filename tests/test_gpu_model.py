@@ -493,3 +493,39 @@ def test_loss_epilogue_path_equals_layered_path(epoch):
         assert abs(res[0][0][k] - res[1][0][k]) <= 2e-6 * max(abs(res[1][0][k]), 1e-3), (k, res[0][0][k], res[1][0][k])
     for n in res[0][1]:
         assert rel_err(res[0][1][n], res[1][1][n]) < 1e-5, (n, rel_err(res[0][1][n], res[1][1][n]))
+
+
+@pytest.mark.parametrize('epoch', [0, 800, 1600])
+def test_native_step_equals_autograd_step(epoch):
+    """native_step.NativeStep (forward + backward kernels in a fixed order, gradients accumulated straight into the flat buffer, one
+    opacity per block instead of one per face) against the autograd iteration `model(inp); total.backward()`: the same flat gradient
+    after one step and the same parameters after three, in each training phase, opacity noise and overlap samples on."""
+    from dbw_amd.parallel import ShardedTrainStep
+    H, W, nb, ts, fpp = 48, 64, 4, 32, 6
+    R, T, Km = O.synthetic_cameras(3, R_world=O.world_rotation(115, 0, 0))
+    imgs = torch.rand(3, 3, H, W, generator=torch.Generator().manual_seed(2))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=imgs, R=R, T=T, K=Km).items()}
+    res = []
+    for native in (True, False):
+        torch.manual_seed(227391)
+        model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, fpp), (H, W)).to(DEV).train()
+        with torch.no_grad():
+            model.T.mul_(0.5)
+            model.alpha_logit.add_(torch.tensor([1.0, -6.0, 0.3, 2.0], device=DEV))       # block 1 is killed / filtered
+        model.set_cur_epoch(epoch)
+        model.sync_free = True
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, use_native=native)
+        assert (step.native is not None) == native and (not native or step.native.supported())
+        out = step(inp)
+        grad1 = step.params.grad.clone()
+        vals = {k: float(v) for k, v in out.items()}
+        for _ in range(2):
+            step(inp)
+        res.append((vals, grad1, step.params.flat.clone(), step.params.names))
+    assert set(res[0][0]) == set(res[1][0])
+    for k in res[0][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) <= 2e-6 * max(abs(res[1][0][k]), 1e-3), (k, res[0][0][k], res[1][0][k])
+    for n, off, k in res[0][3]:
+        a, b = res[0][1][off:off + k], res[1][1][off:off + k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (n, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((res[0][2] - res[1][2]).abs().max()) < 1e-4
