@@ -285,8 +285,11 @@ template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
 #define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, s)
-    if constexpr (KMAX == 1) return DBW_V(16, 16, 2, false);   // hard K=1 pass: large faces (sky dome, ground), fewer tiles re-scan the face
-                                                               // list; the single payload stays in registers
+    if constexpr (KMAX == 1) {                                 // hard K=1 pass: large faces (sky dome, ground); the single payload stays in registers
+        if (g_render_variant == 1) return DBW_V(8, 8, 2, false);
+        if (g_render_variant == 2) return DBW_V(16, 8, 2, false);
+        return DBW_V(16, 16, 2, false);
+    }
     else {
         // soft K-layer passes: one wave64 per 8x8 tile; uv-fragments (the training path) take the specialised shading
 #ifndef DBW_FWD_GROUP

@@ -24,6 +24,7 @@ class NativeStep:
         self.m, self.params = model, params
         self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
         self._env_verts = None
+        self._side, self.overlap_regularisers = None, True
 
     def supported(self):
         m, w = self.m, self.m.loss_weights
@@ -88,29 +89,30 @@ class NativeStep:
         env_verts = self._env_verts
         _lib.call('dbw_posed_mesh_fwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w), _p(T_w),
                   env_verts.data_ptr() + nbv * 12, st)
-        blk_verts = torch.empty(nb * nv, 3, device=dev)
-        _lib.call('dbw_sq_blocks_fwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
-                  float(m.scale_min), float(S_w), _p(R_w), _p(T_w), _p(blk_verts), st)
-        # ---- the two render passes; the fg pass ends in the composite + MSE ----
+        # ---- regularisers: value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405).  They only need the
+        # parameters, opacities and maps prepared above, and ~10 short kernels would otherwise sit in front of the backward: they run on
+        # a side stream next to the render passes and are joined before the parameter gradients are finished ----
+        cur = torch.cuda.current_stream(dev)
+        side = cur
+        if self.overlap_regularisers:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(cur)
+        st_main, st = st, side.cuda_stream
+        torch.cuda.set_stream(side)
         renderer = m.renderer_fine if fine else m.renderer
         R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
         Kmat = renderer.cameras.K[0].to(dev).contiguous()
         Fe, Ff = m._env_faces.shape[0], nb * m.BNF
-        cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True)
-        desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
-        cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
-        p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
-                                                              desc_e, env_maps, None, m.renderer_env._bg, 1)
         desc_f = m._block_map_desc_all if decim_blocks == 1 else m._block_map_desc_dec
         texbins = None if decim_blocks > 1 else (m._block_bin_base, m._block_bin_info, nb * m._bins_per_block)
         cfg_f = renderer._cfg(Ff, lds_aggregate=decim_blocks > 1, texbins=texbins)
-        fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
-        count = float(imgs.numel() if global_count is None else global_count)
-        scale = float(w['rgb']) / count
+        # the blocks' vertices and their projection are independent of the env pass: next to it, not in front of the fg pass
+        blk_verts = torch.empty(nb * nv, 3, device=dev)
+        _lib.call('dbw_sq_blocks_fwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
+                  float(m.scale_min), float(S_w), _p(R_w), _p(T_w), _p(blk_verts), st)
         cl_f = ops.project_clip(blk_verts, m._block_faces_all, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
-        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
-                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale)
-        # ---- regularisers: value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405) ----
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
         if 'parsimony' in w and coarse:
             _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
@@ -128,24 +130,47 @@ class NativeStep:
             _lib.call('dbw_overlap_loss', _p(u), u.shape[1], _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(alpha_full), nb,
                       float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
                       vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
-        # ---- backward of the two passes (upstream gradient 1: nothing sits above this step) ----
+        torch.cuda.set_stream(cur)
+        st = st_main
+        # ---- the two render passes; the fg pass ends in the composite + MSE ----
+        cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True)
+        desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
+        cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
+                                                              desc_e, env_maps, None, m.renderer_env._bg, 1)
+        fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
+        count = float(imgs.numel() if global_count is None else global_count)
+        scale = float(w['rgb']) / count
+        if side is not cur:
+            cur.wait_stream(side)                                      # blocks projected, regularisers done
+        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
+                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale)
+        # ---- backward of the two passes (upstream gradient 1: nothing sits above this step).  What follows the fg backward (projection
+        # backward, blocks -> pose / shape, block textures, opacities) runs on the side stream next to the env backward ----
         g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, cfg_f,
                                                  renderer._bg, 2, g_fg, B, None)
+        if side is not cur:
+            side.wait_stream(cur)
+            torch.cuda.set_stream(side)
+            st = side.cuda_stream
         g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+        _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
+                  float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
+        n, h, ww, _ = m.textures.shape
+        _lib.call('dbw_texture_prep_bwd', _p(m.textures), n, h, ww, decim_blocks, _p(g_blk_maps), _p(g_sig[1]), _p(g['textures']), st)
+        _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+        torch.cuda.set_stream(cur)
+        st = st_main
         g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
                                                 m.renderer_env._bg, 1, g_env, B, None)
         g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
-        # ---- meshes / textures / opacities -> parameters, written straight into the flat gradient buffer ----
         _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
                   g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)
-        _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
-                  float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
-        for tex, d, gm, gs_, name in ((m.texture_bkg, decim, g_env_maps[:ce], g_sig[0], 'texture_bkg'),
-                                      (m.texture_ground, decim, g_env_maps[ce:], g_sig[2], 'texture_ground'),
-                                      (m.textures, decim_blocks, g_blk_maps, g_sig[1], 'textures')):
+        for tex, gm, gs_, name in ((m.texture_bkg, g_env_maps[:ce], g_sig[0], 'texture_bkg'), (m.texture_ground, g_env_maps[ce:], g_sig[2], 'texture_ground')):
             n, h, ww, _ = tex.shape
-            _lib.call('dbw_texture_prep_bwd', _p(tex), n, h, ww, d, _p(gm), _p(gs_), _p(g[name]), st)
-        _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+            _lib.call('dbw_texture_prep_bwd', _p(tex), n, h, ww, decim, _p(gm), _p(gs_), _p(g[name]), st)
+        if side is not cur:
+            cur.wait_stream(side)
         m._alpha, m._alpha_full = alpha, alpha_full
         return LazyLosses(vals, part, scale, [k for k in w if k in _SLOT])
 
