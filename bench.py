@@ -127,8 +127,8 @@ def kernel_breakdown(model, inp, reps=5):
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        res[f'render_fwd_kernel<{K}> ({tag} pass)'] = (t(fwd), (20 * P * K + 16 * P) * B)
-        res[f'shade_blend_bwd_kernel<fused> ({tag} pass)'] = (t(bwd), (20 * P * K + 16 * P) * B)
+        res[f'render_fwd_fused K={K} ({tag} pass)'] = (t(fwd), (20 * P * K + 16 * P) * B)
+        res[f'render_bwd_fused K={K} ({tag} pass)'] = (t(bwd), (20 * P * K + 16 * P) * B)
         if bins is not None:
             res[f'texbin_reduce_kernel ({tag} pass)'] = (t(reduce), 64 * int(cursor_t.clamp(max=cap).sum()))  # record write + read
             BIN_STATS[tag] = {'records_per_fragment_slot': round(float(cursor_t.float().sum() / (B * P * K)), 4), 'bins': bins[2],
@@ -237,6 +237,15 @@ def main():
         global_count = inp['imgs'].numel() * world
         views_total = args.views * world
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
+    # every phase below is measured from the SAME state (freshly initialised parameters + its own warm-up), not from whatever the
+    # previously measured phase left behind (opacities drift, blocks get filtered: the workload would change)
+    if step.native is not None and args.no_overlap:
+        step.native.overlap_regularisers = False      # every kernel alone on one stream: per-kernel averages of a trace are then exact
+    snapshot = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone(), step.n_steps)
+
+    def restore():
+        step.params.flat.copy_(snapshot[0]); step.exp_avg.copy_(snapshot[1]); step.exp_avg_sq.copy_(snapshot[2])
+        step.n_steps = snapshot[3]
 
     def sync():
         if world > 1:
@@ -273,8 +282,9 @@ def main():
             if epoch == args.epoch:
                 d, k = dt, args.steps
             else:
+                restore()
                 model.set_cur_epoch(epoch)
-                for _ in range(3):
+                for _ in range(max(args.warmup, 3)):
                     step(inp, global_count=global_count)
                 k = max(5, min(args.steps, 10))
                 d, _ = timed(k)
@@ -329,7 +339,7 @@ def main():
                        'views_per_gpu': local_views, 'views_per_step': views_total, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks,
                        'faces_per_pixel': args.fpp, 'txt_size': args.txt,
                        'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
-                                 ('' if args.no_overlap else ', env pass on a side stream'),
+                                 ('' if args.no_overlap else ', small kernels on a side stream') + ('' if step.native is None else ', native step (no autograd)'),
                        'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step',
                        'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -58,7 +58,12 @@ __device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec *__restrict__ 
 constexpr int FPROF_BLOCKS = 1 << 17;
 __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 #define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#define FPROF_ADD(i, v) { if (KMAX > 1 && (threadIdx.x & 63) == 0 && blockIdx.x < FPROF_BLOCKS) atomicAdd(&g_fprof[(size_t)blockIdx.x * 16 + (i)], (unsigned long long)(v)); }
+#ifdef DBW_PROFILE_FWD_K1
+#define FPROF_SEL (KMAX == 1)
+#else
+#define FPROF_SEL (KMAX > 1)
+#endif
+#define FPROF_ADD(i, v) { if (FPROF_SEL && (threadIdx.x & 63) == 0 && blockIdx.x < FPROF_BLOCKS) atomicAdd(&g_fprof[(size_t)blockIdx.x * 16 + (i)], (unsigned long long)(v)); }
 #define FPROF_CNT(i, pred) { const unsigned long long m_ = __ballot(pred); if (m_) FPROF_ADD(i, __popcll(m_)); }
 #else
 #define FPROF_T(x)

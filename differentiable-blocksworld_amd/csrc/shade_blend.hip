@@ -520,6 +520,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
                                                               float *__restrict__ gmaps, float *__restrict__ galpha,
                                                               const float *__restrict__ fv, float *__restrict__ gfv) {
     extern __shared__ __attribute__((aligned(16))) float s_uvbwd[];
+    constexpr bool SINGLE = false;      // (cycle accounting macros)
+    (void)SINGLE;
     TexAgg tex_agg;
     FaceAlphaAgg fa_agg;
     tex_agg.bind(s_uvbwd);
@@ -553,11 +555,14 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         const int raw0 = p2f_t[0];
         cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
     }
+    PROF_T(t_begin);
     int kmax = 0;
     for (int k = 0; k < A.K; ++k) {
         if (__ballot(cnt > k) == 0ull) break;
         kmax = k + 1;
     }
+    PROF_T(t_p0);
+    PROF_ADD(0, t_begin, t_p0);
     float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
     struct Raw { int fc; float u, v, jm, a, c0, c1, c2, T, d; };
     auto load = [&](int k, bool ok) {
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     Raw nxt = load(kmax > 0 ? kmax - 1 : 0, kmax > 0 && kmax - 1 < cnt);
 #pragma unroll 1
     for (int k = kmax - 1; k >= 0; --k) {
+        PROF_T(t_it);
         const Raw cur = nxt;
         const bool valid = k < cnt;
         if (k > 0) nxt = load(k - 1, k - 1 < cnt);
@@ -592,6 +598,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         // colour -> texels of the decimated map: the bilinear footprint's texels that fall into the same stored cell are merged
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
+        PROF_T(t_a);
+        PROF_ADD(2, t_it, t_a);
         if (__ballot(tex) != 0ull) {
             const int *md = A.map_desc + (valid ? map : 0) * 8;
             Sample s;
@@ -610,6 +618,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
                 if (tex && wt[q] != 0.f) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);
             }
         }
+        PROF_T(t_b);
+        PROF_ADD(4, t_a, t_b);
         // distance -> the two vertices of the closest edge; opacity; one table update per fragment
         float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
         if (__ballot(gd != 0.f) != 0ull) {
@@ -629,11 +639,17 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             g7[2] = sel == 0 ? gbx : (sel == 2 ? gax : 0.f); g7[3] = sel == 0 ? gby : (sel == 2 ? gay : 0.f);
             g7[4] = sel >= 1 ? gbx : 0.f; g7[5] = sel >= 1 ? gby : 0.f;
         }
+        PROF_T(t_c);
+        PROF_ADD(5, t_b, t_c);
         if (valid && (gd != 0.f || g7[6] != 0.f)) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
         }
+        PROF_T(t_d);
+        PROF_ADD(6, t_c, t_d);
     }
+    PROF_T(t_end);
+    PROF_ADD(7, t_begin, t_end);
     __syncthreads();
     tex_agg.flush(gmaps, threadIdx.x, NT);
     fa_agg.flush(gfv, galpha, threadIdx.x, NT);

@@ -26,8 +26,8 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threa
 
 // d == 1: elementwise.  d > 1: one WAVE per (d x d) cell (lane <-> texel, wave-sum for the cell mean); `maps` is written
 // at CELL resolution (n, h/d, w/d, 3).
-__global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
-                                                               float *__restrict__ maps, float *__restrict__ sig) {
+__device__ __forceinline__ void texture_prep_fwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
+                                                      float *__restrict__ maps, float *__restrict__ sig) {
     if (d <= 1) {
         const long long total = (long long)n * h * w * 3;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -63,10 +63,25 @@ __global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__re
     }
 }
 
+__global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
+                                                               float *__restrict__ maps, float *__restrict__ sig) {
+    texture_prep_fwd_body(tex, n, h, w, d, maps, sig);
+}
+
+// several texture sets in ONE launch (blockIdx.y = set): the three maps of a scene (blocks, sky, ground) differ in shape, and one
+// 5 us launch each is all they cost
+constexpr int MAX_SETS = 4;
+struct TextureSets { dbw_texture_set s[MAX_SETS]; };
+
+__global__ __launch_bounds__(256) void texture_prep_fwd_sets_kernel(const TextureSets S) {
+    const dbw_texture_set &t = S.s[blockIdx.y];
+    texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig);
+}
+
 // elementwise: gtex = (gcell[cell of the texel] / d^2 + gsig) * s(1-s)
-__global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
-                                        const float *__restrict__ gmaps, const float *__restrict__ gsig,
-                                        float *__restrict__ gtex) {
+__device__ __forceinline__ void texture_prep_bwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
+                                                      const float *__restrict__ gmaps, const float *__restrict__ gsig,
+                                                      float *__restrict__ gtex) {
     const long long total = (long long)n * h * w * 3;
     const float inv = 1.f / (float)(d * d);
     const int ch_ = h / d, cw_ = w / d;
@@ -85,10 +100,20 @@ __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, in
     }
 }
 
+__global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
+                                        const float *__restrict__ gmaps, const float *__restrict__ gsig,
+                                        float *__restrict__ gtex) {
+    texture_prep_bwd_body(tex, n, h, w, d, gmaps, gsig, gtex);
+}
+
+__global__ void texture_prep_bwd_sets_kernel(const TextureSets S) {
+    const dbw_texture_set &t = S.s[blockIdx.y];
+    texture_prep_bwd_body(t.texture, t.n, t.h, t.w, t.decim, t.grad_maps, t.grad_sig, t.grad_texture);
+}
+
 // one thread per texel (its three channels); blockIdx.y = row (map * h + y): no integer division anywhere
-__global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m, int n, int h, int w, int wrap,
-                                                     float scale, float *__restrict__ loss, float *__restrict__ gm) {
-    __shared__ float s_red[NT / DBW_WAVE];
+__device__ __forceinline__ void tv_l2sq_body(const float *__restrict__ m, int n, int h, int w, int wrap,
+                                             float scale, float *__restrict__ loss, float *__restrict__ gm, float *s_red) {
     const float sx = 1.f / ((float)h * (float)(w - 1 + (wrap ? 1 : 0)));
     const float sy = 1.f / ((float)(h - 1) * (float)w);
     float part = 0.f;
@@ -112,6 +137,18 @@ __global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m
     }
     const float tot = block_sum(part, s_red);
     if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(loss, scale * tot);
+}
+
+__global__ __launch_bounds__(NT) void tv_l2sq_kernel(const float *__restrict__ m, int n, int h, int w, int wrap,
+                                                     float scale, float *__restrict__ loss, float *__restrict__ gm) {
+    __shared__ float s_red[NT / DBW_WAVE];
+    tv_l2sq_body(m, n, h, w, wrap, scale, loss, gm, s_red);
+}
+
+__global__ __launch_bounds__(NT) void tv_l2sq_sets_kernel(const TextureSets S, float *__restrict__ loss) {
+    __shared__ float s_red[NT / DBW_WAVE];
+    const dbw_texture_set &t = S.s[blockIdx.z];
+    tv_l2sq_body(t.sig, t.n, t.h, t.w, t.wrap_x, t.tv_scale, loss, t.grad_sig_out, s_red);
 }
 
 // 1024-thread blocks: the loss is one atomic per block on a single address (~9 ns each when they queue up), so the same number of
@@ -174,6 +211,23 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+struct AdamGroups { long long end[MAX_SETS]; float step_size[MAX_SETS]; };
+
+// parameter groups that differ in learning rate only (optimizer.py:6-18: textures vs everything else), contiguous in one flat buffer
+__global__ void adam_groups_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                   long long n, const AdamGroups G, float beta1, float beta2, float eps, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float step_size = G.step_size[0];
+#pragma unroll
+        for (int k = 1; k < MAX_SETS; ++k) step_size = i >= G.end[k - 1] ? G.step_size[k] : step_size;
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
 inline unsigned grid_for(long long work) {
     long long b = (work + NT - 1) / NT;
     if (b < 1) b = 1;
@@ -214,6 +268,86 @@ extern "C" int dbw_tv_l2sq(const float *maps, int n, int h, int w, int wrap_x, f
     hipLaunchKernelGGL(tv_l2sq_kernel, dim3((unsigned)((w + NT - 1) / NT), (unsigned)(rows < 512 ? rows : 512)), dim3(NT), 0,
                        (hipStream_t)stream, maps, n, h, w, wrap_x, scale, loss, grad_maps);
     return dbw_check_launch("tv_l2sq_kernel");
+}
+
+namespace {
+int check_sets(const dbw_texture_set *sets, int nsets) {
+    DBW_REQUIRE(sets && nsets >= 1 && nsets <= MAX_SETS, "1..4 texture sets");
+    for (int i = 0; i < nsets; ++i) {
+        const dbw_texture_set &t = sets[i];
+        DBW_REQUIRE(t.n > 0 && t.h > 1 && t.w > 1 && t.decim >= 1, "bad size");
+        DBW_REQUIRE(t.decim == 1 || (t.h % t.decim == 0 && t.w % t.decim == 0), "map size must be a multiple of the decimation factor");
+    }
+    return DBW_OK;
+}
+TextureSets pack_sets(const dbw_texture_set *sets, int nsets) {
+    TextureSets S;
+    for (int i = 0; i < MAX_SETS; ++i) S.s[i] = sets[i < nsets ? i : 0];
+    return S;
+}
+}  // namespace
+
+extern "C" int dbw_texture_prep_fwd_sets(const dbw_texture_set *sets, int nsets, dbw_stream_t stream) {
+    if (int rc = check_sets(sets, nsets)) return rc;
+    long long work = 0;
+    for (int i = 0; i < nsets; ++i) {
+        const dbw_texture_set &t = sets[i];
+        DBW_REQUIRE(t.texture && t.maps, "null pointer");
+        DBW_REQUIRE(t.decim == 1 || t.sig, "sig is required when decimating");
+        const long long wk = t.decim > 1 ? (long long)t.n * (t.h / t.decim) * (t.w / t.decim) * 64 : (long long)t.n * t.h * t.w * 3;
+        work = wk > work ? wk : work;
+    }
+    hipLaunchKernelGGL(texture_prep_fwd_sets_kernel, dim3(grid_for(work), (unsigned)nsets), dim3(NT), 0, (hipStream_t)stream,
+                       pack_sets(sets, nsets));
+    return dbw_check_launch("texture_prep_fwd_sets_kernel");
+}
+
+extern "C" int dbw_texture_prep_bwd_sets(const dbw_texture_set *sets, int nsets, dbw_stream_t stream) {
+    if (int rc = check_sets(sets, nsets)) return rc;
+    long long work = 0;
+    for (int i = 0; i < nsets; ++i) {
+        const dbw_texture_set &t = sets[i];
+        DBW_REQUIRE(t.texture && t.grad_maps && t.grad_texture, "null pointer");
+        const long long wk = (long long)t.n * t.h * t.w * 3;
+        work = wk > work ? wk : work;
+    }
+    hipLaunchKernelGGL(texture_prep_bwd_sets_kernel, dim3(grid_for(work), (unsigned)nsets), dim3(NT), 0, (hipStream_t)stream,
+                       pack_sets(sets, nsets));
+    return dbw_check_launch("texture_prep_bwd_sets_kernel");
+}
+
+extern "C" int dbw_tv_l2sq_sets(const dbw_texture_set *sets, int nsets, float *loss, dbw_stream_t stream) {
+    if (int rc = check_sets(sets, nsets)) return rc;
+    DBW_REQUIRE(loss, "null pointer");
+    long long rows = 0;
+    int w = 0;
+    for (int i = 0; i < nsets; ++i) {
+        DBW_REQUIRE(sets[i].sig, "null pointer");
+        const long long r = (long long)sets[i].n * sets[i].h;
+        rows = r > rows ? r : rows;
+        w = sets[i].w > w ? sets[i].w : w;
+    }
+    hipLaunchKernelGGL(tv_l2sq_sets_kernel, dim3((unsigned)((w + NT - 1) / NT), (unsigned)(rows < 512 ? rows : 512), (unsigned)nsets),
+                       dim3(NT), 0, (hipStream_t)stream, pack_sets(sets, nsets), loss);
+    return dbw_check_launch("tv_l2sq_sets_kernel");
+}
+
+extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
+                                    const float *lr, int ngroups, float beta1, float beta2, float eps, int step, dbw_stream_t stream) {
+    DBW_REQUIRE(param && grad && exp_avg && exp_avg_sq && group_end && lr, "null pointer");
+    DBW_REQUIRE(ngroups >= 1 && ngroups <= MAX_SETS && step >= 1, "1..4 groups, step >= 1");
+    for (int k = 0; k < ngroups; ++k) DBW_REQUIRE(group_end[k] >= (k ? group_end[k - 1] : 0), "group ends must not decrease");
+    const long long n = group_end[ngroups - 1];
+    if (n == 0) return DBW_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    AdamGroups G;
+    for (int k = 0; k < MAX_SETS; ++k) {
+        G.end[k] = k < ngroups ? group_end[k] : n;
+        G.step_size[k] = (float)(lr[k < ngroups ? k : ngroups - 1] / bc1);
+    }
+    hipLaunchKernelGGL(adam_groups_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, G,
+                       beta1, beta2, eps, (float)sqrt(bc2));
+    return dbw_check_launch("adam_groups_kernel");
 }
 
 extern "C" int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W,

@@ -15,6 +15,23 @@ c_f = ctypes.c_float
 c_i64 = ctypes.c_int64
 c_sz = ctypes.c_size_t
 
+
+
+class TextureSet(ctypes.Structure):
+    """dbw_texture_set of include/dbw_hip.h (one texture tensor of a multi-set launch)."""
+    _fields_ = [('texture', c_p), ('n', c_i), ('h', c_i), ('w', c_i), ('decim', c_i), ('maps', c_p), ('sig', c_p), ('wrap_x', c_i),
+                ('tv_scale', c_f), ('grad_sig_out', c_p), ('grad_maps', c_p), ('grad_sig', c_p), ('grad_texture', c_p)]
+
+
+def texture_sets(sets):
+    """list of dicts (missing fields = 0 / NULL) -> (ctypes array, count)"""
+    arr = (TextureSet * len(sets))()
+    for a, d in zip(arr, sets):
+        for k, v in d.items():
+            setattr(a, k, v)
+    return arr, len(sets)
+
+
 # name -> argtypes, exactly the prototypes of include/dbw_hip.h (checked by tests/test_abi.py)
 SIGNATURES = {
     'dbw_project_clip_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
@@ -45,6 +62,10 @@ SIGNATURES = {
     'dbw_sqrt_mean': [c_p, c_i, c_f, c_f, c_p, c_p, c_p],
     'dbw_adam_step': [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i, c_p],
     'dbw_debug_divcheck': [c_p, c_p, c_i64, c_p, c_p],
+    'dbw_texture_prep_fwd_sets': [c_p, c_i, c_p],
+    'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
+    'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
+    'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p],
 }
 
 

@@ -63,21 +63,24 @@ class NativeStep:
         _lib.call('dbw_block_alpha_fwd', _p(m.alpha_logit), _p(noise), noise_scale, thresh, nb, _p(alpha), _p(alpha_full), _p(keep), st)
         keep_p = _p(keep) if masked else 0
         # ---- textures: sigmoid (+ decimation to cell resolution); `sig` = the undecimated maps of the TV term ----
-        def prep(tex, d, out):
-            n, h, ww, _ = tex.shape
-            sig = torch.empty_like(tex) if d > 1 else None
-            _lib.call('dbw_texture_prep_fwd', _p(tex), n, h, ww, d, _p(out), _p(sig), st)
-            return sig
         Te = TS * u_
         ce = (Te // decim) ** 2 * 3
         env_maps = torch.empty(2 * ce, device=dev)                    # [sky | ground]
-        sig_bkg = prep(m.texture_bkg, decim, env_maps[:ce])
-        sig_gnd = prep(m.texture_ground, decim, env_maps[ce:])
         blk_maps = torch.empty(nb * (TS // decim_blocks) ** 2 * 3, device=dev)
-        sig_blk = prep(m.textures, decim_blocks, blk_maps)
-        sig_bkg = env_maps[:ce].view(1, Te, Te, 3) if sig_bkg is None else sig_bkg
-        sig_gnd = env_maps[ce:].view(1, Te, Te, 3) if sig_gnd is None else sig_gnd
-        sig_blk = blk_maps.view(nb, TS, TS, 3) if sig_blk is None else sig_blk
+        tv_f = 1.0 if coarse else 0.1
+        tv = float(w['tv']) * tv_f * rs if 'tv' in w else 0.0
+        sets = []                                                      # the three texture tensors: one launch per pass over them
+        for tex, d, out, wrap, sc, name in ((m.texture_bkg, decim, env_maps[:ce], 0, tv, 'texture_bkg'),
+                                            (m.textures, decim_blocks, blk_maps, 1, tv, 'textures'),
+                                            (m.texture_ground, decim, env_maps[ce:], 0, tv * tv_f, 'texture_ground')):
+            n, h, ww, _ = tex.shape
+            sig = torch.empty_like(tex) if d > 1 else out.view(tex.shape)
+            sets.append(dict(texture=_p(tex), n=n, h=h, w=ww, decim=d, maps=_p(out), sig=_p(sig) if d > 1 else 0, wrap_x=wrap, tv_scale=sc,
+                             grad_texture=_p(g[name]), _sig=sig))
+        def launch(fn, which, *more):
+            arr, k = _lib.texture_sets([{a: b for a, b in sets[i].items() if a[0] != '_'} for i in which])
+            _lib.call(fn, arr, k, *more)
+        launch('dbw_texture_prep_fwd_sets', (0, 1, 2), st)
         # ---- vertices ----
         nbv = m._bkg_verts.shape[0]
         ngv = m._ground_base.shape[0]
@@ -116,14 +119,11 @@ class NativeStep:
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
         if 'parsimony' in w and coarse:
             _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
-        g_sig = [None, None, None]
         if 'tv' in w:
-            tv_f = 1.0 if coarse else 0.1
-            tv = float(w['tv']) * tv_f * rs
-            for i, (mp, wrap, sc) in enumerate(((sig_bkg, 0, tv), (sig_blk, 1, tv), (sig_gnd, 0, tv * tv_f))):
-                n, h, ww, _ = mp.shape
-                g_sig[i] = torch.empty_like(mp)
-                _lib.call('dbw_tv_l2sq', _p(mp), n, h, ww, wrap, sc, vals.data_ptr() + 8, _p(g_sig[i]), st)
+            for t in sets:
+                t['_g_sig'] = torch.empty_like(t['_sig'])
+                t['sig'], t['grad_sig_out'], t['grad_sig'] = _p(t['_sig']), _p(t['_g_sig']), _p(t['_g_sig'])
+            launch('dbw_tv_l2sq_sets', (0, 1, 2), vals.data_ptr() + 8, st)
         if 'overlap' in w and coarse:
             u = m._overlap_u_override if m._overlap_u_override is not None else torch.rand(nb, OVERLAP_N_POINTS, 3, device=dev)
             ws = ops.ARENA.zeros(nb * 18, torch.float32, dev)
@@ -156,8 +156,8 @@ class NativeStep:
         g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
         _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
                   float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
-        n, h, ww, _ = m.textures.shape
-        _lib.call('dbw_texture_prep_bwd', _p(m.textures), n, h, ww, decim_blocks, _p(g_blk_maps), _p(g_sig[1]), _p(g['textures']), st)
+        sets[1]['grad_maps'] = _p(g_blk_maps)
+        launch('dbw_texture_prep_bwd_sets', (1,), st)
         _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
         torch.cuda.set_stream(cur)
         st = st_main
@@ -166,9 +166,8 @@ class NativeStep:
         g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
         _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
                   g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)
-        for tex, gm, gs_, name in ((m.texture_bkg, g_env_maps[:ce], g_sig[0], 'texture_bkg'), (m.texture_ground, g_env_maps[ce:], g_sig[2], 'texture_ground')):
-            n, h, ww, _ = tex.shape
-            _lib.call('dbw_texture_prep_bwd', _p(tex), n, h, ww, decim, _p(gm), _p(gs_), _p(g[name]), st)
+        sets[0]['grad_maps'], sets[2]['grad_maps'] = _p(g_env_maps[:ce]), _p(g_env_maps[ce:])
+        launch('dbw_texture_prep_bwd_sets', (0, 2), st)
         if side is not cur:
             cur.wait_stream(side)
         m._alpha, m._alpha_full = alpha, alpha_full

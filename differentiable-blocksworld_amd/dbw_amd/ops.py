@@ -790,6 +790,16 @@ def fused_losses(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, 
     return _FusedLosses.apply(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg)
 
 
+def adam_step_groups_(param, grad, exp_avg, exp_avg_sq, group_end, lrs, step, betas=(0.9, 0.999), eps=1e-8):
+    """One launch for parameter groups that lie back to back in one flat buffer and differ in learning rate (optimizer.py:10-17)."""
+    import ctypes
+    n = len(lrs)
+    ends = (ctypes.c_int64 * n)(*[int(e) for e in group_end])
+    lr = (ctypes.c_float * n)(*[float(x) for x in lrs])
+    _lib.call('dbw_adam_step_groups', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ends, lr, n, float(betas[0]),
+              float(betas[1]), float(eps), int(step), _stream(param))
+
+
 def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
     """In-place fused Adam on flat fp32 buffers (torch.optim.Adam defaults; optimizer.py:6-18)."""
     _lib.call('dbw_adam_step', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),

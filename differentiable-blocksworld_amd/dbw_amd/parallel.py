@@ -123,6 +123,10 @@ class ShardedTrainStep:
         if self.world_size > 1:
             self.allreduce_gradients()
         self.n_steps += 1
+        if self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda:
+            ops.adam_step_groups_(self.params.flat, self.params.grad, self.exp_avg, self.exp_avg_sq, [b for _, b in self.params.bounds],
+                                  self.lrs, self.n_steps, self.betas, self.eps)       # both learning-rate groups in one launch
+            return losses
         for (a, b), lr in zip(self.params.bounds, self.lrs):
             if b > a:
                 self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,

@@ -204,6 +204,27 @@ int dbw_texture_prep_fwd(const float *texture, int n, int h, int w, int decim, f
 int dbw_texture_prep_bwd(const float *texture, int n, int h, int w, int decim, const float *grad_maps,
                          const float *grad_sig, float *grad_texture, dbw_stream_t stream);
 
+/* The same three passes over SEVERAL texture tensors of different shapes in one launch each (a scene has three: the blocks' maps,
+ * the sky dome, the ground; dbw.py:273-293) -- a launch is ~5 us, which is all these passes cost.  1 <= nsets <= 4; `sets` is host
+ * memory, read during the call.  Per set: texture (n,h,w,3) logits; decim; forward: maps (out, cell resolution) and sig (out, full
+ * resolution; required when decim > 1, else optional); TV (dbw_tv_l2sq_sets): sig (in), wrap_x, tv_scale, grad_sig_out (out or NULL),
+ * every set adding into the one `loss`; backward: grad_maps (in), grad_sig (in or NULL), grad_texture (out). */
+typedef struct dbw_texture_set {
+    const float *texture;
+    int n, h, w, decim;
+    float *maps;
+    float *sig;
+    int wrap_x;
+    float tv_scale;
+    float *grad_sig_out;
+    const float *grad_maps;
+    const float *grad_sig;
+    float *grad_texture;
+} dbw_texture_set;
+int dbw_texture_prep_fwd_sets(const dbw_texture_set *sets, int nsets, dbw_stream_t stream);
+int dbw_texture_prep_bwd_sets(const dbw_texture_set *sets, int nsets, dbw_stream_t stream);
+int dbw_tv_l2sq_sets(const dbw_texture_set *sets, int nsets, float *loss, dbw_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Superquadric deformation + posing of the K block meshes (dbw.py:297-311,343-344,348-352; superquadric.py:10-14):
  *   eps = sigmoid(sq_eps)*1.8+0.1; v = parametric_sq(eta,omega,eps)*ratio; S = exp(S)+scale_min;
@@ -279,6 +300,10 @@ int dbw_overlap_loss(const float *u, int npts, const float *sq_eps, const float 
  * step is the 1-based step count; bias corrections computed on the host. */
 int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, dbw_stream_t stream);
+/* The same over parameter groups that are contiguous in ONE flat buffer and differ only in learning rate (optimizer.py:10-17: the
+ * texture group vs the rest): group k covers [group_end[k-1], group_end[k]) (group_end[-1] = 0), 1 <= ngroups <= 4; host arrays. */
+int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
+                         const float *lr, int ngroups, float beta1, float beta2, float eps, int step, dbw_stream_t stream);
 
 #ifdef __cplusplus
 }

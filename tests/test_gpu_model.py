@@ -206,6 +206,48 @@ def test_fused_adam_matches_torch():
     assert rel_err(ph, p) < 1e-5
 
 
+def test_texture_sets_and_grouped_adam_equal_the_single_launches():
+    """The multi-set launches of the native step (one launch for the blocks', sky and ground maps; one Adam launch for both
+    learning-rate groups) are the single-tensor kernels run per set: bit-identical results."""
+    from dbw_amd import _lib
+    torch.manual_seed(3)
+    shapes, decims, wraps, scales = [(1, 64, 64, 3), (3, 32, 32, 3), (1, 64, 64, 3)], [8, 8, 1], [0, 1, 0], [0.1, 0.1, 0.01]
+    texs = [torch.randn(s, device=DEV) for s in shapes]
+    gmaps = [torch.randn(s[0], s[1] // d, s[2] // d, 3, device=DEV) for s, d in zip(shapes, decims)]
+    st = ops._stream(texs[0])
+    single, sets, keep = [], [], []
+    loss1, loss2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    for t, d, wr, sc, gmp in zip(texs, decims, wraps, scales, gmaps):
+        n, h, w, _ = t.shape
+        maps, sig, gsig, gtex = torch.empty_like(gmp), torch.empty_like(t), torch.empty_like(t), torch.empty_like(t)
+        _lib.call('dbw_texture_prep_fwd', t.data_ptr(), n, h, w, d, maps.data_ptr(), sig.data_ptr(), st)
+        _lib.call('dbw_tv_l2sq', sig.data_ptr(), n, h, w, wr, sc, loss1.data_ptr(), gsig.data_ptr(), st)
+        _lib.call('dbw_texture_prep_bwd', t.data_ptr(), n, h, w, d, gmp.data_ptr(), gsig.data_ptr(), gtex.data_ptr(), st)
+        single.append((maps, sig, gsig, gtex))
+        m2, s2, gs2, gt2 = torch.empty_like(gmp), torch.empty_like(t), torch.empty_like(t), torch.empty_like(t)
+        keep.append((m2, s2, gs2, gt2))
+        sets.append(dict(texture=t.data_ptr(), n=n, h=h, w=w, decim=d, maps=m2.data_ptr(), sig=s2.data_ptr(), wrap_x=wr, tv_scale=sc,
+                         grad_sig_out=gs2.data_ptr(), grad_maps=gmp.data_ptr(), grad_sig=gs2.data_ptr(), grad_texture=gt2.data_ptr()))
+    arr, k = _lib.texture_sets(sets)
+    _lib.call('dbw_texture_prep_fwd_sets', arr, k, st)
+    _lib.call('dbw_tv_l2sq_sets', arr, k, loss2.data_ptr(), st)
+    _lib.call('dbw_texture_prep_bwd_sets', arr, k, st)
+    for a, b in zip(single, keep):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert abs(loss1.item() - loss2.item()) < 1e-6 * abs(loss1.item())          # (atomic order differs)
+    # Adam: two groups, two learning rates
+    n0, n1 = 700, 300
+    p0, g = torch.randn(n0 + n1, device=DEV), torch.randn(n0 + n1, device=DEV)
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for step in (1, 2, 3):
+        ops.adam_step_(pa[:n0], g[:n0], ma[:n0], va[:n0], 5e-3, step)
+        ops.adam_step_(pa[n0:], g[n0:], ma[n0:], va[n0:], 5e-2, step)
+        ops.adam_step_groups_(pb, g, mb, vb, [n0, n0 + n1], [5e-3, 5e-2], step)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
 def _dtu_like_cfg(n_blocks=4, ts=32, fpp=6):
     return {'model': {'name': 'dbw',
                       'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},
@@ -528,4 +570,12 @@ def test_native_step_equals_autograd_step(epoch):
     for n, off, k in res[0][3]:
         a, b = res[0][1][off:off + k], res[1][1][off:off + k]
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (n, float((a - b).abs().max()), float(b.abs().max()))
-    assert float((res[0][2] - res[1][2]).abs().max()) < 1e-4
+    # parameters after three Adam steps.  Adam divides by sqrt(v): an element whose gradient is at the rounding noise of the float
+    # atomics (order differs from run to run) moves by +-lr whatever the noise was, so the bound holds for the elements whose first
+    # gradient is above that noise, and the others must be (very) few
+    diff = (res[0][2] - res[1][2]).abs()
+    for n, off, k in res[0][3]:
+        g1 = res[1][1][off:off + k].abs()
+        solid = g1 > 1e-3 * g1.max()
+        assert float(diff[off:off + k][solid].max() if solid.any() else 0.0) < 1e-4, n
+    assert float((diff > 1e-4).float().mean()) < 1e-3

@@ -15,7 +15,7 @@ dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 8)()
-names = ['pass0', 'pass1', 'p2 load+fetch+blend', 'p2 opacity table', 'p2 texel table/bins', 'p2 raster bwd math', 'p2 face table', 'total']
+names = ['pass0 (layer bound)', 'pass1', 'p2 load+blend', 'p2 opacity table (generic kernel only)', 'p2 footprint + texel table/bins', 'p2 distance / raster bwd math', 'p2 face (+ opacity) table', 'total']
 for ep in [int(x) for x in sys.argv[1:]] or [0]:
     model.set_cur_epoch(ep); model(inp, None)
     torch.cuda.synchronize()
@@ -23,5 +23,5 @@ for ep in [int(x) for x in sys.argv[1:]] or [0]:
     kb = bench.kernel_breakdown(model, inp, reps=1)          # 2 launches of each backward (fg + env share the counters)
     torch.cuda.synchronize()
     lib.dbw_debug_read_profile(buf, 1)
-    tot = buf[7]
+    tot = max(buf[7], 1)
     print('epoch', ep, {n: f'{100.0 * buf[i] / tot:.1f}%' for i, n in enumerate(names[:-1])}, 'wave-cycles', tot)

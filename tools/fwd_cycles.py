@@ -19,11 +19,11 @@ kb = bench.kernel_breakdown(model, inp, reps=1)
 torch.cuda.synchronize()
 lib.dbw_debug_read_fwd_profile(buf, 1)
 v = list(buf)
-L = 3.0                         # kernel_breakdown runs the soft forward three times (first call, warm-up, one timed repetition)
+L = float(os.environ.get('DBW_FPROF_LAUNCHES', 3.0))                         # kernel_breakdown runs the soft forward three times (first call, warm-up, one timed repetition)
 tot = v[3]
 print({k: round(x[0], 3) for k, x in kb.items()})
 print({'prologue': f'{100 * v[12] / tot:.1f}%', 'binning (list walk + staging)': f'{100 * v[0] / tot:.1f}%',
        'staged-face loop (evaluate + insert)': f'{100 * v[1] / tot:.1f}%', 'shading + stores': f'{100 * v[2] / tot:.1f}%'})
-print('per launch (fg pass): tiles %.1f k (%.1f k with staged faces), staged (tile, face) pairs %.3f M (culled by the tile-vs-edge test: %.3f M), '
+print('per launch (%s pass; counted per wave):' % os.environ.get('DBW_FPROF_PASS', 'fg') + ' tiles %.1f k (%.1f k with staged faces), staged (tile, face) pairs %.3f M (culled by the tile-vs-edge test: %.3f M), '
       'with a pixel in the box %.3f M, (pixel, face) evaluations %.2f M, kept %.2f M, wave re-evaluations with IEEE divisions %.4f M' %
       (v[9] / L / 1e3, v[10] / L / 1e3, v[4] / L / 1e6, v[11] / L / 1e6, v[5] / L / 1e6, v[6] / L / 1e6, v[7] / L / 1e6, v[8] / L / 1e6))

@@ -1,11 +1,11 @@
-"""From a rocprofv3 --kernel-trace CSV of bench.py: the kernel sequence of ONE steady-state optimisation step (between two Adam pairs),
+"""From a rocprofv3 --kernel-trace CSV of bench.py: the kernel sequence of ONE steady-state optimisation step (between two Adam launches),
 with durations and the idle gap before each kernel.  usage: step_sequence.py t_kernel_trace.csv"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-adam = [i for i, n in enumerate(names) if 'adam_kernel' in n]
-# steps end with two adam launches: take the step that ends with the 10th pair
-ends = adam[1::2]
+adam = [i for i, n in enumerate(names) if 'adam_' in n]
+# a step ends with the Adam launch(es): one (dbw_adam_step_groups) or two (one per learning-rate group)
+ends = adam if any('adam_groups' in names[i] for i in adam) else adam[1::2]
 a, b = ends[9] + 1, ends[10] + 1
 prev_end, tot, gaps = None, 0.0, 0.0
 print(f'{b - a} kernels in the step')
