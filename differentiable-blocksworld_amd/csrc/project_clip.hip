@@ -178,14 +178,27 @@ __device__ __forceinline__ void clip_point_bwd(f3 pa, f3 pb, float c, int persp,
 // onto the same three mesh vertices (unless clipping or culling shifted the slots of a view), so the wave sums the nine
 // world-space components over its lanes in registers (DPP) and one lane issues 9 atomics -- instead of B x 9 atomics per face
 // that all land on the same V x 3 addresses (measured: 68 us with them, 5 us without, at 49 views x 12.8 k slots).
+// LDS_TABLE: meshes of a few thousand vertices (every scene of this path) keep a V x 3 accumulator in LDS.  When clipping shifts the
+// slots of the views against each other (the ground plane crosses the near plane in every view), the lanes of a wave hold DIFFERENT
+// faces and the register sum does not apply: their B x 9 contributions per slot used to go to the same few hundred global addresses
+// (env pass: 395 k atomics on 730 addresses, 30 us); now they meet in LDS and each workgroup flushes every touched component once.
+constexpr int BWD_SLOTS = 16;          // clipped-face slots per workgroup (LDS_TABLE)
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
     const float *__restrict__ T, const float *__restrict__ Kmat, int B, int V, int F, float eps, float zc, int persp,
     const int *__restrict__ num_faces, const int *__restrict__ c2o, const int *__restrict__ code,
     const float *__restrict__ cw, const float *__restrict__ gfvc, float *__restrict__ gverts) {
+    extern __shared__ float s_acc[];   // LDS_TABLE: V * 3
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * (NT / DBW_WAVE) + (threadIdx.x >> 6);
-    if (j >= 2 * F) return;
+    if (LDS_TABLE) {
+        for (int i = threadIdx.x; i < V * 3; i += NT) s_acc[i] = 0.f;
+        __syncthreads();
+    }
+    constexpr int WAVES = NT / DBW_WAVE, ITERS = LDS_TABLE ? BWD_SLOTS / WAVES : 1;
+    for (int it = 0; it < ITERS; ++it) {
+    const int j = LDS_TABLE ? blockIdx.x * BWD_SLOTS + it * WAVES + (threadIdx.x >> 6) : blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (j >= 2 * F) break;
     for (int b0 = 0; b0 < B; b0 += DBW_WAVE) {
         const int b = b0 + lane;
         bool act = b < B && j < num_faces[b];
@@ -253,12 +266,26 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
             if (lane == leader) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c)
-                    if (s[c] != 0.f) unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), s[c]);
+                    if (s[c] != 0.f) {
+                        if (LDS_TABLE) atomicAdd(&s_acc[vi[c / 3] * 3 + (c % 3)], s[c]);
+                        else unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), s[c]);
+                    }
             }
         } else if (act) {
 #pragma unroll
             for (int c = 0; c < 9; ++c)
-                if (gw[c] != 0.f) unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), gw[c]);
+                if (gw[c] != 0.f) {
+                    if (LDS_TABLE) atomicAdd(&s_acc[vi[c / 3] * 3 + (c % 3)], gw[c]);
+                    else unsafeAtomicAdd(gverts + (long long)vi[c / 3] * 3 + (c % 3), gw[c]);
+                }
+        }
+    }
+    }
+    if (LDS_TABLE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < V * 3; i += NT) {
+            const float v = s_acc[i];
+            if (v != 0.f) unsafeAtomicAdd(gverts + i, v);
         }
     }
 }
@@ -291,8 +318,13 @@ extern "C" int dbw_project_clip_bwd(const float *verts_world, const int32_t *fac
                     grad_face_verts_c && grad_verts_world, "null pointer");
     DBW_REQUIRE(B >= 0 && V > 0 && F > 0, "bad size");
     if (B == 0) return DBW_OK;
-    hipLaunchKernelGGL(project_clip_bwd_kernel, dim3((2 * F + NT / DBW_WAVE - 1) / (NT / DBW_WAVE)), dim3(NT), 0, (hipStream_t)stream,
-                       verts_world, faces, R, T, Kmat, B, V, F, eps, z_clip, perspective_correct, num_faces, c2o,
-                       clip_code, clip_w, grad_face_verts_c, grad_verts_world);
+    if ((size_t)V * 3 * sizeof(float) <= 48 * 1024)
+        hipLaunchKernelGGL(project_clip_bwd_kernel<true>, dim3((2 * F + BWD_SLOTS - 1) / BWD_SLOTS), dim3(NT), (size_t)V * 3 * sizeof(float),
+                           (hipStream_t)stream, verts_world, faces, R, T, Kmat, B, V, F, eps, z_clip, perspective_correct, num_faces, c2o,
+                           clip_code, clip_w, grad_face_verts_c, grad_verts_world);
+    else
+        hipLaunchKernelGGL(project_clip_bwd_kernel<false>, dim3((2 * F + NT / DBW_WAVE - 1) / (NT / DBW_WAVE)), dim3(NT), 0, (hipStream_t)stream,
+                           verts_world, faces, R, T, Kmat, B, V, F, eps, z_clip, perspective_correct, num_faces, c2o,
+                           clip_code, clip_w, grad_face_verts_c, grad_verts_world);
     return dbw_check_launch("project_clip_bwd_kernel");
 }

@@ -246,7 +246,8 @@ void *dbw_workspace_shade_recs(void *workspace, long long F_total) {
 // Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
                        long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
-                       dbw::CoarseBins &cb, hipStream_t s) {
+                       dbw::CoarseBins &cb, hipStream_t s, bool launch) {
+    // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass); only `cb` is rebuilt
     cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
     if (F_total <= 0) return DBW_OK;
     if (F_total >= (1LL << TOPK_ID_BITS) - 1) {
@@ -257,10 +258,13 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
         dbw_set_error("rasteriser: the workspace must be 128-byte aligned");
         return DBW_ERR_INVALID;
     }
-    hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
-                       (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total));
-    int rc = dbw_check_launch("face_setup_kernel");
-    if (rc) return rc;
+    int rc = DBW_OK;
+    if (launch) {
+        hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
+                           (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total));
+        rc = dbw_check_launch("face_setup_kernel");
+        if (rc) return rc;
+    }
     // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
     if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20)) {
         const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
@@ -268,10 +272,12 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
         int *count = (int *)p;
         unsigned *mask = (unsigned *)(count + (size_t)N * nx * ny);
         int *list = (int *)(p + align256((size_t)N * nx * ny * 3 * sizeof(int)));
-        hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
-                           num_faces, H, W, nx, ny, list, count, mask);
-        rc = dbw_check_launch("coarse_bin_kernel");
-        if (rc) return rc;
+        if (launch) {
+            hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
+                               num_faces, H, W, nx, ny, list, count, mask);
+            rc = dbw_check_launch("coarse_bin_kernel");
+            if (rc) return rc;
+        }
         cb.list = list; cb.count = count; cb.mask = mask; cb.nx = nx; cb.ny = ny;
     }
     return DBW_OK;
@@ -296,7 +302,7 @@ extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_i
     float4 *bbox = (float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
     CoarseBins cb;
-    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s);
+    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s, true);
     if (rc) return rc;
 #define DBW_FWD(KM) launch_fwd<KM>(recs, bbox, first_idx, num_faces, N, H, W, K, blur_radius, \
                                    perspective_correct, clip_barycentric_coords, cb, pix_to_face, zbuf, bary, dists, s)

@@ -81,7 +81,7 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 // Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n
 // (keys in `q`, payloads in the LDS array `home`, stride TW * TH, lane threadIdx.x).  Returns false for the padding blocks of the
 // XCD-aware grid.  All threads of the block must call it.  dbg: bit 0 = plain IEEE divisions, bit 1 = no tile culling (parity tests
-// run every variant against the oracle).
+// run every variant against the oracle), bit 3 = hard pass whose distances are only read for their sign (eval_pair's sign_only).
 template <int KMAX, int TW, int TH, int GROUP = 2, bool PAY3 = false>
 __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces, int H, int W, int K,
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
         txmax = pix_to_ndc_fast(W - 1 - x0, ax); txmin = pix_to_ndc_fast(W - 1 - x1, ax);
         tymax = pix_to_ndc_fast(H - 1 - y0, ay); tymin = pix_to_ndc_fast(H - 1 - y1, ay);
     }
-    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2);
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2), sign_only = (dbg & 8) != 0;
     int cnt = 0;
     FPROF_T(t_begin);
     FPROF_ADD(9, 1);
@@ -235,14 +235,14 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
                     bool redo = !(fastdiv && (r.flags & REC_FAST));
                     if (!redo) {
                         bool unsafe = false;
-                        if (inbox) keep = eval_pair<true>(r, p, blur, persp, clipb, pz, sd, bc, unsafe);
+                        if (inbox) keep = eval_pair<true>(r, p, blur, persp, clipb, pz, sd, bc, unsafe, sign_only);
                         redo = __ballot(inbox && unsafe) != 0ull;
                     }
                     if (redo) {
                         FPROF_ADD(8, 1);
                         bool unused;
                         keep = false;
-                        if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused);
+                        if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused, sign_only);
                     }
                     if (__ballot(keep) == 0ull) continue;
                     FPROF_CNT(7, keep);

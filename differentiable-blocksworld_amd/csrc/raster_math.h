@@ -205,7 +205,8 @@ DBW_HD float seg_dist(f2 p, float ox, float oy, float dx, float dy, float l2, fl
 // distance) and bc (the stored barycentrics) are only meaningful then.  FAST: shared-reciprocal divisions; `unsafe` comes back true
 // when an operand left the guarded range, in which case the caller re-evaluates with FAST = false (plain IEEE divisions).
 template <bool FAST>
-DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, float &pz, float &sd, f3 &bc, bool &unsafe) {
+DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, float &pz, float &sd, f3 &bc, bool &unsafe,
+                      bool sign_only = false) {
     unsafe = false;
     const float pax = p.x - r.ax, pay = p.y - r.ay, pbx = p.x - r.bx, pby = p.y - r.by, pcx = p.x - r.cx, pcy = p.y - r.cy;
     const float e0 = pbx * r.dbc_y - pby * r.dbc_x;       // edge_fn(p, b, c)
@@ -248,6 +249,9 @@ DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, 
     }
     pz = bc.x * r.z0 + bc.y * r.z1 + bc.z * r.z2;
     if (pz < 0.f) return false;
+    // hard passes whose consumer only looks at the SIGN of the distance (fused forward, blur == 0: a kept pixel is inside, its opacity
+    // is 1 and the distance carries no gradient): any negative number will do
+    if (sign_only && blur == 0.f) { sd = -1.f; return true; }
     // point_tri_dist: edges (v0, v1), (v0, v2), (v1, v2); the middle one runs along -(a - c)
     const float e01 = seg_dist<FAST>(p, r.ax, r.ay, r.dab_x, r.dab_y, r.l2_ab, r.r_ab, (r.flags & REC_DEG_AB) != 0, r.bx, r.by, pax, pay, unsafe);
     const float e02 = seg_dist<FAST>(p, r.ax, r.ay, -r.dca_x, -r.dca_y, r.l2_ac, r.r_ac, (r.flags & REC_DEG_AC) != 0, r.cx, r.cy, pax, pay, unsafe);

@@ -15,7 +15,7 @@ using namespace dbw;
 // implemented in raster.hip / shade_blend.hip
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
                        long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
-                       dbw::CoarseBins &cb, hipStream_t s);
+                       dbw::CoarseBins &cb, hipStream_t s, bool launch);
 const dbw::FaceRec *dbw_workspace_recs(const void *workspace, long long F_total);
 void *dbw_workspace_shade_recs(void *workspace, long long F_total);
 int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
@@ -38,7 +38,8 @@ extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out16, int reset)
 }
 #endif
 int g_render_variant = 0;
-int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling (dbw_debug_set_flags >> 8)
+int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
+                            // compute their (unused) distances too (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
 void dbw_set_render_dbg(int v) { g_render_dbg = v; }
 
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     TopK<KMAX, UV> q;
     pay4 *home;
     FPROF_T(t_k0);
-    if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb, dbg, n, xi, yi, q, home)) return;
+    if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb,
+                                              (dbg & 3) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home)) return;
     FPROF_T(t_k1);
     if constexpr (UV) shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image);
     else {
@@ -312,7 +314,8 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, const MseArgs *mse, dbw_stream_t stream) {
+                                    int frag_layout, const MseArgs *mse, int stage, dbw_stream_t stream) {
+    DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
     DBW_REQUIRE(blur_radius >= 0.f && F_total >= 0, "bad blur_radius / F_total");
@@ -326,7 +329,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     A.tiled = frag_layout;
     if (mse) {
         DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
-        DBW_REQUIRE(mse->env_img && mse->target && mse->loss_part && mse->g_fg && mse->g_env, "null pointer");
+        DBW_REQUIRE(stage == 1 || (mse->env_img && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
         A.env_img = mse->env_img; A.target = mse->target; A.mse_scale = mse->scale; A.loss_part = mse->loss_part; A.g_fg = mse->g_fg; A.g_env = mse->g_env;
     }
     if (K > DBW_MAX_FACES_PER_PIXEL) {
@@ -337,17 +340,21 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     hipStream_t s = (hipStream_t)stream;
     const float margin = (float)sqrt((double)blur_radius);
     CoarseBins cb;
-    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, c2o ? (long long)Fc_stride : F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s);
+    rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, c2o ? (long long)Fc_stride : F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s,
+                            /*launch=*/stage != 2);
     if (rc) return rc;
     const float4 *bbox = (const float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
     ShadeRec *srec = nullptr;
     if (frag_layout == 2 && K > 1 && F_total > 0) {
         srec = (ShadeRec *)dbw_workspace_shade_recs(workspace, F_total);
-        hipLaunchKernelGGL(shade_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, A, first_idx, num_faces, (long long)F_total, srec);
-        rc = dbw_check_launch("shade_setup_kernel");
-        if (rc) return rc;
+        if (stage != 2) {
+            hipLaunchKernelGGL(shade_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, A, first_idx, num_faces, (long long)F_total, srec);
+            rc = dbw_check_launch("shade_setup_kernel");
+            if (rc) return rc;
+        }
     }
+    if (stage == 1) return DBW_OK;
 #define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
@@ -367,7 +374,7 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
                                     int frag_layout, dbw_stream_t stream) {
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, stream);
+                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, 0, stream);
 }
 
 extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
@@ -378,9 +385,9 @@ extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t
                                         int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                         float *dists, void *workspace, size_t workspace_bytes, const float *env_image,
                                         const float *target, float mse_scale, float *loss_partial, float *grad_fg,
-                                        float *grad_env, dbw_stream_t stream) {
+                                        float *grad_env, int stage, dbw_stream_t stream) {
     const MseArgs mse{env_image, target, mse_scale, loss_partial, grad_fg, grad_env};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stream);
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stage, stream);
 }

@@ -1,8 +1,8 @@
 """Init-time topology of the blocks-world scene (host side, runs once): icosphere, subdivision, plane, UV layouts and
 rotation helpers.  Product-side counterparts of what the reference takes from PyTorch3D (`ico_sphere`,
 `SubdivideMeshes`, `rotation_6d_to_matrix`, `random_rotations`: SURVEY.md A.9) and of src/utils/mesh.py:78-89,104-169,
-210-211, src/model/tools.py:173-207.  Written independently of oracle/oracle.py; tests/test_host_topology.py checks
-the two agree exactly."""
+210-211, src/model/tools.py:173-207.  Written independently of oracle/oracle.py;
+tests/test_host_logic.py::test_topology_generators_agree_with_oracle checks the two agree exactly."""
 import math
 
 import numpy as np

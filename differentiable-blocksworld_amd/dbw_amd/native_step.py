@@ -116,6 +116,10 @@ class NativeStep:
         _lib.call('dbw_sq_blocks_fwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
                   float(m.scale_min), float(S_w), _p(R_w), _p(T_w), _p(blk_verts), st)
         cl_f = ops.project_clip(blk_verts, m._block_faces_all, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+        fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
+        # ... and so is the per-face set-up of the fg pass (boxes, face + shading records, bins)
+        fg_state = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, renderer._bg,
+                                            None, None, 0.0, stage=1)
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
         if 'parsimony' in w and coarse:
             _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
@@ -138,13 +142,13 @@ class NativeStep:
         cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
         p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
                                                               desc_e, env_maps, None, m.renderer_env._bg, 1)
-        fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
         count = float(imgs.numel() if global_count is None else global_count)
         scale = float(w['rgb']) / count
         if side is not cur:
             cur.wait_stream(side)                                      # blocks projected, regularisers done
         p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
-                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale)
+                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
+                                                                      state=fg_state)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step).  What follows the fg backward (projection
         # backward, blocks -> pose / shape, block textures, opacities) runs on the side stream next to the env backward ----
         g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, cfg_f,

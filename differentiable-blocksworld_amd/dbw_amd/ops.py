@@ -365,26 +365,33 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     return g_maps, g_alpha, g_fvc
 
 
-def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, env_img, imgs, scale):
+def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, env_img, imgs, scale, stage=0, state=None):
     """dbw_render_fwd_fused_mse on the clipped faces `cl` of the fg scene (no grad bookkeeping): uv-fragments + per-tile sums of
-    squared differences + d loss / d fg image, d loss / d env image.  -> p2f, bary, dists, part, g_fg, g_env."""
+    squared differences + d loss / d fg image, d loss / d env image.  -> p2f, bary, dists, part, g_fg, g_env.
+    stage 1 (env_img / imgs may be None): only the per-face set-up, on the current stream -> `state` for the stage-2 call that
+    renders (the caller orders the two calls)."""
     fvc = cl['face_verts'].view(-1, 3, 3)
     dev, Ft = fvc.device, fvc.shape[0]
-    ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
-    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
-    p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
-    bary = torch.empty(B, ty, tx, cfg.K, 8, 64, dtype=torch.float32, device=dev)
-    dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
-    part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
-    g_fg = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
-    g_env = torch.empty_like(g_fg)
+    if stage == 2:
+        ws, ws_bytes, out = state
+    else:
+        ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
+        p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
+        bary = torch.empty(B, ty, tx, cfg.K, 8, 64, dtype=torch.float32, device=dev)
+        dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
+        part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
+        g_fg = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+        g_env = torch.empty_like(g_fg)
+        out = (p2f, bary, dists, part, g_fg, g_env)
+    p2f, bary, dists, part, g_fg, g_env = out
     _lib.call('dbw_render_fwd_fused_mse', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
               _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _ptr(env_img), _ptr(imgs), float(scale), _ptr(part),
-              _ptr(g_fg), _ptr(g_env), _stream(fvc))
-    return p2f, bary, dists, part, g_fg, g_env
+              _ptr(g_fg), _ptr(g_env), int(stage), _stream(fvc))
+    return (ws, ws_bytes, out) if stage == 1 else out
 
 
 class _DecoupledRenderMSE(torch.autograd.Function):

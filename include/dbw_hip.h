@@ -158,7 +158,11 @@ int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, co
  * the already rendered sky + ground pass), rec = fg_rgb * mask + (1 - mask) * env_rgb, compares with target (N,3,H,W) and stores
  *   loss_partial (N * ceil(H/8) * ceil(W/8)): the sum of squared differences of each 8x8 tile (loss = mse_scale * their sum),
  *   grad_fg (N,4,H,W), grad_env (N,4,H,W; alpha plane zero) = d(mse_scale * sum of squares) / d(fg image), / d(env image)
- * -- the gradients dbw_composite_mse would produce, without the composite kernel's two round trips of both images through HBM. */
+ * -- the gradients dbw_composite_mse would produce, without the composite kernel's two round trips of both images through HBM.
+ * stage: 0 = the whole pass.  1 = only the per-face set-up (boxes, face and shading records, bins) into `workspace`: needs the
+ * geometry, the tables and faces_alpha but neither env_image nor target (may be NULL), touches no output -- a caller can run it on
+ * another stream while the pass that produces env_image is still rendering.  2 = the pass itself on a workspace that a stage-1 call
+ * with the same arguments filled (the caller orders the two calls: same stream, or an event between them). */
 int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                              const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
                              int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
@@ -166,7 +170,7 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
                              int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
                              int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                              const float *env_image, const float *target, float mse_scale, float *loss_partial,
-                             float *grad_fg, float *grad_env, dbw_stream_t stream);
+                             float *grad_fg, float *grad_env, int stage, dbw_stream_t stream);
 
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus

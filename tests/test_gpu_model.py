@@ -248,6 +248,49 @@ def test_texture_sets_and_grouped_adam_equal_the_single_launches():
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
+def test_camera_ingest_feeds_the_hip_render_path_on_the_pixels_of_the_projection_matrix():
+    """N3 end to end on the GPU: an OpenCV-style projection matrix P goes through dbw_amd.cameras.pytorch3d_KRT_from_proj
+    (dtu.py:75-115) into the HIP projection + rasteriser, and a small facet placed at a world point X is drawn on the pixel that
+    P @ X names -- for every facet, with every covered pixel within its few-pixel extent."""
+    from dbw_amd.cameras import pytorch3d_KRT_from_proj
+    rng = np.random.RandomState(5)
+    H, W = 300, 400
+    for _ in range(3):
+        Q, _r = np.linalg.qr(rng.randn(3, 3))
+        R_w2c = Q * np.sign(np.linalg.det(Q))
+        C = rng.randn(3) * 0.5 + np.array([0, 0, -3.0])
+        Kcv = np.array([[720 + 50 * rng.rand(), 0.0, W / 2 + 10 * rng.randn()], [0, 715.0, H / 2 + 10 * rng.randn()], [0, 0, 1]])
+        P = Kcv @ np.concatenate([R_w2c, (-R_w2c @ C)[:, None]], 1) * 2.3
+        # target pixels on a grid, random depths; X = C + R^T (depth * Kcv^-1 [u, v, 1])
+        uu, vv = np.meshgrid(np.linspace(30, W - 30, 6), np.linspace(30, H - 30, 5))
+        uv = np.stack([uu.ravel() + rng.rand(30), vv.ravel() + rng.rand(30)], 1)
+        depth = 2.0 + 2.0 * rng.rand(30)
+        Kinv = np.linalg.inv(Kcv)
+        def unproject(px, d):
+            return C + R_w2c.T @ (d * (Kinv @ np.array([px[0], px[1], 1.0])))
+        verts, faces = [], []
+        for i in range(30):                                      # a facet of +-5 px around the target, parallel to the image plane
+            for du, dv in ((-5.0, -4.0), (6.0, -3.0), (-1.0, 7.0)):
+                verts.append(unproject(uv[i] + [du, dv], depth[i]))
+            faces.append([3 * i, 3 * i + 1, 3 * i + 2])
+        verts = torch.tensor(np.array(verts), dtype=torch.float32, device=DEV)
+        faces_f = torch.tensor(faces, dtype=torch.int32, device=DEV)
+        faces_b = faces_f[:, [0, 2, 1]].contiguous()             # both windings: the rasteriser does not cull
+        Kp, Rp, Tp = pytorch3d_KRT_from_proj(P, (H, W))
+        for fc in (faces_f, faces_b):
+            cfg = ops.RenderCfg(H, W, 1, 0.0, 0.001, True, False, fc.shape[0], 1e-8)
+            cl, p2f, _, _, _ = ops.render_fragments(verts, fc, Rp[None].to(DEV).contiguous(), Tp[None].to(DEV).contiguous(), Kp.to(DEV), cfg)
+            first = p2f[0, :, :, 0].long()
+            orig = torch.where(first >= 0, cl['c2o'].view(-1).long()[first.clamp(min=0)], torch.full_like(first, -1)).cpu()
+            for i in range(30):
+                u, v = uv[i]
+                assert int(orig[int(np.floor(v)), int(np.floor(u))]) == i, (i, u, v)      # pixel (x, y) covers [x, x+1) x [y, y+1)
+                ys, xs = torch.nonzero(orig == i, as_tuple=True)
+                assert 20 <= len(ys) <= 90                                                 # area of the facet: 60 px^2 ... at its depth
+                assert float((xs.float() + 0.5 - u).abs().max()) <= 7.0 and float((ys.float() + 0.5 - v).abs().max()) <= 8.0
+            assert int((orig >= 0).sum()) == sum(int((orig == i).sum()) for i in range(30))
+
+
 def _dtu_like_cfg(n_blocks=4, ts=32, fpp=6):
     return {'model': {'name': 'dbw',
                       'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},

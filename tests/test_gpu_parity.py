@@ -229,6 +229,25 @@ def test_project_clip_disabled_is_plain_projection():
     assert torch.equal(cl['face_verts'][:, :Fs].cpu(), ndc[:, faces])
 
 
+def test_project_clip_backward_lds_table_equals_global_atomics_path():
+    """dbw_project_clip_bwd accumulates in an LDS table when the mesh has at most 4096 vertices and straight into memory otherwise:
+    the same mesh with 5000 unused vertices appended must give the same gradient (clipped views: slots shifted between views)."""
+    verts, faces, R, T, Kmat = _camera_inside_scene(3, B=7)
+    B, Fs = R.shape[0], faces.shape[0]
+    fi = faces.to(torch.int32).to(DEV)
+    args = (R.to(DEV), T.to(DEV), Kmat.to(DEV))
+    g = torch.randn(B, 2 * Fs, 3, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    out = []
+    for extra in (0, 5000):
+        v = torch.cat([verts, torch.randn(extra, 3)]).to(DEV)
+        cl = ops.project_clip(v, fi, *args, 1e-8, 0.25, True)
+        assert int(cl['num_faces'].min()) != int(cl['num_faces'].max()), 'views must clip differently'
+        out.append(ops.project_clip_bwd(v, fi, *args, cl, g, 1e-8, 0.25, True).clone())
+    nv = verts.shape[0]
+    assert float(out[1][nv:].abs().max()) == 0.0
+    assert rel_err(out[0], out[1][:nv]) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # full render pass (project -> clip -> raster -> shade -> blend) forward + backward
 # ---------------------------------------------------------------------------------------------------------------------
