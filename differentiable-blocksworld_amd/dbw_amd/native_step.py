@@ -149,31 +149,40 @@ class NativeStep:
         p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
                                                                       blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
                                                                       state=fg_state)
-        # ---- backward of the two passes (upstream gradient 1: nothing sits above this step).  What follows the fg backward (projection
-        # backward, blocks -> pose / shape, block textures, opacities) runs on the side stream next to the env backward ----
-        g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, cfg_f,
-                                                 renderer._bg, 2, g_fg, B, None)
+        # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
+        # kernels (projection backward, pose / shape, textures, opacities).  The env backward + tail go to the side stream: either tail
+        # then runs next to the other pass's big kernel instead of alone at the end of the step ----
+        def fg_backward(st):
+            g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
+                                                     cfg_f, renderer._bg, 2, g_fg, B, None)
+            g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
+            _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
+                      float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
+            sets[1]['grad_maps'] = _p(g_blk_maps)
+            launch('dbw_texture_prep_bwd_sets', (1,), st)
+            _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+            return g_blk_maps, g_fa, g_fvc, g_blk_verts
+
+        def env_backward(st):
+            g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
+                                                    m.renderer_env._bg, 1, g_env, B, None)
+            g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+            _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
+                      g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)
+            sets[0]['grad_maps'], sets[2]['grad_maps'] = _p(g_env_maps[:ce]), _p(g_env_maps[ce:])
+            launch('dbw_texture_prep_bwd_sets', (0, 2), st)
+            return g_env_maps, g_fvc_e, g_env_verts
+
         if side is not cur:
-            side.wait_stream(cur)
+            side.wait_stream(cur)                                      # g_fg, g_env written
             torch.cuda.set_stream(side)
-            st = side.cuda_stream
-        g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
-        _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
-                  float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
-        sets[1]['grad_maps'] = _p(g_blk_maps)
-        launch('dbw_texture_prep_bwd_sets', (1,), st)
-        _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
-        torch.cuda.set_stream(cur)
-        st = st_main
-        g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
-                                                m.renderer_env._bg, 1, g_env, B, None)
-        g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
-        _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
-                  g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)
-        sets[0]['grad_maps'], sets[2]['grad_maps'] = _p(g_env_maps[:ce]), _p(g_env_maps[ce:])
-        launch('dbw_texture_prep_bwd_sets', (0, 2), st)
-        if side is not cur:
+            keep_e = env_backward(side.cuda_stream)
+            torch.cuda.set_stream(cur)
+            keep_f = fg_backward(st_main)
             cur.wait_stream(side)
+        else:
+            keep_f = fg_backward(st_main)
+            keep_e = env_backward(st_main)
         m._alpha, m._alpha_full = alpha, alpha_full
         return LazyLosses(vals, part, scale, [k for k in w if k in _SLOT])
 
