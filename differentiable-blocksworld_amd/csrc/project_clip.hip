@@ -182,7 +182,7 @@ __device__ __forceinline__ void clip_point_bwd(f3 pa, f3 pb, float c, int persp,
 // slots of the views against each other (the ground plane crosses the near plane in every view), the lanes of a wave hold DIFFERENT
 // faces and the register sum does not apply: their B x 9 contributions per slot used to go to the same few hundred global addresses
 // (env pass: 395 k atomics on 730 addresses, 30 us); now they meet in LDS and each workgroup flushes every touched component once.
-constexpr int BWD_SLOTS = 16;          // clipped-face slots per workgroup (LDS_TABLE)
+constexpr int BWD_SLOTS = 8;           // clipped-face slots per workgroup (LDS_TABLE)
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,

@@ -371,10 +371,10 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, dbw_stream_t stream) {
+                                    int frag_layout, int stage, dbw_stream_t stream) {
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, 0, stream);
+                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, stage, stream);
 }
 
 extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,

@@ -384,7 +384,8 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
         bool has_g9 = false;
         if ((FUSED ? (want_bary != 0) : (gbary != nullptr)) && in_img || (FUSED && in_img)) {
             float gb[3] = {0.f, 0.f, 0.f};
-            if (FUSED ? (want_bary != 0) : true)
+            // (faces below geom_begin have constant vertices -- the sky dome: nothing flows through their barycentrics)
+            if (FUSED ? (want_bary != 0 && fr.j >= A.geom_begin) : true)
             if (tex) {
                 float gix = 0.f, giy = 0.f;
 #pragma unroll
@@ -754,7 +755,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.agg = 0;
     A.tiled = 0;
     A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0;
-    A.gscale = nullptr; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
+    A.gscale = nullptr; A.geom_begin = 0; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
     return DBW_OK;
 }
 
@@ -866,7 +867,8 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     const float *face_verts_c, int perspective_correct, int detach_bary,
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
                                     int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
-                                    void *bin_records, int bin_cap, const float *grad_scale, dbw_stream_t stream) {
+                                    void *bin_records, int bin_cap, int const_geometry_faces, const float *grad_scale,
+                                    dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -875,8 +877,10 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
     DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
     DBW_REQUIRE(frag_layout != 2 || detach_bary, "frag_layout 2 carries no barycentrics: only valid with detach_bary");
+    DBW_REQUIRE(const_geometry_faces >= 0 && const_geometry_faces <= F, "const_geometry_faces must lie in [0, F]");
     A.tiled = frag_layout;
     A.gscale = grad_scale;
+    A.geom_begin = const_geometry_faces;
     DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap > 0) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none");
     if (bin_records && !lds_aggregate) {
         A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap;

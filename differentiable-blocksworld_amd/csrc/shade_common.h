@@ -32,6 +32,7 @@ struct ShadeArgs {
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
     // backward: device scalar every incoming image gradient is multiplied by (the upstream gradient of the loss node), NULL = 1
     const float *gscale;
+    int geom_begin;             // backward: faces with an original index below it have constant vertices (no geometry gradient)
     // forward, decoupled composite + MSE epilogue (dbw_render_fwd_fused_mse; all NULL otherwise): instead of storing its image the
     // pass composites it over env_img, compares with target and stores d(mse_scale * sum of squares) / d(fg image), d / d(env image)
     // and the tile's sum of squares

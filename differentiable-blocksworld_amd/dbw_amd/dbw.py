@@ -286,7 +286,9 @@ class DifferentiableBlocksWorld(nn.Module):
         verts = torch.cat([bkg_v, ground_v], 0)
         maps = torch.cat([bkg_maps.reshape(-1), g_maps.reshape(-1)])
         desc = self._env_map_desc if decim == 1 else self._env_map_desc_dec
-        return PackedScene(verts, self._env_faces, self._env_face_uvs, self._env_face_map, desc, maps)
+        scene = PackedScene(verts, self._env_faces, self._env_face_uvs, self._env_face_map, desc, maps)
+        scene.const_faces = self._n_bkg_faces       # the sky dome is a buffer (dbw.py:74-76): no gradient flows to its vertices
+        return scene
 
     def get_blocks_verts(self):
         """Block-frame superquadric vertices * ratio (dbw.py:348-352), for callers that want them unposed."""
@@ -471,7 +473,7 @@ class DifferentiableBlocksWorld(nn.Module):
         R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
         Kmat = renderer.cameras.K[0].to(R.device).contiguous()
         alpha = None if fine else self._alpha.repeat_interleave(self.BNF)
-        cfg_e = self.renderer_env._cfg(env.faces.shape[0], lds_aggregate=True)
+        cfg_e = self.renderer_env._cfg(env.faces.shape[0], lds_aggregate=True, const_faces=env.const_faces)
         cfg_f = renderer._cfg(blocks.faces.shape[0], lds_aggregate=self._blocks_decimated, texbins=blocks.texbins)
         imgs = inp['imgs']
         count = imgs.numel() if getattr(self, '_global_count', None) is None else self._global_count

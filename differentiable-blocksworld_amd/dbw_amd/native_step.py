@@ -33,14 +33,19 @@ class NativeStep:
                 and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11)
                 and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS)
 
-    def __call__(self, inp, global_count=None):
-        """Forward + backward of one iteration on this rank's views.  The caller has zeroed the flat gradient buffer and opened the
-        zero arena (ops.ARENA.begin_step).  -> {'rgb', 'parsimony', 'tv', 'overlap', 'total'} as 0-dim device tensors."""
+    def __call__(self, inp, global_count=None, zero_grad=None):
+        """Forward + backward of one iteration on this rank's views.  The caller has opened the zero arena (ops.ARENA.begin_step) and
+        either zeroed the flat gradient buffer or passes `zero_grad` (called here, on the side stream, off the critical path).
+        -> {'rgb', 'parsimony', 'tv', 'overlap', 'total'} as 0-dim device tensors.
+
+        Schedule (two HIP streams; `overlap_regularisers = False` runs the same calls on one):
+          main: ground mesh -> env projection -> env per-face set-up | env pass | fg pass + MSE | fg backward + its tail
+          side: zero grads, opacities, texture prep | blocks' vertices, projection, fg per-face set-up, regularisers | env backward + tail
+        """
         m, g = self.m, self.grad
         w = m.loss_weights
         imgs = inp['imgs']
         dev = imgs.device
-        st = ops._stream(imgs)
         m._ensure_cameras(inp)
         B = imgs.shape[0]
         coarse = m.is_live('coarse_learning')              # (training mode)
@@ -50,8 +55,48 @@ class NativeStep:
         rs = 1.0 / m.world_size
         S_w, R_w, T_w = m._world_consts()
         nb, nv, TS, u_ = m.n_blocks, m._block_nv, m.txt_size, m.txt_bkg_upscale
-        vals = ops.ARENA.zeros(8, torch.float32, dev)      # 0 rgb (filled below), 1 parsimony, 2 tv, 3 overlap
-        # ---- opacities (dbw.py:297-311) ----
+        renderer = m.renderer_fine if fine else m.renderer
+        R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
+        Kmat = renderer.cameras.K[0].to(dev).contiguous()
+        Fe, Ff = m._env_faces.shape[0], nb * m.BNF
+        cur = torch.cuda.current_stream(dev)
+        side = cur
+        if self.overlap_regularisers:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(cur)                          # the previous step's Adam, the zero arena
+        st_main, st_side = cur.cuda_stream, side.cuda_stream
+
+        # ---- main: ground mesh, env projection + clipping, per-face set-up of the env pass (needs no texture) ----
+        st = st_main
+        nbv = m._bkg_verts.shape[0]
+        ngv = m._ground_base.shape[0]
+        key = (float(S_w), m.R_world._version, m.T_world._version, m.R_world.data_ptr())
+        if self._env_verts is None or self._env_key != key:          # the sky dome is constant: written once
+            self._env_verts = torch.empty(nbv + ngv, 3, device=dev)
+            self._env_verts[:nbv] = ((m._bkg_verts * S_w) @ R_w + T_w)
+            self._env_key = key
+        env_verts = self._env_verts
+        _lib.call('dbw_posed_mesh_fwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w), _p(T_w),
+                  env_verts.data_ptr() + nbv * 12, st)
+        Te = TS * u_
+        ce = (Te // decim) ** 2 * 3
+        env_maps = torch.empty(2 * ce, device=dev)                    # [sky | ground]
+        blk_maps = torch.empty(nb * (TS // decim_blocks) ** 2 * 3, device=dev)
+        cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True, const_faces=m._n_bkg_faces)   # the sky dome's vertices are constants
+        desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
+        cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        env_state = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps,
+                                          None, m.renderer_env._bg, 1, stage=1)
+
+        # ---- side: zero the gradients, opacities (dbw.py:297-311), textures: sigmoid (+ decimation to cell resolution); `sig` = the
+        # undecimated maps of the TV term ----
+        torch.cuda.set_stream(side)
+        st = st_side
+        if zero_grad is not None:
+            zero_grad()
+        vals = torch.zeros(8, device=dev)                  # 0 rgb (filled on demand), 1 parsimony, 2 tv, 3 overlap; outlives the step
         noise, noise_scale = None, 0.0
         if m.opacity_noise and coarse:
             noise = m._noise_override if m._noise_override is not None else m._shared_randn_like(m.alpha_logit)
@@ -62,11 +107,6 @@ class NativeStep:
         keep = torch.empty(nb, dtype=torch.int32, device=dev)
         _lib.call('dbw_block_alpha_fwd', _p(m.alpha_logit), _p(noise), noise_scale, thresh, nb, _p(alpha), _p(alpha_full), _p(keep), st)
         keep_p = _p(keep) if masked else 0
-        # ---- textures: sigmoid (+ decimation to cell resolution); `sig` = the undecimated maps of the TV term ----
-        Te = TS * u_
-        ce = (Te // decim) ** 2 * 3
-        env_maps = torch.empty(2 * ce, device=dev)                    # [sky | ground]
-        blk_maps = torch.empty(nb * (TS // decim_blocks) ** 2 * 3, device=dev)
         tv_f = 1.0 if coarse else 0.1
         tv = float(w['tv']) * tv_f * rs if 'tv' in w else 0.0
         sets = []                                                      # the three texture tensors: one launch per pass over them
@@ -81,43 +121,32 @@ class NativeStep:
             arr, k = _lib.texture_sets([{a: b for a, b in sets[i].items() if a[0] != '_'} for i in which])
             _lib.call(fn, arr, k, *more)
         launch('dbw_texture_prep_fwd_sets', (0, 1, 2), st)
-        # ---- vertices ----
-        nbv = m._bkg_verts.shape[0]
-        ngv = m._ground_base.shape[0]
-        key = (float(S_w), m.R_world._version, m.T_world._version, m.R_world.data_ptr())
-        if self._env_verts is None or self._env_key != key:          # the sky dome is constant: written once
-            self._env_verts = torch.empty(nbv + ngv, 3, device=dev)
-            self._env_verts[:nbv] = ((m._bkg_verts * S_w) @ R_w + T_w)
-            self._env_key = key
-        env_verts = self._env_verts
-        _lib.call('dbw_posed_mesh_fwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w), _p(T_w),
-                  env_verts.data_ptr() + nbv * 12, st)
-        # ---- regularisers: value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405).  They only need the
-        # parameters, opacities and maps prepared above, and ~10 short kernels would otherwise sit in front of the backward: they run on
-        # a side stream next to the render passes and are joined before the parameter gradients are finished ----
-        cur = torch.cuda.current_stream(dev)
-        side = cur
-        if self.overlap_regularisers:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            side = self._side
-            side.wait_stream(cur)
-        st_main, st = st, side.cuda_stream
+        maps_ready = None
+        if side is not cur:
+            maps_ready = torch.cuda.Event()
+            maps_ready.record(side)
+
+        # ---- main: the env pass ----
+        torch.cuda.set_stream(cur)
+        st = st_main
+        if maps_ready is not None:
+            cur.wait_event(maps_ready)
+        p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
+                                                              desc_e, env_maps, None, m.renderer_env._bg, 1, stage=2, state=env_state)
+
+        # ---- side, next to the env pass: the blocks' vertices, their projection and the per-face set-up of the fg pass (boxes, face +
+        # shading records, bins); the regularisers: value + gradient in one pass, weights folded into the kernels' scales
+        # (dbw.py:373-405) -- they only need the parameters, opacities and maps prepared above ----
         torch.cuda.set_stream(side)
-        renderer = m.renderer_fine if fine else m.renderer
-        R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
-        Kmat = renderer.cameras.K[0].to(dev).contiguous()
-        Fe, Ff = m._env_faces.shape[0], nb * m.BNF
+        st = st_side
         desc_f = m._block_map_desc_all if decim_blocks == 1 else m._block_map_desc_dec
         texbins = None if decim_blocks > 1 else (m._block_bin_base, m._block_bin_info, nb * m._bins_per_block)
         cfg_f = renderer._cfg(Ff, lds_aggregate=decim_blocks > 1, texbins=texbins)
-        # the blocks' vertices and their projection are independent of the env pass: next to it, not in front of the fg pass
         blk_verts = torch.empty(nb * nv, 3, device=dev)
         _lib.call('dbw_sq_blocks_fwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
                   float(m.scale_min), float(S_w), _p(R_w), _p(T_w), _p(blk_verts), st)
         cl_f = ops.project_clip(blk_verts, m._block_faces_all, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
         fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
-        # ... and so is the per-face set-up of the fg pass (boxes, face + shading records, bins)
         fg_state = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, renderer._bg,
                                             None, None, 0.0, stage=1)
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
@@ -134,14 +163,10 @@ class NativeStep:
             _lib.call('dbw_overlap_loss', _p(u), u.shape[1], _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(alpha_full), nb,
                       float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
                       vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
+
+        # ---- main: the fg pass, ending in the composite + MSE ----
         torch.cuda.set_stream(cur)
         st = st_main
-        # ---- the two render passes; the fg pass ends in the composite + MSE ----
-        cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True)
-        desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
-        cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
-        p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
-                                                              desc_e, env_maps, None, m.renderer_env._bg, 1)
         count = float(imgs.numel() if global_count is None else global_count)
         scale = float(w['rgb']) / count
         if side is not cur:
@@ -150,8 +175,8 @@ class NativeStep:
                                                                       blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
                                                                       state=fg_state)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
-        # kernels (projection backward, pose / shape, textures, opacities).  The env backward + tail go to the side stream: either tail
-        # then runs next to the other pass's big kernel instead of alone at the end of the step ----
+        # kernels (projection backward, pose / shape, textures, opacities), on the two streams: the tail of the pass that finishes first
+        # runs next to the other pass's big kernel instead of alone at the end of the step ----
         def fg_backward(st):
             g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
                                                      cfg_f, renderer._bg, 2, g_fg, B, None)
@@ -174,11 +199,13 @@ class NativeStep:
             return g_env_maps, g_fvc_e, g_env_verts
 
         if side is not cur:
+            # the env chain is the one that finishes last: it stays on the main stream, so that Adam follows it without a cross-stream
+            # wait on a signal that is still pending (~13 us); the fg chain is enqueued first and gets the GPU first
             side.wait_stream(cur)                                      # g_fg, g_env written
             torch.cuda.set_stream(side)
-            keep_e = env_backward(side.cuda_stream)
+            keep_f = fg_backward(side.cuda_stream)
             torch.cuda.set_stream(cur)
-            keep_f = fg_backward(st_main)
+            keep_e = env_backward(st_main)
             cur.wait_stream(side)
         else:
             keep_f = fg_backward(st_main)
@@ -196,7 +223,7 @@ class LazyLosses(dict):
 
     def __init__(self, vals, part, scale, names):
         super().__init__()
-        self._vals, self._part, self._scale, self._names, self._done = vals.clone(), part, scale, names, False
+        self._vals, self._part, self._scale, self._names, self._done = vals, part, scale, names, False
 
     def _finish(self):
         if not self._done:

@@ -252,37 +252,45 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 # The whole Renderer.forward as ONE autograd node: verts/maps/faces_alpha -> (B,4,H,W)
 # ---------------------------------------------------------------------------------------------------------------------
 class RenderCfg:
-    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins')
+    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins', 'const_faces')
 
-    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None):
+    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None, const_faces=0):
         self.lds_aggregate = lds_aggregate
+        self.const_faces = int(const_faces)   # the first that many faces have constant vertices (sky dome): no geometry gradient for them
         self.texbins = texbins          # (bin_base, bin_info, nbins): texture-space binning of texel gradients when not aggregating
         self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
         self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
 
 
-def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None):
+def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None, stage=0, state=None):
+    """stage 1: only the per-face set-up of the pass (needs no texture values) -> `state` for the stage-2 call that renders."""
     TILED_FRAGMENTS = globals()['TILED_FRAGMENTS'] if tiled is None else tiled
     dev = fvc.device
     Ft = fvc.shape[0]
-    ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
-    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    if TILED_FRAGMENTS:     # internal 8x8-tile planar layout (include/dbw_hip.h: frag_layout = 1)
-        ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
-        p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
-        bary = torch.empty(B, ty, tx, cfg.K, 8 if int(TILED_FRAGMENTS) == 2 else 3, 64, dtype=torch.float32, device=dev)
-        dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
+    if stage == 2:
+        ws, ws_bytes, out = state
     else:
-        p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
-        bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
-        dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
-    img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+        ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        if TILED_FRAGMENTS:     # internal 8x8-tile planar layout (include/dbw_hip.h: frag_layout = 1)
+            ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
+            p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
+            bary = torch.empty(B, ty, tx, cfg.K, 8 if int(TILED_FRAGMENTS) == 2 else 3, 64, dtype=torch.float32, device=dev)
+            dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
+        else:
+            p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
+            bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
+            dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
+        img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+        out = (p2f, bary, dists, img)
+    p2f, bary, dists, img = out
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
-              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), _stream(fvc))   # 0 / 1 / 2
-    return p2f, bary, dists, img
+              _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), int(stage),
+              _stream(fvc))   # frag_layout 0 / 1 / 2
+    return (ws, ws_bytes, out) if stage == 1 else out
 
 
 class _RenderScene(torch.autograd.Function):
@@ -359,7 +367,8 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                    (B, cfg.H, cfg.W, cfg.K)),
               _ptr(g_img), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
-              int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, _ptr(gscale), _stream(fvc))
+              int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, int(cfg.const_faces), _ptr(gscale),
+              _stream(fvc))
     if records is not None:
         _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
     return g_maps, g_alpha, g_fvc

@@ -108,12 +108,12 @@ class ShardedTrainStep:
             ops.ARENA.enabled = True
             try:
                 ops.ARENA.begin_step(self.params.flat.device)
-                self.params.zero_grad()
                 native = self.native is not None and self.model.training and inp['imgs'].shape[0] > 0 and self.native.supported()
                 if native:
-                    with torch.no_grad():
-                        losses = self.native(inp, self.model._global_count)
+                    with torch.no_grad():         # (zeroes the gradient buffer itself: on its side stream, off the critical path)
+                        losses = self.native(inp, self.model._global_count, zero_grad=self.params.zero_grad)
                 else:
+                    self.params.zero_grad()
                     losses = self.model(inp, labels)
                     losses['total'].backward()
             finally:

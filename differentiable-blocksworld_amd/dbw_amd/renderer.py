@@ -95,12 +95,12 @@ class Renderer(nn.Module):
     def update_cameras(self, **kwargs):
         self.cameras = self.get_copy_cameras(**kwargs)
 
-    def _cfg(self, n_faces, viz=False, lds_aggregate=False, texbins=None):
+    def _cfg(self, n_faces, viz=False, lds_aggregate=False, texbins=None, const_faces=0):
         H, W = self.img_size
         if viz:   # exact anti-aliased rendering for visualisation (renderer.py:56-60): 4x res, sigma 0, 1 face per pixel
             return ops.RenderCfg(H * 4, W * 4, 1, 0.0, self.z_clip, self.perspective_correct, False, n_faces, EPS)
         return ops.RenderCfg(H, W, self.faces_per_pixel, self.sigma, self.z_clip, self.perspective_correct, self.detach_bary,
-                             n_faces, EPS, lds_aggregate, texbins)
+                             n_faces, EPS, lds_aggregate, texbins, const_faces)
 
     def render_packed(self, scene, R, T, faces_alpha=None, viz_purpose=False, lds_aggregate=False):
         """scene: PackedScene shared by the len(R) views.  lds_aggregate: hint for the backward pass (pays when neighbouring
@@ -110,7 +110,7 @@ class Renderer(nn.Module):
                                       'update_cameras(K=...) first (dbw.py:204-208)')
         Kmat = self.cameras.K[0].to(R.device).contiguous()
         R, T = R.float().contiguous(), T.float().contiguous()
-        cfg = self._cfg(scene.faces.shape[0], viz_purpose, lds_aggregate, getattr(scene, 'texbins', None))
+        cfg = self._cfg(scene.faces.shape[0], viz_purpose, lds_aggregate, getattr(scene, 'texbins', None), getattr(scene, 'const_faces', 0))
         if viz_purpose:
             with torch.no_grad():
                 img = ops.render_scene(scene.verts, scene.maps, None, scene.faces, R, T, Kmat, scene.face_uvs, scene.face_map,

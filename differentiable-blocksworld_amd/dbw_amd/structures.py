@@ -127,6 +127,7 @@ class PackedScene:
     def __init__(self, verts, faces_i32, face_uvs, face_map, map_desc, maps, texbins=None):
         self.verts, self.faces, self.face_uvs, self.face_map, self.map_desc, self.maps = verts, faces_i32, face_uvs, face_map, map_desc, maps
         self.texbins = texbins      # optional (bin_base, bin_info, nbins) from describe_bins
+        self.const_faces = 0        # the first that many faces have constant vertices: the backward skips their geometry gradient
 
     @staticmethod
     def join(scenes):

@@ -151,7 +151,7 @@ int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, co
                          const float *maps, const float *faces_alpha, int alpha_len, int N, int64_t F_total, int H, int W,
                          int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
                          int32_t *pix_to_face, float *bary, float *dists, float *image, void *workspace,
-                         size_t workspace_bytes, int frag_layout, dbw_stream_t stream);
+                         size_t workspace_bytes, int frag_layout, int stage, dbw_stream_t stream);
 
 /* The same forward for the training path's soft pass (uv-fragments, frag_layout 2, K > 1) with the decoupled composite and the MSE
  * (dbw.py:223,366-367) as its epilogue: instead of storing its image the pass composites it in registers over env_image (N,4,H,W:
@@ -182,6 +182,9 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
  * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins) zeroed by the caller; bin_records
  * nbins*bin_cap*32 bytes); dbw_texbin_reduce then sums every bin in LDS and adds it to grad_maps.  Records that do not fit
  * (bin overflow, circular-wrap footprints) fall back to atomics, so the result is exact either way.  All NULL / 0 = off.
+ * const_geometry_faces: the first that many faces of the scene (original indexing) have constant vertices -- the sky dome of the env
+ * scene (dbw.py:74-76: a buffer, not a parameter) -- so nothing is propagated through their barycentrics and their rows of
+ * grad_face_verts_c stay untouched; 0 = every face gets its geometry gradient.
  * grad_scale: DEVICE scalar every value of grad_image is multiplied by (the upstream gradient of a loss node, so that no
  * elementwise pass over the image-sized gradient is needed), NULL = 1. */
 int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
@@ -191,7 +194,7 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
                          int frag_layout, const int32_t *bin_base, int32_t *bin_cursor, void *bin_records, int bin_cap,
-                         const float *grad_scale, dbw_stream_t stream);
+                         int const_geometry_faces, const float *grad_scale, dbw_stream_t stream);
 /* bin_info (nbins,4) int32 = {offset of the bin's map in floats, stored width, stored height, tile_y << 16 | tile_x}. */
 int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap, int nbins,
                       float *grad_maps, dbw_stream_t stream);
