@@ -82,13 +82,14 @@ def kernel_breakdown(model, inp, reps=5):
         passes = [('fg', model.renderer_fine if fine else model.renderer, blocks, alpha, bool(model._blocks_decimated)),
                   ('env', model.renderer_env, model.build_env_scene(), None, True)]
     for tag, r, scene, alpha, agg in passes:
-        cfg = r._cfg(scene.faces.shape[0], lds_aggregate=agg)
+        cfg = r._cfg(scene.faces.shape[0], lds_aggregate=agg, const_faces=getattr(scene, 'const_faces', 0))
         K = cfg.K
         Kmat = r.cameras.K[0].contiguous()
         verts, maps = scene.verts.detach(), scene.maps.detach()
         cl = ops.project_clip(verts, scene.faces, inp['R'], inp['T'], Kmat, cfg.eps, cfg.z_clip, cfg.persp)
         fvc = cl['face_verts'].view(-1, 3, 3)
-        mode = 2 if (cfg.detach_bary and ops.UV_FRAGMENTS) else 1          # fragment layout the training step uses for this pass
+        # fragment layout the training step uses for this pass
+        mode = 2 if (cfg.detach_bary and ops.UV_FRAGMENTS) else ops.hard_layout(cfg, alpha, scene.map_desc)
         fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode)
         p2f, bary, dists, img = fwd()
         g_img = torch.rand_like(img)

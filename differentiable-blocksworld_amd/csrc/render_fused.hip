@@ -96,8 +96,8 @@ __device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMA
             // internal layouts: empty slots carry only the -1 face id (the backward never reads the rest; a wave whose 64
             // pixels are all empty at this depth issues no store at all); the PyTorch3D-shaped layout 0 is filled with -1
             if (valid || A.tiled == 0) {
-                dists[o.s] = v.x;
-                if (A.tiled != 2) {
+                if (A.tiled != 3) dists[o.s] = v.x;           // (layout 3: a kept pixel of a hard pass lies inside its face, that is all)
+                if (A.tiled != 2 && A.tiled != 3) {
                     bary[o.b] = v.y;
                     bary[o.b + o.bstride] = v.z;
                     bary[o.b + 2 * o.bstride] = v.w;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMA
                 Frag fr;
                 const float bc[3] = {v.y, v.z, v.w};
                 decode_frag(A, n, fik, bc, v.x, fr);
-                if (A.tiled == 2) {       // hand the resolved shading inputs to the backward pass
+                if (A.tiled == 2 || A.tiled == 3) {       // hand the resolved shading inputs to the backward pass
                     bary[o.b] = fr.u;
                     bary[o.b + o.bstride] = fr.v;
                     bary[o.b + 2 * o.bstride] = __int_as_float(fr.j | (fr.map << 20));
@@ -323,8 +323,10 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     int rc = dbw_fill_shade_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                                  faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
     if (rc) return rc;
-    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
-    DBW_REQUIRE(frag_layout != 2 || F < (1 << 20), "frag_layout 2 packs the face id in 20 bits");
+    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 3, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar), 2 (planar, uv) or 3 (planar, hard uv)");
+    DBW_REQUIRE(frag_layout < 2 || F < (1 << 20), "frag_layouts 2 and 3 pack the face id in 20 bits");
+    DBW_REQUIRE(frag_layout != 3 || (K == 1 && sigma == 0.f && blur_radius == 0.f && !faces_alpha),
+                "frag_layout 3 is the hard single-layer pass: K == 1, sigma == 0, no faces_alpha");
     DBW_REQUIRE(frag_layout != 2 || F_total < (1LL << FRAG_COUNT_SHIFT), "frag_layout 2 packs the clipped face id in 26 bits");
     A.tiled = frag_layout;
     if (mse) {

@@ -81,7 +81,12 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
 constexpr int PROF_BLOCKS = 1 << 16;
 __device__ unsigned long long g_prof[PROF_BLOCKS * 8];
 #define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#define PROF_ADD(i, a, b) if (!SINGLE && (threadIdx.x & 63) == 0 && blockIdx.x < PROF_BLOCKS) atomicAdd(&g_prof[(size_t)blockIdx.x * 8 + (i)], (b) - (a))
+#ifdef DBW_PROFILE_BWD_K1
+#define PROF_SEL SINGLE
+#else
+#define PROF_SEL !SINGLE
+#endif
+#define PROF_ADD(i, a, b) if (PROF_SEL && (threadIdx.x & 63) == 0 && blockIdx.x < PROF_BLOCKS) atomicAdd(&g_prof[(size_t)blockIdx.x * 8 + (i)], (b) - (a))
 #else
 #define PROF_T(x)
 #define PROF_ADD(i, a, b)
@@ -786,6 +791,122 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
                      alpha_len, N, H, W, K, F, sigma, background3);
 }
 
+
+// ---- the hard single-layer pass (sky + ground), specialised: hard uv-fragments (layout 3) ---------------------------------------------
+// K = 1, sigma = 0, no learned opacity, texel gradients through the LDS hash (magnified / decimated maps).  A kept pixel lies inside
+// its face, its opacity is 1 and nothing flows through the distance, so the forward leaves (clipped face, u, v, face | map) per pixel
+// and this kernel needs no table chain at all for the texture gradient: four coalesced loads, the footprint, the texel table.  The
+// geometry gradient (through the barycentrics: uv -> clipped barycentrics -> perspective correction -> vertices) is only computed for
+// faces whose vertices are variables (geom_begin: the sky dome is a constant), from the face tables, recomputing the barycentrics
+// from the pixel position as the rasteriser backward does anyway.  Same mathematics as shade_blend_bwd_kernel<true, false, true>.
+__global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
+                                                            float *__restrict__ gmaps, const float *__restrict__ fv,
+                                                            float *__restrict__ gfv, int want_bary, int persp) {
+    extern __shared__ __attribute__((aligned(16))) float s_hard[];
+    TexAgg tex_agg;
+    FaceAgg face_agg;
+    tex_agg.bind(s_hard);
+    tex_agg.clear(threadIdx.x, NT);
+    face_agg.bind((char *)s_hard + TexAgg::BYTES);
+    face_agg.clear(threadIdx.x, NT);
+    int n, xi, yi;
+    if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    __syncthreads();
+    const bool in_img = xi < A.W && yi < A.H;
+    const int lane = threadIdx.x & 63;
+    const FragAddr o = frag_addr(A, n, yi, xi, 0);
+    const int fc = in_img ? A.p2f[o.s] : -1;
+    const bool valid = fc >= 0;
+    float u = 0.f, v = 0.f, gr = 0.f, gg = 0.f, gbl = 0.f;
+    int jm = 0;
+    if (valid) {
+        u = A.bary[o.b]; v = A.bary[o.b + o.bstride]; jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
+        const long long plane = (long long)A.H * A.W;
+        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        const float gs = A.gscale ? *A.gscale : 1.f;
+        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs;
+    }
+    const int j = jm & 0xfffff, map = jm >> 20;
+    const float gc[3] = {gr, gg, gbl};               // blend weight of a hard fragment = 1
+    const bool tex = valid && (gr != 0.f || gg != 0.f || gbl != 0.f);
+    Sample s;
+    s.a00 = s.a01 = s.a10 = s.a11 = 0;
+    s.w00 = s.w01 = s.w10 = s.w11 = 0.f;
+    if (__ballot(tex) != 0ull) {
+        const int *md = A.map_desc + (valid ? map : 0) * 8;
+        footprint_desc(u, v, md[0], md[1], md[2], md[3], md[4], md[5], s);
+        // colour -> texels: merge the footprint's texels that fall into the same stored cell; 4 horizontally adjacent pixels usually
+        // share their footprint -- sum them in registers (DPP) and let the first lane of the four update the table
+        float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
+        if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
+        if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
+        if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
+        else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
+        else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
+        const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
+        const float wt[4] = {w00, w01, w10, w11};
+        const int same4 = quad_and((tex && s.a00 == quad_first(s.a00) && s.a11 == quad_first(s.a11)) ? 1 : 0);
+        const bool lead = !same4 || (lane & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float val[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) { const float qs = quad_sum(tex ? val[c3] : 0.f); val[c3] = same4 ? qs : val[c3]; }
+            const bool on = tex && lead && (same4 ? (val[0] != 0.f || val[1] != 0.f || val[2] != 0.f) : wt[q] != 0.f);
+            tex_agg.add_wave(gmaps, (int)((unsigned)ad[q] / 3u), val, on);
+        }
+    }
+    // colour -> uv -> barycentrics -> vertices, for the faces whose vertices are variables
+    const bool geom = tex && want_bary != 0 && j >= A.geom_begin;
+    float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool has_g9 = false;
+    if (__ballot(geom) != 0ull) {
+        if (geom) {
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float t00 = A.maps[s.a00 + ch], t01 = A.maps[s.a01 + ch], t10 = A.maps[s.a10 + ch], t11 = A.maps[s.a11 + ch];
+                gix += gc[ch] * ((t01 - t00) * s.wy0 + (t11 - t10) * s.wy1);
+                giy += gc[ch] * ((t10 - t00) * s.wx0 + (t11 - t01) * s.wx1);
+            }
+            const float gu = gix * s.dudx, gv = giy * s.dvdy;
+            const float *uv = A.face_uvs + (long long)j * 6;
+            const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
+            int cd = -1;
+            float w2 = 0.f, w3 = 0.f;
+            if (A.c2o) {
+                cd = A.code[fc]; w2 = A.cw[(long long)fc * 2]; w3 = A.cw[(long long)fc * 2 + 1];
+            }
+            float gb[3] = {0.f, 0.f, 0.f};
+            convert_bary_bwd(cd, w2, w3, go, gb);
+            if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
+                has_g9 = true;
+                f2 pndc;
+                pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
+                pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
+                const float *q = fv + (long long)fc * 9;
+                const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
+                const float z0 = q[2], z1 = q[5], z2 = q[8];
+                const f3 bary0 = bary_fwd(pndc, a, b, c);
+                const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
+                f3 gg3{gb[0], gb[1], gb[2]};
+                gg3 = clip_bwd(bp, gg3);
+                float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
+                if (persp) gg3 = persp_bwd(bary0, z0, z1, z2, gg3, pz0, pz1, pz2);
+                f2 e0, e1, e2;
+                bary_bwd(pndc, a, b, c, gg3, e0, e1, e2);
+                g9[0] = e0.x; g9[1] = e0.y; g9[2] = pz0;
+                g9[3] = e1.x; g9[4] = e1.y; g9[5] = pz1;
+                g9[6] = e2.x; g9[7] = e2.y; g9[8] = pz2;
+            }
+        }
+        face_agg.add_wave(gfv, valid ? fc : 0, g9, has_g9);
+    }
+    __syncthreads();
+    tex_agg.flush(gmaps, threadIdx.x, NT);
+    face_agg.flush(gfv, threadIdx.x, NT);
+}
+
 static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *grad_image, float *grad_maps,
                       float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate, const float *fv,
                       float *gfv, int want_bary, int persp, hipStream_t s) {
@@ -826,6 +947,11 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
         }
         hipLaunchKernelGGL(render_bwd_uv_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds_uv, s, A, total, grad_image, grad_maps, grad_faces_alpha, fv, gfv);
         return dbw_check_launch("render_bwd_uv_kernel");
+    }
+    if (A.tiled == 3) {       // hard uv-fragments: validated by the caller (K == 1, sigma == 0, no opacities, LDS aggregation)
+        hipLaunchKernelGGL(render_bwd_hard_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAgg::BYTES, s, A, total, grad_image,
+                           grad_maps, fv, gfv, want_bary, persp);
+        return dbw_check_launch("render_bwd_hard_kernel");
     }
     if (fused && A.bin_records)
         hipLaunchKernelGGL((shade_blend_bwd_kernel<true, true, false>), dim3(dbw_xcd_grid(total)), dim3(NT), lds, s, A, total, grad_image, grad_maps,
@@ -875,8 +1001,10 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     if (rc) return rc;
     DBW_REQUIRE(grad_image && grad_maps && face_verts_c && grad_face_verts_c, "null pointer");
     DBW_REQUIRE(!grad_faces_alpha || faces_alpha, "grad_faces_alpha without faces_alpha");
-    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 2, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar) or 2 (planar, uv)");
+    DBW_REQUIRE(frag_layout >= 0 && frag_layout <= 3, "frag_layout must be 0 (N,H,W,K), 1 (8x8-tile planar), 2 (planar, uv) or 3 (planar, hard uv)");
     DBW_REQUIRE(frag_layout != 2 || detach_bary, "frag_layout 2 carries no barycentrics: only valid with detach_bary");
+    DBW_REQUIRE(frag_layout != 3 || (K == 1 && sigma == 0.f && !faces_alpha && lds_aggregate && F < (1 << 20)),
+                "frag_layout 3 is the hard single-layer pass: K == 1, sigma == 0, no faces_alpha, lds_aggregate, F < 2^20");
     DBW_REQUIRE(const_geometry_faces >= 0 && const_geometry_faces <= F, "const_geometry_faces must lie in [0, F]");
     A.tiled = frag_layout;
     A.gscale = grad_scale;

@@ -87,8 +87,9 @@ class NativeStep:
         cfg_e = m.renderer_env._cfg(Fe, lds_aggregate=True, const_faces=m._n_bkg_faces)   # the sky dome's vertices are constants
         desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
         cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
+        lay_e = ops.hard_layout(cfg_e, None, desc_e)                  # 3: hard uv-fragments
         env_state = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps,
-                                          None, m.renderer_env._bg, 1, stage=1)
+                                          None, m.renderer_env._bg, lay_e, stage=1)
 
         # ---- side: zero the gradients, opacities (dbw.py:297-311), textures: sigmoid (+ decimation to cell resolution); `sig` = the
         # undecimated maps of the TV term ----
@@ -132,7 +133,7 @@ class NativeStep:
         if maps_ready is not None:
             cur.wait_event(maps_ready)
         p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
-                                                              desc_e, env_maps, None, m.renderer_env._bg, 1, stage=2, state=env_state)
+                                                              desc_e, env_maps, None, m.renderer_env._bg, lay_e, stage=2, state=env_state)
 
         # ---- side, next to the env pass: the blocks' vertices, their projection and the per-face set-up of the fg pass (boxes, face +
         # shading records, bins); the regularisers: value + gradient in one pass, weights folded into the kernels' scales
@@ -190,7 +191,7 @@ class NativeStep:
 
         def env_backward(st):
             g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
-                                                    m.renderer_env._bg, 1, g_env, B, None)
+                                                    m.renderer_env._bg, lay_e, g_env, B, None)
             g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
             _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
                       g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)

@@ -263,6 +263,17 @@ class RenderCfg:
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
 
 
+HARD_UV_FRAGMENTS = True  # hard single-layer passes (K = 1, sigma = 0) store (u, v, face|map) per pixel: frag_layout 3
+
+
+def hard_layout(cfg, fa, map_desc):
+    """frag_layout of a fused pass that keeps barycentric fragments by default: 3 for the hard single-layer pass whose backward goes
+    through the LDS texel table (include/dbw_hip.h), else 1."""
+    ok = (HARD_UV_FRAGMENTS and cfg.K == 1 and cfg.sigma == 0.0 and fa is None and cfg.lds_aggregate and cfg.F < (1 << 20)
+          and map_desc.shape[0] < (1 << 11))
+    return 3 if ok else 1
+
+
 def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None, stage=0, state=None):
     """stage 1: only the per-face set-up of the pass (needs no texture values) -> `state` for the stage-2 call that renders."""
     TILED_FRAGMENTS = globals()['TILED_FRAGMENTS'] if tiled is None else tiled
@@ -305,6 +316,8 @@ class _RenderScene(torch.autograd.Function):
         ctx.tiled = int(FUSED_FORWARD and FUSED_BACKWARD and TILED_FRAGMENTS)
         if ctx.tiled and UV_FRAGMENTS and cfg.detach_bary and cfg.F < (1 << 20) and map_desc.shape[0] < (1 << 11):
             ctx.tiled = 2          # fragments carry (u, v, face|map) instead of barycentrics
+        elif ctx.tiled:
+            ctx.tiled = hard_layout(cfg, fa, map_desc)
         if FUSED_FORWARD:
             p2f, bary, dists, img = _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps_c, fa, bg, ctx.tiled)
         else:
@@ -421,7 +434,8 @@ class _DecoupledRenderMSE(torch.autograd.Function):
         B, dev = R.shape[0], ve.device
         # env pass: barycentric fragments (layout 1), image kept (the fg epilogue reads it)
         cl_e = project_clip(ve, faces_e, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
-        p2f_e, bary_e, dists_e, img_e = _render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, uv_e, fmap_e, desc_e, me, None, bg_e, 1)
+        lay_e = ctx.lay_e = hard_layout(cfg_e, None, desc_e)
+        p2f_e, bary_e, dists_e, img_e = _render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, uv_e, fmap_e, desc_e, me, None, bg_e, lay_e)
         # fg pass with the composite + MSE epilogue
         cl_f = project_clip(vf, faces_f, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
         p2f, bary, dists, part, g_fg, g_env = render_fwd_fused_mse(cl_f, B, cfg_f, uv_f, fmap_f, desc_f, mf, fa, bg_f, img_e, imgs, scale)
@@ -441,7 +455,7 @@ class _DecoupledRenderMSE(torch.autograd.Function):
         gs = go.detach().to(torch.float32).reshape(1).contiguous()
         gm_f, ga, g_fvc_f = _fused_bwd(p2f, bary, dists, cl_f, uv_f, fmap_f, desc_f, mf, fa, cfg_f, bg_f, 2, g_fg, B, gs)
         gv_f = project_clip_bwd(vf, faces_f, R, T, Kmat, cl_f, g_fvc_f, cfg_f.eps, cfg_f.z_clip, cfg_f.persp) if ctx.needs_input_grad[2] else None
-        gm_e, _, g_fvc_e = _fused_bwd(p2f_e, bary_e, dists_e, cl_e, uv_e, fmap_e, desc_e, me, None, cfg_e, bg_e, 1, g_env, B, gs)
+        gm_e, _, g_fvc_e = _fused_bwd(p2f_e, bary_e, dists_e, cl_e, uv_e, fmap_e, desc_e, me, None, cfg_e, bg_e, ctx.lay_e, g_env, B, gs)
         gv_e = project_clip_bwd(ve, faces_e, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp) if ctx.needs_input_grad[0] else None
         return (gv_e, gm_e, gv_f, gm_f, ga) + (None,) * 11
 

@@ -144,7 +144,10 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
  * the sampled texture colour, transmittance in front of the fragment) -- everything the blend needs already resolved --,
  * and the pix_to_face entry of a pixel's first layer = id | fragment count << 26; for passes whose barycentrics carry no
  * gradient (detach_bary): the backward then needs no per-face table gathers, no texel fetch and no front-to-back pass
- * (F < 2^20, F_total < 2^26, maps < 2^11). */
+ * (F < 2^20, F_total < 2^26, maps < 2^11); 3 = layout 1 whose three `bary` planes hold (u, v, bitcast(face | map << 20)) and whose
+ * `dists` are not written, for the HARD single-layer pass (K == 1, sigma == 0, no faces_alpha; F < 2^20, maps < 2^11): a kept pixel
+ * lies inside its face and its opacity is 1, so that is all the backward needs for the texture gradient, and it rebuilds the
+ * barycentrics from the pixel position for the geometry gradient (dbw_render_bwd_fused then requires lds_aggregate != 0). */
 int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                          const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
                          int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,

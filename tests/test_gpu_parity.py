@@ -260,7 +260,7 @@ def _packed(scene, pads=None):
                        scene['face_map'].to(torch.int32).to(DEV), desc, flat)
 
 
-def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_clip=0.001, bg=(0., 0., 0.), seed=0):
+def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_clip=0.001, bg=(0., 0., 0.), seed=0, lds=False):
     """-> dict of (hip, oracle) pairs: image, grad verts, grad maps, grad alpha."""
     verts_o = scene['verts'].detach().clone().requires_grad_(True)
     maps_o = [m.detach().clone().requires_grad_(True) for m in scene['maps']]
@@ -275,7 +275,7 @@ def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_
     ps.verts.requires_grad_(True)
     ps.maps.requires_grad_(True)
     fa_h = None if faces_alpha is None else faces_alpha.detach().to(DEV).requires_grad_(True)
-    cfg = ops.RenderCfg(H, W, K, sigma, z_clip, True, detach_bary, scene['faces'].shape[0])
+    cfg = ops.RenderCfg(H, W, K, sigma, z_clip, True, detach_bary, scene['faces'].shape[0], lds_aggregate=lds)
     img_h = ops.render_scene(ps.verts, ps.maps, fa_h, ps.faces, R.to(DEV), T.to(DEV), Kmat.to(DEV), ps.face_uvs, ps.face_map,
                              ps.map_desc, ops.make_bg(bg), cfg)
     (img_h * w.to(DEV)).sum().backward()
@@ -316,16 +316,48 @@ def test_render_fine_pass_no_alpha_matches_oracle():
         assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
 
 
-def test_render_env_hard_pass_with_clipping_matches_oracle():
+@pytest.mark.parametrize('rig', [(30.0, 4.82), (5.0, 1.5)])          # cameras looking down at the ground / seeing half sky, half ground
+@pytest.mark.parametrize('lds', [False, True])
+def test_render_env_hard_pass_with_clipping_matches_oracle(lds, rig):
     """env pass: sigma=0, 1 face per pixel, detach_bary=False -> geometry gradient only through barycentrics -> uv;
-    the camera sits inside the dome so z-clipping (cases 3/4 + barycentric back-conversion) is live."""
+    the camera sits inside the dome so z-clipping (cases 3/4 + barycentric back-conversion) is live.
+    lds=True is the training path's form: hard uv-fragments (frag_layout 3) + the specialised backward kernel."""
     m, R, T, Km = _model(seed=7, ts=16)
+    R, T, Km = O.synthetic_cameras(3, R_world=m.R_world[0], dist=2.8, elev_deg=rig[0], f_ndc=rig[1])
     with torch.no_grad():
         scene = m.build_env(True, False)
-    res = _render_both(scene, R, T, Km[0], 48, 64, 0.0, 1, False, None, bg=(0.1, 0.2, 0.3))
+    res = _render_both(scene, R, T, Km[0], 48, 64, 0.0, 1, False, None, bg=(0.1, 0.2, 0.3), lds=lds)
     for k, (a, b) in res.items():
         assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
     assert res['g_verts'][1].abs().max() > 0
+
+
+def test_constant_geometry_faces_get_no_vertex_gradient_and_the_others_the_same():
+    """const_faces (the sky dome's vertices are a buffer): the vertices only those faces use get no gradient, the gradient through
+    every other face and the texture gradient are unchanged -- both fused backward kernels of the hard pass."""
+    m, R, T, Km = _model(seed=7, ts=16)
+    R, T, Km = O.synthetic_cameras(3, R_world=m.R_world[0], dist=2.8, elev_deg=5.0, f_ndc=1.5)       # half sky, half ground
+    with torch.no_grad():
+        scene = m.build_env(True, False)
+    nsky = int((scene['face_map'] == 0).sum())
+    assert 0 < nsky < scene['faces'].shape[0] and bool((scene['face_map'][:nsky] == 0).all())
+    sky_only = torch.ones(scene['verts'].shape[0], dtype=torch.bool)
+    sky_only[scene['faces'][nsky:].reshape(-1).long()] = False
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    for lds in (False, True):
+        out = []
+        for cf in (0, nsky):
+            ps = _packed(scene)
+            ps.maps.requires_grad_(True)
+            ps.verts.requires_grad_(True)
+            cfg = ops.RenderCfg(48, 64, 1, 0.0, 0.001, True, False, scene['faces'].shape[0], lds_aggregate=lds, const_faces=cf)
+            img = ops.render_scene(ps.verts, ps.maps, None, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+            (img * torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)).sum().backward()
+            out.append((ps.maps.grad.cpu(), ps.verts.grad.cpu()))
+        assert rel_err(out[1][0], out[0][0]) < 1e-6
+        assert float(out[0][1][sky_only].abs().max()) > 0 and float(out[1][1][sky_only].abs().max()) == 0.0
+        # vertices shared by sky and ground faces do not exist (two meshes), so the ground's gradient is simply the same
+        assert rel_err(out[1][1][~sky_only], out[0][1][~sky_only]) < 1e-5
 
 
 def test_render_pixel_faces_bit_exact_through_clipping():
