@@ -101,7 +101,7 @@ def kernel_breakdown(model, inp, reps=5):
         if bins is not None:                                               # same sizing as ops._RenderScene.backward
             nbins = bins[2]
             cap = ops.texbin_capacity(B, H, W, K, nbins)
-            cursor_t = torch.zeros(nbins, dtype=torch.int32, device=fvc.device)
+            cursor_t = torch.zeros(nbins * ops.BIN_SUBCURSORS, dtype=torch.int32, device=fvc.device)   # one cursor per record sub-range
             records_t = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             bin_base, cursor, records = bins[0].data_ptr(), cursor_t.data_ptr(), records_t.data_ptr()
 
@@ -131,9 +131,10 @@ def kernel_breakdown(model, inp, reps=5):
         res[f'render_fwd_fused K={K} ({tag} pass)'] = (t(fwd), (20 * P * K + 16 * P) * B)
         res[f'render_bwd_fused K={K} ({tag} pass)'] = (t(bwd), (20 * P * K + 16 * P) * B)
         if bins is not None:
-            res[f'texbin_reduce_kernel ({tag} pass)'] = (t(reduce), 64 * int(cursor_t.clamp(max=cap).sum()))  # record write + read
+            sub_cap = cap // ops.BIN_SUBCURSORS
+            res[f'texbin_reduce_kernel ({tag} pass)'] = (t(reduce), 64 * int(cursor_t.clamp(max=sub_cap).sum()))  # record write + read
             BIN_STATS[tag] = {'records_per_fragment_slot': round(float(cursor_t.float().sum() / (B * P * K)), 4), 'bins': bins[2],
-                              'bins_overflowed': int((cursor_t > cap).sum()), 'capacity': cap}
+                              'subranges_overflowed': int((cursor_t > sub_cap).sum()), 'capacity': cap, 'subranges_per_bin': ops.BIN_SUBCURSORS}
     return res
 
 

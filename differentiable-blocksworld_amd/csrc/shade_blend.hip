@@ -92,7 +92,10 @@ __device__ unsigned long long g_prof[PROF_BLOCKS * 8];
 #define PROF_ADD(i, a, b)
 #endif
 constexpr int BIN_LOG2 = 7, BIN_SLOTS = 1 << BIN_LOG2;   // per-block hash table of touched texture bins
-constexpr int BIN_CHUNK = 8192;                           // records one texbin_reduce workgroup accumulates
+constexpr int BIN_SUB = DBW_BIN_SUBCURSORS;                 // sub-ranges (each with its own cursor) of a bin's record range: a hot bin takes
+                                                          // ~2000 reservations per launch, and returning atomics on ONE address serialise at
+                                                          // ~0.2 us each (0.43 ms of a 0.86 ms kernel); 16 addresses per bin make that 16 chains
+constexpr int BIN_SUB_PER_WG = 4;                         // sub-ranges one texbin_reduce workgroup accumulates
 
 // a footprint the bin's 33x33 LDS tile can hold: at most one row up and one column right of (r0, c0), no wrap
 __device__ __forceinline__ bool bin_regular(const Sample &s) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     if (BINNED) {
         __syncthreads();
         if (threadIdx.x < BIN_SLOTS && s_key[threadIdx.x] >= 0)
-            s_base[threadIdx.x] = atomicAdd(A.bin_cursor + s_key[threadIdx.x], s_cnt[threadIdx.x]);
+            s_base[threadIdx.x] = atomicAdd(A.bin_cursor + s_key[threadIdx.x] * BIN_SUB + (blockIdx.x & (BIN_SUB - 1)), s_cnt[threadIdx.x]);
         __syncthreads();
     }
     PROF_T(t_p1);
@@ -323,11 +326,11 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
                 // borders leaving the halo), hash-table misses and bin overflow fall through to the atomic path below
                 const int ent = s_ent[k * NT];
                 if (tex && ent >= 0) {
-                    const int h = ent >> 16, slot = s_base[h] + (ent & 0xffff);
-                    if (slot < A.bin_cap) {
+                    const int h = ent >> 16, slot = s_base[h] + (ent & 0xffff), sub_cap = A.bin_cap / BIN_SUB;
+                    if (slot < sub_cap) {
                         const unsigned packed = (unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) |
                                                 ((unsigned)(s.c1 - s.c0) << 11);
-                        int4 *dst = A.bin_records + ((long long)s_key[h] * A.bin_cap + slot) * 2;
+                        int4 *dst = A.bin_records + ((long long)s_key[h] * A.bin_cap + (long long)(blockIdx.x & (BIN_SUB - 1)) * sub_cap + slot) * 2;
                         dst[0] = make_int4((int)packed, __float_as_int(s.wx1), __float_as_int(s.wy1), __float_as_int(gc[0]));
                         dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
                         pending = false;
@@ -522,6 +525,19 @@ __device__ __forceinline__ float seg_dist_t(f2 p, f2 a, f2 b, float &tt) {
     return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
 
+// BINNED = true: the texel gradients of FULL-RESOLUTION maps leave as 32 B records in texture-space bins (see shade_blend_bwd_kernel's
+// BINNED instantiation and texbin_reduce_kernel) instead of going through the LDS texel table.  The generic kernel reserves the
+// record slots per workgroup, which costs it a counting pass over all layers; here a WAVE reserves the slots of one layer with one
+// returning atomic per distinct bin (an 8x8-pixel patch of one layer touches one to four 32x32-texel bins), software-pipelined one
+// layer ahead of its use: the fragments are loaded two layers ahead, the reservation for layer k - 1 is issued at the top of
+// iteration k and its result is first looked at in iteration k - 1.  A fragment carries T and its blend opacity, so whether it emits a
+// record at all (weight * pixel gradient != 0) is known without the back-to-front recurrences.
+struct BinRes {            // reservation of one fragment's record: bin, rank among the wave's records of that bin, the lane that holds
+    int bin, rank, leader, base, packed;   // `base` (it issued the atomic), and the footprint in the record's packed form
+    float wx1, wy1;
+};
+
+template <bool BINNED>
 __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                               float *__restrict__ gmaps, float *__restrict__ galpha,
                                                               const float *__restrict__ fv, float *__restrict__ gfv) {
@@ -530,9 +546,11 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     (void)SINGLE;
     TexAgg tex_agg;
     FaceAlphaAgg fa_agg;
-    tex_agg.bind(s_uvbwd);
-    fa_agg.bind((char *)s_uvbwd + TexAgg::BYTES);
-    tex_agg.clear(threadIdx.x, NT);
+    if (!BINNED) {
+        tex_agg.bind(s_uvbwd);
+        tex_agg.clear(threadIdx.x, NT);
+    }
+    fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
     fa_agg.clear(threadIdx.x, NT);
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
@@ -582,13 +600,57 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         }
         return r;
     };
+    // BINNED: footprint of a fragment in record form + the slot reservation of the wave's records of its layer (in the sub-range
+    // `sub` of the bin: neighbouring tiles, which hit the same bins at the same time, use different cursors)
+    const int sub = tile & (BIN_SUB - 1), sub_cap = BINNED ? A.bin_cap / BIN_SUB : 0;
+    auto reserve = [&](const Raw &r, bool ok) {
+        BinRes R;
+        R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f;
+        const float wgt = r.T * r.a;
+        const bool tex = ok && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f);
+        if (__ballot(tex) == 0ull) return R;
+        const int map = __float_as_int(r.jm) >> 20;
+        const int *md = A.map_desc + (tex ? map : 0) * 8;
+        Sample s;
+        footprint_desc(r.u, r.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
+        const bool on = tex && bin_regular(s);
+        if (on) {
+            R.bin = A.bin_base[map] + (s.r0 >> 5) * ((s.ws + 31) >> 5) + (s.c0 >> 5);
+            R.packed = (int)((unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) | ((unsigned)(s.c1 - s.c0) << 11));
+            R.wx1 = s.wx1; R.wy1 = s.wy1;
+        }
+        unsigned long long rem = __ballot(on);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        while (rem) {
+            const int L = __ffsll((long long)rem) - 1;
+            const int b = __shfl(R.bin, L, 64);
+            const bool mine = on && R.bin == b;
+            const unsigned long long mm = __ballot(mine);
+            if (mine) { R.rank = __popcll(mm & below); R.leader = L; }
+            if (lane == L) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));
+            rem &= ~mm;
+        }
+        return R;
+    };
     Raw nxt = load(kmax > 0 ? kmax - 1 : 0, kmax > 0 && kmax - 1 < cnt);
+    Raw nxt2 = nxt;
+    BinRes nres;
+    nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f;
+    if (BINNED) {
+        nxt2 = load(kmax > 1 ? kmax - 2 : 0, kmax > 1 && kmax - 2 < cnt);
+        if (kmax > 0) nres = reserve(nxt, kmax - 1 < cnt);
+    }
 #pragma unroll 1
     for (int k = kmax - 1; k >= 0; --k) {
         PROF_T(t_it);
         const Raw cur = nxt;
+        const BinRes cres = nres;
         const bool valid = k < cnt;
-        if (k > 0) nxt = load(k - 1, k - 1 < cnt);
+        if (BINNED) {
+            nxt = nxt2;
+            if (k > 1) nxt2 = load(k - 2, k - 2 < cnt);
+            if (k > 0) nres = reserve(nxt, k - 1 < cnt);
+        } else if (k > 0) nxt = load(k - 1, k - 1 < cnt);
         const float ak = valid ? cur.a : 0.f, Tk = valid ? cur.T : 1.f;
         const float ga = valid ? Tk * (gr * (cur.c0 - U0) + gg * (cur.c1 - U1) + gbl * (cur.c2 - U2) + gA * Vb) : 0.f;
         const float wgt = Tk * ak;
@@ -601,12 +663,40 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         // geometric alpha e = exp(-max(d, 0) / sigma) (the opacity gradient is ga * e), d/d dist of the blend opacity for d >= 0
         const float e = A.sigma == 0.f ? (cur.d <= 0.f ? 1.f : 0.f) : __expf(-(cur.d > 0.f ? cur.d : 0.f) * A.inv_sigma);
         const float gd = (valid && A.sigma != 0.f && cur.d >= 0.f) ? ga * ak * -A.inv_sigma : 0.f;
-        // colour -> texels of the decimated map: the bilinear footprint's texels that fall into the same stored cell are merged
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
         PROF_T(t_a);
         PROF_ADD(2, t_it, t_a);
-        if (__ballot(tex) != 0ull) {
+        if (BINNED) {
+            // colour -> one record in the fragment's texture bin; irregular footprints (circular wrap, clamped borders leaving the
+            // bin's halo) and bin overflow take the atomic path, so the result is exact either way
+            if (__ballot(tex) != 0ull) {
+                const int base = __shfl(cres.base, cres.leader, 64);
+                bool pending = tex;
+                if (tex && cres.bin >= 0) {
+                    const int slot = base + cres.rank;
+                    if (slot < sub_cap) {
+                        int4 *dst = A.bin_records + ((long long)cres.bin * A.bin_cap + (long long)sub * sub_cap + slot) * 2;
+                        dst[0] = make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0]));
+                        dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                        pending = false;
+                    }
+                }
+                if (pending) {
+                    const int *md = A.map_desc + map * 8;
+                    Sample s;
+                    footprint_desc(cur.u, cur.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        unsafeAtomicAdd(gmaps + s.a00 + ch, gc[ch] * s.w00);
+                        unsafeAtomicAdd(gmaps + s.a01 + ch, gc[ch] * s.w01);
+                        unsafeAtomicAdd(gmaps + s.a10 + ch, gc[ch] * s.w10);
+                        unsafeAtomicAdd(gmaps + s.a11 + ch, gc[ch] * s.w11);
+                    }
+                }
+            }
+        } else if (__ballot(tex) != 0ull) {
+            // colour -> texels of the decimated map: the bilinear footprint's texels that fall into the same stored cell are merged
             const int *md = A.map_desc + (valid ? map : 0) * 8;
             Sample s;
             footprint_desc(cur.u, cur.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
@@ -657,11 +747,11 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     PROF_T(t_end);
     PROF_ADD(7, t_begin, t_end);
     __syncthreads();
-    tex_agg.flush(gmaps, threadIdx.x, NT);
+    if (!BINNED) tex_agg.flush(gmaps, threadIdx.x, NT);
     fa_agg.flush(gfv, galpha, threadIdx.x, NT);
 }
 
-// One workgroup per (texture bin, chunk of BIN_CHUNK records): accumulate the records into a (32+1)x(32+1) texel LDS tile
+// One workgroup per (texture bin, BIN_SUB_PER_WG of its record sub-ranges): accumulate the records into a (32+1)x(32+1) texel LDS tile
 // (1-texel halo: row -1, column +32), then add the tile to the gradient map.  bin_info (nbins,4) = {offset of the map in floats,
 // stored width ws, stored height hs, tile_y << 16 | tile_x}.
 // The tile is accumulated in fp64: on gfx950 ds_add_f32 retires ~1 lane per 3 clk whatever the addresses (193 clk for a full
@@ -674,13 +764,17 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                                                             const int4 *__restrict__ records, int cap, float *__restrict__ gmaps) {
     __shared__ double tile[33 * 33 * 3];
     __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
-    const int bin = blockIdx.x;
-    const int n_all = min(cursor[bin], cap), begin = blockIdx.y * BIN_CHUNK;
-    if (begin >= n_all) return;
-    const int n = min(n_all - begin, BIN_CHUNK);
+    const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG, sub_cap = cap / BIN_SUB;
+    int n_sub[BIN_SUB_PER_WG], total = 0;
+#pragma unroll
+    for (int g = 0; g < BIN_SUB_PER_WG; ++g) { n_sub[g] = min(cursor[bin * BIN_SUB + sub0 + g], sub_cap); total += n_sub[g]; }
+    if (total == 0) return;
     for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0.0;
-    const int4 *rec = records + ((long long)bin * cap + begin) * 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
+    const int n = n_sub[g];
+    const int4 *rec = records + ((long long)bin * cap + (long long)(sub0 + g) * sub_cap) * 2;
     for (int sb = 0; sb < n; sb += BIN_STAGE) {
         const int m = min(n - sb, BIN_STAGE);
         __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
@@ -713,6 +807,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                 atomicAdd(&tile[idx[q] + 2], (double)(g2 * w[q]));
             }
         }
+    }
     }
     __syncthreads();
     const long long off = bin_info[bin * 4];
@@ -803,6 +898,8 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
                                                             float *__restrict__ gmaps, const float *__restrict__ fv,
                                                             float *__restrict__ gfv, int want_bary, int persp) {
     extern __shared__ __attribute__((aligned(16))) float s_hard[];
+    constexpr bool SINGLE = true;       // (cycle accounting macros)
+    (void)SINGLE;
     TexAgg tex_agg;
     FaceAgg face_agg;
     tex_agg.bind(s_hard);
@@ -814,6 +911,7 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
+    PROF_T(t_begin);
     const FragAddr o = frag_addr(A, n, yi, xi, 0);
     const int fc = in_img ? A.p2f[o.s] : -1;
     const bool valid = fc >= 0;
@@ -832,6 +930,8 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     Sample s;
     s.a00 = s.a01 = s.a10 = s.a11 = 0;
     s.w00 = s.w01 = s.w10 = s.w11 = 0.f;
+    PROF_T(t_a);
+    PROF_ADD(2, t_begin, t_a);
     if (__ballot(tex) != 0ull) {
         const int *md = A.map_desc + (valid ? map : 0) * 8;
         footprint_desc(u, v, md[0], md[1], md[2], md[3], md[4], md[5], s);
@@ -856,6 +956,8 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
             tex_agg.add_wave(gmaps, (int)((unsigned)ad[q] / 3u), val, on);
         }
     }
+    PROF_T(t_b);
+    PROF_ADD(4, t_a, t_b);
     // colour -> uv -> barycentrics -> vertices, for the faces whose vertices are variables
     const bool geom = tex && want_bary != 0 && j >= A.geom_begin;
     float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -900,11 +1002,19 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
                 g9[6] = e2.x; g9[7] = e2.y; g9[8] = pz2;
             }
         }
+        PROF_T(t_c);
+        PROF_ADD(5, t_b, t_c);
         face_agg.add_wave(gfv, valid ? fc : 0, g9, has_g9);
+        PROF_T(t_d);
+        PROF_ADD(6, t_c, t_d);
     }
+    PROF_T(t_e);
     __syncthreads();
     tex_agg.flush(gmaps, threadIdx.x, NT);
     face_agg.flush(gfv, threadIdx.x, NT);
+    PROF_T(t_end);
+    PROF_ADD(3, t_e, t_end);
+    PROF_ADD(7, t_begin, t_end);
 }
 
 static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *grad_image, float *grad_maps,
@@ -934,18 +1044,24 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
         }
         raised = true;
     }
-    // the training path's soft pass on decimated maps: uv-fragments, detached barycentrics, LDS aggregation -> the specialised kernel
-    if (fused && !A.bin_records && K > 1 && A.tiled == 2 && !want_bary && (A.agg & 1) && !(g_dbg_flags & (1 << 16))) {
+    // the training path's soft pass: uv-fragments, detached barycentrics; texel gradients through the LDS table (decimated maps) or
+    // through texture-space bins (full-resolution maps) -> the specialised kernel
+    if (fused && K > 1 && A.tiled == 2 && !want_bary && ((A.agg & 1) || A.bin_records) && !(g_dbg_flags & (1 << 16))) {
         static bool raised_uv = false;
-        const size_t lds_uv = TexAgg::BYTES + FaceAlphaAgg::BYTES;
         if (!raised_uv) {
-            if (hipFuncSetAttribute((const void *)render_bwd_uv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
+            if (hipFuncSetAttribute((const void *)render_bwd_uv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)render_bwd_uv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
                 dbw_set_error("shade/blend backward: cannot raise the dynamic LDS limit");
                 return DBW_ERR_LAUNCH;
             }
             raised_uv = true;
         }
-        hipLaunchKernelGGL(render_bwd_uv_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), lds_uv, s, A, total, grad_image, grad_maps, grad_faces_alpha, fv, gfv);
+        if (A.bin_records)
+            hipLaunchKernelGGL(render_bwd_uv_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), FaceAlphaAgg::BYTES, s, A, total, grad_image, grad_maps,
+                               grad_faces_alpha, fv, gfv);
+        else
+            hipLaunchKernelGGL(render_bwd_uv_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAlphaAgg::BYTES, s, A, total,
+                               grad_image, grad_maps, grad_faces_alpha, fv, gfv);
         return dbw_check_launch("render_bwd_uv_kernel");
     }
     if (A.tiled == 3) {       // hard uv-fragments: validated by the caller (K == 1, sigma == 0, no opacities, LDS aggregation)
@@ -1009,7 +1125,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     A.tiled = frag_layout;
     A.gscale = grad_scale;
     A.geom_begin = const_geometry_faces;
-    DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap > 0) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none");
+    DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap >= DBW_BIN_SUBCURSORS) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none (bin_cap >= DBW_BIN_SUBCURSORS)");
     if (bin_records && !lds_aggregate) {
         A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap;
     }
@@ -1020,9 +1136,9 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
 extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
                                  int nbins, float *grad_maps, dbw_stream_t stream) {
     DBW_REQUIRE(bin_info && bin_cursor && bin_records && grad_maps, "null pointer");
-    DBW_REQUIRE(bin_cap > 0 && nbins >= 0, "bad size");
+    DBW_REQUIRE(bin_cap >= DBW_BIN_SUBCURSORS && nbins >= 0, "bad size");
     if (nbins == 0) return DBW_OK;
-    hipLaunchKernelGGL(texbin_reduce_kernel, dim3(nbins, (bin_cap + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), 0, (hipStream_t)stream, bin_info, bin_cursor,
+    hipLaunchKernelGGL(texbin_reduce_kernel, dim3(nbins, BIN_SUB / BIN_SUB_PER_WG), dim3(256), 0, (hipStream_t)stream, bin_info, bin_cursor,
                        (const int4 *)bin_records, bin_cap, grad_maps);
     return dbw_check_launch("texbin_reduce_kernel");
 }

@@ -20,6 +20,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define DBW_BIN_SUBCURSORS 16   /* cursors (and record sub-ranges) per texture bin, see dbw_render_bwd_fused */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -182,7 +184,9 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
  * Texture-space binning (optional; used when lds_aggregate == 0, i.e. full-resolution maps under minification, where a
  * 16x16-pixel tile shares no texels but the whole batch hits every texel ~70 times): instead of 12 scattered atomics per
  * fragment, each fragment appends one 32 B record to the bin of the 32x32-texel tile its footprint starts in
- * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins) zeroed by the caller; bin_records
+ * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins * DBW_BIN_SUBCURSORS) zeroed by the caller: a bin's
+ * record range is split into DBW_BIN_SUBCURSORS sub-ranges of bin_cap / DBW_BIN_SUBCURSORS records with one cursor each, because
+ * returning atomics on one hot address serialise; bin_records
  * nbins*bin_cap*32 bytes); dbw_texbin_reduce then sums every bin in LDS and adds it to grad_maps.  Records that do not fit
  * (bin overflow, circular-wrap footprints) fall back to atomics, so the result is exact either way.  All NULL / 0 = off.
  * const_geometry_faces: the first that many faces of the scene (original indexing) have constant vertices -- the sky dome of the env

@@ -26,12 +26,12 @@ p2f, bary, dists, img = ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, s
 g_img = torch.rand_like(img); g_maps, g_fvc, g_alpha = torch.zeros_like(maps), torch.zeros_like(fvc), torch.zeros_like(alpha)
 bins = scene.texbins; nbins = bins[2]
 cap = ops.texbin_capacity(B, H, W, K, nbins)
-cursor = torch.zeros(nbins, dtype=torch.int32, device=dev); records = torch.zeros(nbins * cap * 8, dtype=torch.int32, device=dev)
+cursor = torch.zeros(nbins * ops.BIN_SUBCURSORS, dtype=torch.int32, device=dev); records = torch.zeros(nbins * cap * 8, dtype=torch.int32, device=dev)
 _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
           cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
           g_alpha.data_ptr(), g_fvc.data_ptr(), 0, 2, bins[0].data_ptr(), cursor.data_ptr(), records.data_ptr(), cap, 0, 0, ops._stream(fvc))
 torch.cuda.synchronize()
-c = cursor.clamp(max=cap).cpu()
+c = cursor.view(nbins, -1).clamp(max=cap // ops.BIN_SUBCURSORS).sum(1).cpu()        # (records sit in BIN_SUBCURSORS sub-ranges of each bin)
 print('records', int(c.sum()), 'max', int(c.max()), 'nonempty bins', int((c > 0).sum()), 'top10', sorted(c.tolist())[-10:])
 rec = records.view(nbins, cap, 8)
 tot = mult = 0
