@@ -25,6 +25,7 @@ class NativeStep:
         self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
         self._env_verts = None
         self._side, self.overlap_regularisers = None, True
+        self.on_block_grads_ready = None      # callback: every gradient that does not depend on the env pass is final (on the current stream)
 
     def supported(self):
         m, w = self.m, self.m.loss_weights
@@ -187,6 +188,8 @@ class NativeStep:
             sets[1]['grad_maps'] = _p(g_blk_maps)
             launch('dbw_texture_prep_bwd_sets', (1,), st)
             _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+            if self.on_block_grads_ready is not None:
+                self.on_block_grads_ready()                            # e.g. the data-parallel driver starts reducing the blocks' textures
             return g_blk_maps, g_fa, g_fvc, g_blk_verts
 
         def env_backward(st):

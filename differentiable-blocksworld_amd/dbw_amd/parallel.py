@@ -52,7 +52,7 @@ class ShardedTrainStep:
     of constant shape.  The gradient all-reduce and the two Adam launches stay outside the graph."""
 
     def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
-                 use_graph=False, graph_warmup=3, seed=None, use_native=True):
+                 use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures'):
         self.model, self.pg = model, process_group
         self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
         if use_graph and not getattr(model, 'sync_free', False):
@@ -72,6 +72,16 @@ class ShardedTrainStep:
         if use_native and hasattr(model, 'loss_weights') and hasattr(model, 'renderer_env'):
             from .native_step import NativeStep
             self.native = NativeStep(model, self.params)
+            self.native.on_block_grads_ready = self.start_early_allreduce
+        # Overlapped all-reduce: the blocks' texture gradient (`early_param`: 83 % of the buffer at config 2) is final long before the
+        # step ends -- the env chain finishes last -- so its slice is reduced on the communicator's own stream while the env backward
+        # still runs, and only the rest (1.6 MB) after the step.  Same collectives in the same order on every rank, whatever path a
+        # rank's step took.  Default: on with RCCL ('nccl'), off elsewhere (the gloo tests switch it on explicitly).
+        self._early_range = next(((off, off + k) for n, off, k in self.params.names if n == early_param), None)
+        if overlap_allreduce is None:
+            overlap_allreduce = dist.is_initialized() and dist.get_backend(process_group) == 'nccl' and self.world_size > 1
+        self.overlap_allreduce = bool(overlap_allreduce) and dist.is_initialized() and self._early_range is not None
+        self._early_work, self._early_done = None, False
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
             s = torch.tensor([seed if seed is not None else 0], dtype=torch.int64)
@@ -120,7 +130,7 @@ class ShardedTrainStep:
                 ops.ARENA.enabled = False
             if not native:
                 losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
-        if self.world_size > 1:
+        if self.world_size > 1 or self.overlap_allreduce:     # (a one-rank group with the overlap forced on: the API smoke test)
             self.allreduce_gradients()
         self.n_steps += 1
         if self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda:
@@ -133,15 +143,38 @@ class ShardedTrainStep:
                              self.betas, self.eps)
         return losses
 
-    def allreduce_gradients(self):
-        """ONE in-place sum all-reduce of the flat gradient buffer (RCCL over xGMI; gloo on CPU tensors in the tests)."""
-        g = self.params.grad
-        if g.is_cuda and dist.get_backend(self.pg) != 'nccl':      # ranks sharing one GPU over gloo (tests, bench's debug mode)
-            h = g.cpu()
+    def _allreduce(self, t, async_op=False):
+        """In-place sum all-reduce of (a slice of) the flat gradient buffer: RCCL over xGMI ('nccl'); gloo on CPU tensors; ranks
+        sharing one GPU over gloo (tests) go through a host copy."""
+        if t.is_cuda and dist.get_backend(self.pg) != 'nccl':
+            h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
-            g.copy_(h)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+
+    def start_early_allreduce(self):
+        """Called (by the native step, on the stream that has just finished them) once the gradients of the early slice are final."""
+        if not self.overlap_allreduce or self._early_done:
+            return
+        a, b = self._early_range
+        self._early_work, self._early_done = self._allreduce(self.params.grad[a:b], async_op=True), True
+
+    def allreduce_gradients(self):
+        """The gradient sum over the ranks: ONE all-reduce of the flat buffer, or -- overlapped mode -- the early slice (possibly
+        already in flight) followed by the rest."""
+        g = self.params.grad
+        if not self.overlap_allreduce:
+            self._allreduce(g)
+            return
+        self.start_early_allreduce()                 # ranks whose step did not announce it (empty batch, autograd path): same order
+        a, b = self._early_range
+        for lo, hi in ((0, a), (b, g.numel())):
+            if hi > lo:
+                self._allreduce(g[lo:hi])
+        if self._early_work is not None:
+            self._early_work.wait()                  # (the current stream waits, not the host)
+        self._early_work, self._early_done = None, False
 
     def _graph_iteration(self, inp):
         if self._graph is None:

@@ -28,6 +28,44 @@ def _views():
     return dict(imgs=imgs, R=R, T=T, K=Km)
 
 
+def _run_nccl_single(rank, port, out):
+    """A ONE-rank RCCL group with the overlapped all-reduce forced on: the async collective on the communicator's stream, launched from
+    the native step's side stream and waited for before Adam, must leave the step unchanged (sum over one rank)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, 'differentiable-blocksworld_amd'), os.path.join(root, 'oracle')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dbw_amd
+    from dbw_amd.parallel import ShardedTrainStep
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    res = []
+    for overlap in (False, True):
+        if overlap:
+            dist.init_process_group('nccl', rank=0, world_size=1)
+        torch.manual_seed(227391)
+        model = dbw_amd.create_model(_cfg(), (H, W)).to(dev).train()
+        model.sync_free = True
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, overlap_allreduce=overlap)
+        assert step.overlap_allreduce == overlap
+        views = {k: v.to(dev) for k, v in _views().items()}
+        for _ in range(3):
+            step(views)
+        torch.cuda.synchronize()
+        res.append(step.params.flat.detach().cpu().clone())
+    dist.destroy_process_group()
+    out[0] = float((res[0] - res[1]).abs().max())
+
+
+def test_overlapped_allreduce_on_a_one_rank_rccl_group_leaves_the_step_unchanged():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_nccl_single, args=(29541, out), nprocs=1, join=True)
+    assert out[0] < 1e-4, out[0]          # (atomics order: not bit-identical from run to run)
+
+
 def _run(rank, world, port, out):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +81,9 @@ def _run(rank, world, port, out):
     torch.manual_seed(227391)
     model = dbw_amd.create_model(_cfg(), (H, W)).to(dev).train()
     model.sync_free = True
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+    # overlapped all-reduce: the native step announces the blocks' texture gradient from its side stream, the rest follows the step
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, overlap_allreduce=world > 1)
+    assert step.overlap_allreduce == (world > 1) and step.native is not None and step.native.on_block_grads_ready is not None
     views = {k: v.to(dev) for k, v in _views().items()}
     a, b = shard_views(V, world, rank)
     local = {k: v[a:b] for k, v in views.items()}

@@ -57,11 +57,19 @@ def torch_adam(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
     p.addcdiv_(m, v.sqrt() / bc2 ** 0.5 + eps, value=-lr / bc1)
 
 
-def _worker(rank, world, port, views, out):
+def _worker(rank, world, port, views, out, overlap=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     model = ToyModel()
-    step = ShardedTrainStep(model, adam_fn=torch_adam)
+    step = ShardedTrainStep(model, adam_fn=torch_adam, overlap_allreduce=overlap, early_param='texture_bkg')
+    assert step.overlap_allreduce == overlap
+    if overlap and rank == 0:            # one rank announces the early slice itself (as the native step does), the other does not
+        rest = step.allreduce_gradients
+        def early_then_rest():
+            step.start_early_allreduce()
+            assert step._early_done
+            rest()
+        step.allreduce_gradients = early_then_rest
     a, b = shard_views(views.shape[0], world, rank)
     for _ in range(3):
         step({'imgs': views[a:b]})
@@ -80,6 +88,17 @@ def test_two_rank_gloo_step_equals_single_process():
     mp.spawn(_worker, args=(2, 29512, views, out), nprocs=2, join=True)
     assert torch.allclose(out[0], out[1], rtol=0, atol=0)                   # replicas stay bit-identical
     assert torch.allclose(out[0], ref.params.flat, rtol=1e-5, atol=1e-6)   # and equal the full-batch run
+
+
+def test_overlapped_allreduce_two_collectives_equal_the_single_one():
+    """overlap_allreduce: the early slice (announced by the step on one rank, not on the other: an empty / autograd step) and then the
+    rest -- same collectives in the same order on both ranks, same result as the single all-reduce."""
+    views = torch.rand(6, 3, 4, 4, generator=torch.Generator().manual_seed(1))
+    mgr = mp.Manager()
+    out, ref = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, 29531, views, ref, False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29532, views, out, True), nprocs=2, join=True)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], ref[0])
 
 
 def test_flat_params_bind_grads_in_place_and_group_textures_last():
