@@ -185,6 +185,9 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    # 20 steps from the freshly initialised scene: the synthetic targets are noise, so the optimiser fades and shrinks the blocks and
+    # the workload gets lighter step by step (tools/diag/window_times.py: 1.21 -> 1.00 ms/step over 300 steps, flat with frozen
+    # parameters) -- a long window would measure that drift, not the configuration
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--views', type=int, default=49, help='views per GPU per step (weak scaling)')
@@ -202,6 +205,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
                     'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
     ap.add_argument('--no-graph', action='store_true', help='(default) eager launches')
+    ap.add_argument('--no-side-priority', action='store_true', help='debug: the side stream of the native step at normal priority')
     ap.add_argument('--no-overlap', action='store_true', help='run the env pass on the main stream instead of a side stream')
     args = ap.parse_args()
 
@@ -241,6 +245,8 @@ def main():
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
     # every phase below is measured from the SAME state (freshly initialised parameters + its own warm-up), not from whatever the
     # previously measured phase left behind (opacities drift, blocks get filtered: the workload would change)
+    if step.native is not None and args.no_side_priority:
+        step.native.side_priority = False
     if step.native is not None and args.no_overlap:
         step.native.overlap_regularisers = False      # every kernel alone on one stream: per-kernel averages of a trace are then exact
     snapshot = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone(), step.n_steps)
@@ -342,7 +348,8 @@ def main():
                        'faces_per_pixel': args.fpp, 'txt_size': args.txt,
                        'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
                                  ('' if args.no_overlap else ', small kernels on a side stream') + ('' if step.native is None else ', native step (no autograd)'),
-                       'parallelism': f'view-sharded dp{world}, 1 RCCL all-reduce of {step.params.flat.numel() * 4 / 1e6:.1f} MB/step',
+                       'parallelism': f'view-sharded dp{world}, {step.params.flat.numel() * 4 / 1e6:.1f} MB of gradients all-reduced per step over RCCL'
+                                      + (' (blocks\' textures overlapped with the env backward, the rest after it)' if step.overlap_allreduce else ''),
                        'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

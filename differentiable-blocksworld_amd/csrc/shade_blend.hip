@@ -894,17 +894,29 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
 // geometry gradient (through the barycentrics: uv -> clipped barycentrics -> perspective correction -> vertices) is only computed for
 // faces whose vertices are variables (geom_begin: the sky dome is a constant), from the face tables, recomputing the barycentrics
 // from the pixel position as the rasteriser backward does anyway.  Same mathematics as shade_blend_bwd_kernel<true, false, true>.
+// (a 64-slot texel table and a 32-slot face table: a 16x16-pixel tile of the magnified env maps touches a few cells and a handful of
+// large faces; with the soft pass's 512 / 128 slots the clears, the flush scans and the lost residency cost a quarter of this kernel:
+// 0.22 -> 0.16 ms with decimated maps, 0.31 -> 0.26 ms at full resolution; 16 slots and fewer overflow at full resolution (0.9 ms).
+// What does not fit goes straight to memory, as always)
+#ifndef DBW_HARD_TEX_LOG2
+#define DBW_HARD_TEX_LOG2 6
+#endif
+#ifndef DBW_HARD_FACE_LOG2
+#define DBW_HARD_FACE_LOG2 5
+#endif
+typedef LdsAgg<3, DBW_HARD_TEX_LOG2> HardTexAgg;
+typedef LdsAgg<9, DBW_HARD_FACE_LOG2> HardFaceAgg;      // a 16x16-pixel tile of the hard pass sees a handful of (large) faces
 __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                             float *__restrict__ gmaps, const float *__restrict__ fv,
                                                             float *__restrict__ gfv, int want_bary, int persp) {
     extern __shared__ __attribute__((aligned(16))) float s_hard[];
     constexpr bool SINGLE = true;       // (cycle accounting macros)
     (void)SINGLE;
-    TexAgg tex_agg;
-    FaceAgg face_agg;
+    HardTexAgg tex_agg;
+    HardFaceAgg face_agg;
     tex_agg.bind(s_hard);
     tex_agg.clear(threadIdx.x, NT);
-    face_agg.bind((char *)s_hard + TexAgg::BYTES);
+    face_agg.bind((char *)s_hard + HardTexAgg::BYTES);
     face_agg.clear(threadIdx.x, NT);
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
@@ -1065,7 +1077,7 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
         return dbw_check_launch("render_bwd_uv_kernel");
     }
     if (A.tiled == 3) {       // hard uv-fragments: validated by the caller (K == 1, sigma == 0, no opacities, LDS aggregation)
-        hipLaunchKernelGGL(render_bwd_hard_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAgg::BYTES, s, A, total, grad_image,
+        hipLaunchKernelGGL(render_bwd_hard_kernel, dim3(dbw_xcd_grid(total)), dim3(NT), HardTexAgg::BYTES + HardFaceAgg::BYTES, s, A, total, grad_image,
                            grad_maps, fv, gfv, want_bary, persp);
         return dbw_check_launch("render_bwd_hard_kernel");
     }

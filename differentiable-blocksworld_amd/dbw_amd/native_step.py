@@ -24,7 +24,7 @@ class NativeStep:
         self.m, self.params = model, params
         self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
         self._env_verts = None
-        self._side, self.overlap_regularisers = None, True
+        self._side, self.overlap_regularisers, self.side_priority = None, True, True
         self.on_block_grads_ready = None      # callback: every gradient that does not depend on the env pass is final (on the current stream)
 
     def supported(self):
@@ -64,7 +64,9 @@ class NativeStep:
         side = cur
         if self.overlap_regularisers:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
+                # high priority: its small kernels overtake the big render kernels of the main stream instead of queueing behind them, and
+                # the fg backward finishes before the (lighter) env backward it shares the GPU with, so that the LONGER tail hides
+                self._side = torch.cuda.Stream(device=dev, priority=-1 if self.side_priority else 0)
             side = self._side
             side.wait_stream(cur)                          # the previous step's Adam, the zero arena
         st_main, st_side = cur.cuda_stream, side.cuda_stream
