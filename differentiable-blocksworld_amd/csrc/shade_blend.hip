@@ -95,7 +95,10 @@ constexpr int BIN_LOG2 = 7, BIN_SLOTS = 1 << BIN_LOG2;   // per-block hash table
 constexpr int BIN_SUB = DBW_BIN_SUBCURSORS;                 // sub-ranges (each with its own cursor) of a bin's record range: a hot bin takes
                                                           // ~2000 reservations per launch, and returning atomics on ONE address serialise at
                                                           // ~0.2 us each (0.43 ms of a 0.86 ms kernel); 16 addresses per bin make that 16 chains
-constexpr int BIN_SUB_PER_WG = 4;                         // sub-ranges one texbin_reduce workgroup accumulates
+#ifndef DBW_BIN_SUB_PER_WG
+#define DBW_BIN_SUB_PER_WG 4
+#endif
+constexpr int BIN_SUB_PER_WG = DBW_BIN_SUB_PER_WG;                         // sub-ranges one texbin_reduce workgroup accumulates
 
 // a footprint the bin's 33x33 LDS tile can hold: at most one row up and one column right of (r0, c0), no wrap
 __device__ __forceinline__ bool bin_regular(const Sample &s) {
@@ -759,7 +762,10 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
 // (profiles/r01_lds_atomic_ubench.txt).  Records arrive in runs of up to 64 written by one wave of the backward (an 8x8 pixel
 // patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
 // transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
-constexpr int BIN_STAGE = 1024, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
+#ifndef DBW_BIN_STAGE
+#define DBW_BIN_STAGE 1024
+#endif
+constexpr int BIN_STAGE = DBW_BIN_STAGE, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
 __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restrict__ bin_info, const int *__restrict__ cursor,
                                                             const int4 *__restrict__ records, int cap, float *__restrict__ gmaps) {
     __shared__ double tile[33 * 33 * 3];
@@ -818,7 +824,9 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
         if (v == 0.f) continue;
         const int ch = i % 3, lc = (i / 3) % 33, lr = i / 99;
         const int r = ty * 32 - 1 + lr, c = tx * 32 + lc;
+#ifndef DBW_REDUCE_NOFLUSH
         if (r >= 0 && r < hs && c < ws) unsafeAtomicAdd(gmaps + off + ((long long)r * ws + c) * 3 + ch, v);
+#endif
     }
 }
 

@@ -205,13 +205,13 @@ class NativeStep:
             return g_env_maps, g_fvc_e, g_env_verts
 
         if side is not cur:
-            # the env chain is the one that finishes last: it stays on the main stream, so that Adam follows it without a cross-stream
-            # wait on a signal that is still pending (~13 us); the fg chain is enqueued first and gets the GPU first
+            # the fg chain (the heavier kernel, the longer tail) finishes last: it stays on the main stream, so that Adam follows it
+            # without a cross-stream wait on a signal that is still pending (~13 us); the env chain's tail hides behind the fg backward
             side.wait_stream(cur)                                      # g_fg, g_env written
+            keep_f = fg_backward(st_main)
             torch.cuda.set_stream(side)
-            keep_f = fg_backward(side.cuda_stream)
+            keep_e = env_backward(side.cuda_stream)
             torch.cuda.set_stream(cur)
-            keep_e = env_backward(st_main)
             cur.wait_stream(side)
         else:
             keep_f = fg_backward(st_main)
