@@ -205,6 +205,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
                     'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
     ap.add_argument('--no-graph', action='store_true', help='(default) eager launches')
+    ap.add_argument('--backward-order', choices=['auto', 'sequential', 'concurrent'], default='auto', help='debug: the two backward kernels')
     ap.add_argument('--no-side-priority', action='store_true', help='debug: the side stream of the native step at normal priority')
     ap.add_argument('--no-overlap', action='store_true', help='run the env pass on the main stream instead of a side stream')
     args = ap.parse_args()
@@ -245,6 +246,8 @@ def main():
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
     # every phase below is measured from the SAME state (freshly initialised parameters + its own warm-up), not from whatever the
     # previously measured phase left behind (opacities drift, blocks get filtered: the workload would change)
+    if step.native is not None and args.backward_order != 'auto':
+        step.native.sequential_backward = args.backward_order == 'sequential'
     if step.native is not None and args.no_side_priority:
         step.native.side_priority = False
     if step.native is not None and args.no_overlap:

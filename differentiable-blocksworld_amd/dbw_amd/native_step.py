@@ -25,6 +25,10 @@ class NativeStep:
         self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
         self._env_verts = None
         self._side, self.overlap_regularisers, self.side_priority = None, True, True
+        # None: by configuration -- one after the other when the blocks' gradients are worth announcing early (data parallel: their
+        # all-reduce then runs next to the env backward) or when a bin reduction follows the fg kernel (full-resolution phases: measured
+        # 2 % faster), both at once otherwise (1 % faster on one GPU with decimated maps); True / False force one or the other
+        self.sequential_backward = None
         self.on_block_grads_ready = None      # callback: every gradient that does not depend on the env pass is final (on the current stream)
 
     def supported(self):
@@ -179,11 +183,10 @@ class NativeStep:
                                                                       blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
                                                                       state=fg_state)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
-        # kernels (projection backward, pose / shape, textures, opacities), on the two streams: the tail of the pass that finishes first
-        # runs next to the other pass's big kernel instead of alone at the end of the step ----
-        def fg_backward(st):
+        # kernels (projection backward, pose / shape, textures, opacities) ----
+        def fg_backward(st, after_kernel=None):
             g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
-                                                     cfg_f, renderer._bg, 2, g_fg, B, None)
+                                                     cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel)
             g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
             _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
                       float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
@@ -205,13 +208,22 @@ class NativeStep:
             return g_env_maps, g_fvc_e, g_env_verts
 
         if side is not cur:
-            # the fg chain (the heavier kernel, the longer tail) finishes last: it stays on the main stream, so that Adam follows it
-            # without a cross-stream wait on a signal that is still pending (~13 us); the env chain's tail hides behind the fg backward
+            # Two kernels that each fill the GPU gain nothing from sharing it (together they take the sum of their solo times), so the
+            # order only decides what hides behind what.  `seq`: the fg backward kernel first, alone; when it is done the env chain
+            # starts on the main stream, and next to it run, on the side stream, the fg tail (and the bin reduction of the
+            # full-resolution phases, a low-occupancy kernel) and -- data parallel -- the all-reduce of the blocks' textures, 83 % of
+            # the gradient bytes; Adam follows the env tail on the main stream.  Otherwise both chains are enqueued at once
             side.wait_stream(cur)                                      # g_fg, g_env written
-            keep_f = fg_backward(st_main)
+            kernel_done = torch.cuda.Event()
             torch.cuda.set_stream(side)
-            keep_e = env_backward(side.cuda_stream)
+            keep_f = fg_backward(side.cuda_stream, lambda: kernel_done.record(side))
             torch.cuda.set_stream(cur)
+            seq = self.sequential_backward
+            if seq is None:
+                seq = m.world_size > 1 or decim_blocks == 1
+            if seq:
+                cur.wait_event(kernel_done)
+            keep_e = env_backward(st_main)
             cur.wait_stream(side)
         else:
             keep_f = fg_backward(st_main)

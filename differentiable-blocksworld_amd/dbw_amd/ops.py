@@ -362,7 +362,7 @@ class _RenderScene(torch.autograd.Function):
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
 
 
-def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale):
+def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale, after_kernel=None):
     """dbw_render_bwd_fused (+ dbw_texbin_reduce when the texel gradients go through texture-space bins) of one pass.
     gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c."""
     fvc = cl['face_verts'].view(-1, 3, 3)
@@ -383,6 +383,8 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
               _ptr(g_img), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
               int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, int(cfg.const_faces), _ptr(gscale),
               _stream(fvc))
+    if after_kernel is not None:
+        after_kernel()            # (the big kernel is enqueued; the bin reduction, a low-occupancy kernel, may share the GPU with other work)
     if records is not None:
         _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
     return g_maps, g_alpha, g_fvc
