@@ -77,7 +77,8 @@ template <int KMAX, int NT>
 __device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMAX> &q, const pay4 *home, int n, int xi, int yi,
                                               int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
                                               float *__restrict__ image) {
-    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    BlendFront bl;
+    blend_front_init(bl);
     int cnt = 0;                             // fragments of this pixel (the list is filled front to back)
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) cnt += (k < A.K && q.valid(k)) ? 1 : 0;
@@ -114,29 +115,27 @@ __device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMA
                 }
                 const float a = fr.e * fr.fa;
                 float c[3] = {0.f, 0.f, 0.f};
+                const float T_front = bl.T;
                 if (a != 0.f) {
                     Sample s;
                     footprint(A, fr, s);
                     fetch(A.maps, s, c);
-                    const float wgt = T * a;
-                    r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+                    blend_front_step(bl, a, c);
                 }
                 if (A.tiled == 2) {       // ... together with the blend opacity, the sampled colour (0 where the opacity is 0) and
                                           // the transmittance in front of the fragment
-                    bary[o.b + 7 * o.bstride] = T;
+                    bary[o.b + 7 * o.bstride] = T_front;
                     bary[o.b + 3 * o.bstride] = a;
                     bary[o.b + 4 * o.bstride] = c[0]; bary[o.b + 5 * o.bstride] = c[1]; bary[o.b + 6 * o.bstride] = c[2];
                 }
-                T *= (1.f - a);
             }
         }
     }
     const long long plane = (long long)A.H * A.W;
     float *out = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-    out[0] = r + T * A.bg[0];
-    out[plane] = g + T * A.bg[1];
-    out[2 * plane] = b + T * A.bg[2];
-    out[3 * plane] = 1.f - T;
+    float px[4];
+    blend_front_finish(bl, A.bg, px);
+    out[0] = px[0]; out[plane] = px[1]; out[2 * plane] = px[2]; out[3 * plane] = px[3];
 }
 
 // ---- the same for the training path's soft pass: 8x8 tile = one wave, uv-fragments (layout 2) --------------------------------------------
@@ -174,7 +173,8 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) cnt += (in_img && k < A.K && q.valid(k)) ? 1 : 0;
     if (in_img && cnt == 0) p2f_t[lane] = -1;         // an empty pixel still tells the backward its fragment count (0)
-    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    BlendFront bl;
+    blend_front_init(bl);
     UvSlot cur = uv_slot(q, home, srec, 0, in_img), nxt = cur;
     bool more = true;
 #pragma unroll
@@ -198,8 +198,8 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         float c[3];
         fetch(A.maps, s, c);
         if (!(a != 0.f)) c[0] = c[1] = c[2] = 0.f;
-        const float wgt = T * a;
-        r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+        const float T = bl.T;                  // transmittance in front of this layer
+        blend_front_step(bl, a, c);
         if (cur.valid) {
             const int o = (k << 6) + lane;
             p2f_t[o] = k == 0 ? (cur.fik | (cnt << FRAG_COUNT_SHIFT)) : cur.fik;
@@ -212,12 +212,13 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
             bp[256] = c[0]; bp[320] = c[1]; bp[384] = c[2];
             bp[448] = T;
         }
-        T *= (1.f - a);
         cur = nxt;
     }
     const long long plane = (long long)A.H * A.W;
     const long long pix = (long long)yi * A.W + xi;
-    const float f0 = r + T * A.bg[0], f1 = g + T * A.bg[1], f2 = b + T * A.bg[2], m = 1.f - T;
+    float px[4];
+    blend_front_finish(bl, A.bg, px);
+    const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
     if (A.target) {
         // decoupled composite + MSE on registers (dbw.py:223,366-367): rec = fg_rgb * mask + (1 - mask) * env_rgb (the fg colour is
         // premultiplied AND multiplied by the mask again); the loss gradient is local to the pixel, so the pass hands

@@ -52,27 +52,25 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
     if (xi >= A.W || yi >= A.H) return;
     const long long pix = ((long long)n * A.H + yi) * A.W + xi;
-    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    BlendFront bl;
+    blend_front_init(bl);
     for (int k = 0; k < A.K; ++k) {
         Frag fr;
         if (!load_frag(A, n, frag_addr(A, n, yi, xi, k), fr)) continue;
         const float a = fr.e * fr.fa;
-        if (a != 0.f) {
+        if (a != 0.f) {             // (a == 0 leaves colour and transmittance as they are: no texel fetch)
             Sample s;
             footprint(A, fr, s);
             float c[3];
             fetch(A.maps, s, c);
-            const float wgt = T * a;
-            r += wgt * c[0]; g += wgt * c[1]; b += wgt * c[2];
+            blend_front_step(bl, a, c);
         }
-        T *= (1.f - a);
     }
     const long long plane = (long long)A.H * A.W;
     float *o = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-    o[0] = r + T * A.bg[0];
-    o[plane] = g + T * A.bg[1];
-    o[2 * plane] = b + T * A.bg[2];
-    o[3 * plane] = 1.f - T;
+    float px[4];
+    blend_front_finish(bl, A.bg, px);
+    o[0] = px[0]; o[plane] = px[1]; o[2 * plane] = px[2]; o[3 * plane] = px[3];
 }
 
 #ifdef DBW_PROFILE_BWD
@@ -241,7 +239,8 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     PROF_T(t_p1);
     PROF_ADD(1, t_p0, t_p1);
     // pass 2 (back to front)
-    float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
+    BlendBack bk;
+    blend_back_init(bk, A.bg);
     // uv-fragments without pass 1: the payload of layer k - 1 is requested while layer k is being processed (the only unhidden
     // latency of the loop is the single hop of coalesced loads at the top of each iteration)
     RawUV nxt;
@@ -268,12 +267,9 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
             if (A.tiled == 2) { c[0] = fr.col[0]; c[1] = fr.col[1]; c[2] = fr.col[2]; }     // sampled by the forward (0 where ak == 0)
             else if (ak != 0.f) fetch(A.maps, s, c);
         }
-        const float ga = valid ? Tk * (gr * (c[0] - U0) + gg * (c[1] - U1) + gbl * (c[2] - U2) + gA * Vb) : 0.f;
+        const float ga_ = blend_back_step(bk, Tk, ak, c[0], c[1], c[2], gr, gg, gbl, gA);      // (ak == 0 for an empty slot: state unchanged)
+        const float ga = valid ? ga_ : 0.f;
         const float wgt = valid ? Tk * ak : 0.f;
-        U0 = ak * c[0] + (1.f - ak) * U0;
-        U1 = ak * c[1] + (1.f - ak) * U1;
-        U2 = ak * c[2] + (1.f - ak) * U2;
-        Vb = (1.f - ak) * Vb;
         PROF_T(t_a);
         PROF_ADD(2, t_it, t_a);
         // geometric alpha -> dists ; learned opacity
@@ -398,14 +394,8 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
             // (faces below geom_begin have constant vertices -- the sky dome: nothing flows through their barycentrics)
             if (FUSED ? (want_bary != 0 && fr.j >= A.geom_begin) : true)
             if (tex) {
-                float gix = 0.f, giy = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float t00 = A.maps[s.a00 + ch], t01 = A.maps[s.a01 + ch], t10 = A.maps[s.a10 + ch], t11 = A.maps[s.a11 + ch];
-                    gix += gc[ch] * ((t01 - t00) * s.wy0 + (t11 - t10) * s.wy1);
-                    giy += gc[ch] * ((t10 - t00) * s.wx0 + (t11 - t01) * s.wx1);
-                }
-                const float gu = gix * s.dudx, gv = giy * s.dvdy;
+                float gu, gv;
+                sample_grad_uv(A.maps, s, gc, gu, gv);
                 const float *uv = A.face_uvs + (long long)fr.j * 6;
                 const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
                 convert_bary_bwd(fr.cd, fr.w2, fr.w3, go, gb);
@@ -590,7 +580,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     }
     PROF_T(t_p0);
     PROF_ADD(0, t_begin, t_p0);
-    float U0 = A.bg[0], U1 = A.bg[1], U2 = A.bg[2], Vb = 1.f;
+    BlendBack bk;
+    blend_back_init(bk, A.bg);
     struct Raw { int fc; float u, v, jm, a, c0, c1, c2, T, d; };
     auto load = [&](int k, bool ok) {
         Raw r;
@@ -655,12 +646,9 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             if (k > 0) nres = reserve(nxt, k - 1 < cnt);
         } else if (k > 0) nxt = load(k - 1, k - 1 < cnt);
         const float ak = valid ? cur.a : 0.f, Tk = valid ? cur.T : 1.f;
-        const float ga = valid ? Tk * (gr * (cur.c0 - U0) + gg * (cur.c1 - U1) + gbl * (cur.c2 - U2) + gA * Vb) : 0.f;
+        const float ga_ = blend_back_step(bk, Tk, ak, cur.c0, cur.c1, cur.c2, gr, gg, gbl, gA);   // (ak == 0 for an empty slot: state unchanged)
+        const float ga = valid ? ga_ : 0.f;
         const float wgt = Tk * ak;
-        U0 = ak * cur.c0 + (1.f - ak) * U0;
-        U1 = ak * cur.c1 + (1.f - ak) * U1;
-        U2 = ak * cur.c2 + (1.f - ak) * U2;
-        Vb = (1.f - ak) * Vb;
         const int jm = __float_as_int(cur.jm);
         const int j = jm & 0xfffff, map = jm >> 20;
         // geometric alpha e = exp(-max(d, 0) / sigma) (the opacity gradient is ga * e), d/d dist of the blend opacity for d >= 0
@@ -984,14 +972,8 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     bool has_g9 = false;
     if (__ballot(geom) != 0ull) {
         if (geom) {
-            float gix = 0.f, giy = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float t00 = A.maps[s.a00 + ch], t01 = A.maps[s.a01 + ch], t10 = A.maps[s.a10 + ch], t11 = A.maps[s.a11 + ch];
-                gix += gc[ch] * ((t01 - t00) * s.wy0 + (t11 - t10) * s.wy1);
-                giy += gc[ch] * ((t10 - t00) * s.wx0 + (t11 - t01) * s.wx1);
-            }
-            const float gu = gix * s.dudx, gv = giy * s.dvdy;
+            float gu, gv;
+            sample_grad_uv(A.maps, s, gc, gu, gv);
             const float *uv = A.face_uvs + (long long)j * 6;
             const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
             int cd = -1;

@@ -3,6 +3,7 @@
 // and the bilinear texture footprint (grid_sample semantics, v flip, circular u wrap, decimation shift).
 #pragma once
 #include "dbw_common.h"
+#include "shade_math.h"
 
 namespace dbw {
 
@@ -41,14 +42,6 @@ struct ShadeArgs {
     float *loss_part, *g_fg, *g_env;
 };
 
-struct Sample {   // bilinear footprint of one fragment
-    int a00, a01, a10, a11;         // float offsets of the 4 texels (RGB triplets) in `maps` (map_desc offsets are int32: < 2^31 floats)
-    float w00, w01, w10, w11;
-    float dudx, dvdy;               // d(ix)/du, d(iy)/dv (0 when clamped at the border)
-    float wx0, wx1, wy0, wy1;
-    int r0, c0, r1, c1, ws;         // stored-resolution texel coordinates of the footprint and stored row width
-};
-
 struct Frag {
     int fc;           // clipped face id of the slot (index into face_verts_c)
     int j;            // local original face id
@@ -65,30 +58,6 @@ struct Frag {
     float u, v;       // texture coordinates
     int map;          // row of map_desc
 };
-
-__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
-
-__device__ __forceinline__ void convert_bary(int cd, float w2, float w3, const float b[3], float bo[3]) {
-    if (cd < 0) { bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2]; return; }
-    const int i1 = cd & 3, kind = cd >> 2;
-    float o1, o2, o3;
-    if (kind == 0) { o1 = b[0] * (1.f - w2) + b[1] * (1.f - w3) + b[2]; o2 = b[0] * w2; o3 = b[1] * w3; }
-    else if (kind == 1) { o1 = b[0] * (1.f - w2) + b[2] * (1.f - w3); o2 = b[0] * w2 + b[1]; o3 = b[2] * w3; }
-    else { o1 = b[0] * (1.f - w3); o2 = b[1]; o3 = b[0] * w3 + b[2]; }
-    // slot i1 <- o1, slot i1+1 <- o2, slot i1+2 <- o3 (mod 3)
-    bo[0] = sel3(i1, o1, o3, o2);
-    bo[1] = sel3(i1, o2, o1, o3);
-    bo[2] = sel3(i1, o3, o2, o1);
-}
-
-__device__ __forceinline__ void convert_bary_bwd(int cd, float w2, float w3, const float go[3], float gb[3]) {
-    if (cd < 0) { gb[0] = go[0]; gb[1] = go[1]; gb[2] = go[2]; return; }
-    const int i1 = cd & 3, kind = cd >> 2;
-    const float g1 = sel3(i1, go[0], go[1], go[2]), g2 = sel3(i1, go[1], go[2], go[0]), g3 = sel3(i1, go[2], go[0], go[1]);
-    if (kind == 0) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g1 * (1.f - w3) + g3 * w3; gb[2] = g1; }
-    else if (kind == 1) { gb[0] = g1 * (1.f - w2) + g2 * w2; gb[1] = g2; gb[2] = g1 * (1.f - w3) + g3 * w3; }
-    else { gb[0] = g1 * (1.f - w3) + g3 * w3; gb[1] = g2; gb[2] = g3; }
-}
 
 // index of a fragment's learned opacity: per face shared by the views (alpha_len == F), per face and view (N * F), or -- alpha_len < 0
 // -- per texture map (one opacity per mesh of the scene: dbw.py:219 repeats each block's opacity over its faces)
@@ -198,15 +167,6 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
     return true;
 }
 
-// c mod w for c in [-pad_left, w + pad_right): one conditional add/subtract when the pads do not exceed the width (the integer
-// modulo is ~25 instructions), the general form otherwise
-__device__ __forceinline__ int wrap_col(int c, int w) {
-    if (c < 0) c += w;
-    if (c >= w) c -= w;
-    if ((unsigned)c >= (unsigned)w) { c %= w; if (c < 0) c += w; }
-    return c;
-}
-
 // frag_layout 2: the ten raw words of one slot, requested without looking at them, so that the backward can ask for the next layer
 // while it works on the current one (`ok` = the slot exists)
 struct RawUV { int fc; float u, v, jm, a, c0, c1, c2, T, d; bool ok; };
@@ -244,33 +204,6 @@ __device__ __forceinline__ void frag_from_raw_uv(const ShadeArgs &A, int n, cons
     fr.aidx = A.faces_alpha ? alpha_index(A, n, fr.j, fr.map) : 0;
 }
 
-// grid_sample(bilinear, align_corners=True, padding_mode='border') on the v-flipped, circularly u-padded map whose descriptor is
-// (off, h, w, pl, pr, sh)
-__device__ __forceinline__ void footprint_desc(float u, float v, int off, int h, int w, int pl, int pr, int sh, Sample &s) {
-    const int wp = w + pl + pr;
-    float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
-    float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
-    s.dudx = (float)(wp - 1); s.dvdy = (float)(h - 1);
-    // clip_coordinates_set_grad of torch's grid_sampler: no gradient at or beyond the border
-    if (!(ix > 0.f)) { ix = 0.f; s.dudx = 0.f; } else if (ix >= (float)(wp - 1)) { ix = (float)(wp - 1); s.dudx = 0.f; }
-    if (!(iy > 0.f)) { iy = 0.f; s.dvdy = 0.f; } else if (iy >= (float)(h - 1)) { iy = (float)(h - 1); s.dvdy = 0.f; }
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const int x1 = min(x0 + 1, wp - 1), y1 = min(y0 + 1, h - 1);
-    s.wx1 = ix - fx; s.wx0 = 1.f - s.wx1;
-    s.wy1 = iy - fy; s.wy0 = 1.f - s.wy1;
-    // padded column -> source column (circular pad), flipped row -> source row
-    int c0 = wrap_col(x0 - pl, w), c1 = wrap_col(x1 - pl, w);
-    // stored resolution = (h >> sh, w >> sh): a decimated map (avg_pool d + nearest upsample, dbw.py:276-278,331-334) is
-    // kept at cell resolution and the nearest upsampling is this shift
-    const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;
-    c0 >>= sh; c1 >>= sh;
-    s.a00 = off + (r0 * ws + c0) * 3; s.a01 = off + (r0 * ws + c1) * 3;
-    s.a10 = off + (r1 * ws + c0) * 3; s.a11 = off + (r1 * ws + c1) * 3;
-    s.w00 = s.wx0 * s.wy0; s.w01 = s.wx1 * s.wy0; s.w10 = s.wx0 * s.wy1; s.w11 = s.wx1 * s.wy1;
-    s.r0 = r0; s.c0 = c0; s.r1 = r1; s.c1 = c1; s.ws = ws;
-}
-
 __device__ __forceinline__ void footprint(const ShadeArgs &A, const Frag &fr, Sample &s) {
     const int *md = A.map_desc + fr.map * 8;
     footprint_desc(fr.u, fr.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
@@ -288,12 +221,6 @@ struct __attribute__((aligned(16))) ShadeRec {
     int off, hw, pads, sh;   // map descriptor: float offset, h << 16 | w, pad_left << 16 | pad_right, decimation shift
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec must be 64 B");
-
-__device__ __forceinline__ void fetch(const float *maps, const Sample &s, float c[3]) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-        c[ch] = maps[s.a00 + ch] * s.w00 + maps[s.a01 + ch] * s.w01 + maps[s.a10 + ch] * s.w10 + maps[s.a11 + ch] * s.w11;
-}
 
 
 }  // namespace dbw
