@@ -5,151 +5,12 @@
 // per-primitive gradient (17 numbers) is reduced inside the wave and written by one lane -- no atomics, no MFMA
 // (~0.1 MFLOP per step, matrix cores do not pay).
 #include "dbw_common.h"
+#include "model_math.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
 
 namespace {
-
-constexpr float NORM_EPS = 1e-12f;   // F.normalize eps
-
-struct Rot6 {
-    float b1[3], b2[3], b3[3], a2[3];
-    float n1, n2, d;
-};
-
-__device__ __forceinline__ void rot6d_fwd(const float *a, Rot6 &r) {
-    r.n1 = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    const float i1 = 1.f / (r.n1 > NORM_EPS ? r.n1 : NORM_EPS);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { r.b1[i] = a[i] * i1; r.a2[i] = a[3 + i]; }
-    r.d = r.b1[0] * a[3] + r.b1[1] * a[4] + r.b1[2] * a[5];
-    float u[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) u[i] = a[3 + i] - r.d * r.b1[i];
-    r.n2 = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const float i2 = 1.f / (r.n2 > NORM_EPS ? r.n2 : NORM_EPS);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r.b2[i] = u[i] * i2;
-    r.b3[0] = r.b1[1] * r.b2[2] - r.b1[2] * r.b2[1];
-    r.b3[1] = r.b1[2] * r.b2[0] - r.b1[0] * r.b2[2];
-    r.b3[2] = r.b1[0] * r.b2[1] - r.b1[1] * r.b2[0];
-}
-
-__device__ __forceinline__ void cross3(const float *a, const float *b, float *c) {
-    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-// G: gradient w.r.t. the rotation matrix rows (b1,b2,b3), row-major 3x3 -> ga[6]
-__device__ __forceinline__ void rot6d_bwd(const Rot6 &r, const float *G, float *ga) {
-    float gb1[3], gb2[3], t[3];
-    cross3(r.b2, G + 6, t);            // b3 = b1 x b2 : g_b1 += b2 x G3
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gb1[i] = G[i] + t[i];
-    cross3(G + 6, r.b1, t);            //                g_b2 += G3 x b1
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gb2[i] = G[3 + i] + t[i];
-    float gu[3];
-    if (r.n2 > NORM_EPS) {
-        const float dt = r.b2[0] * gb2[0] + r.b2[1] * gb2[1] + r.b2[2] * gb2[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = (gb2[i] - r.b2[i] * dt) / r.n2;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = gb2[i] / NORM_EPS;
-    }
-    const float gd = -(gu[0] * r.b1[0] + gu[1] * r.b1[1] + gu[2] * r.b1[2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        gb1[i] += -r.d * gu[i] + gd * r.a2[i];
-        ga[3 + i] = gu[i] + gd * r.b1[i];
-    }
-    if (r.n1 > NORM_EPS) {
-        const float dt = r.b1[0] * gb1[0] + r.b1[1] * gb1[1] + r.b1[2] * gb1[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ga[i] = (gb1[i] - r.b1[i] * dt) / r.n1;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ga[i] = gb1[i] / NORM_EPS;
-    }
-}
-
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
-
-// signed_pow (pytorch.py:31-32) and its derivative w.r.t. the exponent (torch: 0 where the base is 0)
-__device__ __forceinline__ float spow(float t, float e, float &dde) {
-    const float ab = fabsf(t);
-    const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
-    const float pw = powf(ab, e);
-    const float r = sg * pw;
-    dde = ab == 0.f ? 0.f : r * logf(ab);
-    return r;
-}
-
-struct Pose {
-    float e1, e2, se1, se2;   // exponents and sigmoid(sq_eps)
-    float S[3];
-    Rot6 rot;
-    float T[3];
-};
-
-__device__ __forceinline__ void load_pose(const float *sq_eps, const float *S, const float *R6, const float *T, int k,
-                                          float scale_min, Pose &p) {
-    if (sq_eps) {
-        p.se1 = sigmoidf(sq_eps[k * 2]); p.se2 = sigmoidf(sq_eps[k * 2 + 1]);
-        p.e1 = p.se1 * 1.8f + 0.1f; p.e2 = p.se2 * 1.8f + 0.1f;
-    } else { p.se1 = p.se2 = 0.f; p.e1 = p.e2 = 1.f; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { p.S[i] = S ? expf(S[k * 3 + i]) + scale_min : 1.f; p.T[i] = T[k * 3 + i]; }
-    rot6d_fwd(R6 + k * 6, p.rot);
-}
-
-// local (block frame) vertex -> world:  ((v*S)@R + T) * S_world @ R_world + T_world   (row-vector convention)
-__device__ __forceinline__ void pose_fwd(const Pose &p, const float *v, float S_world, const float *Rw, const float *Tw, float *out) {
-    const float s[3] = {v[0] * p.S[0], v[1] * p.S[1], v[2] * p.S[2]};
-    float l[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) l[j] = (s[0] * p.rot.b1[j] + s[1] * p.rot.b2[j] + s[2] * p.rot.b3[j] + p.T[j]) * S_world;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) out[j] = l[0] * Rw[j] + l[1] * Rw[3 + j] + l[2] * Rw[6 + j] + (Tw ? Tw[j] : 0.f);
-}
-
-// acc[0..1] d/d(e1,e2) [filled by caller], acc[2..4] d/dS (post exp+min), acc[5..13] d/dR rows, acc[14..16] d/dT; returns d/dv
-__device__ __forceinline__ void pose_bwd(const Pose &p, const float *v, float S_world, const float *Rw, const float *g, float *acc, float *gv) {
-    float gl[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gl[i] = (g[0] * Rw[i * 3] + g[1] * Rw[i * 3 + 1] + g[2] * Rw[i * 3 + 2]) * S_world;
-    const float s[3] = {v[0] * p.S[0], v[1] * p.S[1], v[2] * p.S[2]};
-    const float *rows[3] = {p.rot.b1, p.rot.b2, p.rot.b3};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        acc[14 + i] += gl[i];
-        const float gs = gl[0] * rows[i][0] + gl[1] * rows[i][1] + gl[2] * rows[i][2];
-        acc[2 + i] += gs * v[i];
-        gv[i] = gs * p.S[i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[5 + i * 3 + j] += s[i] * gl[j];
-    }
-}
-
-// turn the 17 raw accumulators of one primitive into parameter gradients (+=)
-__device__ __forceinline__ void finish_pose_grads(const Pose &p, const float *S, int k, const float *acc, float *g_sq_eps,
-                                                  float *g_S, float *g_R6, float *g_T) {
-    if (g_sq_eps) {
-        g_sq_eps[k * 2] += acc[0] * 1.8f * p.se1 * (1.f - p.se1);
-        g_sq_eps[k * 2 + 1] += acc[1] * 1.8f * p.se2 * (1.f - p.se2);
-    }
-    if (g_S) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) g_S[k * 3 + i] += acc[2 + i] * expf(S[k * 3 + i]);
-    }
-    float ga[6];
-    rot6d_bwd(p.rot, acc + 5, ga);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) g_R6[k * 6 + i] += ga[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) g_T[k * 3 + i] += acc[14 + i];
-}
 
 __device__ __forceinline__ int dense_index(const int *keep, int k) {
     if (!keep) return k;
@@ -174,10 +35,8 @@ __global__ __launch_bounds__(64) void sq_blocks_fwd_kernel(const float *sq_eps, 
     const long long plane = (long long)Kb * nv;
     for (int v = threadIdx.x; v < nv; v += 64) {
         const long long o = (long long)k * nv + v;
-        float d;
-        const float A = spow(trig[o], p.e1, d), C = spow(trig[plane + o], p.e1, d);
-        const float Bc = spow(trig[2 * plane + o], p.e2, d), Bs = spow(trig[3 * plane + o], p.e2, d);
-        const float loc[3] = {A * Bs * ratio, C * ratio, A * Bc * ratio};
+        float loc[3], de1[3], de2[3];
+        parametric_sq_point(trig[o], trig[plane + o], trig[2 * plane + o], trig[3 * plane + o], p.e1, p.e2, ratio, loc, de1, de2);
         pose_fwd(p, loc, S_world, Rw, Tw, verts + ((long long)ko * nv + v) * 3);
     }
 }
@@ -198,14 +57,12 @@ __global__ __launch_bounds__(64) void sq_blocks_bwd_kernel(const float *sq_eps, 
     for (int i = 0; i < 17; ++i) acc[i] = 0.f;
     for (int v = threadIdx.x; v < nv; v += 64) {
         const long long o = (long long)k * nv + v;
-        float dA, dC, dBc, dBs;
-        const float A = spow(trig[o], p.e1, dA), C = spow(trig[plane + o], p.e1, dC);
-        const float Bc = spow(trig[2 * plane + o], p.e2, dBc), Bs = spow(trig[3 * plane + o], p.e2, dBs);
-        const float loc[3] = {A * Bs * ratio, C * ratio, A * Bc * ratio};
+        float loc[3], de1[3], de2[3];
+        parametric_sq_point(trig[o], trig[plane + o], trig[2 * plane + o], trig[3 * plane + o], p.e1, p.e2, ratio, loc, de1, de2);
         float gv[3];
         pose_bwd(p, loc, S_world, Rw, gverts + ((long long)ko * nv + v) * 3, acc, gv);
-        acc[0] += ratio * (gv[0] * dA * Bs + gv[1] * dC + gv[2] * dA * Bc);
-        acc[1] += ratio * (gv[0] * A * dBs + gv[2] * A * dBc);
+        acc[0] += gv[0] * de1[0] + gv[1] * de1[1] + gv[2] * de1[2];
+        acc[1] += gv[0] * de2[0] + gv[1] * de2[1] + gv[2] * de2[2];
     }
 #pragma unroll
     for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
@@ -240,14 +97,6 @@ __global__ __launch_bounds__(64) void posed_mesh_bwd_kernel(const float *base, i
 // ---- overlap ------------------------------------------------------------------------------------------------------
 constexpr int MAX_KB = 64;
 constexpr int NG = 18;   // raw grads per block: e1,e2 | S(3) | R(9) | T(3) | alpha
-
-__device__ __forceinline__ float safe_pow_f(float t, float e, float &dt, float &de) {   // clamp(1e-6).pow(e)
-    const float c = t < 1e-6f ? 1e-6f : t;
-    const float r = powf(c, e);
-    dt = t >= 1e-6f ? e * r / c : 0.f;
-    de = r * logf(c);
-    return r;
-}
 
 struct BlockP {
     float e1, e2, sr[3], R[9], T[3], alpha;   // sr = S*ratio
@@ -289,14 +138,8 @@ __global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, 
                 float pc[3];
                 bool inr[3];
                 for (int i = 0; i < 3; ++i) { inr[i] = inv[i] >= -5.f && inv[i] <= 5.f; pc[i] = inv[i] < -5.f ? -5.f : (inv[i] > 5.f ? 5.f : inv[i]); }
-                const float x2 = pc[0] * pc[0], y2 = pc[1] * pc[1], z2 = pc[2] * pc[2];
-                float dXt, dXe, dYt, dYe, dZt, dZe, dWt, dWe, dQt, dQe;
-                const float X = safe_pow_f(x2, 1.f / b.e2, dXt, dXe), Y = safe_pow_f(y2, 1.f / b.e1, dYt, dYe);
-                const float Z = safe_pow_f(z2, 1.f / b.e2, dZt, dZe);
-                const float Wp = safe_pow_f(X + Z, b.e2 / b.e1, dWt, dWe);
-                const float r = Wp + Y;
-                const float Q = safe_pow_f(r, b.e1 / 2.f, dQt, dQe);
-                const float sdf = Q - 1.f;
+                ImplicitSq im;
+                const float sdf = implicit_sq_sdf2(pc, b.e1, b.e2, im);
                 const float occ = sigmoidf(-sdf * inv_temp);
                 if (pass == 0) { sum += occ * b.alpha; continue; }
                 // backward of scale_over_P * (sum - thresh)
@@ -305,16 +148,9 @@ __global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, 
                 atomicAdd(g + 17, go * occ);
                 const float gsdf = go * b.alpha * occ * (1.f - occ) * (-inv_temp);
                 if (gsdf == 0.f) continue;
-                float ge1 = gsdf * dQe * 0.5f, ge2 = 0.f;
-                const float gr = gsdf * dQt;
-                const float gW = gr, gY = gr;
-                const float gex = gW * dWe;                       // exponent e2/e1
-                ge2 += gex / b.e1; ge1 += gex * (-b.e2 / (b.e1 * b.e1));
-                const float gXZ = gW * dWt;
-                ge2 += (gXZ * dXe + gXZ * dZe) * (-1.f / (b.e2 * b.e2));
-                ge1 += gY * dYe * (-1.f / (b.e1 * b.e1));
-                const float gp[3] = {inr[0] ? gXZ * dXt * 2.f * pc[0] : 0.f, inr[1] ? gY * dYt * 2.f * pc[1] : 0.f,
-                                     inr[2] ? gXZ * dZt * 2.f * pc[2] : 0.f};
+                float ge1, ge2, gpc[3];
+                implicit_sq_sdf2_bwd(pc, b.e1, b.e2, im, gsdf, ge1, ge2, gpc);
+                const float gp[3] = {inr[0] ? gpc[0] : 0.f, inr[1] ? gpc[1] : 0.f, inr[2] ? gpc[2] : 0.f};
                 atomicAdd(g + 0, ge1); atomicAdd(g + 1, ge2);
                 for (int i = 0; i < 3; ++i) {
                     if (gp[i] == 0.f) continue;
