@@ -8,6 +8,7 @@
 // One workgroup per view: faces are classified, an ordered block-wide scan (two ballots per wave: a face emits 0, 1
 // or 2 triangles) assigns output slots in original face order, and each thread writes its own triangles.
 #include "dbw_common.h"
+#include "camera_math.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -15,60 +16,6 @@ using namespace dbw;
 namespace {
 
 constexpr int NT = 256;
-
-struct Cam {
-    float R[9], T[3], K[16];
-};
-
-__device__ __forceinline__ void load_cam(const float *R, const float *T, const float *Kmat, int b, Cam &c) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = R[b * 9 + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c.T[i] = T[b * 3 + i];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c.K[i] = Kmat[i];
-}
-
-struct Proj {
-    float vx, vy, vz;   // view space
-    float px, py, pw;   // before the perspective divide
-    float denom;
-    f3 ndc;             // x,y NDC, z = view depth
-};
-
-__device__ __forceinline__ Proj project(const float *X, const Cam &c, float eps) {
-    Proj o;
-    const float x = X[0], y = X[1], z = X[2];
-    o.vx = x * c.R[0] + y * c.R[3] + z * c.R[6] + c.T[0];
-    o.vy = x * c.R[1] + y * c.R[4] + z * c.R[7] + c.T[1];
-    o.vz = x * c.R[2] + y * c.R[5] + z * c.R[8] + c.T[2];
-    o.px = o.vx * c.K[0] + o.vy * c.K[1] + o.vz * c.K[2] + c.K[3];
-    o.py = o.vx * c.K[4] + o.vy * c.K[5] + o.vz * c.K[6] + c.K[7];
-    o.pw = o.vx * c.K[12] + o.vy * c.K[13] + o.vz * c.K[14] + c.K[15];
-    const float sgn = o.pw > 0.f ? 1.f : (o.pw < 0.f ? -1.f : 1.f);
-    const float ab = o.pw < 0.f ? -o.pw : o.pw;
-    o.denom = sgn * (ab < eps ? eps : ab);
-    o.ndc.x = o.px / o.denom;
-    o.ndc.y = o.py / o.denom;
-    o.ndc.z = o.vz;
-    return o;
-}
-
-// intersection of segment pa->pb with z = c; w returned
-__device__ __forceinline__ f3 clip_point(f3 pa, f3 pb, float c, int persp, float &w) {
-    w = (pa.z - c) / (pa.z - pb.z);
-    const float omw = 1.f - w;
-    f3 q;
-    q.z = pa.z * omw + pb.z * w;
-    if (persp) {
-        q.x = ((pa.x * pa.z) * omw + (pb.x * pb.z) * w) / c;
-        q.y = ((pa.y * pa.z) * omw + (pb.y * pb.z) * w) / c;
-    } else {
-        q.x = pa.x * omw + pb.x * w;
-        q.y = pa.y * omw + pb.y * w;
-    }
-    return q;
-}
 
 __device__ __forceinline__ void store_tri(float *dst, f3 a, f3 b, f3 c) {
     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z;
@@ -89,17 +36,15 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
     int running = 0;
     for (int f0 = 0; f0 < F; f0 += NT) {
         const int f = f0 + tid;
-        f3 p[3];
-        int nbh = 0, behind_mask = 0;
+        ClippedFace cf;
+        cf.emit = 0;
         if (f < F) {
+            f3 p[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int vi = faces[f * 3 + i];
-                p[i] = project(verts + (long long)vi * 3, cam, eps).ndc;
-                if (zc_on && p[i].z < zc) { ++nbh; behind_mask |= 1 << i; }
-            }
+            for (int i = 0; i < 3; ++i) p[i] = project(verts + (long long)faces[f * 3 + i] * 3, cam, eps).ndc;
+            clip_face(p, zc_on, zc, persp, cf);
         }
-        const int emit = f < F ? (nbh == 0 ? 1 : (nbh == 3 ? 0 : (nbh == 2 ? 1 : 2))) : 0;
+        const int emit = cf.emit;
         const unsigned long long m1 = __ballot(emit >= 1), m2 = __ballot(emit == 2);
         const unsigned long long lower = (1ull << lane) - 1ull;
         const int prefix = __popcll(m1 & lower) + __popcll(m2 & lower);
@@ -109,69 +54,19 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
 #pragma unroll
         for (int w = 0; w < NT / DBW_WAVE; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
         const int slot = running + woff + prefix;
-        if (emit == 1 && nbh == 0) {
+        if (emit >= 1) {
             const long long o = base_out + slot;
-            store_tri(fvc + o * 9, p[0], p[1], p[2]);
-            c2o[o] = f; neighbor[o] = -1; code[o] = -1; cw[o * 2] = 0.f; cw[o * 2 + 1] = 0.f;
-        } else if (emit == 1) {   // case 3: two behind, p1 = the vertex in front -> (p4, p5, p1)
-            const int i1 = (behind_mask == 6) ? 0 : (behind_mask == 5 ? 1 : 2);
-            const f3 p1 = i1 == 0 ? p[0] : (i1 == 1 ? p[1] : p[2]), p2 = i1 == 0 ? p[1] : (i1 == 1 ? p[2] : p[0]),
-                     p3 = i1 == 0 ? p[2] : (i1 == 1 ? p[0] : p[1]);      // selects: runtime indexing would spill p[] to scratch
-            float w2, w3;
-            const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
-            const long long o = base_out + slot;
-            store_tri(fvc + o * 9, p4, p5, p1);
-            c2o[o] = f; neighbor[o] = -1; code[o] = i1 | (0 << 2); cw[o * 2] = w2; cw[o * 2 + 1] = w3;
-        } else if (emit == 2) {   // case 4: one behind, p1 = the vertex behind -> t1 (p4,p2,p5), t2 (p5,p2,p3)
-            const int i1 = (behind_mask == 1) ? 0 : (behind_mask == 2 ? 1 : 2);
-            const f3 p1 = i1 == 0 ? p[0] : (i1 == 1 ? p[1] : p[2]), p2 = i1 == 0 ? p[1] : (i1 == 1 ? p[2] : p[0]),
-                     p3 = i1 == 0 ? p[2] : (i1 == 1 ? p[0] : p[1]);      // selects: runtime indexing would spill p[] to scratch
-            float w2, w3;
-            const f3 p4 = clip_point(p1, p2, zc, persp, w2), p5 = clip_point(p1, p3, zc, persp, w3);
-            const long long o = base_out + slot;
-            store_tri(fvc + o * 9, p4, p2, p5);
-            store_tri(fvc + (o + 1) * 9, p5, p2, p3);
-            c2o[o] = f; c2o[o + 1] = f;
-            neighbor[o] = (int)(o + 1); neighbor[o + 1] = (int)o;
-            code[o] = i1 | (1 << 2); code[o + 1] = i1 | (2 << 2);
-            cw[o * 2] = w2; cw[o * 2 + 1] = w3; cw[(o + 1) * 2] = w2; cw[(o + 1) * 2 + 1] = w3;
+            store_tri(fvc + o * 9, cf.t0[0], cf.t0[1], cf.t0[2]);
+            c2o[o] = f; neighbor[o] = emit == 2 ? (int)(o + 1) : -1; code[o] = cf.code0; cw[o * 2] = cf.w2; cw[o * 2 + 1] = cf.w3;
+            if (emit == 2) {
+                store_tri(fvc + (o + 1) * 9, cf.t1[0], cf.t1[1], cf.t1[2]);
+                c2o[o + 1] = f; neighbor[o + 1] = (int)o; code[o + 1] = cf.code1; cw[(o + 1) * 2] = cf.w2; cw[(o + 1) * 2 + 1] = cf.w3;
+            }
         }
         running += tot;
         __syncthreads();
     }
     if (tid == 0) { first_idx[b] = (int)base_out; num_faces[b] = running; }
-}
-
-// d(ndc vertex)/d(world vertex): the world-space gradient of one vertex of one view
-__device__ __forceinline__ f3 vertex_bwd(const float *verts, int vi, const Cam &c, float eps, f3 g) {
-    const Proj pr = project(verts + (long long)vi * 3, c, eps);
-    const float gpx = g.x / pr.denom, gpy = g.y / pr.denom;
-    const float gden = -(g.x * pr.px + g.y * pr.py) / (pr.denom * pr.denom);
-    const float ab = pr.pw < 0.f ? -pr.pw : pr.pw;
-    const float gpw = ab >= eps ? gden : 0.f;
-    const float gvx = gpx * c.K[0] + gpy * c.K[4] + gpw * c.K[12];
-    const float gvy = gpx * c.K[1] + gpy * c.K[5] + gpw * c.K[13];
-    const float gvz = gpx * c.K[2] + gpy * c.K[6] + gpw * c.K[14] + g.z;
-    f3 o;
-    o.x = gvx * c.R[0] + gvy * c.R[1] + gvz * c.R[2];
-    o.y = gvx * c.R[3] + gvy * c.R[4] + gvz * c.R[5];
-    o.z = gvx * c.R[6] + gvy * c.R[7] + gvz * c.R[8];
-    return o;
-}
-
-// grads of q = clip_point(pa, pb) (w detached) pushed to ga, gb
-__device__ __forceinline__ void clip_point_bwd(f3 pa, f3 pb, float c, int persp, float w, f3 gq, f3 &ga, f3 &gb) {
-    const float omw = 1.f - w;
-    ga.z += gq.z * omw; gb.z += gq.z * w;
-    if (persp) {
-        ga.x += gq.x * pa.z * omw / c; ga.y += gq.y * pa.z * omw / c;
-        ga.z += (gq.x * pa.x + gq.y * pa.y) * omw / c;
-        gb.x += gq.x * pb.z * w / c; gb.y += gq.y * pb.z * w / c;
-        gb.z += (gq.x * pb.x + gq.y * pb.y) * w / c;
-    } else {
-        ga.x += gq.x * omw; ga.y += gq.y * omw;
-        gb.x += gq.x * w; gb.y += gq.y * w;
-    }
 }
 
 // Backward of project + clip.  One WAVE per clipped-face slot j, one LANE per view: the B views push their gradient of slot j
