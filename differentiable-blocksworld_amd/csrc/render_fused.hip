@@ -4,6 +4,7 @@
 // (PyTorch3D rasterize -> interpolate -> grid_sample -> ~12 blend kernels, renderer.py:92-94,219-273) re-reads them ~15x.
 #include "raster_common.h"
 #include "shade_common.h"
+#include "loss_math.h"
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
@@ -226,15 +227,13 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         float sq = 0.f;
         if (in_img) {
             const float *ev = A.env_img + (long long)n * 4 * plane + pix, *tg = A.target + (long long)n * 3 * plane + pix;
-            const float e0 = ev[0], e1 = ev[plane], e2 = ev[2 * plane];
-            const float d0 = tg[0] - (f0 * m + (1.f - m) * e0), d1 = tg[plane] - (f1 * m + (1.f - m) * e1), d2 = tg[2 * plane] - (f2 * m + (1.f - m) * e2);
-            sq = d0 * d0 + d1 * d1 + d2 * d2;
-            const float s2 = -2.f * A.mse_scale;
-            const float q0 = s2 * d0, q1 = s2 * d1, q2 = s2 * d2;                 // d loss / d rec
+            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[plane], ev[2 * plane]}, t3[3] = {tg[0], tg[plane], tg[2 * plane]};
+            float rec3[3], gf3[3], ge3[3], gmask;
+            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
             float *gf = A.g_fg + (long long)n * 4 * plane + pix, *ge = A.g_env + (long long)n * 4 * plane + pix;
-            gf[0] = q0 * m; gf[plane] = q1 * m; gf[2 * plane] = q2 * m;
-            gf[3 * plane] = q0 * (f0 - e0) + q1 * (f1 - e1) + q2 * (f2 - e2);
-            ge[0] = q0 * (1.f - m); ge[plane] = q1 * (1.f - m); ge[2 * plane] = q2 * (1.f - m); ge[3 * plane] = 0.f;
+            gf[0] = gf3[0]; gf[plane] = gf3[1]; gf[2 * plane] = gf3[2];
+            gf[3 * plane] = gmask;
+            ge[0] = ge3[0]; ge[plane] = ge3[1]; ge[2 * plane] = ge3[2]; ge[3 * plane] = 0.f;
         }
         const float tot = wave_sum_dpp(sq);
         if (lane == 0) A.loss_part[tile] = tot;

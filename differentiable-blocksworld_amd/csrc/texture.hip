@@ -2,6 +2,7 @@
 // (dbw.py:378-387, loss.py:46) and the fused decoupled composite + MSE forward/backward (dbw.py:223,366-367).
 // All are streaming, HBM-bound passes over O(10 MB) per optimisation step (not per view).
 #include "dbw_common.h"
+#include "loss_math.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -121,17 +122,11 @@ __device__ __forceinline__ void tv_l2sq_body(const float *__restrict__ m, int n,
         const int y = row % h;
         const float *r = m + (long long)row * w * 3;
         for (int x = blockIdx.x * NT + threadIdx.x; x < w; x += gridDim.x * NT) {
-            const int xr = x + 1 < w ? x + 1 : (wrap ? 0 : -1), xl = x > 0 ? x - 1 : (wrap ? w - 1 : -1);
+            float g3[3];
+            part += tv_l2sq_texel(r, x, y, w, h, wrap, sx, sy, g3);
+            if (gm) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = r[x * 3 + c];
-                float g = 0.f;
-                // forward difference owned by this texel (x -> x+1, wrapping to column 0 when wrap)
-                if (xr >= 0) { const float dxf = r[xr * 3 + c] - v; part += dxf * dxf * sx; g -= 2.f * dxf * sx; }
-                if (xl >= 0) { const float dxb = v - r[xl * 3 + c]; g += 2.f * dxb * sx; }
-                if (y + 1 < h) { const float dyf = r[(x + w) * 3 + c] - v; part += dyf * dyf * sy; g -= 2.f * dyf * sy; }
-                if (y > 0) { const float dyb = v - r[(x - w) * 3 + c]; g += 2.f * dyb * sy; }
-                if (gm) gm[((long long)row * w + x) * 3 + c] = scale * g;
+                for (int c = 0; c < 3; ++c) gm[((long long)row * w + x) * 3 + c] = scale * g3[c];
             }
         }
     }
@@ -171,20 +166,14 @@ __global__ __launch_bounds__(CNT) void composite_mse_kernel(const float *__restr
             const float *f = fg + n * 4 * plane + p, *e = env + n * 4 * plane + p;
             const float *t = img ? img + n * 3 * plane + p : nullptr;
             const float mask = f[3 * plane];
-            float gmask = 0.f;
+            const float fc3[3] = {f[0], f[plane], f[2 * plane]}, ec3[3] = {e[0], e[plane], e[2 * plane]};
+            const float t3[3] = {t ? t[0] : 0.f, t ? t[plane] : 0.f, t ? t[2 * plane] : 0.f};
+            float rec3[3], gf3[3], ge3[3], gmask = 0.f;
+            part += composite_mse_pixel(fc3, mask, ec3, t3, t != nullptr, 2.f * scale, rec3, gf3, ge3, gmask);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float fc = f[c * plane], ec = e[c * plane];
-                const float r = fc * mask + (1.f - mask) * ec;
-                const float d = t ? r - t[c * plane] : 0.f;
-                part += d * d;
-                if (rec) rec[n * 3 * plane + c * plane + p] = r;
-                if (gfg) {
-                    const float gr = 2.f * scale * d;
-                    gfg[n * 4 * plane + c * plane + p] = gr * mask;
-                    genv[n * 4 * plane + c * plane + p] = gr * (1.f - mask);
-                    gmask += gr * (fc - ec);
-                }
+                if (rec) rec[n * 3 * plane + c * plane + p] = rec3[c];
+                if (gfg) { gfg[n * 4 * plane + c * plane + p] = gf3[c]; genv[n * 4 * plane + c * plane + p] = ge3[c]; }
             }
             if (gfg) { gfg[n * 4 * plane + 3 * plane + p] = gmask; genv[n * 4 * plane + 3 * plane + p] = 0.f; }
         }
@@ -203,11 +192,7 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
                             float *__restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
                             float bc2_sqrt) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        adam_update(p[i], g[i], m[i], v[i], step_size, beta1, beta2, eps, bc2_sqrt);
     }
 }
 
@@ -220,11 +205,7 @@ __global__ void adam_groups_kernel(float *__restrict__ p, const float *__restric
         float step_size = G.step_size[0];
 #pragma unroll
         for (int k = 1; k < MAX_SETS; ++k) step_size = i >= G.end[k - 1] ? G.step_size[k] : step_size;
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        adam_update(p[i], g[i], m[i], v[i], step_size, beta1, beta2, eps, bc2_sqrt);
     }
 }
 
