@@ -184,18 +184,26 @@ class NativeStep:
                                                                       state=fg_state)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
         # kernels (projection backward, pose / shape, textures, opacities) ----
-        def fg_backward(st, after_kernel=None):
+        fg_out = {}
+
+        def fg_backward(st, after_kernel=None, with_textures=True):
             g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
                                                      cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel)
+            fg_out.update(g_blk_maps=g_blk_maps, g_fa=g_fa)
             g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
             _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
                       float(m.scale_min), float(S_w), _p(R_w), _p(g_blk_verts), _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), st)
-            sets[1]['grad_maps'] = _p(g_blk_maps)
+            if with_textures:
+                fg_textures(st)
+            return g_blk_maps, g_fa, g_fvc, g_blk_verts
+
+        def fg_textures(st):
+            """The half of the fg tail that does not depend on the geometry half: block textures and opacities."""
+            sets[1]['grad_maps'] = _p(fg_out['g_blk_maps'])
             launch('dbw_texture_prep_bwd_sets', (1,), st)
-            _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(g_fa), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
+            _lib.call('dbw_block_alpha_bwd', _p(alpha), keep_p, _p(fg_out['g_fa']), ops.ALPHA_SPREAD, _p(g_alpha_full), nb, _p(g['alpha_logit']), st)
             if self.on_block_grads_ready is not None:
                 self.on_block_grads_ready()                            # e.g. the data-parallel driver starts reducing the blocks' textures
-            return g_blk_maps, g_fa, g_fvc, g_blk_verts
 
         def env_backward(st):
             g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
@@ -215,15 +223,20 @@ class NativeStep:
             # the gradient bytes; Adam follows the env tail on the main stream.  Otherwise both chains are enqueued at once
             side.wait_stream(cur)                                      # g_fg, g_env written
             kernel_done = torch.cuda.Event()
-            torch.cuda.set_stream(side)
-            keep_f = fg_backward(side.cuda_stream, lambda: kernel_done.record(side))
-            torch.cuda.set_stream(cur)
             seq = self.sequential_backward
             if seq is None:
                 seq = m.world_size > 1 or decim_blocks == 1
+            torch.cuda.set_stream(side)
+            keep_f = fg_backward(side.cuda_stream, lambda: kernel_done.record(side), with_textures=seq)
+            torch.cuda.set_stream(cur)
             if seq:
                 cur.wait_event(kernel_done)
             keep_e = env_backward(st_main)
+            if not seq:
+                # both kernels were enqueued at once; the (lighter) env chain is done long before the fg kernel, so the main stream takes
+                # the texture / opacity half of the fg tail while the side stream runs the geometry half
+                cur.wait_event(kernel_done)
+                fg_textures(st_main)
             cur.wait_stream(side)
         else:
             keep_f = fg_backward(st_main)
