@@ -621,7 +621,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             const bool mine = on && R.bin == b;
             const unsigned long long mm = __ballot(mine);
             if (mine) { R.rank = __popcll(mm & below); R.leader = L; }
-            if (lane == L) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));
+            if (lane == L && !(A.dbg & (1 << 18))) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));     // (1 << 18: ablation, tools/diag)
             rem &= ~mm;
         }
         return R;
@@ -668,8 +668,10 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
                     const int slot = base + cres.rank;
                     if (slot < sub_cap) {
                         int4 *dst = A.bin_records + ((long long)cres.bin * A.bin_cap + (long long)sub * sub_cap + slot) * 2;
-                        dst[0] = make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0]));
-                        dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                        if (!(A.dbg & (1 << 17))) {                    // (1 << 17: ablation of the record stores, tools/diag)
+                            dst[0] = make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0]));
+                            dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                        }
                         pending = false;
                     }
                 }
