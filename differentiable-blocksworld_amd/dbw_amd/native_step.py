@@ -6,7 +6,8 @@ Why: `model(inp); loss.backward()` drives the same kernels through ~25 autograd 
 nodes feed one parameter (pose: blocks + overlap; textures: render + TV; opacities: render + parsimony + overlap) autograd inserts an
 elementwise add, plus one more per parameter to accumulate into the preallocated `.grad` -- 18 five-microsecond launches per step, next
 to `cat`s, fills, a `repeat_interleave` pair and three reductions that only exist because tensors travel between nodes
-(profiles/r02_step_sequence_autograd.txt: 66 launches).  Here every kernel writes where its result is needed: 30 launches.
+(66 launches per step when measured).  Here every kernel writes where its result is needed: 32 launches
+(profiles/r02_step_sequence_epoch0.txt).
 
 Same mathematics as DifferentiableBlocksWorld.forward (src/model/dbw.py:198-408) + backward, checked against it
 (tests/test_gpu_model.py::test_native_step_equals_autograd_step).  Scope: the decoupled training render with MSE + parsimony + TV +

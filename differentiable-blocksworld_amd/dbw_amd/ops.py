@@ -285,7 +285,7 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
     else:
         ws_bytes = _workspace_bytes(Ft, B, cfg.H, cfg.W)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-        if TILED_FRAGMENTS:     # internal 8x8-tile planar layout (include/dbw_hip.h: frag_layout = 1)
+        if TILED_FRAGMENTS:     # internal 8x8-tile planar layouts (include/dbw_hip.h: frag_layout 1, 2, 3)
             ty, tx = (cfg.H + 7) // 8, (cfg.W + 7) // 8
             p2f = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.int32, device=dev)
             bary = torch.empty(B, ty, tx, cfg.K, 8 if int(TILED_FRAGMENTS) == 2 else 3, 64, dtype=torch.float32, device=dev)

@@ -48,8 +48,9 @@ class FlatParams:
 
 class ShardedTrainStep:
     """use_graph=True captures zero_grad + forward + backward of one iteration into a hipGraph after `graph_warmup` eager
-    iterations (the ~135 kernel launches of an iteration then replay from one host call); requires model.sync_free and inputs
-    of constant shape.  The gradient all-reduce and the two Adam launches stay outside the graph."""
+    iterations of the AUTOGRAD path (its ~66 kernel launches then replay from one host call; measured slower than eager launches, and
+    the native step does not use it); requires model.sync_free and inputs of constant shape.  The gradient all-reduce and the Adam
+    launch stay outside the graph."""
 
     def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
                  use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures'):
@@ -66,7 +67,7 @@ class ShardedTrainStep:
         self.exp_avg_sq = torch.zeros_like(self.params.flat)
         self.n_steps = 0
         self.adam_fn = adam_fn or ops.adam_step_
-        # the iteration without autograd (native_step.py: same kernels, 30 launches instead of 66) whenever the model is the HIP
+        # the iteration without autograd (native_step.py: same kernels, 32 launches instead of 66) whenever the model is the HIP
         # DifferentiableBlocksWorld in a configuration it covers; the autograd path otherwise
         self.native = None
         if use_native and hasattr(model, 'loss_weights') and hasattr(model, 'renderer_env'):
