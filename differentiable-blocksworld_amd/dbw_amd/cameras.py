@@ -50,3 +50,22 @@ def pytorch3d_KRT_from_proj(P, image_size):
     Rp[:, :2] *= -1                               # OpenCV screen axes point the other way
     Tp[:2] *= -1
     return Kp, Rp, Tp
+
+
+def load_idr_cameras(cam, image_size, n_views=None):
+    """The IDR `cameras.npz` layout DTU / BlendedMVS scenes ship with (dtu.py:42-44): view i projects with
+    `(world_mat_i @ scale_mat_i)[:3, :4]`.  `cam`: a path or an already opened mapping; `image_size` = (H, W) of the RAW images the
+    matrices refer to (the NDC intrinsics are resolution independent, dtu.py:95-106).
+    -> dict(K (N,4,4), R (N,3,3), T (N,3)) ready to be batched into `model(inp)` + scale_mat (4,4) of view 0 (the reference uses it
+    to bring the ground-truth points into the normalised frame, dtu.py:47-50)."""
+    if not hasattr(cam, 'keys'):
+        cam = np.load(cam)
+    if n_views is None:
+        n_views = sum(1 for k in cam.keys() if k.startswith('world_mat_') and not k.startswith('world_mat_inv'))
+    Ks, Rs, Ts = [], [], []
+    for i in range(n_views):
+        P = (np.asarray(cam[f'world_mat_{i}'], dtype=np.float64) @ np.asarray(cam[f'scale_mat_{i}'], dtype=np.float64))[:3, :4]
+        K, R, T = pytorch3d_KRT_from_proj(P, image_size)
+        Ks.append(K); Rs.append(R); Ts.append(T)
+    return {'K': torch.stack(Ks), 'R': torch.stack(Rs), 'T': torch.stack(Ts),
+            'scale_mat': torch.from_numpy(np.asarray(cam['scale_mat_0'], dtype=np.float32))}

@@ -167,6 +167,40 @@ def test_camera_ingest_round_trip_and_pixel_consistency():
         assert torch.all(ndc[:, 2] > 0)
 
 
+def test_idr_cameras_npz_layout_round_trip(tmp_path):
+    """N3: the IDR cameras.npz layout of the DTU / BlendedMVS scenes (dtu.py:42-44): world_mat_i @ scale_mat_i -> (K, R, T); a point
+    of the normalised frame lands on the pixel its projection matrix names."""
+    import numpy as np
+    from dbw_amd.cameras import load_idr_cameras
+    rng = np.random.RandomState(3)
+    H, W, N = 1200, 1600, 4
+    arrays, Ps = {}, []
+    S = np.diag([350.0, 350.0, 350.0, 1.0]); S[:3, 3] = [10.0, -25.0, 600.0]                  # scale_mat: normalised -> world (mm)
+    for i in range(N):
+        Q, _ = np.linalg.qr(rng.randn(3, 3))
+        R_w2c = Q * np.sign(np.linalg.det(Q))
+        C = np.array([10.0, -25.0, 600.0]) + R_w2c.T @ np.array([0.0, 0.0, -900.0]) + rng.randn(3) * 30
+        Kcv = np.array([[2892.3, 0.0, 823.2], [0.0, 2883.2, 619.1], [0.0, 0.0, 1.0]])
+        Wm = np.eye(4); Wm[:3] = Kcv @ np.concatenate([R_w2c, (-R_w2c @ C)[:, None]], 1)
+        arrays[f'world_mat_{i}'], arrays[f'scale_mat_{i}'] = Wm, S
+        arrays[f'world_mat_inv_{i}'] = np.linalg.inv(Wm)                                      # present in the real files: must not be counted
+        Ps.append((Wm @ S)[:3, :4])
+    path = tmp_path / 'cameras.npz'
+    np.savez(path, **arrays)
+    cams = load_idr_cameras(str(path), (H, W))
+    assert cams['K'].shape == (N, 4, 4) and cams['R'].shape == (N, 3, 3) and cams['T'].shape == (N, 3)
+    np.testing.assert_allclose(cams['scale_mat'].numpy(), S, rtol=1e-6)
+    X = torch.from_numpy(rng.rand(50, 3) * 1.2 - 0.6).float()                                 # points of the unit normalised scene
+    for i in range(N):
+        ndc = O.transform_to_ndc(X, cams['R'][i][None], cams['T'][i][None], cams['K'][i])[0]
+        uvw = (torch.from_numpy(Ps[i]).float() @ torch.cat([X, torch.ones(50, 1)], 1).T).T
+        u, v = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+        s = min(H, W) / 2
+        torch.testing.assert_close(W / 2 - ndc[:, 0] * s, u, rtol=1e-4, atol=0.2)
+        torch.testing.assert_close(H / 2 - ndc[:, 1] * s, v, rtol=1e-4, atol=0.2)
+        assert torch.all(ndc[:, 2] > 0)
+
+
 def test_eval_metrics_match_reference_ssim_and_psnr(golden_dir):
     """metrics.ssim (separable 1-D Gaussian filtering) and mse2psnr against the reference's own SSIMLoss / mse2psnr outputs
     (tests/golden/ssim.npz, generated by make_golden.py from src/model/loss.py)."""
