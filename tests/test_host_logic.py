@@ -246,3 +246,30 @@ def test_fancy_cmap_structure():
     assert np.abs(np.diff(fine, axis=0)).max() < 0.12                        # piecewise-linear, no jumps
     import torch
     assert np.allclose(cmap(torch.tensor([0.25, 0.75])), cmap(np.array([0.25, 0.75])))
+
+
+def test_lpips_vgg_architecture_and_weight_layout():
+    """N4: the LPIPS-VGG criterion as a plain-torch module (parity unpinned: no weights offline).  Structure checks: the state layout a user
+    has to bring (torchvision vgg16.features + lpips linear heads), refusal to run without weights, zero distance of an image to
+    itself, non-negativity with non-negative heads, gradient to the reconstruction only."""
+    from dbw_amd.lpips_vgg import LPIPSVGG, _VGG16_CONVS, _CHANNELS
+    net = LPIPSVGG()
+    a, b = torch.rand(2, 3, 32, 48), torch.rand(2, 3, 32, 48)
+    with pytest.raises(RuntimeError, match='no weights'):
+        net(a, b)
+    gen = torch.Generator().manual_seed(0)
+    vgg = {}
+    for i, cin, cout in _VGG16_CONVS:
+        vgg[f'{i}.weight'] = torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+        vgg[f'{i}.bias'] = torch.zeros(cout)
+    lin = {f'lin{k}.model.1.weight': torch.rand(1, c, 1, 1, generator=gen) for k, c in enumerate(_CHANNELS)}
+    net.load_weights(vgg, lin)
+    assert [t.shape[1] for t in net.features(a)] == _CHANNELS and [t.shape[2] for t in net.features(a)] == [32, 16, 8, 4, 2]
+    assert float(net(a, a)) == 0.0
+    rec = b.clone().requires_grad_(True)
+    d = net(a, rec)
+    assert float(d) > 0
+    d.backward()
+    assert rec.grad is not None and float(rec.grad.abs().sum()) > 0 and all(not p.requires_grad for p in net.parameters())
+    # plugs into the model as the perceptual callable (src/model/loss.py:39-40: mean over the batch)
+    assert d.dim() == 0
