@@ -621,3 +621,30 @@ def test_native_step_equals_autograd_step(epoch):
     diff = (res[0][2] - res[1][2]).abs()
     assert float((diff > 1e-4).float().mean()) < 1e-2, float((diff > 1e-4).float().mean())     # (37 k parameters: one flip = 12 texels)
     assert float(diff.max()) < 0.02, float(diff.max())           # (three steps move a parameter by at most 3 lr = 0.15)
+
+
+def test_perceptual_term_with_the_lpips_vgg_module_runs_through_the_model():
+    """N4: `perceptual_weight > 0` + `model.set_perceptual(LPIPSVGG(...))` (random weights here: none exist offline): the term appears in the
+    losses with its phase factor (dbw.py:370), the HIP render path stays differentiable through it (MIOpen convolutions behind the
+    composite), and without a network the model refuses instead of silently dropping the term."""
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    H, W = 48, 64
+    cfg = _dtu_like_cfg(4, 32, 6)
+    cfg['model']['loss']['perceptual_weight'] = 0.1
+    R, T, Km = O.synthetic_cameras(2, R_world=O.world_rotation(115, 0, 0))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(2)), R=R, T=T, K=Km).items()}
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(cfg, (H, W)).to(DEV).train()
+    with pytest.raises(RuntimeError, match='set_perceptual'):
+        model(inp, None)
+    net = LPIPSVGG(allow_random_init=True).to(DEV)
+    model.set_perceptual(net)
+    out = model(inp, None)
+    assert set(out) == {'rgb', 'perceptual', 'parsimony', 'tv', 'overlap', 'total'}
+    rec = model.predict(inp, None).detach()
+    pv = float(out['perceptual'].detach())
+    assert abs(pv / 0.1 - float(net(inp['imgs'], rec))) < 0.2 * pv / 0.1 + 1e-3   # (opacity noise differs between the two renders)
+    out['total'].backward()
+    for n in ('textures', 'S', 'T', 'alpha_logit', 'texture_ground'):
+        g = model.get_parameter(n).grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, n
