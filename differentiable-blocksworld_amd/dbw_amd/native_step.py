@@ -99,23 +99,10 @@ class NativeStep:
         env_state = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps,
                                           None, m.renderer_env._bg, lay_e, stage=1)
 
-        # ---- side: zero the gradients, opacities (dbw.py:297-311), textures: sigmoid (+ decimation to cell resolution); `sig` = the
-        # undecimated maps of the TV term ----
+        # ---- side: textures first -- sigmoid (+ decimation to cell resolution); `sig` = the undecimated maps of the TV term -- because
+        # the env pass on the main stream waits for them; then zero the gradients and the opacities (dbw.py:297-311) ----
         torch.cuda.set_stream(side)
         st = st_side
-        if zero_grad is not None:
-            zero_grad()
-        vals = torch.zeros(8, device=dev)                  # 0 rgb (filled on demand), 1 parsimony, 2 tv, 3 overlap; outlives the step
-        noise, noise_scale = None, 0.0
-        if m.opacity_noise and coarse:
-            noise = m._noise_override if m._noise_override is not None else m._shared_randn_like(m.alpha_logit)
-            noise_scale = float(m.opacity_noise)
-        masked = fine or m.kill_blocks
-        thresh = (0.5 if fine else 0.01) if masked else -1.0
-        alpha, alpha_full = torch.empty(nb, device=dev), torch.empty(nb, device=dev)
-        keep = torch.empty(nb, dtype=torch.int32, device=dev)
-        _lib.call('dbw_block_alpha_fwd', _p(m.alpha_logit), _p(noise), noise_scale, thresh, nb, _p(alpha), _p(alpha_full), _p(keep), st)
-        keep_p = _p(keep) if masked else 0
         tv_f = 1.0 if coarse else 0.1
         tv = float(w['tv']) * tv_f * rs if 'tv' in w else 0.0
         sets = []                                                      # the three texture tensors: one launch per pass over them
@@ -134,6 +121,19 @@ class NativeStep:
         if side is not cur:
             maps_ready = torch.cuda.Event()
             maps_ready.record(side)
+        if zero_grad is not None:
+            zero_grad()
+        vals = torch.zeros(8, device=dev)                  # 0 rgb (filled on demand), 1 parsimony, 2 tv, 3 overlap; outlives the step
+        noise, noise_scale = None, 0.0
+        if m.opacity_noise and coarse:
+            noise = m._noise_override if m._noise_override is not None else m._shared_randn_like(m.alpha_logit)
+            noise_scale = float(m.opacity_noise)
+        masked = fine or m.kill_blocks
+        thresh = (0.5 if fine else 0.01) if masked else -1.0
+        alpha, alpha_full = torch.empty(nb, device=dev), torch.empty(nb, device=dev)
+        keep = torch.empty(nb, dtype=torch.int32, device=dev)
+        _lib.call('dbw_block_alpha_fwd', _p(m.alpha_logit), _p(noise), noise_scale, thresh, nb, _p(alpha), _p(alpha_full), _p(keep), st)
+        keep_p = _p(keep) if masked else 0
 
         # ---- main: the env pass ----
         torch.cuda.set_stream(cur)
