@@ -45,8 +45,9 @@ class NativeStep:
         -> {'rgb', 'parsimony', 'tv', 'overlap', 'total'} as 0-dim device tensors.
 
         Schedule (two HIP streams; `overlap_regularisers = False` runs the same calls on one):
-          main: ground mesh -> env projection -> env per-face set-up | env pass | fg pass + MSE | fg backward + its tail
-          side: zero grads, opacities, texture prep | blocks' vertices, projection, fg per-face set-up, regularisers | env backward + tail
+          main: ground mesh -> env projection -> env per-face set-up | env pass | fg pass + MSE | env backward + tail [| fg textures]
+          side: texture prep, zero grads, opacities | blocks' vertices, projection, fg per-face set-up, regularisers | fg backward + tail
+        (the backward kernels one after the other or both at once: see `sequential_backward`)
         """
         m, g = self.m, self.grad
         w = m.loss_weights
