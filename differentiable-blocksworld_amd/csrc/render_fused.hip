@@ -290,7 +290,7 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
     if constexpr (KMAX == 1) {                                 // hard K=1 pass: large faces (sky dome, ground); the single payload stays in registers
         if (g_render_variant == 1) return DBW_V(8, 8, 2, false);
         if (g_render_variant == 2) return DBW_V(16, 8, 2, false);
-        return DBW_V(16, 16, 2, false);
+        return DBW_V(16, 16, 1, false);        // (one list chunk in flight: a bin of the hard pass holds a few dozen faces, 256 lanes test them at once)
     }
     else {
         // soft K-layer passes: one wave64 per 8x8 tile; uv-fragments (the training path) take the specialised shading
