@@ -199,14 +199,19 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
 struct AdamGroups { long long end[MAX_SETS]; float step_size[MAX_SETS]; };
 
 // parameter groups that differ in learning rate only (optimizer.py:6-18: textures vs everything else), contiguous in one flat buffer
+// zero_buf: scratch the NEXT step expects zero-initialised (the per-step zero arena): cleared here, at the end of a step, so that the
+// next step does not open with a fill launch in front of its first kernel
 __global__ void adam_groups_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                                   long long n, const AdamGroups G, float beta1, float beta2, float eps, float bc2_sqrt) {
+                                   long long n, const AdamGroups G, float beta1, float beta2, float eps, float bc2_sqrt,
+                                   uint4 *__restrict__ zero_buf, long long zero_vec) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float step_size = G.step_size[0];
 #pragma unroll
         for (int k = 1; k < MAX_SETS; ++k) step_size = i >= G.end[k - 1] ? G.step_size[k] : step_size;
         adam_update(p[i], g[i], m[i], v[i], step_size, beta1, beta2, eps, bc2_sqrt);
     }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += (long long)gridDim.x * blockDim.x)
+        zero_buf[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 inline unsigned grid_for(long long work) {
@@ -314,8 +319,11 @@ extern "C" int dbw_tv_l2sq_sets(const dbw_texture_set *sets, int nsets, float *l
 }
 
 extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
-                                    const float *lr, int ngroups, float beta1, float beta2, float eps, int step, dbw_stream_t stream) {
+                                    const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
+                                    int64_t zero_bytes, dbw_stream_t stream) {
     DBW_REQUIRE(param && grad && exp_avg && exp_avg_sq && group_end && lr, "null pointer");
+    DBW_REQUIRE(zero_bytes >= 0 && (zero_bytes == 0 || (zero_buf && zero_bytes % 16 == 0 && ((uintptr_t)zero_buf & 15) == 0)),
+                "zero_buf: 16-byte aligned, a multiple of 16 bytes");
     DBW_REQUIRE(ngroups >= 1 && ngroups <= MAX_SETS && step >= 1, "1..4 groups, step >= 1");
     for (int k = 0; k < ngroups; ++k) DBW_REQUIRE(group_end[k] >= (k ? group_end[k - 1] : 0), "group ends must not decrease");
     const long long n = group_end[ngroups - 1];
@@ -327,7 +335,7 @@ extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_
         G.step_size[k] = (float)(lr[k < ngroups ? k : ngroups - 1] / bc1);
     }
     hipLaunchKernelGGL(adam_groups_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, G,
-                       beta1, beta2, eps, (float)sqrt(bc2));
+                       beta1, beta2, eps, (float)sqrt(bc2), (uint4 *)zero_buf, (long long)(zero_bytes / 16));
     return dbw_check_launch("adam_groups_kernel");
 }
 

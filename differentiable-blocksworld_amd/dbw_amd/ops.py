@@ -37,7 +37,7 @@ class ZeroArena:
 
     def __init__(self):
         self.enabled = False
-        self.buf, self.off, self.want = {}, {}, {}
+        self.buf, self.off, self.want, self.clean = {}, {}, {}, {}
 
     def begin_step(self, device):
         if not self.enabled:
@@ -46,9 +46,21 @@ class ZeroArena:
         buf = self.buf.get(device)
         if buf is None or want > buf.numel():
             self.buf[device] = torch.zeros(max(int(want * 1.25), 1 << 20), dtype=torch.uint8, device=device)
-        elif used:
+        elif used and not self.clean.pop(device, False):
             buf[:used].zero_()
+        self.clean.pop(device, None)
         self.off[device], self.want[device] = 0, 0
+
+    def end_step(self, device):
+        """-> the part of the arena this step dirtied (or None), for a caller that clears it itself at the END of the step (the fused Adam
+        launch does, ops.adam_step_groups_(zero=...)): the next begin_step then issues no fill.  Nothing may take arena memory between
+        this call and the next begin_step."""
+        device = torch.device(device)
+        buf, used = self.buf.get(device), self.off.get(device, 0)
+        if not self.enabled or buf is None or not used or self.want.get(device, 0) > buf.numel():
+            return None
+        self.clean[device] = True
+        return buf[:min((used + 15) // 16 * 16, buf.numel())]
 
     def zeros(self, shape, dtype, device):
         device = torch.device(device)
@@ -824,14 +836,16 @@ def fused_losses(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, 
     return _FusedLosses.apply(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg)
 
 
-def adam_step_groups_(param, grad, exp_avg, exp_avg_sq, group_end, lrs, step, betas=(0.9, 0.999), eps=1e-8):
-    """One launch for parameter groups that lie back to back in one flat buffer and differ in learning rate (optimizer.py:10-17)."""
+def adam_step_groups_(param, grad, exp_avg, exp_avg_sq, group_end, lrs, step, betas=(0.9, 0.999), eps=1e-8, zero=None):
+    """One launch for parameter groups that lie back to back in one flat buffer and differ in learning rate (optimizer.py:10-17).
+    zero: a uint8 device tensor the same launch clears (the zero arena of the next iteration, ZeroArena.end_step)."""
     import ctypes
     n = len(lrs)
     ends = (ctypes.c_int64 * n)(*[int(e) for e in group_end])
     lr = (ctypes.c_float * n)(*[float(x) for x in lrs])
+    zb = 0 if zero is None else (zero.numel() + 15) // 16 * 16
     _lib.call('dbw_adam_step_groups', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ends, lr, n, float(betas[0]),
-              float(betas[1]), float(eps), int(step), _stream(param))
+              float(betas[1]), float(eps), int(step), _ptr(zero), zb, _stream(param))
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):

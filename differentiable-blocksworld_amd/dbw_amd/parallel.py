@@ -111,6 +111,7 @@ class ShardedTrainStep:
         """One optimisation step on this rank's shard of views (possibly EMPTY: the rank then only contributes its share of the
         view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
         self.model._global_count = self._global_count(inp['imgs'], global_count)
+        dirty = None
         if self.use_graph and self.n_steps >= self.graph_warmup:
             losses = self._graph_iteration(inp)
         else:
@@ -127,6 +128,7 @@ class ShardedTrainStep:
                     self.params.zero_grad()
                     losses = self.model(inp, labels)
                     losses['total'].backward()
+                dirty = ops.ARENA.end_step(self.params.flat.device) if (native and self._fused_adam()) else None
             finally:
                 ops.ARENA.enabled = False
             if not native:
@@ -134,15 +136,19 @@ class ShardedTrainStep:
         if self.world_size > 1 or self.overlap_allreduce:     # (a one-rank group with the overlap forced on: the API smoke test)
             self.allreduce_gradients()
         self.n_steps += 1
-        if self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda:
+        if self._fused_adam():
+            # both learning-rate groups in one launch, which also clears the zero arena for the next step
             ops.adam_step_groups_(self.params.flat, self.params.grad, self.exp_avg, self.exp_avg_sq, [b for _, b in self.params.bounds],
-                                  self.lrs, self.n_steps, self.betas, self.eps)       # both learning-rate groups in one launch
+                                  self.lrs, self.n_steps, self.betas, self.eps, zero=dirty)
             return losses
         for (a, b), lr in zip(self.params.bounds, self.lrs):
             if b > a:
                 self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,
                              self.betas, self.eps)
         return losses
+
+    def _fused_adam(self):
+        return self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda
 
     def _allreduce(self, t, async_op=False):
         """In-place sum all-reduce of (a slice of) the flat gradient buffer: RCCL over xGMI ('nccl'); gloo on CPU tensors; ranks

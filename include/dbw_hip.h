@@ -315,9 +315,12 @@ int dbw_overlap_loss(const float *u, int npts, const float *sq_eps, const float 
 int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, dbw_stream_t stream);
 /* The same over parameter groups that are contiguous in ONE flat buffer and differ only in learning rate (optimizer.py:10-17: the
- * texture group vs the rest): group k covers [group_end[k-1], group_end[k]) (group_end[-1] = 0), 1 <= ngroups <= 4; host arrays. */
+ * texture group vs the rest): group k covers [group_end[k-1], group_end[k]) (group_end[-1] = 0), 1 <= ngroups <= 4; host arrays.
+ * zero_buf / zero_bytes (optional, NULL / 0): device scratch cleared by the same launch -- the zero-initialised work space of the NEXT
+ * iteration, so that it does not have to open with a fill (16-byte aligned, a multiple of 16 bytes). */
 int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
-                         const float *lr, int ngroups, float beta1, float beta2, float eps, int step, dbw_stream_t stream);
+                         const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
+                         int64_t zero_bytes, dbw_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -244,7 +244,9 @@ def test_texture_sets_and_grouped_adam_equal_the_single_launches():
     for step in (1, 2, 3):
         ops.adam_step_(pa[:n0], g[:n0], ma[:n0], va[:n0], 5e-3, step)
         ops.adam_step_(pa[n0:], g[n0:], ma[n0:], va[n0:], 5e-2, step)
-        ops.adam_step_groups_(pb, g, mb, vb, [n0, n0 + n1], [5e-3, 5e-2], step)
+        scratch = torch.full((4099,), 7, dtype=torch.uint8, device=DEV)[:4096]          # the launch also clears the next step's zero arena
+        ops.adam_step_groups_(pb, g, mb, vb, [n0, n0 + n1], [5e-3, 5e-2], step, zero=scratch)
+        assert int(scratch.sum()) == 0
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
