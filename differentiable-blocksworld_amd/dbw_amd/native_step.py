@@ -6,7 +6,7 @@ Why: `model(inp); loss.backward()` drives the same kernels through ~25 autograd 
 nodes feed one parameter (pose: blocks + overlap; textures: render + TV; opacities: render + parsimony + overlap) autograd inserts an
 elementwise add, plus one more per parameter to accumulate into the preallocated `.grad` -- 18 five-microsecond launches per step, next
 to `cat`s, fills, a `repeat_interleave` pair and three reductions that only exist because tensors travel between nodes
-(66 launches per step when measured).  Here every kernel writes where its result is needed: 32 launches
+(66 launches per step when measured).  Here every kernel writes where its result is needed: 31 launches
 (profiles/r02_step_sequence_epoch0.txt).
 
 Same mathematics as DifferentiableBlocksWorld.forward (src/model/dbw.py:198-408) + backward, checked against it

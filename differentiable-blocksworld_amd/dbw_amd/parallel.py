@@ -67,7 +67,7 @@ class ShardedTrainStep:
         self.exp_avg_sq = torch.zeros_like(self.params.flat)
         self.n_steps = 0
         self.adam_fn = adam_fn or ops.adam_step_
-        # the iteration without autograd (native_step.py: same kernels, 32 launches instead of 66) whenever the model is the HIP
+        # the iteration without autograd (native_step.py: same kernels, 31 launches instead of 66) whenever the model is the HIP
         # DifferentiableBlocksWorld in a configuration it covers; the autograd path otherwise
         self.native = None
         if use_native and hasattr(model, 'loss_weights') and hasattr(model, 'renderer_env'):
