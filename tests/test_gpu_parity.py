@@ -104,6 +104,24 @@ def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
     assert (outs[0][0] >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize('name', ['front', 'straddle', 'ties'])
+def test_rasterize_reproduces_the_frozen_tiny_scenes(golden_dir, name):
+    """The HIP rasteriser (forward bit-exact, backward within 1e-5) on the committed tiny scenes of tests/golden/raster_tiny.npz
+    (SURVEY.md 8c golden vector 7: K > faces, a triangle straddling the near plane both ways, depth ties)."""
+    from test_oracle_golden import _load, _tiny_scene
+    g = _load(golden_dir, 'raster_tiny.npz')
+    fv, first, num, nbr, size, blur, K = _tiny_scene(g, name)
+    fvd = fv.to(DEV).requires_grad_(True)
+    nb = None if nbr is None else nbr.to(torch.int32).to(DEV)
+    p2f, zbuf, bary, dists = ops.rasterize_meshes(fvd, first.to(torch.int32).to(DEV), num.to(torch.int32).to(DEV), nb, size, blur, K, 0, 0,
+                                                  True, True, False)
+    for got, key in ((p2f, 'p2f'), (zbuf, 'zbuf'), (bary, 'bary'), (dists, 'dists')):
+        assert torch.equal(got.cpu(), g[f'{name}/{key}']), key
+    ((zbuf * g[f'{name}/g_zbuf'].to(DEV)).sum() + (bary * g[f'{name}/g_bary'].to(DEV)).sum() + (dists * g[f'{name}/g_dists'].to(DEV)).sum()).backward()
+    ref = g[f'{name}/g_face_verts']
+    assert float((fvd.grad.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_rasterize_ties_and_degenerates():
     """Coincident faces (identical z everywhere: tie broken by face id), zero-area faces, faces behind the camera."""
     base = random_faces(8, seed=5)

@@ -152,3 +152,15 @@ def test_div_fast_equals_ieee_division_inside_the_guarded_range():
     tn, td = torch.from_numpy(num), torch.from_numpy(den)
     for perturb in (0, 1, -1):
         assert lib().host_divcheck(_p(tn), _p(td), ctypes.c_longlong(tn.numel()), perturb) == 0
+
+
+@pytest.mark.parametrize('name', ['front', 'straddle', 'ties'])
+def test_host_build_reproduces_the_frozen_tiny_scenes(golden_dir, name):
+    """The product's rasteriser arithmetic (host build of csrc/raster_math.h) on the committed tiny scenes of tests/golden/raster_tiny.npz."""
+    from test_oracle_golden import _load, _tiny_scene
+    g = _load(golden_dir, 'raster_tiny.npz')
+    fv, first, num, nbr, size, blur, K = _tiny_scene(g, name)
+    for fastdiv in (0, 1):
+        (p2f, zbuf, bary, dists), _ = host_rasterize(fv, first, num, nbr, size, blur, K, fastdiv=fastdiv)
+        for got, key in ((p2f, 'p2f'), (zbuf, 'zbuf'), (bary, 'bary'), (dists, 'dists')):
+            assert torch.equal(got, g[f'{name}/{key}']), (key, fastdiv)

@@ -218,3 +218,32 @@ def test_render_and_model_gradients_flow():
     for k, v in m.p.items():
         assert v.grad is not None and torch.isfinite(v.grad).all(), k
         assert v.grad.abs().sum() > 0, k
+
+
+def _tiny_scene(g, name):
+    fv = g[f'{name}/face_verts']
+    first, num, nbr = torch.tensor([0]), torch.tensor([fv.shape[0]]), None
+    if float(g[f'{name}/zclip']) >= 0:
+        cl = O.clip_faces(fv, first, num, float(g[f'{name}/zclip']), True)
+        assert torch.equal(cl['face_verts'], g[f'{name}/clipped']) and torch.equal(cl['neighbor'], g[f'{name}/neighbor'])
+        assert torch.equal(cl['clipped_to_orig'], g[f'{name}/clipped_to_orig'])
+        fv, first, num, nbr = cl['face_verts'], cl['first_idx'], cl['num_faces'], cl['neighbor']
+    size = tuple(int(x) for x in g[f'{name}/size'])
+    return fv, first, num, nbr, size, float(g[f'{name}/blur']), int(g[f'{name}/K'])
+
+
+@pytest.mark.parametrize('name', ['front', 'straddle', 'ties'])
+def test_raster_tiny_scenes_are_frozen(golden_dir, name):
+    """SURVEY.md 8(c) golden vector (7): the oracle's rasteriser + clipping on three tiny scenes (K > faces, a triangle straddling the
+    near plane both ways, depth ties) against the committed fixture -- SELF-CONSISTENCY (parity unpinned vs PyTorch3D): it freezes the
+    restatement bit for bit; the host build of the product's arithmetic and the HIP kernels are held to the same file."""
+    g = _load(golden_dir, 'raster_tiny.npz')
+    fv, first, num, nbr, size, blur, K = _tiny_scene(g, name)
+    p2f, zbuf, bary, dists = O.rasterize_fwd_raw(fv, first, num, nbr, size, blur, K)
+    for got, key in ((p2f, 'p2f'), (zbuf, 'zbuf'), (bary, 'bary'), (dists, 'dists')):
+        assert torch.equal(got, g[f'{name}/{key}']), key
+    gfv = O.rasterize_bwd_raw(fv, p2f, g[f'{name}/g_zbuf'], g[f'{name}/g_bary'], g[f'{name}/g_dists'])
+    assert torch.equal(gfv, g[f'{name}/g_face_verts'])
+    if name == 'ties':                                          # equal depth everywhere: the smaller face id comes first
+        v = g['ties/p2f'][..., 0] >= 0
+        assert bool((g['ties/p2f'][..., 0][v] < g['ties/p2f'][..., 1][v]).all() or (g['ties/p2f'][..., 1][v] < 0).any())
