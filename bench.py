@@ -79,8 +79,9 @@ def kernel_breakdown(model, inp, reps=5):
         fine = not model.is_live('coarse_learning')                        # same choices as DifferentiableBlocksWorld.render_layers
         blocks = model.build_blocks_scene(filter_transparent=fine)
         alpha = None if fine else model._alpha.detach().repeat_interleave(model.BNF).contiguous()
-        passes = [('fg', model.renderer_fine if fine else model.renderer, blocks, alpha, bool(model._blocks_decimated)),
-                  ('env', model.renderer_env, model.build_env_scene(), None, True)]
+        passes = [('env', model.renderer_env, model.build_env_scene(), None, True),
+                  ('fg', model.renderer_fine if fine else model.renderer, blocks, alpha, bool(model._blocks_decimated))]
+    img_env = None
     for tag, r, scene, alpha, agg in passes:
         cfg = r._cfg(scene.faces.shape[0], lds_aggregate=agg, const_faces=getattr(scene, 'const_faces', 0))
         K = cfg.K
@@ -90,11 +91,31 @@ def kernel_breakdown(model, inp, reps=5):
         fvc = cl['face_verts'].view(-1, 3, 3)
         # fragment layout the training step uses for this pass
         mode = 2 if (cfg.detach_bary and ops.UV_FRAGMENTS) else ops.hard_layout(cfg, alpha, scene.map_desc)
-        fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode)
-        p2f, bary, dists, img = fwd()
-        g_img = torch.rand_like(img)
+        # the render kernel alone, as the training step launches it: the per-face set-up of the pass (stage 1: records, bins, tile
+        # lists, launch order -- a few small kernels that run ahead of the pass on the other stream) is done once, outside the timed region
+        if tag == 'fg' and mode == 2:
+            # the training step's form of the soft pass: composite over the env image + MSE against the targets in the epilogue, the
+            # two gradient images instead of an image (dbw_render_fwd_fused_mse); one opacity per block as in native_step
+            fa_blk = None if fine else model._alpha.detach().contiguous()
+            scale = 1.0 / inp['imgs'].numel()
+            state = ops.render_fwd_fused_mse(cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, fa_blk, r._bg, None, None, 0.0, stage=1)
+            fwd = lambda: ops.render_fwd_fused_mse(cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, fa_blk, r._bg, img_env,
+                                                   inp['imgs'], scale, stage=2, state=state)
+            p2f, bary, dists, _part, g_img, _g_env = fwd()
+            g_img = g_img.clone()
+            alpha = fa_blk
+        else:
+            state = ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode, stage=1)
+            fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode, stage=2,
+                                                state=state)
+            p2f, bary, dists, img = fwd()
+            g_img = torch.rand_like(img)
+            if tag == 'env':
+                img_env = img
         g_maps, g_fvc = torch.zeros_like(maps), torch.zeros_like(fvc)
         g_alpha = torch.zeros_like(alpha) if alpha is not None else None
+        if alpha is not None and ops._alpha_len(alpha, scene.map_desc, cfg.F) < 0:     # one opacity per map: 64 partial sums each
+            g_alpha = torch.zeros(alpha.numel() * ops.ALPHA_SPREAD, device=alpha.device)
         bins = scene.texbins if (ops.TEXTURE_BINS and not agg and scene.texbins is not None and scene.texbins[2] > 0) else None
         bin_base = cursor = records = 0
         cap = 0

@@ -31,8 +31,10 @@ constexpr int NT = 256;
 // Per-face record + screen box expanded by sqrt(blur_radius); faces that can never be hit (touching/behind the camera plane,
 // zero area, culled) get an empty box.  One rounding per value, same as the oracle's per-pixel expression.
 __global__ void face_setup_kernel(const float *__restrict__ fv, const int *__restrict__ neighbor, long long F, float margin, int cull,
-                                  float4 *__restrict__ bbox, FaceRec *__restrict__ recs) {
+                                  float4 *__restrict__ bbox, FaceRec *__restrict__ recs, int *__restrict__ zero, int nzero) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the cursors of the cell lists, cell_bin_kernel: cleared here, two launches ahead of their first use)
+    for (long long z = i; z < nzero; z += (long long)gridDim.x * blockDim.x) zero[z] = 0;
     if (i >= F) return;
     FaceRec r;
     float box[4];
@@ -109,6 +111,163 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
     }
     if (threadIdx.x == 0) count[n * nb + bin] = cnt;
     if (threadIdx.x < 2) mask[(n * nb + bin) * 2 + threadIdx.x] = s_mask[threadIdx.x];
+}
+
+// Launch order of the tiles of a render pass: the tile count is fixed by the image, the work per tile is not -- a tile of a soft pass
+// costs about as many microseconds as it has faces, two thirds of the tiles have none, and the tiles that were started last with
+// dozens of faces used to keep a handful of waves busy for 80 us after everything else had drained.  Inside every XCD segment of the
+// XCD-aware grid (the tiles xcd_remap gives that XCD: same tiles, same L2 locality) the tiles are ordered by face-count class,
+// heaviest first, and the empty tiles -- whose composite + loss epilogue is pure memory traffic -- are spread evenly between the
+// occupied ones, so that the streaming work hides behind the arithmetic instead of piling up at the end.
+//   cell_bin_kernel: class + rank inside (segment, class) of every tile (returning atomics on hdr[1 + segment * 16 + class])
+//   work_scatter_kernel: thread = tile: work[position] = view * tiles + tile
+constexpr int WORK_CLASSES = 10;
+__device__ __forceinline__ int work_class(int c) {
+    return c < 0 ? 0 : c == 0 ? 9 : c >= 64 ? 0 : c >= 48 ? 1 : c >= 32 ? 2 : c >= 24 ? 3 : c >= 16 ? 4 : c >= 12 ? 5 : c >= 8 ? 6 : c >= 4 ? 7 : 8;
+}
+__global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restrict__ cell, const int *__restrict__ rank, const int *__restrict__ hdr,
+                                                           long long total, int *__restrict__ work) {
+    const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= total) return;
+    const long long per = (total + 7) / 8;
+    const int x = (int)(L / per);
+    const long long seg0 = (long long)x * per;
+    const int len = (int)min(per, total - seg0);
+    const int k = work_class(cell[L].y);
+    int r = rank[L], O = 0;
+#pragma unroll
+    for (int c = 0; c < WORK_CLASSES - 1; ++c) { const int h = hdr[1 + x * 16 + c]; if (c < k) r += h; O += h; }
+    const int E = len - O;
+    unsigned p;
+    const bool small = (unsigned long long)len * (unsigned long long)(len + 1) < (1ull << 32);
+    if (k < WORK_CLASSES - 1) {        // the r-th of O slots spread evenly over the segment
+        if (small) p = ((unsigned)(r + 1) * (unsigned)len + (unsigned)O - 1u) / (unsigned)O - 1u;
+        else p = (unsigned)((((unsigned long long)(r + 1)) * (unsigned long long)len + (unsigned long long)O - 1ull) / (unsigned long long)O - 1ull);
+    } else {                           // the rank-th position that is not a slot (rank among the empty tiles: r - O)
+        const int e = r - O;
+        if (small) p = ((unsigned)e * (unsigned)len) / (unsigned)E;
+        else p = (unsigned)(((unsigned long long)e * (unsigned long long)len) / (unsigned long long)E);
+    }
+    work[seg0 + p] = (int)L;
+}
+
+// Fine level: one workgroup per (view, coarse bin) splits the bin's ordered list into the ordered lists of its 64 cells (8x8 pixels =
+// the tile of one wave of the soft passes), so that a render wave reads exactly the faces it has to evaluate -- no list walk, no
+// compaction, no staging in LDS, no tile-vs-edge test per (tile, face) at render time -- and so that the number of faces of every
+// tile is known before the render kernel starts (work_scatter_kernel).
+//   masks:     thread = list entry: the 64-bit mask of the cells of the entry's box range that the blur-expanded triangle can touch
+//              (tile_culled, conservative)
+//   transpose: 64 ballots per chunk of 64 entries: the column of a cell = bit i set where entry i of the chunk touches the cell
+//   reserve:   one atomic on the pool cursor per bin; a bin whose lists do not fit (or with more than CELL_ENTRY_CAP entries) marks
+//              its cells "walk the coarse list" (count -1)
+//   fill:      thread = (cell, chunk): the set bits of its column, in order, behind the entries of the chunks before it -- every
+//              loop runs over entries that exist, not over the whole list
+constexpr int CELL_ENTRY_CAP = 1024, CELL_CHUNKS = CELL_ENTRY_CAP / 64;
+__global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
+                                                       const int *__restrict__ num_faces, int N, int H, int W, int nx, int ny,
+                                                       const int *__restrict__ clist, const int *__restrict__ ccount, int2 *__restrict__ cell,
+                                                       int *__restrict__ pool, int pool_cap, int *__restrict__ hdr, int *__restrict__ rank) {
+    __shared__ float s_cmin[2][8], s_cmax[2][8];
+    __shared__ unsigned long long s_col[CELL_CHUNKS][64];
+    __shared__ int s_j[CELL_ENTRY_CAP];
+    __shared__ int s_pre[CELL_CHUNKS][64];
+    __shared__ int s_base;
+    const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
+    if (tid < 16) {          // NDC extents of the pixel centres of cell column / row c (as coarse_bin_kernel)
+        const int axis = tid >> 3, c = tid & 7;
+        const int S1 = axis ? H : W, S2 = axis ? W : H, p0 = (axis ? y0 : x0) + 8 * c, p1 = min(p0 + 7, S1 - 1);
+        s_cmax[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p0, S1, S2) : -INFINITY;
+        s_cmin[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p1, S1, S2) : INFINITY;
+    }
+    __syncthreads();
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3, tiles = tiles_x * tiles_y;
+    const int f_begin = first_idx[n], cnt_all = ccount[n * nb + bin];
+    const bool too_long = cnt_all > CELL_ENTRY_CAP;
+    const int cnt = too_long ? 0 : cnt_all, chunks = (cnt + 63) >> 6;
+    const int *lst = clist + (long long)f_begin * nb + (long long)bin * num_faces[n];
+    for (int ch = wv; ch < chunks; ch += 4) {
+        const int idx = ch * 64 + lane;
+        unsigned mlo = 0u, mhi = 0u;
+        if (idx < cnt) {
+            const int e = lst[idx];
+            const int j = e & 0xfffff, ex0 = (e >> 20) & 7, ex1 = (e >> 23) & 7, ey0 = (e >> 26) & 7, ey1 = (e >> 29) & 7;
+            s_j[idx] = j;
+            // (by value, through 128-bit loads: every field the tile test reads sits in registers before the loop over the cells starts --
+            // a reference left a dependent global load per edge test inside it)
+            FaceRec r;
+            {
+                const uint4 *src = (const uint4 *)(recs + f_begin + j);
+                uint4 *dst = (uint4 *)&r;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dst[w] = src[w];
+            }
+            for (int cy = ey0; cy <= ey1; ++cy)
+                for (int cx = ex0; cx <= ex1; ++cx)
+                    if (!tile_culled(r, s_cmin[0][cx], s_cmax[0][cx], s_cmin[1][cy], s_cmax[1][cy])) {
+                        if (cy < 4) mlo |= 1u << (8 * cy + cx); else mhi |= 1u << (8 * (cy - 4) + cx);
+                    }
+        }
+        unsigned long long col = 0ull;          // lane c: the entries of this chunk that touch cell c
+#pragma unroll 2
+        for (int c = 0; c < 32; ++c) {
+            const unsigned long long b0 = __ballot((mlo >> c) & 1u), b1 = __ballot((mhi >> c) & 1u);
+            if (lane == c) col = b0;
+            if (lane == c + 32) col = b1;
+        }
+        s_col[ch][lane] = col;
+    }
+    __syncthreads();
+    // per cell (wave 0, lane = cell): entries per chunk -> exclusive prefix over the chunks, total; then over the cells
+    const int px = x0 + 8 * (lane & 7), py = y0 + 8 * (lane >> 3);
+    const bool in_img = px < W && py < H;
+    const int tile = (py >> 3) * tiles_x + (px >> 3);
+    if (wv == 0) {
+        int all = 0;
+        for (int ch = 0; ch < chunks; ++ch) { s_pre[ch][lane] = all; all += __popcll(s_col[ch][lane]); }
+        int incl = all;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int total = __shfl(incl, 63, 64);
+        int base_off = 0;
+        if (lane == 0 && total > 0) base_off = atomicAdd(&hdr[0], total);
+        base_off = __shfl(base_off, 0, 64);
+        const bool overflow = too_long || (total > 0 && (long long)base_off + total > (long long)pool_cap);
+        const int off = base_off + (incl - all);
+        for (int ch = 0; ch < chunks; ++ch) s_pre[ch][lane] += off;
+        if (lane == 0) s_base = (overflow || total == 0) ? -1 : 0;
+        const int count = overflow ? -1 : all;
+        const long long L = (long long)n * tiles + tile;
+        if (in_img) cell[L] = make_int2(overflow ? 0 : off, count);
+        // rank of the tile inside its (XCD segment, face-count class): one returning atomic per distinct key of the wave
+        // (work_scatter_kernel turns class + rank into the tile's place in the launch order)
+        const long long per = ((long long)N * tiles + 7) / 8;
+        const int key = in_img ? (int)(L / per) * 16 + work_class(count) : -1;
+        unsigned long long rem = __ballot(key >= 0);
+        int r = 0;
+        while (rem) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const int k0 = __shfl(key, leader, 64);
+            const unsigned long long m = __ballot(key == k0);
+            int b0 = 0;
+            if (lane == leader) b0 = atomicAdd(&hdr[1 + k0], __popcll(m));
+            b0 = __shfl(b0, leader, 64);
+            if (key == k0) r = b0 + __popcll(m & ((1ull << lane) - 1ull));
+            rem &= ~m;
+        }
+        if (in_img) rank[L] = r;
+    }
+    __syncthreads();
+    if (s_base < 0) return;
+    for (int ch = wv; ch < chunks; ch += 4) {
+        unsigned long long bits = s_col[ch][lane];
+        int o = s_pre[ch][lane];
+        while (bits) {
+            const int i = __ffsll((long long)bits) - 1;
+            pool[o++] = s_j[ch * 64 + i];
+            bits &= bits - 1ull;
+        }
+    }
 }
 
 template <int KMAX, int TW, int TH>
@@ -228,10 +387,24 @@ extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) {
     return align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec)) + align256(F * 64);
 }
 
-extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
+// ... [coarse-bin lists][cell-list header: pool cursor, 8 x 16 class cursors][cell table (N, tiles) int2][work list (N * tiles)]
+//     [tile ranks (N * tiles)][cell-list pool]
+constexpr int CELL_HDR_INTS = 1 + 8 * 16;
+static size_t coarse_bytes(int64_t F_total, int N, int H, int W) {
     const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
-    return dbw_rasterize_workspace_bytes(F_total) + align256((size_t)(N > 0 ? N : 1) * nb * 3 * sizeof(int)) +
-           (size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int);
+    return align256((size_t)(N > 0 ? N : 1) * nb * 3 * sizeof(int)) + align256((size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int));
+}
+static size_t cell_tiles(int H, int W) { return (size_t)((W + 7) / 8) * ((H + 7) / 8); }
+static size_t cell_pool_entries(int64_t F_total, int N, int H, int W) {
+    // room for DBW_CELL_POOL_PER_TILE faces per cell on average (config 2 needs 5, config 5 about 20); a bin that does not fit falls
+    // back to walking its coarse list, so this is a performance knob, not a limit
+    const size_t want = (size_t)(N > 0 ? N : 1) * cell_tiles(H, W) * DBW_CELL_POOL_PER_TILE;
+    return want < ((size_t)1 << 30) ? want : ((size_t)1 << 30);
+}
+extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
+    const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
+    return dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W) + align256(CELL_HDR_INTS * sizeof(int)) +
+           align256(n * t * sizeof(int2)) + 2 * align256(n * t * sizeof(int)) + align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
 }
 
 const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
@@ -246,9 +419,10 @@ void *dbw_workspace_shade_recs(void *workspace, long long F_total) {
 // Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
                        long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
-                       dbw::CoarseBins &cb, hipStream_t s, bool launch) {
+                       dbw::CoarseBins &cb, hipStream_t s, bool launch, bool want_cells) {
     // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass); only `cb` is rebuilt
     cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
+    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
     if (F_total <= 0) return DBW_OK;
     if (F_total >= (1LL << TOPK_ID_BITS) - 1) {
         dbw_set_error("rasteriser: %lld packed faces, the per-pixel list keys hold face ids below 2^%d - 1", F_total, TOPK_ID_BITS);
@@ -259,16 +433,19 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
         return DBW_ERR_INVALID;
     }
     int rc = DBW_OK;
+    // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
+    const bool binned = workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20);
+    const bool cells = binned && want_cells && !(g_raster_dbg & 4096) && DBW_CELL_LISTS;
+    char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
+    int *hdr = (int *)(p + coarse_bytes(F_total, N, H, W));
     if (launch) {
         hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
-                           (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total));
+                           (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total), cells ? hdr : nullptr, cells ? CELL_HDR_INTS : 0);
         rc = dbw_check_launch("face_setup_kernel");
         if (rc) return rc;
     }
-    // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
-    if (workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20)) {
+    if (binned) {
         const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
-        char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
         int *count = (int *)p;
         unsigned *mask = (unsigned *)(count + (size_t)N * nx * ny);
         int *list = (int *)(p + align256((size_t)N * nx * ny * 3 * sizeof(int)));
@@ -279,6 +456,25 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
             if (rc) return rc;
         }
         cb.list = list; cb.count = count; cb.mask = mask; cb.nx = nx; cb.ny = ny;
+        if (cells) {
+            const size_t t = cell_tiles(H, W);
+            int2 *cell = (int2 *)((char *)hdr + align256(CELL_HDR_INTS * sizeof(int)));
+            int *work = (int *)((char *)cell + align256((size_t)N * t * sizeof(int2)));
+            int *rank = (int *)((char *)work + align256((size_t)N * t * sizeof(int)));
+            int *pool = (int *)((char *)rank + align256((size_t)N * t * sizeof(int)));
+            const size_t cap = cell_pool_entries(F_total, N, H, W);
+            if (launch) {
+                hipLaunchKernelGGL(cell_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, dbw_workspace_recs(workspace, F_total), first_idx,
+                                   num_faces, N, H, W, nx, ny, list, count, cell, pool, (int)cap, hdr, rank);
+                rc = dbw_check_launch("cell_bin_kernel");
+                if (rc) return rc;
+                const long long total = (long long)N * (long long)t;
+                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cell, rank, hdr, total, work);
+                rc = dbw_check_launch("work_scatter_kernel");
+                if (rc) return rc;
+            }
+            cb.cell = cell; cb.pool = pool; cb.work = work;
+        }
     }
     return DBW_OK;
 }
@@ -302,7 +498,7 @@ extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_i
     float4 *bbox = (float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);
     CoarseBins cb;
-    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s, true);
+    int rc = dbw_prepare_raster(face_verts, first_idx, num_faces, neighbor, N, F_total, F_total, H, W, margin, cull_backfaces, workspace, workspace_bytes, cb, s, true, /*want_cells=*/K > 1);
     if (rc) return rc;
 #define DBW_FWD(KM) launch_fwd<KM>(recs, bbox, first_idx, num_faces, N, H, W, K, blur_radius, \
                                    perspective_correct, clip_barycentric_coords, cb, pix_to_face, zbuf, bary, dists, s)
@@ -329,6 +525,19 @@ extern "C" int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_
 }
 
 extern "C" void dbw_debug_set_raster_flags(int flags) { g_raster_dbg = flags; }
+
+// tools/diag only: byte offsets, inside a binned workspace, of {cell-list header, cell table, work list, tile ranks, pool} and the
+// pool capacity in entries -- lets a script read the per-tile face counts of a pass and try launch orders of its own
+extern "C" void dbw_debug_cell_layout(int64_t F_total, int N, int H, int W, unsigned long long *out6) {
+    const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
+    size_t o = dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W);
+    out6[0] = o; o += align256(CELL_HDR_INTS * sizeof(int));
+    out6[1] = o; o += align256(n * t * sizeof(int2));
+    out6[2] = o; o += align256(n * t * sizeof(int));
+    out6[3] = o; o += align256(n * t * sizeof(int));
+    out6[4] = o;
+    out6[5] = cell_pool_entries(F_total, N, H, W);
+}
 
 // Test hook: div_fast (shared-reciprocal division of the rasteriser, raster_math.h) against the IEEE quotient on the real v_rcp_f32,
 // for caller-supplied operands; *mismatches (device, zeroed by the caller) counts the lanes whose bits differ (NaN == NaN).

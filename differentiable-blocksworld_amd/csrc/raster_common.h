@@ -28,7 +28,17 @@ struct CoarseBins {
     const int *count;   // (N, nb)
     const unsigned *mask;   // (N, nb, 2): bit (8 * row + column) = some entry reaches that cell
     int nx, ny;         // bins per row / column, nb = nx * ny
+    // fine level (cell_bin_kernel, raster.hip): the ordered face list of every cell = 8x8-pixel tile.  nullptr: coarse level only
+    const int2 *cell;   // (N, tiles): {first entry in `pool`, count}; count < 0: the pool was full, the tile walks its coarse bin
+    const int *pool;    // view-local face indices
+    const int *work;    // (N * tiles): launch order of the tiles (work_order_kernel): position in the XCD-aware grid -> view * tiles + tile
 };
+#ifndef DBW_CELL_LISTS
+#define DBW_CELL_LISTS 1
+#endif
+#ifndef DBW_CELL_POOL_PER_TILE
+#define DBW_CELL_POOL_PER_TILE 48
+#endif
 // minimum waves per SIMD the raster kernels are compiled for (the LDS home array of the payloads bounds the residency anyway:
 // KMAX * 16 B per pixel)
 #define DBW_RASTER_WAVES(KMAX) ((KMAX) <= 4 ? 4 : (KMAX) <= 10 ? 3 : (KMAX) <= 16 ? 2 : 1)
@@ -78,6 +88,47 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 #define DBW_RASTER_TILECULL 1
 #endif
 
+// One chunk of up to 64 staged faces (lane i of `jl` = view-local index of the i-th one) evaluated for the pixels of this wave:
+// records arrive in SGPRs (two s_load_dwordx16 per face), lanes are pixels.  Shared by the cell-list path and the legacy staging path.
+template <int KMAX, bool PAY3>
+__device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
+                                                  int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false) {
+#pragma unroll 1
+    for (int i = 0; i < mcnt; ++i) {
+        const int j = __builtin_amdgcn_readlane(jl, i);
+        const FaceRec r = load_rec_uniform(recs + f_begin + j);
+        const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
+        if (__ballot(inbox) == 0ull) continue;
+        FPROF_ADD(5, 1);
+        FPROF_CNT(6, inbox);
+        float pz = 0.f, sd = 0.f;
+        f3 bc{0.f, 0.f, 0.f};
+        bool keep = false;
+        bool redo = !(fastdiv && (r.flags & REC_FAST));
+        if (!redo) {
+            bool unsafe = false;
+            if (inbox) keep = eval_pair<true>(r, p, blur, persp, clipb, pz, sd, bc, unsafe, sign_only);
+            redo = __ballot(inbox && unsafe) != 0ull;
+        }
+        if (redo) {
+            FPROF_ADD(8, 1);
+            bool unused;
+            keep = false;
+            if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused, sign_only);
+        }
+        if (__ballot(keep) == 0ull || no_insert) continue;        // (no_insert: ablation switch of tools/diag, dbw_debug_set_flags 32768)
+        FPROF_CNT(7, keep);
+        const pay4 v{sd, bc.x, bc.y, bc.z};
+        bool done = false;
+        if (r.nb != -1) done = q.sibling(K, keep, r.nb, sd < 0.f ? -sd : sd, pz, f_begin + j, v, home, NT, tid);
+#if DBW_TOPK_ORDERED
+        q.insert_ordered(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
+#else
+        q.insert(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
+#endif
+    }
+}
+
 // Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n
 // (keys in `q`, payloads in the LDS array `home`, stride TW * TH, lane threadIdx.x).  Returns false for the padding blocks of the
 // XCD-aware grid.  All threads of the block must call it.  dbg: bit 0 = plain IEEE divisions, bit 1 = no tile culling (parity tests
@@ -88,7 +139,11 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
                                             float blur, int persp, int clipb, long long total_blocks, const CoarseBins &cb, int dbg,
                                             int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home) {
     static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
-    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = 2 * GROUP * NT;      // staged face indices: flushed when more than half full
+    // 8x8 tiles read the cell lists of cell_bin_kernel; walking the coarse bin (below) is their fallback -- a bin whose cell lists did
+    // not fit the pool, or a caller without a binned workspace -- and gets by with the smallest staging area
+    constexpr bool CELLS = DBW_CELL_LISTS && TW == 8 && TH == 8;
+    constexpr int G = CELLS ? 1 : GROUP;
+    constexpr int NT = TW * TH, NW = NT / DBW_WAVE, CAP = (CELLS ? 1 : 2) * G * NT;      // staged face indices: flushed when more than half full
     __shared__ int s_list[CAP];
     __shared__ int s_wcnt[NW];
     __shared__ pay4 s_home[KMAX == 1 ? 1 : (PAY3 ? (KMAX * NT * 3 + 3) / 4 : KMAX * NT)];
@@ -103,8 +158,18 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     if (logical < 0) return false;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const unsigned per_view = (unsigned)(tiles_x * tiles_y), lg = (unsigned)logical;      // total_blocks < 2^31 (checked by the host side)
-    n = (int)(lg / per_view);
-    const int t = (int)(lg - (unsigned)n * per_view);
+    bool cell_mode = false, empty_tile = false;
+    int coff = 0, ccnt = 0;
+    unsigned lt = lg;
+    if (CELLS && cb.cell) {
+        // the tile this position of the grid was given (heavy tiles first, the empty ones spread between them) and its face list
+        lt = (unsigned)cb.work[lg];
+        const int2 c = cb.cell[lt];
+        if (c.y == 0) empty_tile = true;
+        else if (c.y > 0) { cell_mode = true; coff = c.x; ccnt = c.y; }
+    }
+    n = (int)(lt / per_view);
+    const int t = (int)(lt - (unsigned)n * per_view);
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // a wave always owns an 8-aligned compact footprint: lanes 0..63 -> 8x8 (TW == 8) or 16x4 (TW == 16) pixels
@@ -120,7 +185,8 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     const int *lst = nullptr;
     // cells (8x8-pixel squares of the coarse bin) this tile covers
     const int ccx0 = (x0 & (COARSE - 1)) >> 3, ccx1 = (x1 & (COARSE - 1)) >> 3, ccy0 = (y0 & (COARSE - 1)) >> 3, ccy1 = (y1 & (COARSE - 1)) >> 3;
-    if (cb.list) {
+    if (cell_mode || empty_tile) nf = 0;
+    else if (cb.list) {
         const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
         nf = cb.count[n * nb + bin];
         // occupied cells of the bin: a tile that covers none of them has nothing to rasterise (two of three tiles of a sparse soft
@@ -143,14 +209,14 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     }
     f2 p{0.f, 0.f};
     float txmax = 0.f, txmin = 0.f, tymax = 0.f, tymin = 0.f;
-    if (nf > 0) {
+    if (nf > 0 || ccnt > 0) {
         const NdcAxis ax = ndc_axis(W, H), ay = ndc_axis(H, W);
         p.x = pix_to_ndc_fast(W - 1 - xi, ax);
         p.y = pix_to_ndc_fast(H - 1 - yi, ay);
         txmax = pix_to_ndc_fast(W - 1 - x0, ax); txmin = pix_to_ndc_fast(W - 1 - x1, ax);
         tymax = pix_to_ndc_fast(H - 1 - y0, ay); tymin = pix_to_ndc_fast(H - 1 - y1, ay);
     }
-    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2), sign_only = (dbg & 8) != 0;
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2), sign_only = (dbg & 8) != 0, no_insert = (dbg & 128) != 0;
     int cnt = 0;
     FPROF_T(t_begin);
     FPROF_ADD(9, 1);
@@ -159,15 +225,31 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     unsigned long long t_evsum = 0;
     bool any_staged = false;
 #endif
-    // The face scan is latency bound: fetch the boxes of GROUP chunks with independent loads before consuming them, so a tile
-    // pays nf / (GROUP * NT) memory round trips instead of nf / NT.
+    if (cell_mode && ccnt > 0) {
+        // the tile's own face list: nothing to test, nothing to stage
+        FPROF_T(t_ev0);
+        FPROF_ADD(4, ccnt);
+        const int fb = first_idx[n];
+        const int *__restrict__ cl = cb.pool + coff;
 #pragma unroll 1
-    for (int base0 = 0; base0 < nf; base0 += GROUP * NT) {
-        bool hits[GROUP];
-        int fjs[GROUP];
+        for (int cb0 = 0; cb0 < ccnt; cb0 += DBW_WAVE) {
+            const int jl = cb0 + lane < ccnt ? cl[cb0 + lane] : 0;
+            eval_staged_chunk<KMAX, PAY3>(recs, fb, jl, min(DBW_WAVE, ccnt - cb0), in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert);
+        }
+#ifdef DBW_PROFILE_FWD
+        t_evsum += __builtin_readcyclecounter() - t_ev0;
+        any_staged = true;
+#endif
+    }
+    // The face scan is latency bound: fetch the boxes of G chunks with independent loads before consuming them, so a tile
+    // pays nf / (G * NT) memory round trips instead of nf / NT.
+#pragma unroll 1
+    for (int base0 = 0; base0 < nf; base0 += G * NT) {
+        bool hits[G];
+        int fjs[G];
         if (lst) {      // coarse-bin entries carry the cell range of the face's box: one load decides
 #pragma unroll
-            for (int g = 0; g < GROUP; ++g) {
+            for (int g = 0; g < G; ++g) {
                 const int j = base0 + g * NT + tid;
                 const int e = j < nf ? lst[j] : 0;
                 fjs[g] = e & 0xfffff;
@@ -175,7 +257,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < GROUP; ++g) {
+            for (int g = 0; g < G; ++g) {
                 const int j = base0 + g * NT + tid;
                 fjs[g] = j;
                 hits[g] = false;
@@ -187,11 +269,11 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
         }
         if (tilecull) {
 #pragma unroll
-            for (int g = 0; g < GROUP; ++g)
+            for (int g = 0; g < G; ++g)
                 if (hits[g] && tile_culled(recs[f_begin + fjs[g]], txmin, txmax, tymin, tymax)) { hits[g] = false; FPROF_CNT(11, true); }
         }
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
+        for (int g = 0; g < G; ++g) {
             const int base = base0 + g * NT;
             if (base >= nf) break;
             const bool hit = hits[g];
@@ -210,7 +292,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
             if (NW > 1) __syncthreads();         // s_wcnt is rewritten by the next chunk
         }
         __syncthreads();
-        if (cnt > CAP - GROUP * NT || base0 + GROUP * NT >= nf) {
+        if (cnt > CAP - G * NT || base0 + G * NT >= nf) {
             // every wave walks the staged faces: records arrive in SGPRs, lanes are pixels
             FPROF_T(t_ev0);
             FPROF_ADD(4, cnt);
@@ -221,36 +303,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
             for (int cb0 = 0; cb0 < cnt; cb0 += DBW_WAVE) {
                 const int jl = cb0 + lane < cnt ? s_list[cb0 + lane] : 0;
                 const int mcnt = min(DBW_WAVE, cnt - cb0);
-#pragma unroll 1
-                for (int i = 0; i < mcnt; ++i) {
-                    const int j = __builtin_amdgcn_readlane(jl, i);
-                    const FaceRec r = load_rec_uniform(recs + f_begin + j);
-                    const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
-                    if (__ballot(inbox) == 0ull) continue;
-                    FPROF_ADD(5, 1);
-                    FPROF_CNT(6, inbox);
-                    float pz = 0.f, sd = 0.f;
-                    f3 bc{0.f, 0.f, 0.f};
-                    bool keep = false;
-                    bool redo = !(fastdiv && (r.flags & REC_FAST));
-                    if (!redo) {
-                        bool unsafe = false;
-                        if (inbox) keep = eval_pair<true>(r, p, blur, persp, clipb, pz, sd, bc, unsafe, sign_only);
-                        redo = __ballot(inbox && unsafe) != 0ull;
-                    }
-                    if (redo) {
-                        FPROF_ADD(8, 1);
-                        bool unused;
-                        keep = false;
-                        if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused, sign_only);
-                    }
-                    if (__ballot(keep) == 0ull) continue;
-                    FPROF_CNT(7, keep);
-                    const pay4 v{sd, bc.x, bc.y, bc.z};
-                    bool done = false;
-                    if (r.nb != -1) done = q.sibling(K, keep, r.nb, sd < 0.f ? -sd : sd, pz, f_begin + j, v, home, NT, tid);
-                    q.insert(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
-                }
+eval_staged_chunk<KMAX, PAY3>(recs, f_begin, jl, mcnt, in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert);
             }
             cnt = 0;
             if (NW > 1) __syncthreads();

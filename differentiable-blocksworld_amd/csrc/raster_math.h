@@ -27,6 +27,12 @@
 #endif
 
 #define DBW_EPS 1e-8f
+#ifndef DBW_CLAMP_MED3
+#define DBW_CLAMP_MED3 1        // the t clamp of the point-segment distance as one v_med3_f32 (same value for every finite t)
+#endif
+#ifndef DBW_TOPK_ORDERED
+#define DBW_TOPK_ORDERED 1      // TopK::insert_ordered instead of TopK::insert in the kernels
+#endif
 
 namespace dbw {
 
@@ -36,6 +42,32 @@ struct __attribute__((aligned(16))) pay4 { float x, y, z, w; };       // payload
 
 DBW_HD uint32_t f2u(float x) { union { float f; uint32_t u; } c; c.f = x; return c.u; }
 DBW_HD float u2f(uint32_t x) { union { float f; uint32_t u; } c; c.u = x; return c.f; }
+
+// wave-level "any lane" (the host build evaluates one pixel at a time), median of three unsigned / clamp of a float to [0, 1]
+#if defined(__HIP_DEVICE_COMPILE__)
+DBW_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+DBW_HD int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+DBW_HD uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DBW_HD float clamp01(float t) {
+#if DBW_CLAMP_MED3
+    return __builtin_amdgcn_fmed3f(t, 0.f, 1.f);
+#else
+    return t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+#endif
+}
+#else
+inline float clamp01(float t) { return t < 0.f ? 0.f : (t > 1.f ? 1.f : t); }
+inline bool wave_any(bool p) { return p; }
+inline int wave_uniform(int x) { return x; }
+inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+#endif
 
 // SURVEY A.1 NonSquarePixToNdc
 DBW_HD float pix_to_ndc(int i, int S1, int S2) {
@@ -196,7 +228,8 @@ DBW_HD float seg_dist(f2 p, float ox, float oy, float dx, float dy, float l2, fl
     float t;
     if (FAST) { t = div_fast(num, l2, rr); unsafe |= guard_key(num) < GUARD_LO; }
     else t = num / l2;
-    const float tt = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    // (FAST: t is finite -- guarded numerator over a squared length > 1e-8 -- so the clamp is one median instruction)
+    const float tt = FAST ? clamp01(t) : (t < 0.f ? 0.f : (t > 1.f ? 1.f : t));
     const float qx = ox + tt * dx, qy = oy + tt * dy;
     return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
@@ -233,7 +266,7 @@ DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, 
         if (FAST) {
             const float rd = rcp_refined(denom);
             bp.x = div_fast(t0, denom, rd); bp.y = div_fast(t1, denom, rd); bp.z = div_fast(t2, denom, rd);
-            unsafe |= !guard3(t0, t1, t2) | !guard_den(denom);
+            unsafe |= (int)!guard3(t0, t1, t2) | (int)!guard_den(denom);
         } else { bp.x = t0 / denom; bp.y = t1 / denom; bp.z = t2 / denom; }
     }
     bc = bp;
@@ -244,7 +277,7 @@ DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, 
         if (FAST) {
             const float rs = rcp_refined(s);
             bc.x = div_fast(c0, s, rs); bc.y = div_fast(c1, s, rs); bc.z = div_fast(c2, s, rs);
-            unsafe |= !guard3(c0, c1, c2) | !(s < 1.0995116e12f);
+            unsafe |= (int)!guard3(c0, c1, c2) | (int)!(s < 1.0995116e12f);
         } else { bc.x = c0 / s; bc.y = c1 / s; bc.z = c2 / s; }
     }
     pz = bc.x * r.z0 + bc.y * r.z1 + bc.z * r.z2;
@@ -282,12 +315,14 @@ struct TopK {
     // 64-bit compare (selects of whole 64-bit values are canonicalised into umin / umax, each lowered with a compare of its own)
     uint32_t khi[KMAX], klo[KMAX];
     pay4 pay1;                   // KMAX == 1: the single payload stays in registers
+    int cnt;                     // valid entries (maintained by insert_ordered only)
 
     DBW_HD static uint64_t cat(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | (uint64_t)lo; }
     DBW_HD void init() {
 #pragma unroll
         for (int i = 0; i < KMAX; ++i) { khi[i] = 0xffffffffu; klo[i] = (uint32_t)TOPK_EMPTY | (uint32_t)i; }
         pay1.x = pay1.y = pay1.z = pay1.w = -1.f;
+        cnt = 0;
     }
     DBW_HD static uint32_t key_hi(float pz) { return f2u(pz + 0.0f); }
     DBW_HD static uint32_t key_lo(int id, uint32_t slot) { return ((uint32_t)id << 5) | slot; }
@@ -340,6 +375,36 @@ struct TopK {
             klo[i] = m[i] ? blo : klo[i];
         }
         store(home, stride, lane, slot, v, ins);
+    }
+    // ---- ordered insert (the one the kernels use) ---------------------------------------------------------------------------------
+    // Same result as insert() under the one precondition every caller meets: candidates arrive in ASCENDING face id (tiles walk
+    // their face lists in face order), so a candidate whose depth equals an entry's goes behind it -- the (pz, id) order of the
+    // oracle -- and the 64-bit key compare reduces to a 32-bit compare of the depth words; the depth words of the shifted list are
+    // then one median each (sorted a[i-1] <= a[i]: the new a[i] is the candidate clamped into [a[i-1], a[i]]): 4 instructions per
+    // slot instead of 6.  Payload slots are handed out in arrival order (`cnt`) until the list is full, after that the entry that
+    // falls off the end hands over its slot.  Do not mix with insert() on one list (that one takes free slots from the sentinels).
+    // (Measured and dropped, profiles/r03_experiments.md: shifting only the slots below the wave's deepest list -- 6.9 of 10 on
+    // average at config 2 -- through a switch over the depth; the register copies at the join cost more than the skipped slots.)
+    DBW_HD void insert_ordered(int K, bool on, float pz, int id, const pay4 &v, pay4 *home, int stride, int lane) {
+        uint32_t lhi, llo;
+        last(K, lhi, llo);
+        uint32_t chi = key_hi(pz);
+        const bool ins = on && chi < lhi;                 // (a list that is not full ends in a sentinel: always admitted)
+        const uint32_t slot = cnt < K ? (uint32_t)cnt : (llo & 31u);
+        const uint32_t clo = key_lo(id, slot);
+        if (!ins) chi = 0xffffffffu;
+        bool m[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) m[i] = chi < khi[i];
+#pragma unroll
+        for (int i = KMAX - 1; i > 0; --i) {
+            klo[i] = m[i] ? (m[i - 1] ? klo[i - 1] : clo) : klo[i];
+            khi[i] = umed3(khi[i - 1], chi, khi[i]);
+        }
+        klo[0] = m[0] ? clo : klo[0];
+        khi[0] = m[0] ? chi : khi[0];
+        store(home, stride, lane, slot, v, ins);
+        cnt += (ins && cnt < K) ? 1 : 0;
     }
     DBW_HD void cswap(int i) {
         const bool c = cat(khi[i + 1], klo[i + 1]) < cat(khi[i], klo[i]);

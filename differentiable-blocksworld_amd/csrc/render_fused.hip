@@ -16,7 +16,7 @@ using namespace dbw;
 // implemented in raster.hip / shade_blend.hip
 int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
                        long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
-                       dbw::CoarseBins &cb, hipStream_t s, bool launch);
+                       dbw::CoarseBins &cb, hipStream_t s, bool launch, bool want_cells);
 const dbw::FaceRec *dbw_workspace_recs(const void *workspace, long long F_total);
 void *dbw_workspace_shade_recs(void *workspace, long long F_total);
 int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
@@ -36,6 +36,22 @@ extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out16, int reset)
     for (size_t b = 0; b < (size_t)dbw::FPROF_BLOCKS; ++b)
         for (int i = 0; i < 16; ++i) out16[i] += host[b * 16 + i];
     if (reset) { memset(host, 0, bytes); (void)hipMemcpyToSymbol(HIP_SYMBOL(dbw::g_fprof), host, bytes); }
+}
+#endif
+#ifndef DBW_FWD_FAST_EXP
+#define DBW_FWD_FAST_EXP 1
+#endif
+#ifdef DBW_PROFILE_FWD
+// the raw per-workgroup records (tools/fwd_timeline.py): out = nblocks x 16
+extern "C" void dbw_debug_read_fwd_profile_raw(unsigned long long *out, int nblocks, int reset) {
+    (void)hipDeviceSynchronize();
+    const size_t bytes = (size_t)(nblocks < dbw::FPROF_BLOCKS ? nblocks : dbw::FPROF_BLOCKS) * 16 * sizeof(unsigned long long);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dbw::g_fprof), bytes);
+    if (reset) {
+        unsigned long long *z = (unsigned long long *)calloc((size_t)dbw::FPROF_BLOCKS * 16, sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(dbw::g_fprof), z, (size_t)dbw::FPROF_BLOCKS * 16 * sizeof(unsigned long long));
+        free(z);
+    }
 }
 #endif
 int g_render_variant = 0;
@@ -161,7 +177,8 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
 template <int KMAX>
 __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
-                                          float *__restrict__ image) {
+                                          float *__restrict__ image, int dbg) {
+    // dbg (tools/diag ablations, dbw_debug_set_flags): 32 = no fragment stores (flags 8192), 64 = no layer loop at all (16384)
     const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
@@ -176,8 +193,11 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     if (in_img && cnt == 0) p2f_t[lane] = -1;         // an empty pixel still tells the backward its fragment count (0)
     BlendFront bl;
     blend_front_init(bl);
-    UvSlot cur = uv_slot(q, home, srec, 0, in_img), nxt = cur;
-    bool more = true;
+    bool more = __ballot(cnt > 0) != 0ull && !(dbg & 64);       // (a tile without fragments goes straight to the epilogue)
+    UvSlot cur;
+    cur.valid = false; cur.fik = 0; cur.v = pay4{0.f, 0.f, 0.f, 0.f};
+    if (more) cur = uv_slot(q, home, srec, 0, in_img);
+    UvSlot nxt = cur;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         more = more && k < A.K && __ballot(cnt > k) != 0ull;               // wave-uniform: lists are filled front to back
@@ -192,7 +212,14 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         const float d = cur.v.x;
         float e;
         if (A.sigma == 0.f) e = d <= 0.f ? 1.f : 0.f;
+#if DBW_FWD_FAST_EXP
+        // v_exp_f32 on d * (1 / sigma): |d / sigma| <= 9.3 inside the blur radius, so the two roundings of the argument move the
+        // opacity by < 1e-6 relative -- far inside the 1e-4 bar of the rendered colours; libm's expf and an IEEE division cost ~25
+        // instructions per layer here
+        else e = __expf(-(d > 0.f ? d : 0.f) * A.inv_sigma);
+#else
         else e = expf(-(d > 0.f ? d : 0.f) / A.sigma);
+#endif
         const float a = cur.valid ? e * sr.fa : 0.f;
         Sample s;
         footprint_desc(u, v, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
@@ -201,7 +228,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         if (!(a != 0.f)) c[0] = c[1] = c[2] = 0.f;
         const float T = bl.T;                  // transmittance in front of this layer
         blend_front_step(bl, a, c);
-        if (cur.valid) {
+        if (cur.valid && !(dbg & 32)) {
             const int o = (k << 6) + lane;
             p2f_t[o] = k == 0 ? (cur.fik | (cnt << FRAG_COUNT_SHIFT)) : cur.fik;
             dists_t[o] = d;
@@ -260,10 +287,11 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     TopK<KMAX, UV> q;
     pay4 *home;
     FPROF_T(t_k0);
+    FPROF_ADD(13, wall_clock64());            // (100 MHz, common to the XCDs: the wave's place on the kernel's time line)
     if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb,
-                                              (dbg & 3) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home)) return;
+                                              (dbg & (3 | 128)) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home)) return;
     FPROF_T(t_k1);
-    if constexpr (UV) shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image);
+    if constexpr (UV) shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg);
     else {
         if (xi >= A.W || yi >= A.H) return;
         shade_generic<KMAX, TW * TH>(A, q, home, n, xi, yi, p2f, bary, dists, image);
@@ -271,6 +299,7 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     FPROF_T(t_k2);
     FPROF_ADD(2, t_k2 - t_k1);
     FPROF_ADD(3, t_k2 - t_k0);
+    FPROF_ADD(14, wall_clock64());
 }
 
 template <int KMAX, int TW, int TH, int GROUP, bool UV>
@@ -343,7 +372,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     const float margin = (float)sqrt((double)blur_radius);
     CoarseBins cb;
     rc = dbw_prepare_raster(face_verts_c, first_idx, num_faces, neighbor, N, F_total, c2o ? (long long)Fc_stride : F_total, H, W, margin, 0, workspace, workspace_bytes, cb, s,
-                            /*launch=*/stage != 2);
+                            /*launch=*/stage != 2, /*want_cells: the 8x8-tile kernels*/ K > 1 || g_render_variant == 1);
     if (rc) return rc;
     const float4 *bbox = (const float4 *)workspace;
     const FaceRec *recs = dbw_workspace_recs(workspace, F_total);

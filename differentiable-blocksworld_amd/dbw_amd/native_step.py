@@ -46,7 +46,7 @@ class NativeStep:
 
         Schedule (two HIP streams; `overlap_regularisers = False` runs the same calls on one):
           main: ground mesh -> env projection -> env per-face set-up | env pass | fg pass + MSE | env backward + tail [| fg textures]
-          side: texture prep, zero grads, opacities | blocks' vertices, projection, fg per-face set-up, regularisers | fg backward + tail
+          side: texture prep, zero grads, opacities | blocks' vertices, projection, fg per-face set-up | regularisers | fg backward + tail
         (the backward kernels one after the other or both at once: see `sequential_backward`)
         """
         m, g = self.m, self.grad
@@ -159,6 +159,10 @@ class NativeStep:
         fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
         fg_state = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, renderer._bg,
                                             None, None, 0.0, stage=1)
+        fg_ready = None
+        if side is not cur:                                            # the fg pass only waits for its set-up, not for the regularisers
+            fg_ready = torch.cuda.Event()                              # behind it (they run next to the fg forward)
+            fg_ready.record(side)
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
         if 'parsimony' in w and coarse:
             _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
@@ -179,8 +183,8 @@ class NativeStep:
         st = st_main
         count = float(imgs.numel() if global_count is None else global_count)
         scale = float(w['rgb']) / count
-        if side is not cur:
-            cur.wait_stream(side)                                      # blocks projected, regularisers done
+        if fg_ready is not None:
+            cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
         p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
                                                                       blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
                                                                       state=fg_state)

@@ -38,7 +38,8 @@ int dbw_abi_version(void);
 const char *dbw_last_error(void);
 /* profiling/ablation switches used by tools/ and by the parity tests (0 = product behaviour); bits 0-7: shading ablations,
  * 16: no fragment stores, 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal
- * div_fast, which is bit-identical inside its guards), 512: no conservative tile-vs-edge culling in the binning */
+ * div_fast, which is bit-identical inside its guards), 512: no conservative tile-vs-edge culling in the binning, 4096: no per-tile
+ * face lists (every tile walks its coarse bin) */
 void dbw_debug_set_flags(int flags);
 /* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
  * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */

@@ -16,7 +16,7 @@ struct Stats { long long evals, unsafe, culled, staged; };
 
 template <int KMAX>
 void run(const float *fv, const int64_t *first, const int64_t *num, const int64_t *nbr, int N, int H, int W, int K, float blur, int persp,
-         int clipb, int cull, int fastdiv, int tile, int64_t *p2f, float *zbuf, float *bary, float *dists, Stats &st) {
+         int clipb, int cull, int fastdiv, int tile, int bounded, int64_t *p2f, float *zbuf, float *bary, float *dists, Stats &st) {
     const float margin = (float)sqrt((double)blur);
     for (int n = 0; n < N; ++n) {
         const int64_t f0 = first[n], nf = num[n];
@@ -61,7 +61,8 @@ void run(const float *fv, const int64_t *first, const int64_t *num, const int64_
                     const pay4 v{sd, bc.x, bc.y, bc.z};
                     bool done = false;
                     if (r.nb != -1) done = q.sibling(K, true, r.nb, sd < 0.f ? -sd : sd, pz, (int)(f0 + j), v, home, 1, 0);
-                    q.insert(K, !done, pz, (int)(f0 + j), v, home, 1, 0);
+                    if (bounded) q.insert_ordered(K, !done, pz, (int)(f0 + j), v, home, 1, 0);
+                    else q.insert(K, !done, pz, (int)(f0 + j), v, home, 1, 0);
                 }
                 const int64_t o = (((int64_t)n * H + yi) * W + xi) * K;
                 for (int k = 0; k < K; ++k) {
@@ -82,11 +83,11 @@ void run(const float *fv, const int64_t *first, const int64_t *num, const int64_
 }  // namespace
 
 extern "C" int host_rasterize(const float *fv, const int64_t *first, const int64_t *num, const int64_t *nbr, int N, int H, int W, int K,
-                              float blur, int persp, int clipb, int cull, int fastdiv, int tile, int rcp_perturb, int exact_k,
+                              float blur, int persp, int clipb, int cull, int fastdiv, int tile, int rcp_perturb, int exact_k, int bounded,
                               int64_t *p2f, float *zbuf, float *bary, float *dists, long long *stats4) {
     g_host_rcp_perturb = rcp_perturb;
     Stats st{0, 0, 0, 0};
-#define RUN(KM) run<KM>(fv, first, num, nbr, N, H, W, K, blur, persp, clipb, cull, fastdiv, tile, p2f, zbuf, bary, dists, st)
+#define RUN(KM) run<KM>(fv, first, num, nbr, N, H, W, K, blur, persp, clipb, cull, fastdiv, tile, bounded, p2f, zbuf, bary, dists, st)
     if (exact_k && K == 1) RUN(1);
     else if (exact_k && K == 4) RUN(4);
     else if (exact_k && K == 10) RUN(10);

@@ -73,7 +73,7 @@ def test_shared_reciprocal_division_equals_ieee_division_on_this_gpu():
     (32, 64, 16, 20, 5e-3, False, False),     # K > faces hit, no perspective correction / clipping
     (48, 80, 25, 700, 2e-4, True, True),      # > LIST_CAP faces per tile flush path, max K
 ])
-@pytest.mark.parametrize('flags', [0, 256, 512, 768])     # product / IEEE divisions / no tile culling / neither (include/dbw_hip.h)
+@pytest.mark.parametrize('flags', [0, 256, 512, 768, 4096])     # product / IEEE divisions / no tile culling / neither / no per-tile face lists (include/dbw_hip.h)
 def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb, flags, raster_flags):
     raster_flags(flags)
     fv = random_faces(nf, seed=nf + K)
@@ -102,6 +102,54 @@ def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert (outs[0][0] >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize('H,W,nf,size,K', [
+    (64, 64, 260, 3.0, 6),        # one bin: 260 faces that each cover the whole image -> 16 640 list entries for a pool of 3 072
+    (150, 200, 700, 1.5, 10),     # twelve bins with ragged borders, all of them far over their share of the pool
+    (130, 70, 1200, 0.8, 4),      # some bins fit, some do not (whichever reserves last): the result must not depend on it
+])
+def test_per_tile_face_lists_fall_back_to_the_coarse_bins_when_the_pool_is_full(H, W, nf, size, K, raster_flags):
+    """cell_bin_kernel splits every 64x64-pixel bin into the face lists of its 8x8-pixel tiles; the lists live in a pool sized for
+    DBW_CELL_POOL_PER_TILE faces per tile.  Scenes of large faces overflow it: the bins that do not fit mark their tiles and those
+    tiles walk the coarse bin as before -- bit-exact against the oracle either way, and identical to the run without tile lists."""
+    fv = random_faces(nf, seed=nf + H, size=size, spread=0.8)
+    first, num = torch.tensor([0]), torch.tensor([nf])
+    blur = 1e-3
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), blur, K, True, True, n_threads=8)
+    outs = []
+    for flags in (0, 4096):
+        raster_flags(flags)
+        out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (H, W), blur, K, 0, 0, True, True, False)
+        outs.append(out)
+        assert torch.equal(out[0].cpu(), ref[0]), (flags, (out[0].cpu() != ref[0]).sum().item())
+        for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
+            assert torch.equal(a.cpu(), b), (flags, name)
+    # the scene does overflow the pool: NDC boxes of the faces against the 8x8-pixel tiles, on the host
+    s = max(H, W) / min(H, W)
+    xr, yr = (s if W > H else 1.0), (s if H > W else 1.0)
+    lo, hi = fv[..., :2].min(1).values, fv[..., :2].max(1).values
+    tx = ((hi[:, 0].clamp(-xr, xr) - lo[:, 0].clamp(-xr, xr)) / (2 * xr) * W / 8).clamp(min=1)
+    ty = ((hi[:, 1].clamp(-yr, yr) - lo[:, 1].clamp(-yr, yr)) / (2 * yr) * H / 8).clamp(min=1)
+    tiles = ((H + 7) // 8) * ((W + 7) // 8)
+    assert float((tx * ty).sum()) > 1.5 * tiles * 48
+
+
+def test_per_tile_face_lists_on_sparse_multi_view_scenes_match_the_coarse_walk(raster_flags):
+    """Several views with different face counts (one empty), small faces: most tiles are empty, the work list of every view puts
+    the occupied tiles first -- outputs identical to the walk of the coarse bins, bit for bit, for the soft and the hard pass."""
+    H, W = 150, 200
+    fv = torch.cat([random_faces(400, seed=1, size=0.08), random_faces(30, seed=2, size=0.3), random_faces(200, seed=3, size=0.12)], 0).to(DEV)
+    first, num = torch.tensor([0, 400, 400, 430]).to(DEV), torch.tensor([400, 0, 30, 200]).to(DEV)
+    for K, blur in ((10, math.log(1e4 - 1) * 1e-4), (1, 0.0), (4, 1e-3)):
+        outs = []
+        for flags in (0, 4096):
+            raster_flags(flags)
+            outs.append(ops.rasterize_meshes(fv, first, num, None, (H, W), blur, K, 0, 0, True, True, False))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert (outs[0][0] >= 0).sum() > 500
+        assert (outs[0][0][1] >= 0).sum() == 0
 
 
 @pytest.mark.parametrize('name', ['front', 'straddle', 'ties'])

@@ -9,9 +9,14 @@ class A: pass
 args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 300, 400, 10, 10, 256
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
+from dbw_amd import _lib
+if os.environ.get('DBW_DEBUG_FLAGS'):
+    _lib.load().dbw_debug_set_flags(int(os.environ['DBW_DEBUG_FLAGS']))
+if os.environ.get('DBW_RENDER_VARIANT'):
+    _lib.load().dbw_debug_set_render_variant(int(os.environ['DBW_RENDER_VARIANT']))
 model.sync_free = True
 model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
 step = ShardedTrainStep(model, seed=1)
-for _ in range(3):
+for _ in range(int(os.environ.get('DBW_STEPS', '3'))):
     step(inp)
 torch.cuda.synchronize()
