@@ -23,7 +23,7 @@ __device__ __forceinline__ void edge_fn_bwd(f2 p, f2 a, f2 b, float g, f2 &gp, f
 }
 
 __device__ __forceinline__ f3 bary_fwd(f2 p, f2 v0, f2 v1, f2 v2) {
-    const float area = edge_fn(v2, v0, v1) + DBW_EPS;
+    const float area = DBW_AREA_EPS(edge_fn(v2, v0, v1));
     f3 w;
     w.x = edge_fn(p, v1, v2) / area;
     w.y = edge_fn(p, v2, v0) / area;
@@ -32,7 +32,7 @@ __device__ __forceinline__ f3 bary_fwd(f2 p, f2 v0, f2 v1, f2 v2) {
 }
 
 __device__ __forceinline__ void bary_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g, f2 &g0, f2 &g1, f2 &g2) {
-    const float area = edge_fn(v2, v0, v1) + DBW_EPS;
+    const float area = DBW_AREA_EPS(edge_fn(v2, v0, v1));
     const float area2 = area * area;
     const float area_inv = 1.0f / area;
     const float e0 = edge_fn(p, v1, v2);

@@ -27,6 +27,10 @@
 #endif
 
 #define DBW_EPS 1e-8f
+// PyTorch3D's kEpsilon is a double (`const auto kEpsilon = 1e-8;`): the one place it enters ARITHMETIC -- the barycentric denominator
+// area = EdgeFunction(v2, v0, v1) + kEpsilon -- promotes the float edge function, adds in double and rounds to float once
+// (oracle/raster_ref.c header); comparisons against it decide the same in float
+#define DBW_AREA_EPS(e) ((float)((double)(e) + 1e-8))
 #ifndef DBW_CLAMP_MED3
 #define DBW_CLAMP_MED3 1        // the t clamp of the point-segment distance as one v_med3_f32 (same value for every finite t)
 #endif
@@ -166,7 +170,7 @@ DBW_HD void make_face_rec(const float *p, float margin, int cull, int nb, FaceRe
     const bool dead = (zmin < DBW_EPS) || (face_area <= DBW_EPS && face_area >= -DBW_EPS) || (cull && face_area < 0.f);
     r.ax = a.x; r.ay = a.y; r.bx = b.x; r.by = b.y; r.cx = c.x; r.cy = c.y;
     r.z0 = z0; r.z1 = z1; r.z2 = z2;
-    r.area = edge_fn(c, a, b) + DBW_EPS;
+    r.area = DBW_AREA_EPS(edge_fn(c, a, b));
     r.dab_x = b.x - a.x; r.dab_y = b.y - a.y;
     r.dbc_x = c.x - b.x; r.dbc_y = c.y - b.y;
     r.dca_x = a.x - c.x; r.dca_y = a.y - c.y;

@@ -44,6 +44,13 @@ void dbw_debug_set_flags(int flags);
 /* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
  * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */
 int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream);
+/* test hook: the model-side arithmetic of the kernels evaluated on the device (its powf / logf / expf), for the tests that hold it to
+ * the golden vectors of the reference's own functions.  what = 0: superquadric surface point (superquadric.py:10-14) from
+ * a = (cos eta, sin eta, cos omega, sin omega) x n and b = (eps1, eps2) -> out (n, 9) = point * ratio, d / d eps1, d / d eps2;
+ * 1: implicit superquadric distance (superquadric.py:17-38, as_sdf = 2, as the overlap term applies it: clamp to [-5, 5]) of
+ * a = points (n, 3) with b = (eps1, eps2) x n and upstream gradient c (n) -> out (n, 6) = sdf, d / d eps1, d / d eps2, d / d point;
+ * 2: safe_pow (pytorch.py:35-36) of a = t (n) to the power b[0] -> out (n, 2) = value, d / d t;  3: signed_pow (pytorch.py:31-32) */
+int dbw_debug_model_math(int what, const float *a, const float *b, const float *c, int n, float ratio, float *out, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Camera transform + z-clipping of one scene seen from B cameras.

@@ -16,7 +16,15 @@
  * contraction -- build with -ffp-contract=off).
  *
  * Deliberate choices where SURVEY.md's from-memory notes are ambiguous:
- *  - kEpsilon is applied in fp32 (1e-8f), as the CUDA flavour does.
+ *  - kEpsilon: PyTorch3D declares `const auto kEpsilon = 1e-8;` (geometry_utils.h and .cuh alike), i.e. a DOUBLE.  Where it is an
+ *    operand of arithmetic -- `area = EdgeFunctionForward(v2, v0, v1) + kEpsilon` in BarycentricCoordinates{Forward,Backward} --
+ *    the float edge function is promoted, the sum is taken in double and rounded to float once; that is what AREA_EPS() does.
+ *    Where it is only compared (`zmin < kEpsilon`, `face_area <= kEpsilon`, `l2 <= kEpsilon`) or passed through std::max<T> /
+ *    fmaxf (the perspective denominator), float and double readings decide identically except for a value that equals 1e-8f
+ *    to the bit, so those stay in `real`.  Rounds 1-2 added 1e-8f in float; -DKEPS_FLOAT keeps that build for
+ *    tests/test_oracle_golden.py, which counts how many output slots the two readings move: none on the tiny scenes, none among the
+ *    670 917 occupied slots of three config-2 views (the sums differ by 6e-17, far below an ulp of a block face's area), 106 of
+ *    35 199 barycentric values on slivers whose area is within two decades of kEpsilon.
  *  - BarycentricClipForward clamps the LOWER bound only (max(b,0)) and
  *    renormalises by max(sum,1e-5): that is what pytorch3d>=0.3 ships
  *    ("Only clamp negative values to 0.0"); SURVEY A.5 step 5 wrote clamp(0,1).
@@ -26,8 +34,9 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.
  *
- * Compiled twice: REAL=float (the oracle proper) and REAL=double (used to
- * validate the hand-derived backward by finite differences).
+ * Compiled three times: REAL=float (the oracle proper), REAL=double (used to
+ * validate the hand-derived backward by finite differences) and REAL=float with
+ * -DKEPS_FLOAT (suffix f32e: the float reading of kEpsilon, see above).
  */
 #include <math.h>
 #include <stdint.h>
@@ -50,6 +59,11 @@
 typedef REAL real;
 
 #define K_EPS ((real)1e-8)
+#ifdef KEPS_FLOAT
+#define AREA_EPS(e) ((e) + K_EPS)
+#else
+#define AREA_EPS(e) ((real)((double)(e) + 1e-8))
+#endif
 #define MAX_K 64
 
 typedef struct { real x, y; } v2;
@@ -78,7 +92,7 @@ static void edge_fn_bwd(v2 p, v2 a, v2 b, real g, v2 *gp, v2 *ga, v2 *gb) {
 
 /* SURVEY A.5 step 3 */
 static v3 bary_fwd(v2 p, v2 v0, v2 v1, v2 v2_) {
-    const real area = edge_fn(v2_, v0, v1) + K_EPS;
+    const real area = AREA_EPS(edge_fn(v2_, v0, v1));
     v3 w;
     w.x = edge_fn(p, v1, v2_) / area;
     w.y = edge_fn(p, v2_, v0) / area;
@@ -87,7 +101,7 @@ static v3 bary_fwd(v2 p, v2 v0, v2 v1, v2 v2_) {
 }
 
 static void bary_bwd(v2 p, v2 v0, v2 v1, v2 v2_, v3 g, v2 *g0, v2 *g1, v2 *g2) {
-    const real area = edge_fn(v2_, v0, v1) + K_EPS;
+    const real area = AREA_EPS(edge_fn(v2_, v0, v1));
     const real area2 = area * area;
     const real area_inv = (real)1.0 / area;
     const real e0 = edge_fn(p, v1, v2_);

@@ -677,3 +677,20 @@ def test_full_size_gradient_paths_agree(monkeypatch):
     expect = (g_img[:, :3] * out['default'][0][:, 3:4]).sum(dim=(0, 2, 3)).double()
     got = out['default'][1].view(-1, 3).double().sum(0)
     assert torch.allclose(got, expect, rtol=2e-4), (got, expect)
+
+
+def test_rasterize_slivers_follow_the_double_reading_of_kepsilon():
+    """area = EdgeFunction + kEpsilon with kEpsilon a DOUBLE (PyTorch3D; header of oracle/raster_ref.c): on slivers whose area is
+    within two decades of 1e-8 the float and the double sum round differently; face_setup_kernel adds in double (DBW_AREA_EPS) and
+    reproduces the oracle's canonical reading bit for bit -- and not the float reading of rounds 1-2."""
+    g = torch.Generator().manual_seed(5)
+    c = (torch.rand(4000, 1, 2, generator=g) * 2 - 1) * 0.9
+    fv = torch.cat([c + (torch.rand(4000, 3, 2, generator=g) * 2 - 1) * 4e-4, torch.rand(4000, 3, 1, generator=g) + 1.0], -1).contiguous()
+    first, num = torch.tensor([0]), torch.tensor([4000])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=8)
+    old = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=8, keps_float=True)
+    assert (ref[2] != old[2]).sum() > 0
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (64, 64), 1e-3, 8, 0, 0, True, True, False)
+    assert torch.equal(out[0].cpu(), ref[0])
+    for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
+        assert torch.equal(a.cpu(), b), name

@@ -141,6 +141,22 @@ def test_ordered_insert_on_meshes_with_shared_vertices_equal_depths_and_overfull
             assert_same(out, ref)
 
 
+def test_slivers_whose_area_is_close_to_kepsilon_follow_the_double_reading():
+    """area = EdgeFunction + kEpsilon with kEpsilon a double (PyTorch3D; oracle/raster_ref.c header): on faces whose area is within two
+    decades of 1e-8 the float and the double sum round differently -- the product's record (make_face_rec: DBW_AREA_EPS) must follow the
+    oracle's canonical (double) reading bit for bit, and must NOT equal the float reading everywhere."""
+    g = torch.Generator().manual_seed(5)
+    c = (torch.rand(4000, 1, 2, generator=g) * 2 - 1) * 0.9
+    fv = torch.cat([c + (torch.rand(4000, 3, 2, generator=g) * 2 - 1) * 4e-4, torch.rand(4000, 3, 1, generator=g) + 1.0], -1).contiguous()
+    first, num = torch.tensor([0]), torch.tensor([4000])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=4)
+    old = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=4, keps_float=True)
+    assert (ref[2] != old[2]).sum() > 0
+    for fastdiv in (0, 1):
+        out, _ = host_rasterize(fv, first, num, None, (64, 64), 1e-3, 8, fastdiv=fastdiv, tile=8)
+        assert_same(out, ref)
+
+
 def test_large_faces_with_near_plane_coordinates():
     """Env-pass-like geometry: few huge faces, some with NDC coordinates in the thousands (clipped at z = 1e-3)."""
     g = torch.Generator().manual_seed(3)

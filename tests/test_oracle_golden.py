@@ -247,3 +247,56 @@ def test_raster_tiny_scenes_are_frozen(golden_dir, name):
     if name == 'ties':                                          # equal depth everywhere: the smaller face id comes first
         v = g['ties/p2f'][..., 0] >= 0
         assert bool((g['ties/p2f'][..., 0][v] < g['ties/p2f'][..., 1][v]).all() or (g['ties/p2f'][..., 1][v] < 0).any())
+
+
+def test_keps_double_vs_float_reading_is_quantified_on_a_config2_view_and_the_tiny_scenes(golden_dir):
+    """PyTorch3D's kEpsilon is a double; the one place it enters arithmetic is the barycentric denominator area + kEpsilon (header of
+    oracle/raster_ref.c).  Rounds 1-2 added 1e-8f in float.  This test counts what the two readings differ by, so that the residual
+    risk of the (unpinned) restatement is a number: nothing on the tiny scenes, and on a full config-2 view of the blocks (300x400,
+    K = 10, 10 superquadric blocks) no face index and at most a few last-bit barycentric / depth values per million slots."""
+    import math
+    g = _load(golden_dir, 'raster_tiny.npz')
+    for name in ('front', 'straddle', 'ties'):
+        fv, first, num, nbr, size, blur, K = _tiny_scene(g, name)
+        a = O.rasterize_fwd_raw(fv, first, num, nbr, size, blur, K)
+        b = O.rasterize_fwd_raw(fv, first, num, nbr, size, blur, K, keps_float=True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), name
+    m = O.OracleDBW((300, 400), n_blocks=10, txt_size=16, faces_per_pixel=10, seed=227391)
+    R, T, Km = O.synthetic_cameras(49, R_world=m.R_world[0])
+    with torch.no_grad():
+        sc = m.build_blocks(training=True, coarse=True, decimate=False, opacity_noise=None)
+    verts, faces = sc['verts'], sc['faces']
+    moved = {'p2f': 0, 'zbuf': 0, 'bary': 0, 'dists': 0}
+    slots = 0
+    for v in (0, 17, 33):
+        ndc = O.transform_to_ndc(verts, R[v:v + 1], T[v:v + 1], Km[0])
+        fv = ndc[:, faces].reshape(-1, 3, 3)
+        first, num = torch.tensor([0]), torch.tensor([fv.shape[0]])
+        cl = O.clip_faces(fv, first, num, 0.001, True)
+        blur = math.log(1. / 1e-4 - 1.) * 1e-4
+        a = O.rasterize_fwd_raw(cl['face_verts'], cl['first_idx'], cl['num_faces'], cl['neighbor'], (300, 400), blur, 10, n_threads=8)
+        b = O.rasterize_fwd_raw(cl['face_verts'], cl['first_idx'], cl['num_faces'], cl['neighbor'], (300, 400), blur, 10, n_threads=8,
+                                keps_float=True)
+        slots += int((a[0] >= 0).sum())
+        for key, x, y in zip(('p2f', 'zbuf', 'bary', 'dists'), a, b):
+            moved[key] += int((x != y).sum())
+        # where a value moves it moves by an ulp
+        for x, y in ((a[1], b[1]), (a[2], b[2])):
+            d = (x - y).abs()
+            assert float(d.max()) <= 2.4e-7 * float(x.abs().max())
+    assert slots > 200_000
+    print('kEpsilon double vs float over %d occupied slots of three config-2 views:' % slots, moved)
+    assert moved['p2f'] == 0 and moved['dists'] == 0            # no face index, no distance (the area is not part of the distance)
+    assert moved['zbuf'] <= 50 and moved['bary'] <= 150         # at most a few last-bit values per million (measured: none)
+    # ... and the count is not vacuous: on slivers whose area is within two decades of kEpsilon, where 1e-8 (double) and 1e-8f differ
+    # by a sizeable fraction of an ulp of the sum, the two readings do part ways
+    gen = torch.Generator().manual_seed(5)
+    c = (torch.rand(4000, 1, 2, generator=gen) * 2 - 1) * 0.9
+    fv = torch.cat([c + (torch.rand(4000, 3, 2, generator=gen) * 2 - 1) * 4e-4, torch.rand(4000, 3, 1, generator=gen) + 1.0], -1).contiguous()
+    first, num = torch.tensor([0]), torch.tensor([4000])
+    a = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=8)
+    b = O.rasterize_fwd_raw(fv, first, num, None, (64, 64), 1e-3, 8, n_threads=8, keps_float=True)
+    diff = int((a[2] != b[2]).sum())
+    print('slivers (area ~ 1e-7): %d of %d barycentric values differ between the readings' % (diff, int((a[0] >= 0).sum()) * 3))
+    assert diff > 0
