@@ -65,6 +65,52 @@ def build_workload(args, dev):
 BIN_STATS = {}
 
 
+def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0):
+    """One more workload measured like the headline (same step, same launch path, inputs resident), outside its timed region:
+    -> ms per step, views / s and the share of the HBM roofline the WHOLE-PATH algorithmic bytes (64 P K + 140 P per view)
+    reach.  read_losses: every loss value is read on the host after every step, as the reference's trainer does
+    (src/trainer.py:143); lr_scale = 0: frozen parameters (Adam runs, nothing moves); min_seconds: keep stepping that long."""
+    from dbw_amd.parallel import ShardedTrainStep
+
+    class A:
+        pass
+    a = A()
+    a.views, a.H, a.W, a.blocks, a.fpp, a.txt = views, H, W, blocks, fpp, txt
+    model, inp = build_workload(a, dev)
+    model.set_cur_epoch(epoch)
+    model.sync_free = True
+    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391)
+    for _ in range(warmup):
+        out = step(inp)
+        if read_losses:
+            _ = {k: float(v) for k, v in out.items()}
+    torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats(dev)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(steps):
+            out = step(inp)
+            if read_losses:
+                vals = {k: float(v) for k, v in out.items()}          # six scalars, one device -> host read each (trainer.py:143)
+        n += steps
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    total = float(out['total'])
+    assert total == total, 'loss is NaN'
+    P = H * W
+    vps = views * n / dt
+    st1 = torch.cuda.memory_stats(dev)
+    res = {'workload': f'{views} views/step, {W}x{H}, {blocks} blocks, faces_per_pixel={fpp}, {txt}^2 textures', 'steps': n,
+           'ms_per_step': dt / n * 1e3, 'views_per_s': vps, 'whole_path_frac': vps * (64 * P * fpp + 140 * P) / 1e9 / HBM_PEAK_GBS,
+           # device allocations (hipMalloc) inside the timed region: must be 0 -- every buffer of a step comes out of torch's cache
+           'device_allocs_in_timed_region': int(st1.get('num_device_alloc', 0) - st0.get('num_device_alloc', 0))}
+    del step, model, inp
+    torch.cuda.empty_cache()
+    return res
+
+
 def kernel_breakdown(model, inp, reps=5):
     """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the four
     kernels that dominate an iteration -- the fused forward and fused backward of the fg (soft, K faces per pixel) and env
@@ -222,6 +268,8 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak', help='weak: --views per GPU (default); strong: --views in total, '
                     'sharded over the ranks (BASELINE config 3: 49 views -> 7,6,...,6)')
     ap.add_argument('--no-phases', action='store_true', help='skip the measurement of the two other training phases')
+    ap.add_argument('--no-extras', action='store_true', help='skip the measurements reported next to the headline at N = 1: the reference\'s own '
+                    'operating point (batch 4, loss values read every step), BASELINE configs 4 and 5 (per-GPU share) and the sustained run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
                     'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
@@ -250,6 +298,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+        # the communicator itself has to agree with the launch: --gpus ranks, one per process
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank, (dist.get_world_size(), args.gpus, dist.get_rank(), rank)
 
     from dbw_amd.parallel import ShardedTrainStep, shard_views
     model, inp = build_workload(args, dev)
@@ -387,6 +437,27 @@ def main():
             'phases': phases, 'allreduce_ms': allreduce_ms,
             'final_loss': total_loss,
         }
+        if world == 1 and not args.no_extras and not args.graph:
+            default = (args.views, args.H, args.W, args.blocks, args.fpp, args.txt, args.epoch) == (49, 300, 400, 10, 10, 256, 0)
+            if default:
+                del step, model, inp
+                torch.cuda.empty_cache()
+                # the reference's operating point: configs/dtu/default.yml:28 trains with batch_size 4 and src/trainer.py:143 reads every
+                # loss value on the host each iteration
+                out['batch4'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True)
+                out['batch4']['what'] = ('batch_size 4 (configs/dtu/default.yml:28), the loss values read on the host after every step '
+                                         '(src/trainer.py:143): launch-bound, ~31 launches per step')
+                out['batch4_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=False)
+                # >= 2 s of steps from the initial scene with frozen parameters (learning rates 0: Adam runs, the workload does not drift)
+                out['sustained'] = measure_other(49, 300, 400, 10, 10, 256, dev, steps=200, warmup=10, lr_scale=0.0, min_seconds=2.0)
+                out['sustained']['what'] = '>= 2 s of steps of the headline workload with both learning rates 0 (the scene does not drift)'
+                # BASELINE configs 4 and 5, the share of ONE GPU (31 views on 4 GPUs -> 8; 200 views on 8 GPUs -> 25)
+                out['configs'] = {
+                    'c4': measure_other(8, 576, 768, 20, 16, 256, dev, steps=20, warmup=3),
+                    'c5': measure_other(25, 1080, 1920, 50, 16, 512, dev, steps=5, warmup=2),
+                }
+                out['configs']['c4']['what'] = 'BASELINE config 4 (BlendedMVS-like, 31 views, 768x576, K=20, fpp 16, 4 GPUs): the 8 views of one GPU'
+                out['configs']['c5']['what'] = 'BASELINE config 5 (Nerfstudio-like, 200 views, 1080x1920, K=50, 512^2 textures, fpp 16, 8 GPUs): the 25 views of one GPU'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))

@@ -396,8 +396,8 @@ static size_t coarse_bytes(int64_t F_total, int N, int H, int W) {
 }
 static size_t cell_tiles(int H, int W) { return (size_t)((W + 7) / 8) * ((H + 7) / 8); }
 static size_t cell_pool_entries(int64_t F_total, int N, int H, int W) {
-    // room for DBW_CELL_POOL_PER_TILE faces per cell on average (config 2 needs 5, config 5 about 20); a bin that does not fit falls
-    // back to walking its coarse list, so this is a performance knob, not a limit
+    // room for DBW_CELL_POOL_PER_TILE faces per cell on average (config 2 needs 5 of them; 50 overlapping blocks at config 5 several
+    // dozen); a bin that does not fit falls back to walking its coarse list, so this is a performance knob, not a limit
     const size_t want = (size_t)(N > 0 ? N : 1) * cell_tiles(H, W) * DBW_CELL_POOL_PER_TILE;
     return want < ((size_t)1 << 30) ? want : ((size_t)1 << 30);
 }

@@ -37,7 +37,7 @@ struct CoarseBins {
 #define DBW_CELL_LISTS 1
 #endif
 #ifndef DBW_CELL_POOL_PER_TILE
-#define DBW_CELL_POOL_PER_TILE 48
+#define DBW_CELL_POOL_PER_TILE 128
 #endif
 // minimum waves per SIMD the raster kernels are compiled for (the LDS home array of the payloads bounds the residency anyway:
 // KMAX * 16 B per pixel)

@@ -26,6 +26,16 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
 
 
+def off_entries(a, b, rel=REL, floor=1e-2):
+    """Element-wise form of the bar: entries with |a - b| > rel * |b| + rel * floor * max|b| (the max-norm check above leaves small
+    entries unconstrained; this one holds every entry to 1e-4 of ITSELF, with a floor of 1e-6 of the largest entry so that values four
+    orders of magnitude down are not held to their own last bits).  -> (number of entries off, worst excess as a multiple of the bar)"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    tol = rel * b.abs() + rel * floor * b.abs().max()
+    ex = (a - b).abs() / tol.clamp(min=1e-300)
+    return int((ex > 1).sum()), float(ex.max())
+
+
 def _packed(scene, pads=None):
     maps = scene['maps']
     pads = pads or [(0, 0)] * len(maps)
@@ -119,6 +129,10 @@ def _iteration(shape, seed, epoch, decimate):
             assert (gh is None or gh.abs().max() == 0) and (v.grad is None or v.grad.abs().max() == 0), k
             continue
         errs['grad ' + k] = rel_err(gh, v.grad)
+        if v.grad.numel() <= 64:          # the small pose / shape / opacity gradients: every entry, not just the largest (floor: 1e-5
+            n_off, worst = off_entries(gh, v.grad, floor=0.1)          # of the largest entry -- each entry is a sum of ~10^4 terms of
+            if n_off:                                                   # either sign, accumulated in fp32 on both sides)
+                errs['grad ' + k] = max(errs['grad ' + k], REL * worst)
     flips = _fragment_flips(model, orc, inp, coarse, decimate, noise if coarse else None) if max(errs.values()) >= REL else 0
     if flips == 0 and max(errs.values()) >= REL:
         # No fragment differs, yet a gradient is off by more than 1e-4 of its largest entry: then it must be an ill-conditioned sum
@@ -138,7 +152,9 @@ def _iteration(shape, seed, epoch, decimate):
                 e_hip, e_orc = rel_err(getattr(model, k).grad, truth), rel_err(v.grad, truth)
                 cond = float(v.grad.abs().max() / truth.abs().max().clamp(min=1e-30))
                 print(f'{k}: |hip - fp64| = {e_hip:.2e}, |fp32 oracle - fp64| = {e_orc:.2e} (relative to max |fp64|), seed {seed}')
-                assert e_hip <= REL, (k, e_hip, e_orc, cond)
+                # within 1e-4 of the float64 value -- or, where fp32 accumulation itself cannot get that close (the fp32 oracle is
+                # further away than that), at least as close to it as the fp32 oracle is
+                assert e_hip <= max(REL, 1.2 * e_orc), (k, e_hip, e_orc, cond)
                 errs[key] = 0.0
     return errs, flips
 
@@ -147,7 +163,7 @@ C1 = (75, 100, 4, 256, 4, 4)          # BASELINE configs[0]: H, W, blocks, textu
 
 
 @pytest.mark.parametrize('epoch,decimate', [(0, True), (800, False), (1600, False)])
-def test_config1_training_iteration_matches_oracle(epoch, decimate):
+def test_config1_training_iteration_matches_oracle(epoch, decimate, record_property):
     """BASELINE configs[0] exactly: 4 views, 100x75 (W x H), 4 superquadric blocks (the model has no cube primitive),
     faces_per_pixel 4, configs/dtu/default.yml otherwise (256^2 textures, opacity noise, kill_blocks, decimation until 750), in each
     of the three training phases: every loss term and the gradient of every parameter tensor within 1e-4.  A draw of the perturbed
@@ -160,6 +176,11 @@ def test_config1_training_iteration_matches_oracle(epoch, decimate):
         errs, flips = _iteration(shape, seed, epoch, decimate)
         worst = max(errs, key=errs.get)
         if errs[worst] < REL:
+            # how many draws had to be replaced is part of the result: a regression in the flip frequency (a kernel that moves more
+            # borderline fragments than an ulp of libm explains) shows up here long before all five draws are used up
+            record_property('draws_replaced', len(tried))
+            print(f'config 1, epoch {epoch}: {len(tried)} of the parameter draws replaced because of a borderline fragment flip {tried}')
+            assert len(tried) <= 2, tried
             return
         assert flips > 0, f'seed {seed}: {worst} off by {errs[worst]:.2e} although the fragment lists are identical'
         tried.append((seed, worst, errs[worst], flips))
@@ -194,10 +215,16 @@ def test_config2_render_passes_match_oracle_at_full_size(phase):
     assert set(res) == ({'image', 'g_maps', 'g_verts', 'g_alpha'} if coarse else {'image', 'g_maps', 'g_verts'})
     for k, (a, b) in res.items():
         assert rel_err(a, b) < REL, f'fg {k}: rel err {rel_err(a, b)}'
+        if k in ('image', 'g_alpha'):           # element-wise too: every pixel of the image, every opacity gradient
+            n_off, worst = off_entries(a, b)
+            assert n_off == 0, f'fg {k}: {n_off} entries off, worst {worst:.2f} x the element-wise bar'
     if phase != 'coarse':                       # the env pass does not depend on coarse / fine, only on the decimation
         res = _render_both(env, R, T, Km[0], H, W, 0.0, 1, False, None)
         for k, (a, b) in res.items():
             assert rel_err(a, b) < REL, f'env {k}: rel err {rel_err(a, b)}'
+            if k == 'image':
+                n_off, worst = off_entries(a, b)
+                assert n_off == 0, f'env {k}: {n_off} entries off, worst {worst:.2f} x the element-wise bar'
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -105,13 +105,13 @@ def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
 
 
 @pytest.mark.parametrize('H,W,nf,size,K', [
-    (64, 64, 260, 3.0, 6),        # one bin: 260 faces that each cover the whole image -> 16 640 list entries for a pool of 3 072
-    (150, 200, 700, 1.5, 10),     # twelve bins with ragged borders, all of them far over their share of the pool
-    (130, 70, 1200, 0.8, 4),      # some bins fit, some do not (whichever reserves last): the result must not depend on it
+    (64, 64, 900, 3.0, 6),        # one bin: 900 faces that each cover most of the image -> ~30 000 list entries for a pool of 8 192
+    (150, 200, 1500, 1.5, 10),    # twelve bins with ragged borders, all of them far over their share of the pool
+    (130, 70, 3600, 0.8, 4),      # some bins fit, some do not (whichever reserves last): the result must not depend on it
 ])
 def test_per_tile_face_lists_fall_back_to_the_coarse_bins_when_the_pool_is_full(H, W, nf, size, K, raster_flags):
     """cell_bin_kernel splits every 64x64-pixel bin into the face lists of its 8x8-pixel tiles; the lists live in a pool sized for
-    DBW_CELL_POOL_PER_TILE faces per tile.  Scenes of large faces overflow it: the bins that do not fit mark their tiles and those
+    DBW_CELL_POOL_PER_TILE = 128 faces per tile.  Scenes of large faces overflow it: the bins that do not fit mark their tiles and those
     tiles walk the coarse bin as before -- bit-exact against the oracle either way, and identical to the run without tile lists."""
     fv = random_faces(nf, seed=nf + H, size=size, spread=0.8)
     first, num = torch.tensor([0]), torch.tensor([nf])
@@ -132,7 +132,7 @@ def test_per_tile_face_lists_fall_back_to_the_coarse_bins_when_the_pool_is_full(
     tx = ((hi[:, 0].clamp(-xr, xr) - lo[:, 0].clamp(-xr, xr)) / (2 * xr) * W / 8).clamp(min=1)
     ty = ((hi[:, 1].clamp(-yr, yr) - lo[:, 1].clamp(-yr, yr)) / (2 * yr) * H / 8).clamp(min=1)
     tiles = ((H + 7) // 8) * ((W + 7) // 8)
-    assert float((tx * ty).sum()) > 1.5 * tiles * 48
+    assert float((tx * ty).sum()) > 1.5 * tiles * 128           # DBW_CELL_POOL_PER_TILE (csrc/raster_common.h)
 
 
 def test_per_tile_face_lists_on_sparse_multi_view_scenes_match_the_coarse_walk(raster_flags):

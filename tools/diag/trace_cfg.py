@@ -1,0 +1,16 @@
+"""Workload for rocprofv3 kernel traces of other configurations: a few training steps.  usage: trace_cfg.py views H W blocks fpp txt [steps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
+import torch, bench
+from dbw_amd.parallel import ShardedTrainStep
+class A: pass
+args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = [int(x) for x in sys.argv[1:7]]
+dev = torch.device('cuda', 0)
+model, inp = bench.build_workload(args, dev)
+model.sync_free = True
+model.set_cur_epoch(0)
+step = ShardedTrainStep(model, seed=1)
+for _ in range(int(sys.argv[7]) if len(sys.argv) > 7 else 4):
+    step(inp)
+torch.cuda.synchronize()
