@@ -358,10 +358,25 @@ class DifferentiableBlocksWorld(nn.Module):
             for r in (self.renderer, self.renderer_fine, self.renderer_env):
                 r.update_cameras(device=inp['imgs'].device, K=inp['K'][0:1])
 
+    def render_joined(self, inp, filter_transparent=False):
+        """-> (B,4,H,W): the NON-decoupled rendering (dbw.py:225-232, `decouple_rendering: False`; no shipped config uses it): sky dome,
+        ground and blocks joined into one scene and rendered in ONE soft pass of the phase's renderer, the env faces fully opaque
+        (alpha_env = 1) next to the blocks' learned opacities.  Same kernels as the fg pass of the decoupled path."""
+        self._ensure_cameras(inp)
+        fine = not self.is_live('coarse_learning')
+        filter_tsp = filter_transparent or fine
+        renderer = self.renderer_fine if fine else self.renderer
+        scene = self.build_scene(filter_transparent=filter_tsp)
+        alpha = None
+        if not filter_tsp:
+            n_blk = scene.faces.shape[0] - self.env_n_faces
+            alpha = torch.cat([torch.ones(self.env_n_faces, device=scene.verts.device), self._alpha.repeat_interleave(self.BNF)[:n_blk]])
+        return renderer.render_packed(scene, inp['R'], inp['T'], faces_alpha=alpha)
+
     def render_layers(self, inp, filter_transparent=False):
         """-> fg (B,4,H,W), env (B,4,H,W): the two passes of the decoupled rendering (dbw.py:213-222)."""
         if not self.decouple_rendering:
-            raise NotImplementedError('decouple_rendering=False (every shipped config sets it True, default.yml:19)')
+            raise NotImplementedError('render_layers is the decoupled rendering; decouple_rendering=False renders one joined scene: render_joined')
         self._ensure_cameras(inp)
         R, T = inp['R'], inp['T']
         fine = not self.is_live('coarse_learning')
@@ -389,13 +404,22 @@ class DifferentiableBlocksWorld(nn.Module):
         return fg, env
 
     def predict(self, inp, labels=None, w_edges=False, filter_transparent=False):
-        fg, env = self.render_layers(inp, filter_transparent)
-        rec = ops.composite(fg, env)                                   # rec = rec_fg*mask + (1-mask)*rec_env (dbw.py:223)
+        if self.decouple_rendering:
+            fg, env = self.render_layers(inp, filter_transparent)
+            rec = ops.composite(fg, env)                               # rec = rec_fg*mask + (1-mask)*rec_env (dbw.py:223)
+        else:
+            rec = self.render_joined(inp, filter_transparent)[:, :3]   # rec, mask = renderer(scene).split([3, 1]) (dbw.py:232)
         if w_edges:                                                    # dbw.py:234-238: wireframe of the joined scene, coloured per block
             fine = not self.is_live('coarse_learning')
             filter_tsp = filter_transparent or fine
             with torch.no_grad():
-                scene = self.build_scene(filter_transparent=filter_tsp)
+                # host-packed scene (only the kept blocks): the colour table below has one row per KEPT face, while the sync-free
+                # scene of the training path keeps all n_blocks blocks (culled ones collapsed to a point) and its face ids run over all
+                sf, self.sync_free = self.sync_free, False
+                try:
+                    scene = self.build_scene(filter_transparent=filter_tsp)
+                finally:
+                    self.sync_free = sf
                 colors = self.get_scene_face_colors(filter_transparent=filter_tsp).repeat(len(inp['R']), 1)
                 renderer = self.renderer_fine if fine else self.renderer
                 rec = renderer.draw_edges(rec, scene, inp['R'], inp['T'], colors=colors)
@@ -408,7 +432,11 @@ class DifferentiableBlocksWorld(nn.Module):
         self._ensure_cameras(inp)
         was_training = self.training
         self.eval()
-        blocks = self.build_blocks_scene(filter_transparent=True)
+        sf, self.sync_free = self.sync_free, False         # host-packed: `colors` / `desc` below hold the kept blocks only
+        try:
+            blocks = self.build_blocks_scene(filter_transparent=True)
+        finally:
+            self.sync_free = sf
         self.train(was_training)
         if blocks is None:
             return torch.ones_like(inp['imgs'])
@@ -446,6 +474,8 @@ class DifferentiableBlocksWorld(nn.Module):
             self.build_env_scene()
             self.build_blocks_scene(filter_transparent=not self.is_live('coarse_learning'))
             return self.compute_losses(inp['imgs'], None, layers=None)
+        if not self.decouple_rendering:                                # one joined scene, one soft pass; losses through the general path
+            return self.compute_losses(inp['imgs'], self.render_joined(inp)[:, :3])
         fused = self._forward_fused(inp) if self.fused_loss_epilogue else None
         if fused is not None:
             return fused
@@ -571,7 +601,9 @@ class DifferentiableBlocksWorld(nn.Module):
         losses = {k: torch.zeros((), device=dev) for k in w}          # (fill kernel: hipGraph-capturable, unlike an H2D copy)
         empty = imgs.shape[0] == 0                                     # no views on this rank in this step: regularisers only
         if 'rgb' in losses and not empty:
-            losses['rgb'] = w['rgb'] * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
+            # a mean over the GLOBAL batch under view-sharded data parallelism (the ranks' gradients are summed)
+            share = imgs.numel() / float(self._global_count) if (ws > 1 and getattr(self, '_global_count', None)) else 1.0
+            losses['rgb'] = w['rgb'] * share * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
         if 'perceptual' in losses and not empty:
             losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse)
         if 'parsimony' in losses:
@@ -582,14 +614,14 @@ class DifferentiableBlocksWorld(nn.Module):
             factor = 1 if coarse else 0.1
             tv = ops.tv_l2sq(self._bkg_maps) + ops.tv_l2sq(self._blocks_maps, wrap_x=True) + ops.tv_l2sq(self._ground_maps) * factor
             losses['tv'] = w['tv'] * factor * rs * tv
-        if 'overlap' in losses:
-            factor = 1 if coarse else 0
+        if 'overlap' in losses and coarse:
+            # (the term is switched off after the coarse phase, dbw.py:390: no samples are drawn then -- the fused and the native path
+            # do not draw either, and the ranks' default generators have to stay in lock step)
             u = self._overlap_u_override
             if u is None:
                 u = torch.rand(self.n_blocks, OVERLAP_N_POINTS, 3, device=dev)
-            alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()
-            ov = ops.overlap_loss(self.sq_eps, self.S, self.R_6d, self.T, alpha, u, self.ratio_block_scene, self.scale_min,
+            ov = ops.overlap_loss(self.sq_eps, self.S, self.R_6d, self.T, self._alpha_full, u, self.ratio_block_scene, self.scale_min,
                                   OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS)
-            losses['overlap'] = w['overlap'] * factor * rs * ov
+            losses['overlap'] = w['overlap'] * rs * ov
         losses['total'] = sum(losses.values())
         return losses

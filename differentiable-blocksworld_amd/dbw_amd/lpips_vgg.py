@@ -2,7 +2,10 @@
 src/model/loss.py:32-40 (`lpips.LPIPS(net='vgg')`, called with normalize=True, mean over the batch), written in plain torch so that it
 runs on MIOpen convolutions next to the HIP render path -- outside of it, as SURVEY.md 8(a) A10 prescribes.
 
-Neither the `lpips` package nor any weights exist in this environment, so this module is the ARCHITECTURE only, PARITY UNPINNED:
+Neither the `lpips` package nor any weights exist in this environment, so REAL-WEIGHT PARITY IS UNPINNED.  What is pinned is the
+architecture: oracle/lpips_ref.py restates the published forward of lpips 0.1.4 independently, tests/golden/lpips_random.npz freezes
+it on seeded random weights, and this module reproduces that fixture -- forward and gradient, CPU and GPU -- when loaded with the same
+weights (tests/test_lpips.py); the model's perceptual term is checked against the restatement too.  Sources of the constants:
   * the scaling layer constants and the layer taps (relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 of VGG16) are those of the published
     lpips 0.1.4 package (environment.yml:29), restated from its documentation;
   * `load_weights` takes the two state dicts a user has to bring: torchvision's `vgg16().features` ('0.weight', '0.bias', '2.weight', ...)

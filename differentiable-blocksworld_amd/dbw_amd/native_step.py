@@ -239,6 +239,11 @@ class NativeStep:
             seq = self.sequential_backward
             if seq is None:
                 seq = m.world_size > 1 or decim_blocks == 1
+            if cfg_f.texbins is not None:
+                # full-resolution maps: the texel gradients of the blocks leave the fg kernel as binned records and only reach
+                # g_blk_maps in the bin reduction that follows it on the side stream -- `kernel_done` is recorded in front of that, so the
+                # texture half of the tail must not move to the main stream (the concurrent order would read an incomplete gradient)
+                seq = True
             torch.cuda.set_stream(side)
             keep_f = fg_backward(side.cuda_stream, lambda: kernel_done.record(side), with_textures=seq)
             torch.cuda.set_stream(cur)
@@ -306,3 +311,19 @@ class LazyLosses(dict):
     def __contains__(self, k):
         self._finish()
         return dict.__contains__(self, k)
+
+    def get(self, k, default=None):
+        self._finish()
+        return dict.get(self, k, default)
+
+    def copy(self):
+        self._finish()
+        return dict(self)
+
+    def __repr__(self):
+        self._finish()
+        return dict.__repr__(self)
+
+    def __reduce__(self):                       # pickling / deepcopy: a plain dict of the finished values
+        self._finish()
+        return (dict, (dict(self),))

@@ -45,9 +45,21 @@ class MultiStepLR:
         return {'last_epoch': self.last_epoch, 'lrs': list(self.lrs)}
 
     def load_state_dict(self, state):
-        self.last_epoch = state['last_epoch']
+        """Own state ({'last_epoch', 'lrs'}) or the state_dict of the reference's torch scheduler (src/scheduler.py: 'last_epoch',
+        '_last_lr', '_step_count', ...): there the decayed rates are read from '_last_lr', or replayed from the base rates and the
+        milestones when that key is missing too -- never left at the base values past a milestone."""
+        self.last_epoch = int(state['last_epoch'])
         if 'lrs' in state:
-            self.lrs = list(state['lrs'])
+            self.lrs = [float(x) for x in state['lrs']]
+        elif '_last_lr' in state and len(state['_last_lr']) == len(self.base_lrs):
+            self.lrs = [float(x) for x in state['_last_lr']]
+        else:
+            target, self.last_epoch = self.last_epoch, 0
+            self.lrs = self._next(list(self.base_lrs))
+            if self.warmup > 0:
+                self.lrs = [lr / self.warmup for lr in self.lrs]
+            while self.last_epoch < target:
+                self.step()
 
 
 class Trainer:
@@ -132,9 +144,12 @@ class Trainer:
     # trainer.py:201-209 / 84-107
     def state_dict(self):
         """Same keys as trainer.py:201-209.  'epoch' / 'batch' = the last COMPLETED epoch and its number of batches, like the
-        reference's end-of-epoch save, so either trainer resumes the other's checkpoint at the same epoch; 'model_state' and
-        'scheduler_state' interchange.  'optimizer_state' does NOT: it holds the fused Adam's flat moment buffers
-        ({'exp_avg', 'exp_avg_sq', 'n_steps'} in FlatParams order), not a torch.optim.Adam state_dict."""
+        reference's end-of-epoch save, so either trainer resumes the other's checkpoint at the same epoch.  'model_state'
+        interchanges; 'scheduler_state' is read in either form (MultiStepLR.load_state_dict takes the torch scheduler's keys too,
+        this trainer writes {'last_epoch', 'lrs'}).  'optimizer_state' does NOT interchange: it holds the fused Adam's flat moment
+        buffers ({'exp_avg', 'exp_avg_sq', 'n_steps'} in FlatParams order), not a torch.optim.Adam state_dict.  Under data
+        parallelism 'batch' counts this trainer's batches per epoch, ceil(largest shard / batch_size), not the reference's
+        len(loader) over all views: the reference would take such a checkpoint for a mid-epoch one."""
         return {'epoch': self.epoch - 1, 'batch': self.n_batches, 'model_name': self.model.name, 'model_kwargs': self.model.init_kwargs,
                 'model_state': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
                 'optimizer_state': {'exp_avg': self.step_fn.exp_avg.clone(), 'exp_avg_sq': self.step_fn.exp_avg_sq.clone(),

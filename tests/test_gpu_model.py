@@ -551,6 +551,102 @@ def test_edge_overlays_and_log_tick_members():
     assert cols.shape == (model.env_n_faces + (nb - 1) * model.BNF, 3)
 
 
+def test_log_tick_members_with_sync_free_and_a_killed_block_equal_the_host_packed_results():
+    """The trainer and the bench run with model.sync_free = True, where culled blocks stay in the scene (collapsed to a point) and face
+    ids run over all n_blocks blocks; the visualisation members build colour tables for the KEPT blocks only, so they pack the scene
+    on the host themselves -- same images as with sync_free = False, with a block in the middle killed (kill_blocks threshold) in
+    training mode and another one filtered (opacity < 0.5) by the hard renders."""
+    H, W, nb, ts = 40, 56, 5, 16
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_dtu_like_cfg(nb, ts, 6), (H, W))
+    with torch.no_grad():
+        model.alpha_logit[1] = -8.0          # sigmoid < 0.01: killed
+        model.alpha_logit[3] = -1.0          # kept by training renders, filtered by the hard ones
+    model = model.to(DEV)
+    R, T, Km = O.synthetic_cameras(2, R_world=O.world_rotation(115, 0, 0))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(2, 3, H, W), R=R, T=T, K=Km).items()}
+    outs = {}
+    for sf in (False, True):
+        model.sync_free = sf
+        model.eval()
+        outs[sf] = (model.predict(inp, None, w_edges=True), model.predict(inp, None, w_edges=True, filter_transparent=True),
+                    model.predict_synthetic(inp, None))
+        model.train()
+        model._noise_override = torch.zeros(nb, device=DEV)
+        outs[sf] += (model.predict(inp, None, w_edges=True),)
+        assert model.sync_free == sf
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.isfinite(b).all() and float((a - b).abs().max()) < 1e-5
+    assert float((outs[True][0] - outs[True][1]).abs().max()) > 1e-3       # the filtered block does change the picture
+
+
+@pytest.mark.parametrize('epoch', [0, 1600])
+def test_non_decoupled_rendering_matches_the_oracle_render_of_the_joined_scene(epoch):
+    """dbw.py:225-232 (`decouple_rendering: False`, no shipped config): sky dome + ground + blocks as ONE scene in ONE soft pass, env faces
+    with opacity 1 next to the blocks' learned opacities (coarse phase) / no opacities (fine phase).  Image and the gradient of an
+    MSE against noise w.r.t. the scene's vertices, maps and opacities against the oracle's render of the same joined scene; then the
+    model's forward / backward end to end (all loss terms present, every parameter receives a finite gradient)."""
+    H, W, nb, ts, fpp = 48, 64, 4, 32, 6
+    cfg = _dtu_like_cfg(nb, ts, fpp)
+    cfg['model']['rend_optim']['decouple_rendering'] = False
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(cfg, (H, W)).to(DEV).train()
+    model.set_cur_epoch(epoch)
+    model._noise_override = torch.zeros(nb, device=DEV)
+    R, T, Km = O.synthetic_cameras(2, R_world=O.world_rotation(115, 0, 0))
+    imgs = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(2))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=imgs, R=R, T=T, K=Km).items()}
+    coarse = epoch < 1500
+    out4 = model.render_joined(inp)
+    assert out4.shape == (2, 4, H, W)
+    scene = model.build_scene(filter_transparent=not coarse)
+    n_env = model.env_n_faces
+    alpha = None
+    if coarse:
+        alpha = torch.cat([torch.ones(n_env, device=DEV), model._alpha.detach().repeat_interleave(model.BNF)]).cpu()
+    # the oracle on the very same scene tensors (vertices, faces, uvs, maps): verts / maps / opacities as leaves
+    desc = scene.map_desc.cpu()
+    flat = scene.maps.detach().cpu()
+    leaves, maps = [], []                  # leaves: the unpadded maps as the product stores them; the oracle samples the circularly padded ones
+    for off, h, w, pl, pr, sh, _, _ in desc.tolist():
+        hs, ws_ = h >> sh, w >> sh                 # decimated maps are stored at cell resolution (nearest upsampling = the sampler's shift)
+        leaf = flat[off:off + hs * ws_ * 3].view(hs, ws_, 3).clone().requires_grad_(True)
+        leaves.append(leaf)
+        full = leaf.repeat_interleave(1 << sh, 0).repeat_interleave(1 << sh, 1) if sh else leaf
+        maps.append(torch.nn.functional.pad(full.permute(2, 0, 1)[None], (pl, pr, 0, 0), mode='circular')[0].permute(1, 2, 0) if (pl or pr) else full)
+    verts_o = scene.verts.detach().cpu().requires_grad_(True)
+    alpha_o = None if alpha is None else alpha.clone().requires_grad_(True)
+    sc = dict(verts=verts_o, faces=scene.faces.cpu().long(), face_uvs=scene.face_uvs.cpu(), face_map=scene.face_map.cpu().long(), maps=maps)
+    sigma = 1e-4 if coarse else 5e-6
+    ref = O.render(sc, R, T, Km[0], (H, W), sigma, fpp, True, None if alpha_o is None else alpha_o.repeat(2), 0.001, n_threads=8)
+    assert rel_err(out4, ref) < REL
+    # gradients of sum((rgb - noise)^2) through the joined render: product op vs oracle autograd
+    from dbw_amd.structures import PackedScene
+    v_h = scene.verts.detach().clone().requires_grad_(True)
+    m_h = scene.maps.detach().clone().requires_grad_(True)
+    a_h = None if alpha is None else alpha.to(DEV).requires_grad_(True)
+    sc_h = PackedScene(v_h, scene.faces, scene.face_uvs, scene.face_map, scene.map_desc, m_h)
+    renderer = model.renderer if coarse else model.renderer_fine
+    img_h = renderer.render_packed(sc_h, inp['R'], inp['T'], faces_alpha=a_h)
+    ((img_h[:, :3] - inp['imgs']) ** 2).sum().backward()
+    ((ref[:, :3] - imgs) ** 2).sum().backward()
+    assert rel_err(v_h.grad, verts_o.grad) < REL
+    if a_h is not None:
+        assert rel_err(a_h.grad[n_env:], alpha_o.grad[n_env:]) < REL
+    assert rel_err(m_h.grad, torch.cat([leaf.grad.reshape(-1) for leaf in leaves])) < REL
+    # end to end through the model
+    losses = model(inp, None)
+    assert set(losses) == {'rgb', 'parsimony', 'tv', 'overlap', 'total'}
+    assert abs(float(losses['rgb']) - float(((out4[:, :3] - inp['imgs']) ** 2).mean())) < 1e-5 * float(losses['rgb'])
+    losses['total'].backward()
+    for n in ('textures', 'texture_bkg', 'texture_ground', 'S', 'T', 'R_6d', 'sq_eps', 'R_6d_ground', 'T_ground') + (('alpha_logit',) if coarse else ()):
+        g = model.get_parameter(n).grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, n
+    # predict = the joined render's colour channels
+    model.eval()
+    assert model.predict(inp, None).shape == (2, 3, H, W)
+
+
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
 def test_loss_epilogue_path_equals_layered_path(epoch):
     """The training forward with composite + MSE as the epilogue of the fg pass (ops.render_decoupled_mse: no fg image, no composite

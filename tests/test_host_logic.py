@@ -139,6 +139,50 @@ def test_multistep_lr_matches_reference_scheduler(golden_dir):
         np.testing.assert_allclose(np.array(trace), g[tag], rtol=1e-12, atol=0)
 
 
+def test_multistep_lr_resumes_from_a_torch_scheduler_state_past_the_milestone(golden_dir):
+    """A checkpoint of the REFERENCE's trainer carries a torch scheduler state ('last_epoch', '_last_lr', '_step_count', ...), not this
+    trainer's {'last_epoch', 'lrs'}: loading it past the milestone must continue at the DECAYED rates (from '_last_lr', or replayed
+    from the milestones when that key is missing too) -- not at the base values, i.e. ten times too high."""
+    import os
+    import numpy as np
+    from dbw_amd.trainer import MultiStepLR
+    g = np.load(os.path.join(golden_dir, 'lr_schedule.npz'))
+    for tag, kwargs in [('dtu', dict(gamma=[0.1, 0.1], milestones=[1700])), ('warm', dict(gamma=[0.5, 0.1], milestones=[5, 9, 9], warmup=3))]:
+        trace = g[tag]
+        for epoch in (0, 2, 4, 6, 10, trace.shape[0] - 2):
+            if epoch >= trace.shape[0] - 1:
+                continue
+            for state in ({'last_epoch': epoch, '_last_lr': list(trace[epoch]), '_step_count': epoch + 1}, {'last_epoch': epoch}):
+                sch = MultiStepLR([5.0e-3, 5.0e-2], **kwargs)
+                sch.load_state_dict(state)
+                np.testing.assert_allclose(sch.get_last_lr(), trace[epoch], rtol=1e-12)
+                np.testing.assert_allclose(sch.step(), trace[epoch + 1], rtol=1e-12)
+        own = MultiStepLR([5.0e-3, 5.0e-2], **kwargs)
+        for _ in range(7):
+            own.step()
+        twin = MultiStepLR([5.0e-3, 5.0e-2], **kwargs)
+        twin.load_state_dict(own.state_dict())
+        assert twin.get_last_lr() == own.get_last_lr() and twin.step() == own.step()
+
+
+def test_lazy_losses_behave_like_the_dict_they_stand_for():
+    """native_step.LazyLosses reduces the loss values on first access: every way of reading a dict has to trigger that, not only
+    __getitem__ (get / copy / repr / pickling used to see the empty underlying dict)."""
+    import copy
+    import pickle
+    from dbw_amd.native_step import LazyLosses
+    def make():
+        vals = torch.zeros(8)
+        vals[1], vals[2], vals[3] = 0.25, 0.5, 0.125
+        return LazyLosses(vals, torch.tensor([1.0, 2.0, 3.0]), 0.5, ['rgb', 'parsimony', 'tv', 'overlap'])
+    want = {'rgb': 3.0, 'parsimony': 0.25, 'tv': 0.5, 'overlap': 0.125, 'total': 3.875}
+    assert float(make().get('rgb')) == 3.0 and make().get('nope', 7) == 7
+    assert {k: float(v) for k, v in make().copy().items()} == want
+    assert 'rgb' in repr(make()) and len(make()) == 5 and 'total' in make()
+    assert {k: float(v) for k, v in pickle.loads(pickle.dumps(make())).items()} == want
+    assert {k: float(v) for k, v in copy.deepcopy(make()).items()} == want
+
+
 def test_camera_ingest_round_trip_and_pixel_consistency():
     """N3: P = K_cv [R|t] -> (K_ndc, R, T) -> the render path's NDC projection lands on the same pixels as P."""
     import numpy as np

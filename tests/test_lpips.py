@@ -1,0 +1,96 @@
+"""The perceptual criterion (src/model/loss.py:32-40 -> lpips==0.1.4, absent here, weights absent too).
+oracle/lpips_ref.py restates the published forward independently; tests/golden/lpips_random.npz freezes it on seeded random weights
+(float64).  The product module a user loads real weights into (dbw_amd/lpips_vgg.py: LPIPSVGG) must reproduce the fixture with the same
+weights -- forward and gradient -- on the CPU here and on the GPU (MIOpen convolutions) under -m gpu, and the model's perceptual term
+must be weight x phase factor x batch share x that value.  REAL-WEIGHT PARITY STAYS UNPINNED: what is pinned is the architecture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lpips_ref as L                                   # oracle/ (checker only)
+
+
+def _fixture(golden_dir):
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, 'lpips_random.npz')).items()}
+    vgg, lin = L.random_weights(int(g['seed']))
+    return g, vgg, lin
+
+
+def test_restated_lpips_forward_is_frozen_by_the_fixture(golden_dir):
+    g, vgg, lin = _fixture(golden_dir)
+    vgg64, lin64 = L.random_weights(int(g['seed']), torch.float64)
+    r = g['rec'].double().requires_grad_(True)
+    per = L.lpips_vgg(g['imgs'].double(), r, vgg64, lin64)
+    per.mean().backward()
+    assert torch.allclose(per.view(-1), g['per_sample'], rtol=1e-12, atol=0) and abs(float(per.mean()) - float(g['loss'])) < 1e-15
+    assert torch.allclose(r.grad, g['g_rec'], rtol=1e-9, atol=1e-16)
+    assert float(g['per_sample'][2]) == 0.0 and float(g['per_sample'][:2].min()) > 1e-3           # identical pair / different pairs
+    # the same function in float32 (what runs in practice) stays within 1e-5 of it
+    per32 = L.lpips_vgg(g['imgs'], g['rec'], vgg, lin).view(-1).double()
+    assert float((per32 - g['per_sample']).abs().max()) < 1e-5 * float(g['per_sample'].max())
+
+
+def _check_module(net, g, dev, rel):
+    imgs, rec = g['imgs'].to(dev), g['rec'].to(dev).requires_grad_(True)
+    per = torch.stack([net(imgs[i:i + 1], rec[i:i + 1]) for i in range(imgs.shape[0])])
+    ref = g['per_sample'].to(dev)
+    assert float((per.double() - ref).abs().max()) < rel * float(ref.max()), (per.tolist(), ref.tolist())
+    loss = net(imgs, rec)                                                  # the reference's .mean() over the batch
+    assert abs(float(loss) - float(g['loss'])) < rel * float(g['loss'])
+    loss.backward()
+    gr, gref = rec.grad.double().cpu(), g['g_rec']
+    assert float((gr - gref).abs().max()) < rel * float(gref.abs().max())
+    assert float(gr[2].abs().max()) <= 1e-3 * float(gref.abs().max())     # (the identical pair: zero gradient up to 0/0-guard noise)
+
+
+def test_product_lpips_module_reproduces_the_fixture_with_the_same_weights(golden_dir):
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    g, vgg, lin = _fixture(golden_dir)
+    net = LPIPSVGG().load_weights(vgg, lin)
+    _check_module(net, g, 'cpu', 1e-4)
+
+
+@pytest.mark.gpu
+def test_product_lpips_module_on_the_gpu_reproduces_the_fixture(golden_dir):
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    g, vgg, lin = _fixture(golden_dir)
+    net = LPIPSVGG().load_weights(vgg, lin).to('cuda')
+    _check_module(net, g, 'cuda', 1e-4)
+
+
+@pytest.mark.gpu
+def test_model_perceptual_term_is_weight_times_phase_factor_times_batch_share_times_lpips(golden_dir):
+    """dbw.py:370: perceptual_weight x (1 coarse | 0.1 fine) x LPIPS(imgs, rec) with rec the composite the HIP path renders; under
+    view-sharded data parallelism a rank's term carries its share of the global batch (the gradients of the ranks are summed).  The
+    value is checked against the ORACLE's restatement evaluated on the very images the model handed to the criterion."""
+    import dbw_amd
+    import oracle as O
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    from test_gpu_model import _dtu_like_cfg
+    DEV = 'cuda'
+    g, vgg, lin = _fixture(golden_dir)
+    H, W = 48, 64
+    cfg = _dtu_like_cfg(4, 32, 6)
+    cfg['model']['loss']['perceptual_weight'] = 0.1
+    R, T, Km = O.synthetic_cameras(2, R_world=O.world_rotation(115, 0, 0))
+    inp = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(2)), R=R, T=T, K=Km).items()}
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(cfg, (H, W)).to(DEV).train()
+    net = LPIPSVGG().load_weights(vgg, lin).to(DEV)
+    seen = {}
+
+    def criterion(imgs, rec):
+        seen['imgs'], seen['rec'] = imgs.detach().cpu(), rec.detach().cpu()
+        return net(imgs, rec)
+    model.set_perceptual(criterion)
+    for epoch, factor in ((0, 1.0), (1600, 0.1)):
+        model.set_cur_epoch(epoch)
+        for world, count, share in ((1, None, 1.0), (4, 4 * inp['imgs'].numel(), 0.25)):
+            model.world_size, model._global_count = world, count
+            out = model(inp, None)
+            ref = float(L.lpips_loss(seen['imgs'], seen['rec'], vgg, lin))
+            got = float(out['perceptual'])
+            assert abs(got - 0.1 * factor * share * ref) <= 1e-4 * 0.1 * factor * share * ref, (epoch, world, got, ref)
+    model.world_size, model._global_count = 1, None
