@@ -65,7 +65,7 @@ def build_workload(args, dev):
 BIN_STATS = {}
 
 
-def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0):
+def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0, use_graph=False):
     """One more workload measured like the headline (same step, same launch path, inputs resident), outside its timed region:
     -> ms per step, views / s and the share of the HBM roofline the WHOLE-PATH algorithmic bytes (64 P K + 140 P per view)
     reach.  read_losses: every loss value is read on the host after every step, as the reference's trainer does
@@ -79,7 +79,7 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
     model, inp = build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391)
+    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391, use_graph=use_graph, graph_warmup=2)
     for _ in range(warmup):
         out = step(inp)
         if read_losses:
@@ -144,16 +144,19 @@ def kernel_breakdown(model, inp, reps=5):
             # two gradient images instead of an image (dbw_render_fwd_fused_mse); one opacity per block as in native_step
             fa_blk = None if fine else model._alpha.detach().contiguous()
             scale = 1.0 / inp['imgs'].numel()
-            state = ops.render_fwd_fused_mse(cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, fa_blk, r._bg, None, None, 0.0, stage=1)
+            target = ops.tile_image(inp['imgs'])                          # (the step tiles the targets once)
+            state = ops.render_fwd_fused_mse(cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, fa_blk, r._bg, None, None, 0.0, stage=1,
+                                             img_tiled=True)
             fwd = lambda: ops.render_fwd_fused_mse(cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, fa_blk, r._bg, img_env,
-                                                   inp['imgs'], scale, stage=2, state=state)
+                                                   target, scale, stage=2, state=state, img_tiled=True)
             p2f, bary, dists, _part, g_img, _g_env = fwd()
             g_img = g_img.clone()
             alpha = fa_blk
         else:
-            state = ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode, stage=1)
+            state = ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode, stage=1,
+                                          img_tiled=True)
             fwd = lambda: ops._render_fwd_fused(fvc, cl, B, cfg, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, r._bg, mode, stage=2,
-                                                state=state)
+                                                state=state, img_tiled=True)
             p2f, bary, dists, img = fwd()
             g_img = torch.rand_like(img)
             if tag == 'env':
@@ -179,7 +182,7 @@ def kernel_breakdown(model, inp, reps=5):
                                                                alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
                       0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap,
-                      int(getattr(scene, 'const_faces', 0)), 0, ops._stream(fvc))
+                      int(getattr(scene, 'const_faces', 0)), 0, 1, ops._stream(fvc))          # image_layout 1: the step's tiled images
 
         def reduce():
             _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, bins[2], g_maps.data_ptr(), ops._stream(fvc))
@@ -448,6 +451,10 @@ def main():
                 out['batch4']['what'] = ('batch_size 4 (configs/dtu/default.yml:28), the loss values read on the host after every step '
                                          '(src/trainer.py:143): launch-bound, ~31 launches per step')
                 out['batch4_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=False)
+                # the same with the step replayed from a hipGraph (ShardedTrainStep(use_graph=True): one host call per step + the Adam launch)
+                out['batch4_graph'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True, use_graph=True)
+                out['batch4_graph']['what'] = 'batch_size 4, loss values read every step, the native step replayed from a hipGraph'
+                out['batch4_graph_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, use_graph=True)
                 # >= 2 s of steps from the initial scene with frozen parameters (learning rates 0: Adam runs, the workload does not drift)
                 out['sustained'] = measure_other(49, 300, 400, 10, 10, 256, dev, steps=200, warmup=10, lr_scale=0.0, min_seconds=2.0)
                 out['sustained']['what'] = '>= 2 s of steps of the headline workload with both learning rates 0 (the scene does not drift)'

@@ -92,13 +92,13 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 // records arrive in SGPRs (two s_load_dwordx16 per face), lanes are pixels.  Shared by the cell-list path and the legacy staging path.
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
-                                                  int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false) {
+                                                  int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false) {
 #pragma unroll 1
     for (int i = 0; i < mcnt; ++i) {
         const int j = __builtin_amdgcn_readlane(jl, i);
         const FaceRec r = load_rec_uniform(recs + f_begin + j);
         const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
-        if (__ballot(inbox) == 0ull) continue;
+        if (__ballot(inbox) == 0ull || no_eval) continue;           // (no_eval: ablation switch of tools/diag)
         FPROF_ADD(5, 1);
         FPROF_CNT(6, inbox);
         float pz = 0.f, sd = 0.f;
@@ -216,7 +216,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
         txmax = pix_to_ndc_fast(W - 1 - x0, ax); txmin = pix_to_ndc_fast(W - 1 - x1, ax);
         tymax = pix_to_ndc_fast(H - 1 - y0, ay); tymin = pix_to_ndc_fast(H - 1 - y1, ay);
     }
-    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2), sign_only = (dbg & 8) != 0, no_insert = (dbg & 128) != 0;
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1), tilecull = DBW_RASTER_TILECULL && !(dbg & 2), sign_only = (dbg & 8) != 0, no_insert = (dbg & 128) != 0, no_eval = (dbg & 256) != 0, no_faces = (dbg & 512) != 0;
     int cnt = 0;
     FPROF_T(t_begin);
     FPROF_ADD(9, 1);
@@ -225,6 +225,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     unsigned long long t_evsum = 0;
     bool any_staged = false;
 #endif
+    if (no_faces) { ccnt = 0; nf = 0; }                       // (ablation: every tile treated as empty)
     if (cell_mode && ccnt > 0) {
         // the tile's own face list: nothing to test, nothing to stage
         FPROF_T(t_ev0);
@@ -234,7 +235,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
 #pragma unroll 1
         for (int cb0 = 0; cb0 < ccnt; cb0 += DBW_WAVE) {
             const int jl = cb0 + lane < ccnt ? cl[cb0 + lane] : 0;
-            eval_staged_chunk<KMAX, PAY3>(recs, fb, jl, min(DBW_WAVE, ccnt - cb0), in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert);
+            eval_staged_chunk<KMAX, PAY3>(recs, fb, jl, min(DBW_WAVE, ccnt - cb0), in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert, no_eval);
         }
 #ifdef DBW_PROFILE_FWD
         t_evsum += __builtin_readcyclecounter() - t_ev0;
@@ -303,7 +304,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
             for (int cb0 = 0; cb0 < cnt; cb0 += DBW_WAVE) {
                 const int jl = cb0 + lane < cnt ? s_list[cb0 + lane] : 0;
                 const int mcnt = min(DBW_WAVE, cnt - cb0);
-eval_staged_chunk<KMAX, PAY3>(recs, f_begin, jl, mcnt, in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert);
+eval_staged_chunk<KMAX, PAY3>(recs, f_begin, jl, mcnt, in_img, p, K, blur, persp, clipb, fastdiv, sign_only, q, home, NT, tid, no_insert, no_eval);
             }
             cnt = 0;
             if (NW > 1) __syncthreads();

@@ -148,11 +148,11 @@ __device__ __forceinline__ void shade_generic(const ShadeArgs &A, const TopK<KMA
             }
         }
     }
-    const long long plane = (long long)A.H * A.W;
-    float *out = image + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+    const ImgAddr ia = img_addr(A, n, yi, xi, 4);
+    float *out = image + ia.base;
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    out[0] = px[0]; out[plane] = px[1]; out[2 * plane] = px[2]; out[3 * plane] = px[3];
+    out[0] = px[0]; out[ia.cstride] = px[1]; out[2 * ia.cstride] = px[2]; out[3 * ia.cstride] = px[3];
 }
 
 // ---- the same for the training path's soft pass: 8x8 tile = one wave, uv-fragments (layout 2) --------------------------------------------
@@ -242,8 +242,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         }
         cur = nxt;
     }
-    const long long plane = (long long)A.H * A.W;
-    const long long pix = (long long)yi * A.W + xi;
+    const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
     float px[4];
     blend_front_finish(bl, A.bg, px);
     const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
@@ -253,23 +252,24 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
         float sq = 0.f;
         if (in_img) {
-            const float *ev = A.env_img + (long long)n * 4 * plane + pix, *tg = A.target + (long long)n * 3 * plane + pix;
-            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[plane], ev[2 * plane]}, t3[3] = {tg[0], tg[plane], tg[2 * plane]};
+            const float *ev = A.env_img + i4.base, *tg = A.target + i3.base;
+            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[i4.cstride], ev[2 * i4.cstride]}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
             float rec3[3], gf3[3], ge3[3], gmask;
             sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
-            float *gf = A.g_fg + (long long)n * 4 * plane + pix, *ge = A.g_env + (long long)n * 4 * plane + pix;
-            gf[0] = gf3[0]; gf[plane] = gf3[1]; gf[2 * plane] = gf3[2];
-            gf[3 * plane] = gmask;
-            ge[0] = ge3[0]; ge[plane] = ge3[1]; ge[2 * plane] = ge3[2]; ge[3 * plane] = 0.f;
+            float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
+            const long long cs = i4.cstride;
+            gf[0] = gf3[0]; gf[cs] = gf3[1]; gf[2 * cs] = gf3[2];
+            gf[3 * cs] = gmask;
+            ge[0] = ge3[0]; ge[cs] = ge3[1]; ge[2 * cs] = ge3[2]; ge[3 * cs] = 0.f;
         }
         const float tot = wave_sum_dpp(sq);
         if (lane == 0) A.loss_part[tile] = tot;
     } else if (in_img) {
-        float *out = image + (long long)n * 4 * plane + pix;
+        float *out = image + i4.base;
         out[0] = f0;
-        out[plane] = f1;
-        out[2 * plane] = f2;
-        out[3 * plane] = m;
+        out[i4.cstride] = f1;
+        out[2 * i4.cstride] = f2;
+        out[3 * i4.cstride] = m;
     }
 }
 
@@ -343,7 +343,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, const MseArgs *mse, int stage, dbw_stream_t stream) {
+                                    int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream) {
     DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
@@ -357,7 +357,9 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     DBW_REQUIRE(frag_layout != 3 || (K == 1 && sigma == 0.f && blur_radius == 0.f && !faces_alpha),
                 "frag_layout 3 is the hard single-layer pass: K == 1, sigma == 0, no faces_alpha");
     DBW_REQUIRE(frag_layout != 2 || F_total < (1LL << FRAG_COUNT_SHIFT), "frag_layout 2 packs the clipped face id in 26 bits");
+    DBW_REQUIRE(image_layout == 0 || image_layout == 1, "image_layout must be 0 (N,C,H,W) or 1 (8x8-tile planar)");
     A.tiled = frag_layout;
+    A.img_tiled = image_layout;
     if (mse) {
         DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
         DBW_REQUIRE(stage == 1 || (mse->env_img && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
@@ -402,10 +404,10 @@ extern "C" int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *fi
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, int stage, dbw_stream_t stream) {
+                                    int frag_layout, int stage, int image_layout, dbw_stream_t stream) {
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, stage, stream);
+                           bary, dists, image, workspace, workspace_bytes, frag_layout, nullptr, stage, image_layout, stream);
 }
 
 extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
@@ -416,9 +418,9 @@ extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t
                                         int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                         float *dists, void *workspace, size_t workspace_bytes, const float *env_image,
                                         const float *target, float mse_scale, float *loss_partial, float *grad_fg,
-                                        float *grad_env, int stage, dbw_stream_t stream) {
+                                        float *grad_env, int stage, int image_layout, dbw_stream_t stream) {
     const MseArgs mse{env_image, target, mse_scale, loss_partial, grad_fg, grad_env};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stage, stream);
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stage, image_layout, stream);
 }

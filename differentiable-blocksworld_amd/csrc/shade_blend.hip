@@ -148,9 +148,10 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     const long long plane = (long long)A.H * A.W;
     float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
     if (in_img) {
-        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        const ImgAddr ia = img_addr(A, n, yi, xi, 4);
+        const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs; gA = gi[3 * plane] * gs;
+        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs; gA = gi[3 * ia.cstride] * gs;
     }
     // The deepest layer in which any pixel of this wave holds a fragment: only ~20 % of the slots of a soft render are occupied
     // and most waves see few layers, so both passes stop there instead of walking all K layers.  Fragments written by
@@ -539,27 +540,10 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     (void)SINGLE;
     TexAgg tex_agg;
     FaceAlphaAgg fa_agg;
-    if (!BINNED) {
-        tex_agg.bind(s_uvbwd);
-        tex_agg.clear(threadIdx.x, NT);
-    }
-    fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
-    fa_agg.clear(threadIdx.x, NT);
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
-    __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
-    f2 pndc;
-    pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
-    pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
-    const long long plane = (long long)A.H * A.W;
-    float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
-    if (in_img) {
-        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
-        const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs; gA = gi[3 * plane] * gs;
-    }
     // wave-uniform tile of the 8x8-tile planar fragment layout
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -567,10 +551,31 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     const int *__restrict__ p2f_t = A.p2f + tb + lane;
     const float *__restrict__ dists_t = A.dists + tb + lane;
     const float *__restrict__ bary_t = A.bary + tb * 8 + lane;
+    // the fragment counts of the block's pixels are requested first; the tables are cleared while they travel; a block none of whose
+    // pixels holds a fragment -- six of ten at config 2 -- leaves at the barrier that ends the clearing: no gradient image loads, no
+    // second barrier, no flush scans
     int cnt = 0;
     if (in_img && (yi >> 3) < tiles_y && (xi >> 3) < tiles_x) {
         const int raw0 = p2f_t[0];
         cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
+    }
+    if (!BINNED) {
+        tex_agg.bind(s_uvbwd);
+        tex_agg.clear(threadIdx.x, NT);
+    }
+    fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
+    fa_agg.clear(threadIdx.x, NT);
+    if (!__syncthreads_or(cnt > 0)) return;
+    f2 pndc;
+    pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
+    pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
+    const long long plane = (long long)A.H * A.W;
+    float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
+    if (in_img) {
+        const ImgAddr ia = img_addr(A, n, yi, xi, 4);
+        const float *gi = gimg + ia.base;
+        const float gs = A.gscale ? *A.gscale : 1.f;
+        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs; gA = gi[3 * ia.cstride] * gs;
     }
     PROF_T(t_begin);
     int kmax = 0;
@@ -854,6 +859,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.tiled = 0;
     A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0;
     A.gscale = nullptr; A.geom_begin = 0; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
+    A.img_tiled = 0;
     return DBW_OK;
 }
 
@@ -929,10 +935,10 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     int jm = 0;
     if (valid) {
         u = A.bary[o.b]; v = A.bary[o.b + o.bstride]; jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
-        const long long plane = (long long)A.H * A.W;
-        const float *gi = gimg + (long long)n * 4 * plane + (long long)yi * A.W + xi;
+        const ImgAddr ia = img_addr(A, n, yi, xi, 4);
+        const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[plane] * gs; gbl = gi[2 * plane] * gs;
+        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs;
     }
     const int j = jm & 0xfffff, map = jm >> 20;
     const float gc[3] = {gr, gg, gbl};               // blend weight of a hard fragment = 1
@@ -1114,7 +1120,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
                                     int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
                                     void *bin_records, int bin_cap, int const_geometry_faces, const float *grad_scale,
-                                    dbw_stream_t stream) {
+                                    int image_layout, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -1126,7 +1132,9 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     DBW_REQUIRE(frag_layout != 3 || (K == 1 && sigma == 0.f && !faces_alpha && lds_aggregate && F < (1 << 20)),
                 "frag_layout 3 is the hard single-layer pass: K == 1, sigma == 0, no faces_alpha, lds_aggregate, F < 2^20");
     DBW_REQUIRE(const_geometry_faces >= 0 && const_geometry_faces <= F, "const_geometry_faces must lie in [0, F]");
+    DBW_REQUIRE(image_layout == 0 || image_layout == 1, "image_layout must be 0 (N,4,H,W) or 1 (8x8-tile planar)");
     A.tiled = frag_layout;
+    A.img_tiled = image_layout;
     A.gscale = grad_scale;
     A.geom_begin = const_geometry_faces;
     DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap >= DBW_BIN_SUBCURSORS) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none (bin_cap >= DBW_BIN_SUBCURSORS)");

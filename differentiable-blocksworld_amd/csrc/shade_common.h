@@ -40,7 +40,28 @@ struct ShadeArgs {
     const float *env_img, *target;
     float mse_scale;
     float *loss_part, *g_fg, *g_env;
+    // layout of the image-shaped buffers of a pass (its image, the gradient image of its backward, the env image / target / gradient
+    // images of the loss epilogue): 0 = (N, C, H, W) planes as torch holds them; 1 = 8x8-tile planar [n][tile_y][tile_x][C][64], the
+    // layout of the fragments -- a wave's access to one plane of its tile is then ONE 256 B line instead of eight 32 B row pieces
+    int img_tiled;
 };
+
+// element (n, channel c of C, yi, xi) of an image-shaped buffer
+struct ImgAddr { long long base; long long cstride; };
+__device__ __forceinline__ ImgAddr img_addr(const ShadeArgs &A, int n, int yi, int xi, int C) {
+    ImgAddr a;
+    if (A.img_tiled) {
+        const int tx = (A.W + 7) >> 3, ty = (A.H + 7) >> 3;
+        const long long tile = ((long long)n * ty + (yi >> 3)) * tx + (xi >> 3);
+        a.base = tile * (C * 64) + (((yi & 7) << 3) | (xi & 7));
+        a.cstride = 64;
+    } else {
+        const long long plane = (long long)A.H * A.W;
+        a.base = (long long)n * C * plane + (long long)yi * A.W + xi;
+        a.cstride = plane;
+    }
+    return a;
+}
 
 struct Frag {
     int fc;           // clipped face id of the slot (index into face_verts_c)

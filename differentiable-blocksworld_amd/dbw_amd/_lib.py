@@ -42,11 +42,11 @@ SIGNATURES = {
     'dbw_shade_blend_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
                             c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     'dbw_render_fwd_fused': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i, c_i, c_i, c_i, c_f, c_f,
-                             c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_p],
+                             c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p],
     'dbw_render_fwd_fused_mse': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i, c_i, c_i, c_i, c_f, c_f,
-                                 c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_p],
+                                 c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p],
     'dbw_render_bwd_fused': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
-                             c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+                             c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
     'dbw_texbin_reduce': [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     'dbw_texture_prep_fwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_texture_prep_bwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],

@@ -12,6 +12,8 @@ to `cat`s, fills, a `repeat_interleave` pair and three reductions that only exis
 Same mathematics as DifferentiableBlocksWorld.forward (src/model/dbw.py:198-408) + backward, checked against it
 (tests/test_gpu_model.py::test_native_step_equals_autograd_step).  Scope: the decoupled training render with MSE + parsimony + TV +
 overlap (every shipped config minus LPIPS); anything else -> `supported()` is False and the caller uses the autograd path."""
+import weakref
+
 import torch
 
 from . import _lib, ops
@@ -26,12 +28,23 @@ class NativeStep:
         self.m, self.params = model, params
         self.grad = {n: model.get_parameter(n).grad for n, _, _ in params.names}       # views of the flat gradient buffer
         self._env_verts = None
+        self._target, self._target_key = None, None
         self._side, self.overlap_regularisers, self.side_priority = None, True, True
         # None: by configuration -- one after the other when the blocks' gradients are worth announcing early (data parallel: their
         # all-reduce then runs next to the env backward) or when a bin reduction follows the fg kernel (full-resolution phases: measured
         # 2 % faster), both at once otherwise (1 % faster on one GPU with decimated maps); True / False force one or the other
         self.sequential_backward = None
         self.on_block_grads_ready = None      # callback: every gradient that does not depend on the env pass is final (on the current stream)
+
+    def _tiled_target(self, imgs):
+        """The target images in the tile-planar layout, tiled ONCE per tensor (the training views are static: the bench and a trainer
+        that keeps its views resident hand over the same tensor every step; a fresh mini-batch costs one permute kernel)."""
+        # keyed on the tensor OBJECT (and its version counter), not on its address: the allocator hands a freed mini-batch's address
+        # to the next one
+        src = self._target_key[0]() if self._target_key is not None else None
+        if src is not imgs or self._target_key[1] != imgs._version:
+            self._target, self._target_key = ops.tile_image(imgs), (weakref.ref(imgs), imgs._version)
+        return self._target
 
     def supported(self):
         m, w = self.m, self.m.loss_weights
@@ -104,8 +117,11 @@ class NativeStep:
         desc_e = m._env_map_desc if decim == 1 else m._env_map_desc_dec
         cl_e = ops.project_clip(env_verts, m._env_faces, R, T, Kmat, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
         lay_e = ops.hard_layout(cfg_e, None, desc_e)                  # 3: hard uv-fragments
+        # image-shaped buffers of the step (env image, the two gradient images) live in the 8x8-tile planar layout of the fragments
+        # (include/dbw_hip.h: image_layout 1) and the targets are tiled once: every wave access to them is one 256 B line
         env_state = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps,
-                                          None, m.renderer_env._bg, lay_e, stage=1)
+                                          None, m.renderer_env._bg, lay_e, stage=1, img_tiled=True)
+        target = self._tiled_target(imgs)
 
         # ---- side: textures first -- sigmoid (+ decimation to cell resolution); `sig` = the undecimated maps of the TV term -- because
         # the env pass on the main stream waits for them; then zero the gradients and the opacities (dbw.py:297-311) ----
@@ -149,7 +165,8 @@ class NativeStep:
         if maps_ready is not None:
             cur.wait_event(maps_ready)
         p2f_e, bary_e, dists_e, img_e = ops._render_fwd_fused(cl_e['face_verts'].view(-1, 3, 3), cl_e, B, cfg_e, m._env_face_uvs, m._env_face_map,
-                                                              desc_e, env_maps, None, m.renderer_env._bg, lay_e, stage=2, state=env_state)
+                                                              desc_e, env_maps, None, m.renderer_env._bg, lay_e, stage=2, state=env_state,
+                                                              img_tiled=True)
 
         # ---- side, next to the env pass: the blocks' vertices, their projection and the per-face set-up of the fg pass (boxes, face +
         # shading records, bins); the regularisers: value + gradient in one pass, weights folded into the kernels' scales
@@ -165,7 +182,7 @@ class NativeStep:
         cl_f = ops.project_clip(blk_verts, m._block_faces_all, R, T, Kmat, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
         fa = None if fine else alpha                                   # one opacity per block = per texture map (alpha_len < 0)
         fg_state = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa, renderer._bg,
-                                            None, None, 0.0, stage=1)
+                                            None, None, 0.0, stage=1, img_tiled=True)
         fg_ready = None
         if side is not cur:                                            # the fg pass only waits for its set-up, not for the regularisers
             fg_ready = torch.cuda.Event()                              # behind it (they run next to the fg forward)
@@ -193,15 +210,15 @@ class NativeStep:
         if fg_ready is not None:
             cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
         p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
-                                                                      blk_maps, fa, renderer._bg, img_e, imgs, scale, stage=2,
-                                                                      state=fg_state)
+                                                                      blk_maps, fa, renderer._bg, img_e, target, scale, stage=2,
+                                                                      state=fg_state, img_tiled=True)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
         # kernels (projection backward, pose / shape, textures, opacities) ----
         fg_out = {}
 
         def fg_backward(st, after_kernel=None, with_textures=True):
             g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
-                                                     cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel)
+                                                     cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel, img_tiled=True)
             fg_out.update(g_blk_maps=g_blk_maps, g_fa=g_fa)
             g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
             _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),
@@ -220,7 +237,7 @@ class NativeStep:
 
         def env_backward(st):
             g_env_maps, _, g_fvc_e = ops._fused_bwd(p2f_e, bary_e, dists_e, cl_e, m._env_face_uvs, m._env_face_map, desc_e, env_maps, None, cfg_e,
-                                                    m.renderer_env._bg, lay_e, g_env, B, None)
+                                                    m.renderer_env._bg, lay_e, g_env, B, None, img_tiled=True)
             g_env_verts = ops.project_clip_bwd(env_verts, m._env_faces, R, T, Kmat, cl_e, g_fvc_e, cfg_e.eps, cfg_e.z_clip, cfg_e.persp)
             _lib.call('dbw_posed_mesh_bwd', _p(m._ground_base), ngv, _p(m.R_6d_ground), _p(m.T_ground), float(S_w), _p(R_w),
                       g_env_verts.data_ptr() + nbv * 12, _p(g['R_6d_ground']), _p(g['T_ground']), st)

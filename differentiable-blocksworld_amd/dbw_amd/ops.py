@@ -287,7 +287,27 @@ def hard_layout(cfg, fa, map_desc):
     return 3 if ok else 1
 
 
-def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None, stage=0, state=None):
+def tiled_image_empty(B, C, H, W, device):
+    """Uninitialised image in the 8x8-tile planar layout of include/dbw_hip.h (image_layout 1): (B, ceil(H/8), ceil(W/8), C, 64)."""
+    return torch.empty(B, (H + 7) // 8, (W + 7) // 8, C, 64, dtype=torch.float32, device=device)
+
+
+def tile_image(img):
+    """(B, C, H, W) -> the 8x8-tile planar layout (B, ceil(H/8), ceil(W/8), C, 64); rows / columns beyond the image are zero."""
+    B, C, H, W = img.shape
+    ty, tx = (H + 7) // 8, (W + 7) // 8
+    if (H, W) != (ty * 8, tx * 8):
+        img = torch.nn.functional.pad(img, (0, tx * 8 - W, 0, ty * 8 - H))
+    return img.view(B, C, ty, 8, tx, 8).permute(0, 2, 4, 1, 3, 5).reshape(B, ty, tx, C, 64).contiguous()
+
+
+def untile_image(t, H, W):
+    """Inverse of tile_image: (B, ty, tx, C, 64) -> (B, C, H, W)."""
+    B, ty, tx, C, _ = t.shape
+    return t.view(B, ty, tx, C, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(B, C, ty * 8, tx * 8)[:, :, :H, :W].contiguous()
+
+
+def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, tiled=None, stage=0, state=None, img_tiled=False):
     """stage 1: only the per-face set-up of the pass (needs no texture values) -> `state` for the stage-2 call that renders."""
     TILED_FRAGMENTS = globals()['TILED_FRAGMENTS'] if tiled is None else tiled
     dev = fvc.device
@@ -306,14 +326,14 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
             p2f = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.int32, device=dev)
             bary = torch.empty(B, cfg.H, cfg.W, cfg.K, 3, dtype=torch.float32, device=dev)
             dists = torch.empty(B, cfg.H, cfg.W, cfg.K, dtype=torch.float32, device=dev)
-        img = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+        img = tiled_image_empty(B, 4, cfg.H, cfg.W, dev) if img_tiled else torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
         out = (p2f, bary, dists, img)
     p2f, bary, dists, img = out
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
               _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(img), _ptr(ws), ws_bytes, int(TILED_FRAGMENTS), int(stage),
-              _stream(fvc))   # frag_layout 0 / 1 / 2
+              int(img_tiled), _stream(fvc))   # frag_layout 0 / 1 / 2
     return (ws, ws_bytes, out) if stage == 1 else out
 
 
@@ -374,7 +394,7 @@ class _RenderScene(torch.autograd.Function):
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
 
 
-def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale, after_kernel=None):
+def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale, after_kernel=None, img_tiled=False):
     """dbw_render_bwd_fused (+ dbw_texbin_reduce when the texel gradients go through texture-space bins) of one pass.
     gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c."""
     fvc = cl['face_verts'].view(-1, 3, 3)
@@ -394,7 +414,7 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
                                                    (B, cfg.H, cfg.W, cfg.K)),
               _ptr(g_img), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
               int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, int(cfg.const_faces), _ptr(gscale),
-              _stream(fvc))
+              int(img_tiled), _stream(fvc))
     if after_kernel is not None:
         after_kernel()            # (the big kernel is enqueued; the bin reduction, a low-occupancy kernel, may share the GPU with other work)
     if records is not None:
@@ -402,7 +422,7 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     return g_maps, g_alpha, g_fvc
 
 
-def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, env_img, imgs, scale, stage=0, state=None):
+def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg, env_img, imgs, scale, stage=0, state=None, img_tiled=False):
     """dbw_render_fwd_fused_mse on the clipped faces `cl` of the fg scene (no grad bookkeeping): uv-fragments + per-tile sums of
     squared differences + d loss / d fg image, d loss / d env image.  -> p2f, bary, dists, part, g_fg, g_env.
     stage 1 (env_img / imgs may be None): only the per-face set-up, on the current stream -> `state` for the stage-2 call that
@@ -419,7 +439,7 @@ def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg,
         bary = torch.empty(B, ty, tx, cfg.K, 8, 64, dtype=torch.float32, device=dev)
         dists = torch.empty(B, ty, tx, cfg.K, 64, dtype=torch.float32, device=dev)
         part = torch.empty(B * ty * tx, dtype=torch.float32, device=dev)
-        g_fg = torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
+        g_fg = tiled_image_empty(B, 4, cfg.H, cfg.W, dev) if img_tiled else torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
         g_env = torch.empty_like(g_fg)
         out = (p2f, bary, dists, part, g_fg, g_env)
     p2f, bary, dists, part, g_fg, g_env = out
@@ -427,7 +447,7 @@ def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg,
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
               _bg_ptr(bg), _ptr(p2f), _ptr(bary), _ptr(dists), _ptr(ws), ws_bytes, _ptr(env_img), _ptr(imgs), float(scale), _ptr(part),
-              _ptr(g_fg), _ptr(g_env), int(stage), _stream(fvc))
+              _ptr(g_fg), _ptr(g_env), int(stage), int(img_tiled), _stream(fvc))
     return (ws, ws_bytes, out) if stage == 1 else out
 
 

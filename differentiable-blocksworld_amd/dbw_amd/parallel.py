@@ -56,6 +56,7 @@ class ShardedTrainStep:
                  use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures'):
         self.model, self.pg = model, process_group
         self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
+        self._graph_key = None
         if use_graph and not getattr(model, 'sync_free', False):
             raise ValueError('use_graph=True needs model.sync_free = True (no device->host sync inside the iteration)')
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -112,7 +113,9 @@ class ShardedTrainStep:
         view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
         self.model._global_count = self._global_count(inp['imgs'], global_count)
         dirty = None
-        if self.use_graph and self.n_steps >= self.graph_warmup:
+        if self.use_graph and self.n_steps >= self.graph_warmup and self._native_graph_ok(inp):
+            losses = self._native_graph_iteration(inp)
+        elif self.use_graph and self.n_steps >= self.graph_warmup:
             losses = self._graph_iteration(inp)
         else:
             # gradients accumulate into the preallocated flat buffer, so nothing carved out of the zero arena outlives the
@@ -182,6 +185,43 @@ class ShardedTrainStep:
         if self._early_work is not None:
             self._early_work.wait()                  # (the current stream waits, not the host)
         self._early_work, self._early_done = None, False
+
+    # ---- the native step as ONE hipGraph -----------------------------------------------------------------------------------------
+    # At the reference's own operating point (batch_size 4, configs/dtu/default.yml:28) a step is ~0.1 ms of kernels behind ~0.45 ms
+    # of Python: 33 launches through ctypes, events, small torch allocations.  Captured once per training phase, the same launches
+    # (both streams, their fork / join events, the zero fills) replay from one host call; the fused Adam stays outside (its step
+    # count and learning rates change every iteration).  Single process only: the early all-reduce hook is a host-side callback.
+    def _native_graph_ok(self, inp):
+        return (self.native is not None and self.world_size == 1 and not self.overlap_allreduce and self.model.training
+                and inp['imgs'].shape[0] > 0 and self.native.supported() and self._fused_adam())
+
+    def _native_graph_iteration(self, inp):
+        from .native_step import LazyLosses
+        m = self.model
+        dev = self.params.flat.device
+        key = (m.is_live('coarse_learning'), m.is_live('decimate_txt'), float(m._global_count), tuple(inp['imgs'].shape),
+               m._noise_override is None, m._overlap_u_override is None)
+        if self._graph is None or self._graph_key != key:
+            self._static_inp = {k: v.clone() for k, v in inp.items()}
+            torch.cuda.synchronize()
+            self._graph, self._graph_key = torch.cuda.CUDAGraph(), key
+            ops.ARENA.enabled = True
+            try:
+                with torch.no_grad(), torch.cuda.graph(self._graph):
+                    ops.ARENA.clean.pop(dev, None)              # the graph clears the arena itself, every replay
+                    ops.ARENA.begin_step(dev)
+                    ll = self.native(self._static_inp, m._global_count, zero_grad=self.params.zero_grad)
+                ops.ARENA.end_step(dev)
+                ops.ARENA.clean.pop(dev, None)
+            finally:
+                ops.ARENA.enabled = False
+            self._static_losses = (ll._vals, ll._part, ll._scale, ll._names)
+            del ll
+        for k, v in inp.items():
+            if v.data_ptr() != self._static_inp[k].data_ptr():
+                self._static_inp[k].copy_(v)
+        self._graph.replay()
+        return LazyLosses(*self._static_losses)
 
     def _graph_iteration(self, inp):
         if self._graph is None:

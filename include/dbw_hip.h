@@ -157,14 +157,19 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
  * (F < 2^20, F_total < 2^26, maps < 2^11); 3 = layout 1 whose three `bary` planes hold (u, v, bitcast(face | map << 20)) and whose
  * `dists` are not written, for the HARD single-layer pass (K == 1, sigma == 0, no faces_alpha; F < 2^20, maps < 2^11): a kept pixel
  * lies inside its face and its opacity is 1, so that is all the backward needs for the texture gradient, and it rebuilds the
- * barycentrics from the pixel position for the geometry gradient (dbw_render_bwd_fused then requires lds_aggregate != 0). */
+ * barycentrics from the pixel position for the geometry gradient (dbw_render_bwd_fused then requires lds_aggregate != 0).
+ * image_layout (this entry point, dbw_render_fwd_fused_mse and dbw_render_bwd_fused): layout of every image-shaped buffer of the
+ * call -- `image`, `env_image`, `target`, `grad_fg`, `grad_env`, `grad_image`: 0 = (N,C,H,W) planes; 1 = 8x8-tile planar
+ * [N][ceil(H/8)][ceil(W/8)][C][64] (C = 4, targets 3; the buffers then hold N*ceil(H/8)*ceil(W/8)*C*64 floats), the layout of the
+ * fragments: a wave's access to one plane of its tile is one 256 B line instead of eight 32 B row pieces.  The training step keeps its
+ * intermediate images (env image, the two gradient images) in that layout and tiles the targets once. */
 int dbw_render_fwd_fused(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                          const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code, const float *clip_w,
                          int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
                          const float *maps, const float *faces_alpha, int alpha_len, int N, int64_t F_total, int H, int W,
                          int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
                          int32_t *pix_to_face, float *bary, float *dists, float *image, void *workspace,
-                         size_t workspace_bytes, int frag_layout, int stage, dbw_stream_t stream);
+                         size_t workspace_bytes, int frag_layout, int stage, int image_layout, dbw_stream_t stream);
 
 /* The same forward for the training path's soft pass (uv-fragments, frag_layout 2, K > 1) with the decoupled composite and the MSE
  * (dbw.py:223,366-367) as its epilogue: instead of storing its image the pass composites it in registers over env_image (N,4,H,W:
@@ -183,7 +188,7 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
                              int K, int F, float sigma, float blur_radius, int perspective_correct, const float *background3,
                              int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                              const float *env_image, const float *target, float mse_scale, float *loss_partial,
-                             float *grad_fg, float *grad_env, int stage, dbw_stream_t stream);
+                             float *grad_fg, float *grad_env, int stage, int image_layout, dbw_stream_t stream);
 
 /* Fused backward of one render pass: dbw_shade_blend_bwd followed by dbw_rasterize_bwd (clip_barycentric_coords = 1,
  * grad_zbuf = 0) without the grad_dists / grad_bary round trip through memory.  Same inputs as dbw_shade_blend_bwd plus
@@ -209,7 +214,7 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
                          int frag_layout, const int32_t *bin_base, int32_t *bin_cursor, void *bin_records, int bin_cap,
-                         int const_geometry_faces, const float *grad_scale, dbw_stream_t stream);
+                         int const_geometry_faces, const float *grad_scale, int image_layout, dbw_stream_t stream);
 /* bin_info (nbins,4) int32 = {offset of the bin's map in floats, stored width, stored height, tile_y << 16 | tile_x}. */
 int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap, int nbins,
                       float *grad_maps, dbw_stream_t stream);

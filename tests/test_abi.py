@@ -35,7 +35,7 @@ def parse_header():
 def test_library_builds_and_loads_without_gpu():
     lib = _lib.load()
     assert os.path.exists(_lib.LIB_PATH)
-    assert lib.dbw_abi_version() == 1
+    assert lib.dbw_abi_version() == 2
     assert lib.dbw_last_error() is not None
 
 
