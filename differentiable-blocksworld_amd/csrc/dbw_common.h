@@ -6,6 +6,7 @@
 // helpers are written with explicit ternaries instead of fmaxf/fminf.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 #include "raster_math.h"      // f2 / f3, pix_to_ndc, edge_fn, FaceRec, eval_pair, TopK (host + device)

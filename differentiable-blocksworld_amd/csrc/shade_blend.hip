@@ -21,6 +21,30 @@
 
 using namespace dbw;
 
+// Fragments, gradient images and texel-gradient records are produced once and consumed once, a gigabyte of traffic later: they are
+// loaded / stored non-temporally so that they stream past the L2 instead of evicting the tables the kernels keep coming back to
+#ifndef DBW_NT_LOADS
+#define DBW_NT_LOADS 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+#if DBW_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream4(int4 *p, int4 v) {
+#if DBW_NT_LOADS
+    int *q = (int *)p;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, (v4i *)q);
+#else
+    *p = v;
+#endif
+}
+
 namespace {
 
 #ifndef DBW_BWD_UNROLL
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
         const ImgAddr ia = img_addr(A, n, yi, xi, 4);
         const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs; gA = gi[3 * ia.cstride] * gs;
+        gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs; gA = ld_stream(gi + 3 * ia.cstride) * gs;
     }
     // The deepest layer in which any pixel of this wave holds a fragment: only ~20 % of the slots of a soft render are occupied
     // and most waves see few layers, so both passes stop there instead of walking all K layers.  Fragments written by
@@ -556,7 +580,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     // second barrier, no flush scans
     int cnt = 0;
     if (in_img && (yi >> 3) < tiles_y && (xi >> 3) < tiles_x) {
-        const int raw0 = p2f_t[0];
+        const int raw0 = ld_stream(p2f_t);
         cnt = raw0 < 0 ? 0 : (raw0 >> FRAG_COUNT_SHIFT);
     }
     if (!BINNED) {
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         const ImgAddr ia = img_addr(A, n, yi, xi, 4);
         const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs; gA = gi[3 * ia.cstride] * gs;
+        gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs; gA = ld_stream(gi + 3 * ia.cstride) * gs;
     }
     PROF_T(t_begin);
     int kmax = 0;
@@ -592,10 +616,11 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         Raw r;
         r.fc = 0; r.u = r.v = r.jm = r.a = r.c0 = r.c1 = r.c2 = r.d = 0.f; r.T = 1.f;
         if (ok) {
-            r.fc = p2f_t[k << 6] & FRAG_FACE_MASK;
+            r.fc = ld_stream(p2f_t + (k << 6)) & FRAG_FACE_MASK;
             const float *b = bary_t + (k << 9);
-            r.u = b[0]; r.v = b[64]; r.jm = b[128]; r.a = b[192]; r.c0 = b[256]; r.c1 = b[320]; r.c2 = b[384]; r.T = b[448];
-            r.d = dists_t[k << 6];
+            r.u = ld_stream(b); r.v = ld_stream(b + 64); r.jm = ld_stream(b + 128); r.a = ld_stream(b + 192);
+            r.c0 = ld_stream(b + 256); r.c1 = ld_stream(b + 320); r.c2 = ld_stream(b + 384); r.T = ld_stream(b + 448);
+            r.d = ld_stream(dists_t + (k << 6));
         }
         return r;
     };
@@ -674,8 +699,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
                     if (slot < sub_cap) {
                         int4 *dst = A.bin_records + ((long long)cres.bin * A.bin_cap + (long long)sub * sub_cap + slot) * 2;
                         if (!(A.dbg & (1 << 17))) {                    // (1 << 17: ablation of the record stores, tools/diag)
-                            dst[0] = make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0]));
-                            dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                            st_stream4(dst, make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0])));
+                            st_stream4(dst + 1, make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0));
                         }
                         pending = false;
                     }
@@ -709,14 +734,14 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                if (tex && wt[q] != 0.f) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);
+                if (tex && wt[q] != 0.f && !(A.dbg & 1)) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
             }
         }
         PROF_T(t_b);
         PROF_ADD(4, t_a, t_b);
         // distance -> the two vertices of the closest edge; opacity; one table update per fragment
         float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
-        if (__ballot(gd != 0.f) != 0ull) {
+        if (__ballot(gd != 0.f) != 0ull && !(A.dbg & 16)) {
             const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
             const f2 v0{q[0], q[1]}, v1{q[3], q[4]}, v2{q[6], q[7]};
             float t01, t02, t12;
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         }
         PROF_T(t_c);
         PROF_ADD(5, t_b, t_c);
-        if (valid && (gd != 0.f || g7[6] != 0.f)) {
+        if (valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2)) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
         }
@@ -745,6 +770,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     PROF_T(t_end);
     PROF_ADD(7, t_begin, t_end);
     __syncthreads();
+    if (A.dbg & 128) return;
     if (!BINNED) tex_agg.flush(gmaps, threadIdx.x, NT);
     fa_agg.flush(gfv, galpha, threadIdx.x, NT);
 }
@@ -929,16 +955,16 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     const int lane = threadIdx.x & 63;
     PROF_T(t_begin);
     const FragAddr o = frag_addr(A, n, yi, xi, 0);
-    const int fc = in_img ? A.p2f[o.s] : -1;
+    const int fc = in_img ? ld_stream(A.p2f + o.s) : -1;
     const bool valid = fc >= 0;
     float u = 0.f, v = 0.f, gr = 0.f, gg = 0.f, gbl = 0.f;
     int jm = 0;
     if (valid) {
-        u = A.bary[o.b]; v = A.bary[o.b + o.bstride]; jm = __float_as_int(A.bary[o.b + 2 * o.bstride]);
+        u = ld_stream(A.bary + o.b); v = ld_stream(A.bary + o.b + o.bstride); jm = __float_as_int(ld_stream(A.bary + o.b + 2 * o.bstride));
         const ImgAddr ia = img_addr(A, n, yi, xi, 4);
         const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = gi[0] * gs; gg = gi[ia.cstride] * gs; gbl = gi[2 * ia.cstride] * gs;
+        gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs;
     }
     const int j = jm & 0xfffff, map = jm >> 20;
     const float gc[3] = {gr, gg, gbl};               // blend weight of a hard fragment = 1
