@@ -406,7 +406,7 @@ def main():
         # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE with the gfx950 correction) and the SQ issue counters
         traffic, counters = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_counters.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_counters.json')))
             if inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0) and dom in pmc:
                 traffic, counters = pmc[dom].get('hbm_bytes'), {k: v for k, v in pmc[dom].items() if k != 'hbm_bytes'}
         except (OSError, ValueError, KeyError):
@@ -434,8 +434,11 @@ def main():
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS,
                          'counters': counters,
+                         'counters_source': None if counters is None else 'profiles/r03_pmc_counters.json: separate rocprofv3 --pmc passes of this '
+                                            'workload on this build (tools/pmc_sq.sh), committed -- NOT measured in this run (a counter pass '
+                                            'serialises the kernels); avg_ms_per_launch, achieved and frac ARE measured in this run (HIP events)',
                          'limiter': 'instruction issue and latency, not HBM: see `counters` (share of the SIMD time the VALU is busy, lane '
-                                    'utilisation, HBM traffic per launch; profiles/r02_pmc_counters.json) and DESIGN.md section 4; frac is the '
+                                    'utilisation, HBM traffic per launch; profiles/r03_pmc_counters.json) and DESIGN.md section 4; frac is the '
                                     'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
             'phases': phases, 'allreduce_ms': allreduce_ms,
             'final_loss': total_loss,

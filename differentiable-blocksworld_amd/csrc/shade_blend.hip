@@ -555,6 +555,8 @@ struct BinRes {            // reservation of one fragment's record: bin, rank am
     float wx1, wy1;
 };
 
+constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
+constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_SPREAD * sizeof(double);
 template <bool BINNED>
 __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                               float *__restrict__ gmaps, float *__restrict__ galpha,
@@ -589,6 +591,15 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     }
     fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
     fa_agg.clear(threadIdx.x, NT);
+    // one opacity per texture map (the training path: one per block, alpha_len = -M) with few maps: the opacity gradient goes to a small
+    // DIRECT-mapped fp64 array, map * 8 + a lane-derived spread -- a fire-and-forget ds_add_f64 per fragment, no slot look-up.  The
+    // face table then only sees the fragments whose distance carries a gradient (outside their face, inside the blur band): the
+    // fragments inside their face, four of ten, used to claim a slot (ds_cmpst, a round trip the wave waits for) for that one value
+    double *alpha_dir = (double *)((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES) + FaceAlphaAgg::BYTES);
+    const int n_maps = -A.alpha_len;
+    const bool alpha_direct = galpha && A.faces_alpha && A.alpha_len < 0 && n_maps <= ALPHA_DIRECT_MAPS;
+    if (alpha_direct)
+        for (int i = threadIdx.x; i < n_maps * ALPHA_DIRECT_SPREAD; i += NT) alpha_dir[i] = 0.0;
     if (!__syncthreads_or(cnt > 0)) return;
     f2 pndc;
     pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
@@ -741,6 +752,10 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         PROF_ADD(4, t_a, t_b);
         // distance -> the two vertices of the closest edge; opacity; one table update per fragment
         float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
+        if (alpha_direct) {
+            if (g7[6] != 0.f) atomicAdd(&alpha_dir[map * ALPHA_DIRECT_SPREAD + (lane & (ALPHA_DIRECT_SPREAD - 1))], (double)g7[6]);
+            g7[6] = 0.f;
+        }
         if (__ballot(gd != 0.f) != 0ull && !(A.dbg & 16)) {
             const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
             const f2 v0{q[0], q[1]}, v1{q[3], q[4]}, v2{q[6], q[7]};
@@ -773,6 +788,11 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     if (A.dbg & 128) return;
     if (!BINNED) tex_agg.flush(gmaps, threadIdx.x, NT);
     fa_agg.flush(gfv, galpha, threadIdx.x, NT);
+    if (alpha_direct)            // -> the DBW_ALPHA_SPREAD partial sums of every map (alpha_grad_index), spread by workgroup
+        for (int i = threadIdx.x; i < n_maps * ALPHA_DIRECT_SPREAD; i += NT) {
+            const float x = (float)alpha_dir[i];
+            if (x != 0.f) unsafeAtomicAdd(galpha + (long long)(i / ALPHA_DIRECT_SPREAD) * DBW_ALPHA_SPREAD + ((blockIdx.x * ALPHA_DIRECT_SPREAD + i) & (DBW_ALPHA_SPREAD - 1)), x);
+        }
 }
 
 // One workgroup per (texture bin, BIN_SUB_PER_WG of its record sub-ranges): accumulate the records into a (32+1)x(32+1) texel LDS tile
@@ -1093,10 +1113,10 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
             raised_uv = true;
         }
         if (A.bin_records)
-            hipLaunchKernelGGL(render_bwd_uv_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), FaceAlphaAgg::BYTES, s, A, total, grad_image, grad_maps,
+            hipLaunchKernelGGL(render_bwd_uv_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total, grad_image, grad_maps,
                                grad_faces_alpha, fv, gfv);
         else
-            hipLaunchKernelGGL(render_bwd_uv_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAlphaAgg::BYTES, s, A, total,
+            hipLaunchKernelGGL(render_bwd_uv_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total,
                                grad_image, grad_maps, grad_faces_alpha, fv, gfv);
         return dbw_check_launch("render_bwd_uv_kernel");
     }

@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(out, 'g*', '**', '*counter_collection.csv'), rec
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
         n = n.split('(')[0].strip()
-        if not any(k in n for k in ('render_fwd', 'render_bwd', 'shade_blend_bwd', 'composite', 'texbin', 'coarse_bin', 'face_setup', 'shade_setup', 'project_clip', 'env')):
+        if not any(k in n for k in ('render_fwd', 'render_bwd', 'shade_blend_bwd', 'composite', 'texbin', 'coarse_bin', 'cell_bin', 'work_scatter', 'face_setup', 'shade_setup', 'project_clip', 'env')):
             continue
         vals.setdefault(n, {}).setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
         vals[n][r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
@@ -42,7 +42,8 @@ json.dump(res, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 # the file bench.py reads: keyed by its kernel labels
 LABEL = {'render_fwd_kernel<10, 8, 8, 2, true>': 'render_fwd_fused K=10 (fg pass)', 'render_bwd_uv_kernel<false>': 'render_bwd_fused K=10 (fg pass)',
          'render_bwd_uv_kernel<true>': 'render_bwd_fused K=10 (fg pass)', 'render_bwd_uv_kernel': 'render_bwd_fused K=10 (fg pass)',
-         'render_fwd_kernel<1, 16, 16, 2, false>': 'render_fwd_fused K=1 (env pass)', 'render_bwd_hard_kernel': 'render_bwd_fused K=1 (env pass)',
+         'render_fwd_kernel<1, 16, 16, 2, false>': 'render_fwd_fused K=1 (env pass)', 'render_fwd_kernel<1, 16, 16, 1, false>': 'render_fwd_fused K=1 (env pass)',
+         'render_bwd_hard_kernel': 'render_bwd_fused K=1 (env pass)',
          'shade_blend_bwd_kernel<true, false, true>': 'render_bwd_fused K=1 (env pass)', 'texbin_reduce_kernel': 'texbin_reduce_kernel (fg pass)'}
 bench = {'_how': 'rocprofv3 --kernel-trace --pmc <group> -- python tools/pmc_target.py, one run per counter group (tools/pmc_sq.sh); medians over the '
                  'dispatches; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; '

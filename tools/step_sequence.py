@@ -1,7 +1,7 @@
 """From a rocprofv3 --kernel-trace CSV of bench.py: the kernel sequence of ONE steady-state optimisation step (between two Adam launches),
 with start offsets, the idle gap before each kernel (negative: it overlaps a kernel of the other stream) and durations.  usage: step_sequence.py t_kernel_trace.csv"""
 import csv, sys
-rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+rows = sorted(csv.DictReader(open(sys.argv[1], encoding='utf-8', errors='replace')), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 adam = [i for i, n in enumerate(names) if 'adam_' in n]
 # a step ends with the Adam launch(es): one (dbw_adam_step_groups) or two (one per learning-rate group)
