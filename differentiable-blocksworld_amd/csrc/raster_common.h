@@ -137,7 +137,7 @@ template <int KMAX, int TW, int TH, int GROUP = 2, bool PAY3 = false>
 __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces, int H, int W, int K,
                                             float blur, int persp, int clipb, long long total_blocks, const CoarseBins &cb, int dbg,
-                                            int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home) {
+                                            int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home, bool *known_empty = nullptr) {
     static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
     // 8x8 tiles read the cell lists of cell_bin_kernel; walking the coarse bin (below) is their fallback -- a bin whose cell lists did
     // not fit the pool, or a caller without a binned workspace -- and gets by with the smallest staging area
@@ -179,6 +179,8 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     const int x0 = tx * TW, y0 = ty * TH;
     const int x1 = min(x0 + TW - 1, W - 1), y1 = min(y0 + TH - 1, H - 1);
 
+    if (known_empty) *known_empty = empty_tile;
+    if (known_empty && empty_tile) return true;        // (the caller has a path of its own for tiles without faces: no list to set up)
     q.init();
 
     int f_begin = 0, nf;

@@ -189,6 +189,60 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
     return s;
 }
 
+// the pixel's blended colour -> the image, or (training) the composite + MSE partials and the two image gradients
+__device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
+                                             float *__restrict__ image) {
+    const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
+    const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
+    if (A.target) {
+        // decoupled composite + MSE on registers (dbw.py:223,366-367): rec = fg_rgb * mask + (1 - mask) * env_rgb (the fg colour is
+        // premultiplied AND multiplied by the mask again, SURVEY.md B.2); the loss gradient is local to the pixel, so the pass hands
+        // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
+        float sq = 0.f;
+        if (in_img) {
+            const float *ev = A.env_img + i4.base, *tg = A.target + i3.base;
+            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[i4.cstride], ev[2 * i4.cstride]}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
+            float rec3[3], gf3[3], ge3[3], gmask;
+            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
+            float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
+            const long long cs = i4.cstride;
+#if DBW_NT_STORES
+            __builtin_nontemporal_store(gf3[0], gf); __builtin_nontemporal_store(gf3[1], gf + cs); __builtin_nontemporal_store(gf3[2], gf + 2 * cs);
+            __builtin_nontemporal_store(gmask, gf + 3 * cs);
+            __builtin_nontemporal_store(ge3[0], ge); __builtin_nontemporal_store(ge3[1], ge + cs); __builtin_nontemporal_store(ge3[2], ge + 2 * cs);
+            __builtin_nontemporal_store(0.f, ge + 3 * cs);
+#else
+            gf[0] = gf3[0]; gf[cs] = gf3[1]; gf[2 * cs] = gf3[2];
+            gf[3 * cs] = gmask;
+            ge[0] = ge3[0]; ge[cs] = ge3[1]; ge[2 * cs] = ge3[2]; ge[3 * cs] = 0.f;
+#endif
+        }
+        const float tot = wave_sum_dpp(sq);
+        if (lane == 0) A.loss_part[tile] = tot;
+    } else if (in_img) {
+        float *out = image + i4.base;
+        out[0] = f0;
+        out[i4.cstride] = f1;
+        out[2 * i4.cstride] = f2;
+        out[3 * i4.cstride] = m;
+    }
+}
+
+// a tile no face reaches (cell list of length 0): every pixel is the background; the fragment record is the count 0
+template <int KMAX>
+__device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image) {
+    const int lane = threadIdx.x;
+    const bool in_img = xi < A.W && yi < A.H;
+    const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
+    const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
+    if (in_img) p2f[(((long long)tile * A.K) << 6) + lane] = -1;
+    BlendFront bl;
+    blend_front_init(bl);
+    float px[4];
+    blend_front_finish(bl, A.bg, px);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image);
+}
+
 template <int KMAX>
 __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
@@ -202,9 +256,13 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     int *__restrict__ p2f_t = p2f + tb;
     float *__restrict__ dists_t = dists + tb;
     float *__restrict__ bary_t = bary + tb * 8;
+#if DBW_TOPK_ORDERED
+    const int cnt = in_img ? q.cnt : 0;              // (insert_ordered keeps the fill of the list)
+#else
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) cnt += (in_img && k < A.K && q.valid(k)) ? 1 : 0;
+#endif
     if (in_img && cnt == 0) p2f_t[lane] = -1;         // an empty pixel still tells the backward its fragment count (0)
     BlendFront bl;
     blend_front_init(bl);
@@ -222,8 +280,8 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         const float bc[3] = {cur.v.y, cur.v.z, cur.v.w};
         float bo[3];
         convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
-        const float u = bo[0] * sr.uv[0] + bo[1] * sr.uv[2] + bo[2] * sr.uv[4];
-        const float v = bo[0] * sr.uv[1] + bo[1] * sr.uv[3] + bo[2] * sr.uv[5];
+        float u, v;
+        interp_uv(bo, sr.uv, u, v);
         const float d = cur.v.x;
         float e;
         if (A.sigma == 0.f) e = d <= 0.f ? 1.f : 0.f;
@@ -269,42 +327,9 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
         }
         cur = nxt;
     }
-    const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
-    if (A.target) {
-        // decoupled composite + MSE on registers (dbw.py:223,366-367): rec = fg_rgb * mask + (1 - mask) * env_rgb (the fg colour is
-        // premultiplied AND multiplied by the mask again, SURVEY.md B.2); the loss gradient is local to the pixel, so the pass hands
-        // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
-        float sq = 0.f;
-        if (in_img) {
-            const float *ev = A.env_img + i4.base, *tg = A.target + i3.base;
-            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[i4.cstride], ev[2 * i4.cstride]}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
-            float rec3[3], gf3[3], ge3[3], gmask;
-            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
-            float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
-            const long long cs = i4.cstride;
-#if DBW_NT_STORES
-            __builtin_nontemporal_store(gf3[0], gf); __builtin_nontemporal_store(gf3[1], gf + cs); __builtin_nontemporal_store(gf3[2], gf + 2 * cs);
-            __builtin_nontemporal_store(gmask, gf + 3 * cs);
-            __builtin_nontemporal_store(ge3[0], ge); __builtin_nontemporal_store(ge3[1], ge + cs); __builtin_nontemporal_store(ge3[2], ge + 2 * cs);
-            __builtin_nontemporal_store(0.f, ge + 3 * cs);
-#else
-            gf[0] = gf3[0]; gf[cs] = gf3[1]; gf[2 * cs] = gf3[2];
-            gf[3 * cs] = gmask;
-            ge[0] = ge3[0]; ge[cs] = ge3[1]; ge[2 * cs] = ge3[2]; ge[3 * cs] = 0.f;
-#endif
-        }
-        const float tot = wave_sum_dpp(sq);
-        if (lane == 0) A.loss_part[tile] = tot;
-    } else if (in_img) {
-        float *out = image + i4.base;
-        out[0] = f0;
-        out[i4.cstride] = f1;
-        out[2 * i4.cstride] = f2;
-        out[3 * i4.cstride] = m;
-    }
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image);
 }
 
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
@@ -322,10 +347,15 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     pay4 *home;
     FPROF_T(t_k0);
     FPROF_ADD(13, wall_clock64());            // (100 MHz, common to the XCDs: the wave's place on the kernel's time line)
+    bool empty = false;
     if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb,
-                                              (dbg & (3 | 128)) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home)) return;
+                                              (dbg & (3 | 128)) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home,
+                                              UV ? &empty : nullptr)) return;
     FPROF_T(t_k1);
-    if constexpr (UV) shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg);
+    if constexpr (UV) {
+        if (empty) shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, image);
+        else shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg);
+    }
     else {
         if (xi >= A.W || yi >= A.H) return;
         shade_generic<KMAX, TW * TH>(A, q, home, n, xi, yi, p2f, bary, dists, image);

@@ -97,6 +97,11 @@ __global__ __launch_bounds__(NT) void shade_blend_fwd_kernel(ShadeArgs A, long l
     o[0] = px[0]; o[plane] = px[1]; o[2 * plane] = px[2]; o[3 * plane] = px[3];
 }
 
+#ifdef DBW_STATS_BWD
+// table-traffic statistics of the uv backward (tools/diag/bwd_stats.py only; -DDBW_STATS_BWD implies -DDBW_PROFILE_BWD's buffer and read
+// hook, with the cycle stamps off): per wave and layer, how many lanes update the texel / face tables and how they share their keys
+#define DBW_PROFILE_BWD 1
+#endif
 #ifdef DBW_PROFILE_BWD
 // cycle accounting of the fused backward (tools/bwd_cycles.py only): per-wave s_memtime deltas of the phases, kept per workgroup (a
 // shared counter would serialise the atomics of 10^5 waves and distort what it measures) and summed on the host
@@ -108,7 +113,28 @@ __device__ unsigned long long g_prof[PROF_BLOCKS * 8];
 #else
 #define PROF_SEL !SINGLE
 #endif
+#ifdef DBW_STATS_BWD
+#define PROF_ADD(i, a, b)
+#define STAT_ADD(i, v) if ((threadIdx.x & 63) == 0 && blockIdx.x < PROF_BLOCKS) atomicAdd(&g_prof[(size_t)blockIdx.x * 8 + (i)], (unsigned long long)(v))
+// lanes of `on` grouped by key: number of distinct keys, and the sum over the four 16-lane groups of the largest number of lanes that
+// share one key (an LDS atomic replays once per lane of the most contended address of each group, profiles/r01_lds_atomic_ubench.txt)
+__device__ __forceinline__ void key_stats(int key, bool on, int &distinct, int &replays) {
+    unsigned long long rem = __ballot(on);
+    int mx[4] = {0, 0, 0, 0};
+    distinct = 0;
+    while (rem) {
+        const int L = __ffsll((long long)rem) - 1;
+        const int k0 = __shfl(key, L, 64);
+        const unsigned long long mm = __ballot(on && key == k0);
+        for (int g = 0; g < 4; ++g) mx[g] = max(mx[g], __popc((unsigned)((mm >> (16 * g)) & 0xffffull)));
+        ++distinct;
+        rem &= ~mm;
+    }
+    replays = mx[0] + mx[1] + mx[2] + mx[3];
+}
+#else
 #define PROF_ADD(i, a, b) if (PROF_SEL && (threadIdx.x & 63) == 0 && blockIdx.x < PROF_BLOCKS) atomicAdd(&g_prof[(size_t)blockIdx.x * 8 + (i)], (b) - (a))
+#endif
 #else
 #define PROF_T(x)
 #define PROF_ADD(i, a, b)
@@ -557,8 +583,12 @@ struct BinRes {            // reservation of one fragment's record: bin, rank am
 
 constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
 constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_SPREAD * sizeof(double);
+#ifndef DBW_UVB_WAVES
+#define DBW_UVB_WAVES 4      // (the binned instantiation keeps two layers of fragments + one of vertices in flight: 4 waves of 128 VGPRs, no spills --
+                             // a spill reload in the layer loop is a vmcnt(0); 4 / 5 / 6 waves per SIMD measured alike before)
+#endif
 template <bool BINNED>
-__global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
+__global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                               float *__restrict__ gmaps, float *__restrict__ galpha,
                                                               const float *__restrict__ fv, float *__restrict__ gfv) {
     extern __shared__ __attribute__((aligned(16))) float s_uvbwd[];
@@ -591,6 +621,15 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     }
     fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
     fa_agg.clear(threadIdx.x, NT);
+    __shared__ __attribute__((aligned(16))) int s_md[BINNED ? MD_CACHE_MAPS * 8 : 8];
+#ifndef DBW_LAST_WAVE_FLUSH
+#define DBW_LAST_WAVE_FLUSH 1
+#endif
+    constexpr bool LAST_WAVE_FLUSH = BINNED && DBW_LAST_WAVE_FLUSH;
+    __shared__ int s_done;                     // waves of the workgroup that have finished their layers
+    if (threadIdx.x == 0) s_done = 0;
+    MapDescCache mdc;
+    mdc.load(A, s_md, BINNED ? A.bin_base : nullptr, threadIdx.x, NT, BINNED);
     // one opacity per texture map (the training path: one per block, alpha_len = -M) with few maps: the opacity gradient goes to a small
     // DIRECT-mapped fp64 array, map * 8 + a lane-derived spread -- a fire-and-forget ds_add_f64 per fragment, no slot look-up.  The
     // face table then only sees the fragments whose distance carries a gradient (outside their face, inside the blur band): the
@@ -635,6 +674,37 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         }
         return r;
     };
+    // BINNED: the memory schedule of the layer loop.  vmcnt counts loads, stores and returning atomics in ONE in-order counter, so
+    // waiting for anything drains whatever was issued before it; the loop therefore issues, at its top and unconditionally (a known
+    // number of operations, in one basic block), the fragment loads of layer k - 2 and the vertex loads of layer k - 1's faces --
+    // everything consumed in an iteration was requested at least one iteration earlier, and the record stores / the cursor atomic of
+    // an iteration are only waited for in the next one.  (Before: the distance backward loaded its face's vertices where it needed
+    // them, and that wait drained the loads issued ahead, the record stores and the atomic of the same iteration -- 69 % of the
+    // wave time was waiting, whatever the occupancy.)  Layer indices are clamped; every lane of a launched tile owns a slot in every
+    // plane, so the unmasked loads stay inside the fragment buffers and are masked when they are consumed.
+    auto load_u = [&](int k) {
+        Raw r;
+        r.fc = ld_stream(p2f_t + (k << 6));
+        const float *b = bary_t + (k << 9);
+        r.u = ld_stream(b); r.v = ld_stream(b + 64); r.jm = ld_stream(b + 128); r.a = ld_stream(b + 192);
+        r.c0 = ld_stream(b + 256); r.c1 = ld_stream(b + 320); r.c2 = ld_stream(b + 384); r.T = ld_stream(b + 448);
+        r.d = ld_stream(dists_t + (k << 6));
+        return r;
+    };
+    auto masked = [&](const Raw &x, bool ok) {
+        Raw r;
+        r.fc = ok ? (x.fc & FRAG_FACE_MASK) : 0;
+        r.u = ok ? x.u : 0.f; r.v = ok ? x.v : 0.f; r.jm = ok ? x.jm : 0.f; r.a = ok ? x.a : 0.f;
+        r.c0 = ok ? x.c0 : 0.f; r.c1 = ok ? x.c1 : 0.f; r.c2 = ok ? x.c2 : 0.f; r.T = ok ? x.T : 1.f; r.d = ok ? x.d : 0.f;
+        return r;
+    };
+    struct FaceXY { float2 v0, v1, v2; };
+    auto load_xy = [&](int fc) {
+        FaceXY q;
+        const float *p = fv + (long long)fc * 9;
+        q.v0 = make_float2(p[0], p[1]); q.v1 = make_float2(p[3], p[4]); q.v2 = make_float2(p[6], p[7]);
+        return q;
+    };
     // BINNED: footprint of a fragment in record form + the slot reservation of the wave's records of its layer (in the sub-range
     // `sub` of the bin: neighbouring tiles, which hit the same bins at the same time, use different cursors)
     const int sub = tile & (BIN_SUB - 1), sub_cap = BINNED ? A.bin_cap / BIN_SUB : 0;
@@ -642,15 +712,16 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         BinRes R;
         R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f;
         const float wgt = r.T * r.a;
-        const bool tex = ok && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f);
+        const bool tex = ok && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f) && !(A.dbg & (1 << 19));      // (1 << 19: ablation of the whole record path)
         if (__ballot(tex) == 0ull) return R;
         const int map = __float_as_int(r.jm) >> 20;
-        const int *md = A.map_desc + (tex ? map : 0) * 8;
+        int md[6];
+        mdc.get(A, s_md, tex ? map : 0, md);
         Sample s;
         footprint_desc(r.u, r.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
         const bool on = tex && bin_regular(s);
         if (on) {
-            R.bin = A.bin_base[map] + (s.r0 >> 5) * ((s.ws + 31) >> 5) + (s.c0 >> 5);
+            R.bin = mdc.get_extra(s_md, A.bin_base, map) + (s.r0 >> 5) * ((s.ws + 31) >> 5) + (s.c0 >> 5);
             R.packed = (int)((unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) | ((unsigned)(s.c1 - s.c0) << 11));
             R.wx1 = s.wx1; R.wy1 = s.wy1;
         }
@@ -658,7 +729,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         const unsigned long long below = (1ull << lane) - 1ull;
         while (rem) {
             const int L = __ffsll((long long)rem) - 1;
-            const int b = __shfl(R.bin, L, 64);
+            const int b = __shfl(R.bin, L, 64);          // (v_readlane instead of this ds_bpermute: 0.46 -> 0.55 ms -- the shorter loop issues the
+                                                         // returning atomics of the hot bins closer together, profiles/r03_experiments.md)
             const bool mine = on && R.bin == b;
             const unsigned long long mm = __ballot(mine);
             if (mine) { R.rank = __popcll(mm & below); R.leader = L; }
@@ -671,8 +743,11 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
     Raw nxt2 = nxt;
     BinRes nres;
     nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f;
+    FaceXY nxtq;
+    nxtq.v0 = nxtq.v1 = nxtq.v2 = make_float2(0.f, 0.f);
     if (BINNED) {
-        nxt2 = load(kmax > 1 ? kmax - 2 : 0, kmax > 1 && kmax - 2 < cnt);
+        nxt2 = load_u(kmax > 1 ? kmax - 2 : 0);
+        nxtq = load_xy(nxt.fc);
         if (kmax > 0) nres = reserve(nxt, kmax - 1 < cnt);
     }
 #pragma unroll 1
@@ -680,10 +755,12 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         PROF_T(t_it);
         const Raw cur = nxt;
         const BinRes cres = nres;
+        const FaceXY curq = nxtq;
         const bool valid = k < cnt;
         if (BINNED) {
-            nxt = nxt2;
-            if (k > 1) nxt2 = load(k - 2, k - 2 < cnt);
+            nxt = masked(nxt2, k > 0 && k - 1 < cnt);
+            nxt2 = load_u(k > 1 ? k - 2 : 0);
+            nxtq = load_xy(nxt.fc);
             if (k > 0) nres = reserve(nxt, k - 1 < cnt);
         } else if (k > 0) nxt = load(k - 1, k - 1 < cnt);
         const float ak = valid ? cur.a : 0.f, Tk = valid ? cur.T : 1.f;
@@ -696,7 +773,7 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         const float e = A.sigma == 0.f ? (cur.d <= 0.f ? 1.f : 0.f) : __expf(-(cur.d > 0.f ? cur.d : 0.f) * A.inv_sigma);
         const float gd = (valid && A.sigma != 0.f && cur.d >= 0.f) ? ga * ak * -A.inv_sigma : 0.f;
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
-        const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f);
+        const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f) && !(BINNED && (A.dbg & (1 << 19)));
         PROF_T(t_a);
         PROF_ADD(2, t_it, t_a);
         if (BINNED) {
@@ -717,7 +794,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
                     }
                 }
                 if (pending) {
-                    const int *md = A.map_desc + map * 8;
+                    int md[6];
+                    mdc.get(A, s_md, map, md);
                     Sample s;
                     footprint_desc(cur.u, cur.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
 #pragma unroll
@@ -731,7 +809,8 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             }
         } else if (__ballot(tex) != 0ull) {
             // colour -> texels of the decimated map: the bilinear footprint's texels that fall into the same stored cell are merged
-            const int *md = A.map_desc + (valid ? map : 0) * 8;
+            int md[6];
+            mdc.get(A, s_md, valid ? map : 0, md);
             Sample s;
             footprint_desc(cur.u, cur.v, md[0], md[1], md[2], md[3], md[4], md[5], s);
             float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
@@ -742,6 +821,20 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
             const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
             const float wt[4] = {w00, w01, w10, w11};
+#ifdef DBW_STATS_BWD
+            {
+                int dk, rp, taps = 0, tap_lanes = 0, tap_replays = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const bool onq = tex && wt[q] != 0.f;
+                    key_stats((int)((unsigned)ad[q] / 3u), onq, dk, rp);
+                    taps += __ballot(onq) != 0ull ? 1 : 0;
+                    tap_lanes += __popcll(__ballot(onq));
+                    tap_replays += rp;
+                    if (q == 0) STAT_ADD(2, dk);
+                }
+                STAT_ADD(1, tap_lanes); STAT_ADD(3, taps); STAT_ADD(7, tap_replays);
+            }
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
@@ -757,8 +850,12 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
             g7[6] = 0.f;
         }
         if (__ballot(gd != 0.f) != 0ull && !(A.dbg & 16)) {
-            const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
-            const f2 v0{q[0], q[1]}, v1{q[3], q[4]}, v2{q[6], q[7]};
+            f2 v0, v1, v2;
+            if (BINNED) { v0 = f2{curq.v0.x, curq.v0.y}; v1 = f2{curq.v1.x, curq.v1.y}; v2 = f2{curq.v2.x, curq.v2.y}; }
+            else {
+                const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
+                v0 = f2{q[0], q[1]}; v1 = f2{q[3], q[4]}; v2 = f2{q[6], q[7]};
+            }
             float t01, t02, t12;
             const float e01 = seg_dist_t(pndc, v0, v1, t01), e02 = seg_dist_t(pndc, v0, v2, t02), e12 = seg_dist_t(pndc, v1, v2, t12);
             const int sel = (e01 <= e02 && e01 <= e12) ? 0 : ((e02 <= e01 && e02 <= e12) ? 1 : ((e12 <= e01 && e12 <= e02) ? 2 : 3));
@@ -775,6 +872,14 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         }
         PROF_T(t_c);
         PROF_ADD(5, t_b, t_c);
+#ifdef DBW_STATS_BWD
+        {
+            int dk, rp;
+            const bool f_on = valid && (gd != 0.f || g7[6] != 0.f);
+            key_stats(cur.fc, f_on, dk, rp);
+            STAT_ADD(0, 1); STAT_ADD(4, __popcll(__ballot(f_on))); STAT_ADD(5, dk); STAT_ADD(6, rp);
+        }
+#endif
         if (valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2)) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
@@ -783,16 +888,32 @@ __global__ __launch_bounds__(NT, 5) void render_bwd_uv_kernel(ShadeArgs A, long 
         PROF_ADD(6, t_c, t_d);
     }
     PROF_T(t_end);
-    PROF_ADD(7, t_begin, t_end);
-    __syncthreads();
-    if (A.dbg & 128) return;
-    if (!BINNED) tex_agg.flush(gmaps, threadIdx.x, NT);
-    fa_agg.flush(gfv, galpha, threadIdx.x, NT);
+    // The workgroup's tables are flushed by whichever of its waves finishes LAST; the others leave at once.  The four tiles of a
+    // workgroup hold very different numbers of layers, and behind a closing barrier the waves of the light tiles kept their
+    // registers and wave slots while waiting for the heaviest one -- 19 % (decimated maps), 20 % and 33 % (full-resolution phases) of
+    // the wave time (tools/bwd_cycles.py).  A wave's LDS instructions execute in the order it issued them, so its table updates
+    // precede its increment of the counter, and the wave that reads NW - 1 there sees the updates of all the others.
+    // (decimated maps: the kernel is bound by the LDS atomic unit and by the workgroups' LDS allocations, waiting waves cost nothing
+    // there, and four waves scan the 512 + 128 slots faster than one: the closing barrier stays, 0.39 vs 0.42 ms)
+    int last = 0;
+    if (LAST_WAVE_FLUSH) {
+        if (lane == 0) last = atomicAdd(&s_done, 1) == NT / 64 - 1 ? 1 : 0;
+        last = __builtin_amdgcn_readfirstlane(last);
+    } else __syncthreads();
+    PROF_T(t_sync);
+    PROF_ADD(3, t_end, t_sync);
+    if ((LAST_WAVE_FLUSH && !last) || (A.dbg & 128)) return;
+    const int f_tid = LAST_WAVE_FLUSH ? lane : (int)threadIdx.x, f_n = LAST_WAVE_FLUSH ? 64 : NT;
+    if (!BINNED) tex_agg.flush(gmaps, f_tid, f_n);
+    fa_agg.flush(gfv, galpha, f_tid, f_n);
     if (alpha_direct)            // -> the DBW_ALPHA_SPREAD partial sums of every map (alpha_grad_index), spread by workgroup
-        for (int i = threadIdx.x; i < n_maps * ALPHA_DIRECT_SPREAD; i += NT) {
+        for (int i = f_tid; i < n_maps * ALPHA_DIRECT_SPREAD; i += f_n) {
             const float x = (float)alpha_dir[i];
             if (x != 0.f) unsafeAtomicAdd(galpha + (long long)(i / ALPHA_DIRECT_SPREAD) * DBW_ALPHA_SPREAD + ((blockIdx.x * ALPHA_DIRECT_SPREAD + i) & (DBW_ALPHA_SPREAD - 1)), x);
         }
+    PROF_T(t_fl);
+    PROF_ADD(1, t_sync, t_fl);                 // (flushes)
+    PROF_ADD(7, t_begin, t_fl);
 }
 
 // One workgroup per (texture bin, BIN_SUB_PER_WG of its record sub-ranges): accumulate the records into a (32+1)x(32+1) texel LDS tile

@@ -46,6 +46,52 @@ struct ShadeArgs {
     int img_tiled;
 };
 
+// The map descriptors of a pass in LDS.  A fragment's footprint starts with its map's six descriptor ints; read from memory that is
+// a dependent round trip per fragment (face | map comes out of the fragment itself) in front of every table update of the backward.
+// Row 0 of map_desc carries the number of rows in its 7th int (include/dbw_hip.h; 0 = not given): tables of up to MD_CACHE_MAPS rows are
+// copied to LDS once per workgroup, larger or uncounted ones are read from memory as before.  Used by the binned uv backward only: the
+// instantiation for decimated maps is bound by the LDS atomic unit, and the extra LDS reads cost it 0.39 -> 0.41 ms.
+#ifndef DBW_MD_LDS
+#define DBW_MD_LDS 1
+#endif
+constexpr int MD_CACHE_MAPS = 64;
+// (the LDS array is passed to every call by name: a pointer member would make the compiler merge it with the memory pointer into a
+// generic one -- flat loads, which wait for the vector-memory AND the LDS counters)
+struct MapDescCache {
+    bool in_lds;
+    // all threads of the workgroup; the caller's next barrier publishes the copy.  `extra` (optional, one int per map) goes to the
+    // 8th int of the rows: the first texture bin of each map for the binned backward
+    __device__ __forceinline__ void load(const ShadeArgs &A, int *s_md, const int *extra, int tid, int nthreads, bool enable) {
+        const int rows = (DBW_MD_LDS && enable) ? __builtin_amdgcn_readfirstlane(A.map_desc[6]) : 0;
+        in_lds = rows > 0 && rows <= MD_CACHE_MAPS;
+        if (in_lds)
+            for (int i = tid; i < rows * 8; i += nthreads) s_md[i] = ((i & 7) == 7 && extra) ? extra[i >> 3] : A.map_desc[i];
+    }
+    __device__ __forceinline__ void get(const ShadeArgs &A, const int *s_md, int map, int (&d)[6]) const {
+        if (in_lds) {
+            const int4 a = *(const int4 *)(s_md + map * 8);
+            const int2 b = *(const int2 *)(s_md + map * 8 + 4);
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y;
+        } else {
+            const int *md = A.map_desc + map * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = md[i];
+            // (consumed INSIDE this branch: the wait for these loads would otherwise sit where the two paths meet, i.e. the LDS path
+            // too would drain the vector-memory counter -- every load issued ahead -- at each descriptor look-up)
+            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+        }
+    }
+    __device__ __forceinline__ int get_extra(const int *s_md, const int *extra, int map) const {
+        int v;
+        if (in_lds) v = s_md[map * 8 + 7];
+        else {
+            v = extra[map];
+            asm volatile("" : "+v"(v));      // (as above; it also keeps the two loads from being merged into one flat load)
+        }
+        return v;
+    }
+};
+
 // element (n, channel c of C, yi, xi) of an image-shaped buffer
 struct ImgAddr { long long base; long long cstride; };
 __device__ __forceinline__ ImgAddr img_addr(const ShadeArgs &A, int n, int yi, int xi, int C) {
@@ -125,8 +171,7 @@ __device__ __forceinline__ void decode_frag(const ShadeArgs &A, int n, int fc, c
     }
     convert_bary(fr.cd, fr.w2, fr.w3, b, fr.bo);
     const float *uv = A.face_uvs + (long long)fr.j * 6;
-    fr.u = fr.bo[0] * uv[0] + fr.bo[1] * uv[2] + fr.bo[2] * uv[4];
-    fr.v = fr.bo[0] * uv[1] + fr.bo[1] * uv[3] + fr.bo[2] * uv[5];
+    interp_uv(fr.bo, uv, fr.u, fr.v);
     fr.map = A.face_map[fr.j];
     fr.d = d;
     frag_alpha<FAST>(A, n, fr);

@@ -17,6 +17,21 @@ struct Sample {   // bilinear footprint of one fragment
 
 DBW_HD float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
+// Experiment switch (profiles/r03_experiments.md): with 1 the bilinear fetch and the front-to-back blend contract a*b+c into one fma
+// (~15 VALU instructions per layer, forward fg pass 0.306 -> 0.302 ms: inside the noise).  Off: the operator-level and the fused kernels
+// then stay bit-equal on the hard pass (the contraction the compiler picks depends on the code around the inlined function).  Never
+// for the texture coordinates (convert_bary, interp_uv, footprint_desc): floor() of the sample position picks the texel cell, the
+// gradient to (u, v) is piecewise constant per cell, and one ulp of difference to the reference's unfused arithmetic moves pixels
+// across cell borders (measured: 0.7 % of the env pass's vertex gradient at config 2).
+#ifndef DBW_SHADE_FMA
+#define DBW_SHADE_FMA 0
+#endif
+#if DBW_SHADE_FMA && defined(__clang__)
+#define DBW_FMA_SCOPE _Pragma("clang fp contract(fast)")
+#else
+#define DBW_FMA_SCOPE
+#endif
+
 DBW_HD void convert_bary(int cd, float w2, float w3, const float b[3], float bo[3]) {
     if (cd < 0) { bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2]; return; }
     const int i1 = cd & 3, kind = cd >> 2;
@@ -28,6 +43,12 @@ DBW_HD void convert_bary(int cd, float w2, float w3, const float b[3], float bo[
     bo[0] = sel3(i1, o1, o3, o2);
     bo[1] = sel3(i1, o2, o1, o3);
     bo[2] = sel3(i1, o3, o2, o1);
+}
+
+// texture coordinates of a fragment: the (clip-converted) barycentrics times the face's three (u, v) vertices
+DBW_HD void interp_uv(const float bo[3], const float uv[6], float &u, float &v) {
+    u = bo[0] * uv[0] + bo[1] * uv[2] + bo[2] * uv[4];
+    v = bo[0] * uv[1] + bo[1] * uv[3] + bo[2] * uv[5];
 }
 
 DBW_HD void convert_bary_bwd(int cd, float w2, float w3, const float go[3], float gb[3]) {
@@ -76,6 +97,7 @@ DBW_HD void footprint_desc(float u, float v, int off, int h, int w, int pl, int 
 }
 
 DBW_HD void fetch(const float *maps, const Sample &s, float c[3]) {
+    DBW_FMA_SCOPE
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
         c[ch] = maps[s.a00 + ch] * s.w00 + maps[s.a01 + ch] * s.w01 + maps[s.a10 + ch] * s.w10 + maps[s.a11 + ch] * s.w11;
@@ -106,11 +128,13 @@ DBW_HD float geometric_alpha(float d, float sigma) {
 struct BlendFront { float T, r, g, b; };     // forward, front to back: transmittance in front of the next layer, colour so far
 DBW_HD void blend_front_init(BlendFront &s) { s.T = 1.f; s.r = s.g = s.b = 0.f; }
 DBW_HD void blend_front_step(BlendFront &s, float a, const float c[3]) {
+    DBW_FMA_SCOPE
     const float wgt = s.T * a;
     s.r += wgt * c[0]; s.g += wgt * c[1]; s.b += wgt * c[2];
     s.T *= (1.f - a);
 }
 DBW_HD void blend_front_finish(const BlendFront &s, const float bg[3], float out[4]) {
+    DBW_FMA_SCOPE
     out[0] = s.r + s.T * bg[0]; out[1] = s.g + s.T * bg[1]; out[2] = s.b + s.T * bg[2]; out[3] = 1.f - s.T;
 }
 

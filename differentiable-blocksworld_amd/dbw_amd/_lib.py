@@ -92,6 +92,8 @@ def load():
     lib = ctypes.CDLL(os.environ.get('DBW_HIP_LIB') or LIB_PATH)
     lib.dbw_last_error.restype = ctypes.c_char_p
     lib.dbw_abi_version.restype = c_i
+    if hasattr(lib, 'dbw_bin_subcursors'):      # (absent from tuning builds of older sources, tools/variants.sh: 16 there)
+        lib.dbw_bin_subcursors.restype = c_i
     lib.dbw_rasterize_workspace_bytes.restype = c_sz
     lib.dbw_rasterize_workspace_bytes.argtypes = [c_i64]
     lib.dbw_rasterize_workspace_bytes_binned.restype = c_sz

@@ -331,6 +331,7 @@ class DifferentiableBlocksWorld(nn.Module):
                               self.scale_min, S_w, R_w, T_w, dense=not self.sync_free)
         maps = maps_all if (keep is None or self.sync_free) else maps_all[keep.bool()]
         F_ = nb * self.BNF
+        # (a view of the full table: its row 0 announces all n_blocks rows, which stay readable behind the nb rows in use)
         desc = (self._block_map_desc_all if decim == 1 else self._block_map_desc_dec)[:nb]
         self._blocks_decimated = decim > 1
         nbins = nb * self._bins_per_block

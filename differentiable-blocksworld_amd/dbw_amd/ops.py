@@ -15,7 +15,18 @@ from . import _lib
 
 MAX_FACES_PER_PIXEL = 25
 ALPHA_SPREAD = 64          # partial sums per per-map opacity gradient (csrc/shade_common.h: DBW_ALPHA_SPREAD)
-BIN_SUBCURSORS = 16        # cursors per texture bin (include/dbw_hip.h: DBW_BIN_SUBCURSORS)
+
+def bin_subcursors():
+    """Cursors per texture bin of the loaded library (include/dbw_hip.h: DBW_BIN_SUBCURSORS, dbw_bin_subcursors())."""
+    lib = _lib.load()
+    return int(lib.dbw_bin_subcursors()) if hasattr(lib, 'dbw_bin_subcursors') else 16
+
+
+def __getattr__(name):             # ops.BIN_SUBCURSORS: the library's value, asked for on first use
+    if name == 'BIN_SUBCURSORS':
+        return bin_subcursors()
+    raise AttributeError(name)
+
 COARSE_BINS = True        # two-level face binning in the rasteriser (64x64-pixel coarse bins); False: every tile scans every face
 TEXTURE_BINS = True       # full-resolution texel gradients: bin records by 32x32-texel tile and reduce in LDS (vs 12 atomics/fragment)
 UV_FRAGMENTS = True       # detach_bary passes: the forward stores resolved (u, v, face|map) per fragment for the backward
@@ -408,7 +419,7 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     if bins is not None and bins[2] > 0:
         bin_base, bin_info, nbins = bins
         cap = texbin_capacity(B, cfg.H, cfg.W, cfg.K, nbins)
-        cursor = ARENA.zeros(nbins * BIN_SUBCURSORS, torch.int32, fvc.device)
+        cursor = ARENA.zeros(nbins * bin_subcursors(), torch.int32, fvc.device)
         records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
     _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                    (B, cfg.H, cfg.W, cfg.K)),
@@ -509,8 +520,10 @@ def texbin_capacity(B, H, W, K, nbins):
     """Records per texture bin: room for max(K/2, 2) fragments per pixel spread evenly over the bins (a soft K-layer render
     fills ~20 % of its slots, a hard 1-layer render all of them; what does not fit falls back to atomics), at most 16 GiB
     of the 288 GB (config 5 -- 25 views of 1080x1920, K = 16 -- asks for 13 GB)."""
-    cap = int(min(max(B * H * W * max(K, 4) // (2 * nbins), 256), (16 << 30) // (32 * nbins)))
-    return (cap + BIN_SUBCURSORS - 1) // BIN_SUBCURSORS * BIN_SUBCURSORS          # a bin's range = BIN_SUBCURSORS equal sub-ranges
+    import os
+    cap = int(min(max(int(float(os.environ.get('DBW_CAP_SCALE', 1)) * B * H * W * max(K, 4)) // (2 * nbins), 256), (16 << 30) // (32 * nbins)))
+    sub = bin_subcursors()
+    return (cap + sub - 1) // sub * sub          # a bin's range = DBW_BIN_SUBCURSORS equal sub-ranges
 
 
 def render_scene(verts, maps, faces_alpha, faces_i32, R, T, Kmat, face_uvs, face_map, map_desc, bg, cfg):

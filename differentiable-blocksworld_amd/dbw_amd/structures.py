@@ -142,13 +142,17 @@ class PackedScene:
             fmap.append(s.face_map + m_off)
             d = s.map_desc.clone()
             d[:, 0] += f_off
+            d[:, 6] = 0                    # (the row count lives in row 0 of the joined table only)
             desc.append(d)
             maps.append(s.maps.reshape(-1))
             v_off += s.verts.shape[0]
             m_off += s.map_desc.shape[0]
             f_off += s.maps.numel()
+        desc = torch.cat(desc, 0).contiguous()
+        if desc.shape[0]:
+            desc[0, 6] = desc.shape[0]
         return PackedScene(torch.cat(verts, 0), torch.cat(faces, 0).to(torch.int32).contiguous(), torch.cat(uvs, 0).contiguous(),
-                           torch.cat(fmap, 0).to(torch.int32).contiguous(), torch.cat(desc, 0).contiguous(), torch.cat(maps))
+                           torch.cat(fmap, 0).to(torch.int32).contiguous(), desc, torch.cat(maps))
 
     @staticmethod
     def describe_maps(shapes, pads, device, shift=0):
@@ -157,6 +161,8 @@ class PackedScene:
         for (h, w), (pl, pr) in zip(shapes, pads):
             rows.append([off, h, w, pl, pr, shift, 0, 0])
             off += (h >> shift) * (w >> shift) * 3
+        if rows:
+            rows[0][6] = len(rows)        # the table's row count (include/dbw_hip.h: small tables are kept in LDS by the backward kernels)
         return torch.tensor(rows, dtype=torch.int32, device=device), off
 
     @staticmethod

@@ -20,7 +20,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define DBW_BIN_SUBCURSORS 16   /* cursors (and record sub-ranges) per texture bin, see dbw_render_bwd_fused */
+#ifndef DBW_BIN_SUBCURSORS
+#define DBW_BIN_SUBCURSORS 16   /* cursors (and record sub-ranges) per texture bin, see dbw_render_bwd_fused; the value a library was
+                                 * built with: dbw_bin_subcursors() */
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -35,6 +38,7 @@ extern "C" {
 typedef void *dbw_stream_t;
 
 int dbw_abi_version(void);
+int dbw_bin_subcursors(void);      /* DBW_BIN_SUBCURSORS of this build: callers size bin_cursor and round bin_cap with it */
 const char *dbw_last_error(void);
 /* profiling/ablation switches used by tools/ and by the parity tests (0 = product behaviour); bits 0-7: shading ablations,
  * 16: no fragment stores, 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal
@@ -113,7 +117,8 @@ int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const
  *    dbw_project_clip_fwd); c2o/clip_code/clip_w as above, or all NULL when the fragments already index original
  *    faces (then pix_to_face = b*F + j).
  *  face_uvs (F,3,2)   face_map (F) -> row of map_desc
- *  map_desc (M,8) int32: {offset in floats into maps, height h, width w (unpadded), pad_left, pad_right, shift, 0, 0}
+ *  map_desc (M,8) int32: {offset in floats into maps, height h, width w (unpadded), pad_left, pad_right, shift, rows, 0};
+ *                        rows: M in row 0 (0 = not given: allowed, the kernels then read every descriptor from memory), 0 elsewhere
  *  maps: flat fp32 buffer of RGB maps in [0,1], fewer than 2^31 floats in total (texels are addressed with the int32 offsets);
  *    map m is STORED as (h>>shift, w>>shift, 3): shift > 0 is a decimated map
  *    (avg_pool2d(2^shift) kept at cell resolution; the nearest upsampling of dbw.py:278,334 is the shift)

@@ -42,14 +42,14 @@ def test_library_builds_and_loads_without_gpu():
 def test_every_declared_symbol_is_exported_with_matching_signature():
     lib = _lib.load()
     protos = parse_header()
-    assert len(protos) == 34
+    assert len(protos) == 35
     for name, (ret, types) in protos.items():
         assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
         if name in _lib.SIGNATURES:
             assert _lib.SIGNATURES[name] == types, f'{name}: ctypes signature differs from the header'
     missing = set(_lib.SIGNATURES) - set(protos)
     assert not missing, f'bound but not declared: {missing}'
-    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_rasterize_workspace_bytes_binned', 'dbw_debug_set_flags', 'dbw_debug_set_raster_flags'}
+    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_bin_subcursors', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_rasterize_workspace_bytes_binned', 'dbw_debug_set_flags', 'dbw_debug_set_raster_flags'}
     assert not undeclared_compute, f'declared but not bound: {undeclared_compute}'
 
 

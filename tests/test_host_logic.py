@@ -114,8 +114,8 @@ def test_meshes_join_and_packed_scene_layout():
     ps = PackedScene.from_meshes(scene.extend(3))
     assert ps.faces.dtype == torch.int32 and ps.face_uvs.shape == (22, 3, 2)
     assert ps.face_map.tolist() == [0] * 20 + [1] * 2
-    assert ps.map_desc.tolist() == [[0, 4, 6, 0, 0, 0, 0, 0], [72, 8, 8, 1, 2, 0, 0, 0]]
-    assert PackedScene.describe_maps([(16, 16)] * 2, [(0, 3)] * 2, 'cpu', shift=3)[0].tolist() == [[0, 16, 16, 0, 3, 3, 0, 0], [12, 16, 16, 0, 3, 3, 0, 0]]
+    assert ps.map_desc.tolist() == [[0, 4, 6, 0, 0, 0, 2, 0], [72, 8, 8, 1, 2, 0, 0, 0]]       # (row 0, 7th int: the row count)
+    assert PackedScene.describe_maps([(16, 16)] * 2, [(0, 3)] * 2, 'cpu', shift=3)[0].tolist() == [[0, 16, 16, 0, 3, 3, 2, 0], [12, 16, 16, 0, 3, 3, 0, 0]]
     assert ps.maps.numel() == 72 + 192
     batch = Meshes(torch.rand(3, 12, 3), f1[None].expand(3, -1, -1), TexturesUV(torch.rand(3, 4, 4, 3), f1, torch.rand(12, 2)))
     js = join_meshes_as_scene(batch)
@@ -276,6 +276,7 @@ def test_packed_scene_join_rebases_faces_and_maps():
     assert j.verts.shape == (9, 3) and j.faces.tolist() == [[0, 1, 2], [2, 3, 4], [5, 6, 8]] and j.face_map.tolist() == [0, 0, 2]
     assert j.map_desc[:, 0].tolist() == [0, n1, n1 + 12] and j.map_desc[1, 3:5].tolist() == [1, 1]
     assert torch.equal(j.maps, torch.cat([s1.maps, s2.maps])) and j.faces.dtype == torch.int32
+    assert j.map_desc[:, 6].tolist() == [3, 0, 0]                 # the row count of the JOINED table, in its row 0 only
 
 
 def test_fancy_cmap_structure():

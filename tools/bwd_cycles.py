@@ -15,7 +15,7 @@ dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 8)()
-names = ['pass0 (layer bound)', 'pass1', 'p2 load+blend', 'p2 opacity table (generic kernel) / final sync + flushes (hard kernel)', 'p2 footprint + texel table/bins', 'p2 distance / raster bwd math', 'p2 face (+ opacity) table', 'total']
+names = ['pass0 (layer bound)', 'pass1 (uv kernel: flushes)', 'p2 load+blend', 'p2 opacity table (generic kernel) / final sync + flushes (hard kernel) / wait for the slowest wave of the workgroup (uv kernel)', 'p2 footprint + texel table/bins', 'p2 distance / raster bwd math', 'p2 face (+ opacity) table', 'total']
 for ep in [int(x) for x in sys.argv[1:]] or [0]:
     model.set_cur_epoch(ep); model(inp, None)
     torch.cuda.synchronize()

@@ -20,3 +20,5 @@ for rep in range(2):
         kb = bench.kernel_breakdown(model, inp, reps=10)
         print('flags %5d variant %d:' % c, {k.replace('render_', '').replace('_fused', ''): round(v[0], 4) for k, v in kb.items()})
 lib.dbw_debug_set_flags(0); lib.dbw_debug_set_render_variant(0)
+if bench.BIN_STATS:
+    print('texture bins:', bench.BIN_STATS)
