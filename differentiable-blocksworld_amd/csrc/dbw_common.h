@@ -195,6 +195,34 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += dpp_<0x4E, 0xf, 0xf>(v);
     return v;
 }
+// Neighbouring lanes that update the same key of an LDS table are merged before the table sees them.  An LDS atomic replays once per
+// lane of the most contended address of each 16-lane group (profiles/r01_lds_atomic_ubench.txt: ~3 clk per replay for ds_add_f64), and
+// the lanes that share a face or a texel are neighbouring pixels: in the 8x8-tile layout lanes 4i..4i+3 are four horizontally
+// adjacent pixels, lanes i and i + 8 of a 16-lane row are vertical neighbours.  STEPS merging steps, each halving the candidates:
+// lane ^ 1, lane ^ 2 (quad permutes), lane + 4, lane + 8 (row shifts) -- a lane whose partner (the one with the step's bit clear)
+// is active with the same key hands its values over and drops out.  VALU only (DPP); `key` >= 0.
+template <int NV, int STEPS>
+__device__ __forceinline__ void lane_merge(int key, bool &active, float (&v)[NV]) {
+    if (STEPS <= 0) return;
+    const int lane = threadIdx.x & 63;
+    int k = active ? key : -1000 - lane;              // an inactive lane matches nobody
+#define DBW_MERGE_STEP(CTRL_PARTNER, CTRL_FROM_GIVER, BIT)                                                        \
+    {                                                                                                             \
+        const int kp = __builtin_amdgcn_update_dpp(-1, k, CTRL_PARTNER, 0xf, 0xf, false);                         \
+        const bool give = (lane & (BIT)) && kp == k;                                                              \
+        _Pragma("unroll") for (int c = 0; c < NV; ++c) {                                                          \
+            const float t = give ? v[c] : 0.f;                                                                    \
+            v[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), CTRL_FROM_GIVER, 0xf, 0xf, false)); \
+        }                                                                                                         \
+        if (give) { active = false; k = -1000 - lane; }                                                           \
+    }
+    DBW_MERGE_STEP(0xB1, 0xB1, 1)                     // quad_perm [1,0,3,2]
+    if (STEPS >= 2) DBW_MERGE_STEP(0x4E, 0x4E, 2)     // quad_perm [2,3,0,1]
+    if (STEPS >= 3) DBW_MERGE_STEP(0x114, 0x104, 4)   // the giver looks at lane - 4 (row_shr:4), the receiver takes from lane + 4 (row_shl:4)
+    if (STEPS >= 4) DBW_MERGE_STEP(0x118, 0x108, 8)
+#undef DBW_MERGE_STEP
+}
+
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     const float t = v;
     v += dpp_<0x111, 0xf, 0xf>(t);           // row_shr:1

@@ -583,6 +583,14 @@ struct BinRes {            // reservation of one fragment's record: bin, rank am
 
 constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
 constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_SPREAD * sizeof(double);
+// merging steps (lane_merge, dbw_common.h) in front of the texel table and the face table of the uv backward
+#ifndef DBW_TEX_MERGE
+#define DBW_TEX_MERGE 2
+#endif
+#ifndef DBW_FACE_MERGE
+#define DBW_FACE_MERGE 2
+#endif
+constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
 #ifndef DBW_UVB_WAVES
 #define DBW_UVB_WAVES 4      // (the binned instantiation keeps two layers of fragments + one of vertices in flight: 4 waves of 128 VGPRs, no spills --
                              // a spill reload in the layer loop is a vmcnt(0); 4 / 5 / 6 waves per SIMD measured alike before)
@@ -837,8 +845,10 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 #endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                if (tex && wt[q] != 0.f && !(A.dbg & 1)) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
+                float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                bool on = tex && wt[q] != 0.f && !(A.dbg & 1);
+                if (TEX_MERGE > 0 && __ballot(on) != 0ull) lane_merge<3, TEX_MERGE>((int)((unsigned)ad[q] / 3u), on, v3);
+                if (on) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
             }
         }
         PROF_T(t_b);
@@ -880,7 +890,9 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             STAT_ADD(0, 1); STAT_ADD(4, __popcll(__ballot(f_on))); STAT_ADD(5, dk); STAT_ADD(6, rp);
         }
 #endif
-        if (valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2)) {
+        bool f_on = valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2);
+        if (FACE_MERGE > 0 && __ballot(f_on) != 0ull) lane_merge<7, FACE_MERGE>(cur.fc, f_on, g7);
+        if (f_on) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
         }
@@ -991,6 +1003,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
 #endif
     }
 }
+
 
 int g_dbg_flags = 0;
 #ifdef DBW_PROFILE_BWD
