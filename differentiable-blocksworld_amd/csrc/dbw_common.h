@@ -317,7 +317,7 @@ struct LdsAgg {
         const unsigned long long am = __ballot(active);
         if (am == 0ull) return;
         const int leader = __ffsll((long long)am) - 1;
-        const int k0 = __shfl(key, leader, 64);
+        const int k0 = __builtin_amdgcn_readlane(key, leader);          // (the leader is wave-uniform: no LDS round trip for the broadcast)
         if (__popcll(am) >= 8 && __ballot(active && key == k0) == am) {
             float s[NV];
 #pragma unroll

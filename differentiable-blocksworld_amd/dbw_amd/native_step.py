@@ -30,6 +30,8 @@ class NativeStep:
         self._env_verts = None
         self._target, self._target_key = None, None
         self._side, self.overlap_regularisers, self.side_priority = None, True, True
+        self.binned_concurrent = None         # full-resolution phases: env backward chain next to the fg backward kernel instead of
+                                              # behind it (None: on one GPU; 1.655 -> 1.635 and 1.017 -> 1.007 ms per step)
         # None: by configuration -- one after the other when the blocks' gradients are worth announcing early (data parallel: their
         # all-reduce then runs next to the env backward) or when a bin reduction follows the fg kernel (full-resolution phases: measured
         # 2 % faster), both at once otherwise (1 % faster on one GPU with decimated maps); True / False force one or the other
@@ -187,6 +189,21 @@ class NativeStep:
         if side is not cur:                                            # the fg pass only waits for its set-up, not for the regularisers
             fg_ready = torch.cuda.Event()                              # behind it (they run next to the fg forward)
             fg_ready.record(side)
+        # ---- main: the fg pass, ending in the composite + MSE ----
+        torch.cuda.set_stream(cur)
+        st = st_main
+        count = float(imgs.numel() if global_count is None else global_count)
+        scale = float(w['rgb']) / count
+        if fg_ready is not None:
+            cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
+        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
+                                                                      blk_maps, fa, renderer._bg, img_e, target, scale, stage=2,
+                                                                      state=fg_state, img_tiled=True)
+        # ---- side: the regularisers, enqueued AFTER the main stream's fg pass: a stream that waits for an event of another stream was
+        # observed to wait for everything that stream had been given by then (the fg pass started when the last regulariser ended, 15 us
+        # after the env pass it really depends on) ----
+        torch.cuda.set_stream(side)
+        st = st_side
         g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
         if 'parsimony' in w and coarse:
             _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
@@ -202,16 +219,8 @@ class NativeStep:
                       float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
                       vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
 
-        # ---- main: the fg pass, ending in the composite + MSE ----
         torch.cuda.set_stream(cur)
         st = st_main
-        count = float(imgs.numel() if global_count is None else global_count)
-        scale = float(w['rgb']) / count
-        if fg_ready is not None:
-            cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
-        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
-                                                                      blk_maps, fa, renderer._bg, img_e, target, scale, stage=2,
-                                                                      state=fg_state, img_tiled=True)
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
         # kernels (projection backward, pose / shape, textures, opacities) ----
         fg_out = {}
@@ -256,15 +265,17 @@ class NativeStep:
             seq = self.sequential_backward
             if seq is None:
                 seq = m.world_size > 1 or decim_blocks == 1
+            both = False
             if cfg_f.texbins is not None:
                 # full-resolution maps: the texel gradients of the blocks leave the fg kernel as binned records and only reach
                 # g_blk_maps in the bin reduction that follows it on the side stream -- `kernel_done` is recorded in front of that, so the
                 # texture half of the tail must not move to the main stream (the concurrent order would read an incomplete gradient)
+                both = (m.world_size == 1) if self.binned_concurrent is None else bool(self.binned_concurrent)
                 seq = True
             torch.cuda.set_stream(side)
             keep_f = fg_backward(side.cuda_stream, lambda: kernel_done.record(side), with_textures=seq)
             torch.cuda.set_stream(cur)
-            if seq:
+            if seq and not both:
                 cur.wait_event(kernel_done)
             keep_e = env_backward(st_main)
             if not seq:

@@ -575,9 +575,13 @@ def test_texture_space_binning_equals_atomic_scatter(monkeypatch):
     args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
     w = torch.rand(3, 4, 72, 96, generator=torch.Generator().manual_seed(5)).to(DEV)
     grads = []
-    for binned in (False, True):
+    for binned, counted in ((False, True), (True, True), (True, False)):
         monkeypatch.setattr(ops, 'TEXTURE_BINS', binned)
         ps = _packed(dict(scene, maps=unpadded), pads=[(pl, pr)] * len(unpadded))
+        assert int(ps.map_desc[0, 6]) == len(unpadded)
+        if not counted:                       # a descriptor table without its row count (include/dbw_hip.h: allowed): the kernels
+            ps.map_desc = ps.map_desc.clone()  # read the descriptors from memory instead of their LDS copy
+            ps.map_desc[0, 6] = 0
         ps.maps.requires_grad_(True)
         bins = PackedScene.describe_bins([(64, 64)] * len(unpadded), DEV)
         cfg = ops.RenderCfg(72, 96, 8, 1e-4, 0.001, True, True, scene['faces'].shape[0], lds_aggregate=False, texbins=bins)
@@ -586,6 +590,7 @@ def test_texture_space_binning_equals_atomic_scatter(monkeypatch):
         grads.append(ps.maps.grad)
     assert bins[2] == 4 * len(unpadded) and grads[0].abs().max() > 0
     assert rel_err(grads[1], grads[0]) < 1e-5
+    assert rel_err(grads[2], grads[0]) < 1e-5
 
 
 def test_lds_aggregation_is_equivalent_on_magnified_env_pass():

@@ -1,0 +1,30 @@
+"""GPU helper: ms per training step with the backward kernels of the full-resolution phases one after the other / side by side."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
+import torch, bench
+from dbw_amd.parallel import ShardedTrainStep
+class A: pass
+args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 300, 400, 10, 10, 256
+dev = torch.device('cuda', 0)
+epoch = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+res = {}
+for rep in range(3):
+    for both in (False, True):
+        torch.manual_seed(0)
+        model, inp = bench.build_workload(args, dev)
+        model.sync_free = True
+        model.set_cur_epoch(epoch)
+        step = ShardedTrainStep(model, seed=1)
+        step.native.binned_concurrent = both
+        for _ in range(5):
+            step(inp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            step(inp)
+        e1.record(); torch.cuda.synchronize()
+        res.setdefault(both, []).append(e0.elapsed_time(e1) / 20)
+for k, v in res.items():
+    print('side by side' if k else 'one after the other', ' '.join('%.4f' % x for x in v))
