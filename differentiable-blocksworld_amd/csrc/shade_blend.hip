@@ -583,12 +583,14 @@ struct BinRes {            // reservation of one fragment's record: bin, rank am
 
 constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
 constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_SPREAD * sizeof(double);
-// merging steps (lane_merge, dbw_common.h) in front of the texel table and the face table of the uv backward
+// merging steps (lane_merge, dbw_common.h) in front of the texel table and the face table of the uv backward: 0 / 1 / 2 / 3 / 4 steps on
+// both: 0.390 / 0.356 / 0.354 / 0.377 / 0.390 ms (decimated maps); one step costs half the VALU instructions of two (+17 % instead of
+// +34 % of the kernel) for the same time, alone and in the step
 #ifndef DBW_TEX_MERGE
-#define DBW_TEX_MERGE 2
+#define DBW_TEX_MERGE 1
 #endif
 #ifndef DBW_FACE_MERGE
-#define DBW_FACE_MERGE 2
+#define DBW_FACE_MERGE 1
 #endif
 constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
 #ifndef DBW_UVB_WAVES
