@@ -30,6 +30,7 @@ class NativeStep:
         self._env_verts = None
         self._target, self._target_key = None, None
         self._side, self.overlap_regularisers, self.side_priority = None, True, True
+        self.regularisers_behind_fg = True
         self.binned_concurrent = None         # full-resolution phases: env backward chain next to the fg backward kernel instead of
                                               # behind it (None: on one GPU; 1.655 -> 1.635 and 1.017 -> 1.007 ms per step)
         # None: by configuration -- one after the other when the blocks' gradients are worth announcing early (data parallel: their
@@ -189,38 +190,51 @@ class NativeStep:
         if side is not cur:                                            # the fg pass only waits for its set-up, not for the regularisers
             fg_ready = torch.cuda.Event()                              # behind it (they run next to the fg forward)
             fg_ready.record(side)
-        # ---- main: the fg pass, ending in the composite + MSE ----
-        torch.cuda.set_stream(cur)
-        st = st_main
         count = float(imgs.numel() if global_count is None else global_count)
         scale = float(w['rgb']) / count
-        if fg_ready is not None:
-            cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
-        p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
-                                                                      blk_maps, fa, renderer._bg, img_e, target, scale, stage=2,
-                                                                      state=fg_state, img_tiled=True)
-        # ---- side: the regularisers, enqueued AFTER the main stream's fg pass: a stream that waits for an event of another stream was
-        # observed to wait for everything that stream had been given by then (the fg pass started when the last regulariser ended, 15 us
-        # after the env pass it really depends on) ----
-        torch.cuda.set_stream(side)
-        st = st_side
-        g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
-        if 'parsimony' in w and coarse:
-            _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
-        if 'tv' in w:
-            for t in sets:
-                t['_g_sig'] = torch.empty_like(t['_sig'])
-                t['sig'], t['grad_sig_out'], t['grad_sig'] = _p(t['_sig']), _p(t['_g_sig']), _p(t['_g_sig'])
-            launch('dbw_tv_l2sq_sets', (0, 1, 2), vals.data_ptr() + 8, st)
-        if 'overlap' in w and coarse:
-            u = m._overlap_u_override if m._overlap_u_override is not None else torch.rand(nb, OVERLAP_N_POINTS, 3, device=dev)
-            ws = ops.ARENA.zeros(nb * 18, torch.float32, dev)
-            _lib.call('dbw_overlap_loss', _p(u), u.shape[1], _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(alpha_full), nb,
-                      float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
-                      vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
 
-        torch.cuda.set_stream(cur)
-        st = st_main
+        def fg_pass():
+            # ---- main: the fg pass, ending in the composite + MSE ----
+            torch.cuda.set_stream(cur)
+            st = st_main
+            if fg_ready is not None:
+                cur.wait_event(fg_ready)                                   # blocks projected, per-face records, tile lists
+            p2f, bary, dists, part, g_fg, g_env = ops.render_fwd_fused_mse(cl_f, B, cfg_f, m._block_face_uvs_all, m._block_face_map_all, desc_f,
+                                                                          blk_maps, fa, renderer._bg, img_e, target, scale, stage=2,
+                                                                          state=fg_state, img_tiled=True)
+            return p2f, bary, dists, part, g_fg, g_env
+
+        def regularisers():
+            # ---- side: the regularisers, enqueued AFTER the main stream's fg pass: a stream that waits for an event of another stream was
+            # observed to wait for everything that stream had been given by then (the fg pass started when the last regulariser ended, 15 us
+            # after the env pass it really depends on) ----
+            torch.cuda.set_stream(side)
+            st = st_side
+            g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
+            if 'parsimony' in w and coarse:
+                _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
+            if 'tv' in w:
+                for t in sets:
+                    t['_g_sig'] = torch.empty_like(t['_sig'])
+                    t['sig'], t['grad_sig_out'], t['grad_sig'] = _p(t['_sig']), _p(t['_g_sig']), _p(t['_g_sig'])
+                launch('dbw_tv_l2sq_sets', (0, 1, 2), vals.data_ptr() + 8, st)
+            if 'overlap' in w and coarse:
+                u = m._overlap_u_override if m._overlap_u_override is not None else torch.rand(nb, OVERLAP_N_POINTS, 3, device=dev)
+                ws = ops.ARENA.zeros(nb * 18, torch.float32, dev)
+                _lib.call('dbw_overlap_loss', _p(u), u.shape[1], _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(alpha_full), nb,
+                          float(m.ratio_block_scene), float(m.scale_min), OVERLAP_TEMPERATURE, OVERLAP_N_BLOCKS, float(w['overlap']) * rs,
+                          vals.data_ptr() + 12, _p(g['sq_eps']), _p(g['S']), _p(g['R_6d']), _p(g['T']), _p(g_alpha_full), _p(ws), st)
+
+            torch.cuda.set_stream(cur)
+            st = st_main
+            return g_alpha_full
+
+        if self.regularisers_behind_fg:
+            p2f, bary, dists, part, g_fg, g_env = fg_pass()
+            g_alpha_full = regularisers()
+        else:
+            g_alpha_full = regularisers()
+            p2f, bary, dists, part, g_fg, g_env = fg_pass()
         # ---- backward of the two passes (upstream gradient 1: nothing sits above this step), each followed by its tail of small
         # kernels (projection backward, pose / shape, textures, opacities) ----
         fg_out = {}
