@@ -612,7 +612,11 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     const int lane = threadIdx.x & 63;
     // wave-uniform tile of the 8x8-tile planar fragment layout
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
-    const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
+    // (a 16x16 workgroup at the lower / right image border can hold 8x8 quadrants that lie outside the tile grid -- H or W not a multiple of
+    // 16: such a wave holds no pixel of the image; it is pointed at the view's first tile so that the unconditional loads of the binned
+    // instantiation stay inside the fragment buffers)
+    const bool phantom = (yi >> 3) >= tiles_y || (xi >> 3) >= tiles_x;
+    const int tile = __builtin_amdgcn_readfirstlane(phantom ? n * tiles_y * tiles_x : (n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
     const long long tb = ((long long)tile * A.K) << 6;
     const int *__restrict__ p2f_t = A.p2f + tb + lane;
     const float *__restrict__ dists_t = A.dists + tb + lane;
