@@ -43,7 +43,8 @@ const char *dbw_last_error(void);
 /* profiling/ablation switches used by tools/ and by the parity tests (0 = product behaviour); bits 0-7: shading ablations,
  * 16: no fragment stores, 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal
  * div_fast, which is bit-identical inside its guards), 512: no conservative tile-vs-edge culling in the binning, 4096: no per-tile
- * face lists (every tile walks its coarse bin) */
+ * face lists (every tile walks its coarse bin); bits 16 and up: wall-clock ablations of the fused kernels for tools/diag (results
+ * are wrong by construction): 1 << 17 no record stores, 1 << 18 no cursor atomics, 1 << 19 no record path in the binned backward */
 void dbw_debug_set_flags(int flags);
 /* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
  * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */
