@@ -1341,6 +1341,30 @@ extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cur
     return dbw_check_launch("texbin_reduce_kernel");
 }
 
+// test hook: lane_merge on caller-supplied keys / values (tests/test_gpu_parity.py)
+template <int STEPS>
+__global__ __launch_bounds__(64) void lane_merge_test_kernel(const int *__restrict__ keys, const int *__restrict__ active,
+                                                             const float *__restrict__ values, int *__restrict__ active_out,
+                                                             float *__restrict__ values_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    bool on = active[i] != 0;
+    float v[3] = {values[i * 3], values[i * 3 + 1], values[i * 3 + 2]};
+    lane_merge<3, STEPS>(keys[i], on, v);
+    active_out[i] = on ? 1 : 0;
+    values_out[i * 3] = v[0]; values_out[i * 3 + 1] = v[1]; values_out[i * 3 + 2] = v[2];
+}
+extern "C" int dbw_debug_lane_merge(const int32_t *keys, const int32_t *active, const float *values, int waves, int steps,
+                                    int32_t *active_out, float *values_out, dbw_stream_t stream) {
+    DBW_REQUIRE(keys && active && values && active_out && values_out, "null pointer");
+    DBW_REQUIRE(waves >= 0 && steps >= 1 && steps <= 4, "bad size / steps must be 1..4");
+    if (waves == 0) return DBW_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define DBW_LM(S) hipLaunchKernelGGL(lane_merge_test_kernel<S>, dim3(waves), dim3(64), 0, s, keys, active, values, active_out, values_out)
+    if (steps == 1) DBW_LM(1); else if (steps == 2) DBW_LM(2); else if (steps == 3) DBW_LM(3); else DBW_LM(4);
+#undef DBW_LM
+    return dbw_check_launch("lane_merge_test_kernel");
+}
+
 // Ablation hook for profiling scripts (tools/): not part of the rendering contract.
 extern "C" void dbw_debug_set_raster_flags(int flags);
 void dbw_set_render_dbg(int v);

@@ -56,6 +56,11 @@ int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned l
  * a = points (n, 3) with b = (eps1, eps2) x n and upstream gradient c (n) -> out (n, 6) = sdf, d / d eps1, d / d eps2, d / d point;
  * 2: safe_pow (pytorch.py:35-36) of a = t (n) to the power b[0] -> out (n, 2) = value, d / d t;  3: signed_pow (pytorch.py:31-32) */
 int dbw_debug_model_math(int what, const float *a, const float *b, const float *c, int n, float ratio, float *out, dbw_stream_t stream);
+/* test hook: lane_merge (csrc/dbw_common.h), the in-register merge of neighbouring lanes that update the same key in front of the LDS
+ * tables of the backward kernels, applied to waves * 64 lanes with `steps` (1..4) merging steps: keys (>= 0), active (0 / 1) and
+ * values (lane, 3) in; active and values out (a lane that handed its values over comes back inactive) */
+int dbw_debug_lane_merge(const int32_t *keys, const int32_t *active, const float *values, int waves, int steps, int32_t *active_out,
+                         float *values_out, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Camera transform + z-clipping of one scene seen from B cameras.

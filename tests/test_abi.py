@@ -42,7 +42,7 @@ def test_library_builds_and_loads_without_gpu():
 def test_every_declared_symbol_is_exported_with_matching_signature():
     lib = _lib.load()
     protos = parse_header()
-    assert len(protos) == 35
+    assert len(protos) == 36
     for name, (ret, types) in protos.items():
         assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
         if name in _lib.SIGNATURES:
@@ -51,6 +51,19 @@ def test_every_declared_symbol_is_exported_with_matching_signature():
     assert not missing, f'bound but not declared: {missing}'
     undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_bin_subcursors', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_rasterize_workspace_bytes_binned', 'dbw_debug_set_flags', 'dbw_debug_set_raster_flags'}
     assert not undeclared_compute, f'declared but not bound: {undeclared_compute}'
+
+
+def test_bin_cursor_count_comes_from_the_library():
+    """The host sizes the cursor array and rounds the record capacity of the texture bins with the library's DBW_BIN_SUBCURSORS
+    (dbw_bin_subcursors), not with a constant of its own."""
+    import re
+    from dbw_amd import ops
+    lib = _lib.load()
+    declared = int(re.search(r'#define DBW_BIN_SUBCURSORS (\d+)', open(HEADER).read()).group(1))
+    assert lib.dbw_bin_subcursors() == declared == ops.BIN_SUBCURSORS == ops.bin_subcursors()
+    for nbins in (1, 7, 640):
+        cap = ops.texbin_capacity(49, 300, 400, 10, nbins)
+        assert cap % declared == 0 and cap >= 256
 
 
 def test_argument_validation_happens_before_any_launch():

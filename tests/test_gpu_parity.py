@@ -699,3 +699,38 @@ def test_rasterize_slivers_follow_the_double_reading_of_kepsilon():
     assert torch.equal(out[0].cpu(), ref[0])
     for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
         assert torch.equal(a.cpu(), b), name
+
+
+@pytest.mark.parametrize('steps', [1, 2, 3, 4])
+def test_lane_merge_preserves_the_per_key_sums(steps):
+    """lane_merge (csrc/dbw_common.h): neighbouring lanes that update the same key hand their values over in registers before the LDS
+    tables of the backward see them.  Whatever the key pattern, the sums per key over the ACTIVE lanes must not change (integer-valued
+    floats: exact in any order), no lane may become active, inactive lanes must not contribute, and runs of equal keys must shrink:
+    2^steps aligned neighbours of one key leave one active lane."""
+    from dbw_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(steps)
+    waves = 64
+    n = waves * 64
+    keys = torch.randint(0, 7, (n,), generator=g)
+    run = 1 << steps
+    keys[:16 * 64] = (torch.arange(16 * 64) // run) % 5                 # aligned runs of 2^steps equal keys
+    keys[16 * 64:24 * 64] = 3                                           # one key for whole waves
+    active = (torch.rand(n, generator=g) < 0.8).int()
+    active[:24 * 64] = 1
+    vals = torch.randint(-8, 9, (n, 3), generator=g).float()
+    k_d, a_d, v_d = keys.int().to(DEV), active.to(DEV), vals.to(DEV)
+    a_out, v_out = torch.zeros_like(a_d), torch.zeros_like(v_d)
+    rc = lib.dbw_debug_lane_merge(k_d.data_ptr(), a_d.data_ptr(), v_d.data_ptr(), waves, steps, a_out.data_ptr(), v_out.data_ptr(), 0)
+    assert rc == 0, lib.dbw_last_error()
+    torch.cuda.synchronize()
+    a_out, v_out = a_out.cpu(), v_out.cpu()
+    assert bool(((a_out == 1) <= (active == 1)).all())                  # nobody wakes up
+    wave = torch.arange(n) // 64
+    idx = wave * 8 + keys                                               # merging never crosses a wave
+    before = torch.zeros(waves * 8, 3).index_add_(0, idx, vals * active[:, None].float())
+    after = torch.zeros(waves * 8, 3).index_add_(0, idx, v_out * a_out[:, None].float())
+    assert torch.equal(before, after)
+    assert int(a_out[:16 * 64].sum()) == 16 * 64 // run                 # aligned runs: one lane left per run
+    assert int(a_out[16 * 64:24 * 64].sum()) == 8 * 64 // min(run, 16)  # (a wave of one key: 2^steps lanes into one, 16 at most)
+    assert int(a_out.sum()) < int(active.sum())
