@@ -1,4 +1,5 @@
-"""GPU helper: ms per training step with the backward kernels of the full-resolution phases one after the other / side by side."""
+"""GPU helper: ms per training step of the full-resolution phases with the env backward chain behind / next to the fg backward kernel.
+usage: ab_sched.py [epoch]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
@@ -10,7 +11,7 @@ dev = torch.device('cuda', 0)
 epoch = int(sys.argv[1]) if len(sys.argv) > 1 else 800
 res = {}
 for rep in range(3):
-    for both in (False, True):
+    for both, parts in ((False, 1), (True, 1)):
         torch.manual_seed(0)
         model, inp = bench.build_workload(args, dev)
         model.sync_free = True
@@ -25,6 +26,6 @@ for rep in range(3):
         for _ in range(20):
             step(inp)
         e1.record(); torch.cuda.synchronize()
-        res.setdefault(both, []).append(e0.elapsed_time(e1) / 20)
-for k, v in res.items():
-    print('side by side' if k else 'one after the other', ' '.join('%.4f' % x for x in v))
+        res.setdefault((both, parts), []).append(e0.elapsed_time(e1) / 20)
+for (both, parts), v in res.items():
+    print('env backward %s, %d part(s):' % ('next to the fg backward' if both else 'behind the fg backward', parts), ' '.join('%.4f' % x for x in v))
