@@ -181,11 +181,11 @@ def kernel_breakdown(model, inp, reps=5):
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
                                                                alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap,
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap, 0,
                       int(getattr(scene, 'const_faces', 0)), 0, 1, ops._stream(fvc))          # image_layout 1: the step's tiled images
 
         def reduce():
-            _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, bins[2], g_maps.data_ptr(), ops._stream(fvc))
+            _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, 0, bins[2], g_maps.data_ptr(), ops._stream(fvc))
 
         def t(fn):
             fn()

@@ -148,6 +148,21 @@ constexpr int BIN_SUB = DBW_BIN_SUBCURSORS;                 // sub-ranges (each 
 #endif
 constexpr int BIN_SUB_PER_WG = DBW_BIN_SUB_PER_WG;                         // sub-ranges one texbin_reduce workgroup accumulates
 
+// the record sub-range (bin, sub): its first record in the record array and its capacity -- from the caller's layout table when there
+// is one (capacities that follow the demand of the previous launch, ops.py), else bin_cap / BIN_SUB records each, bins back to back
+struct SubRange { unsigned first; int cap; };
+__device__ __forceinline__ SubRange sub_range(const ShadeArgs &A, int bin, int sub) {
+    SubRange r;
+    if (A.bin_layout) {
+        const uint2 l = *(const uint2 *)(A.bin_layout + ((long long)bin * BIN_SUB + sub) * 2);
+        r.first = l.x; r.cap = (int)l.y;
+    } else {
+        const int sub_cap = A.bin_cap / BIN_SUB;
+        r.first = (unsigned)bin * (unsigned)A.bin_cap + (unsigned)sub * (unsigned)sub_cap; r.cap = sub_cap;
+    }
+    return r;
+}
+
 // a footprint the bin's 33x33 LDS tile can hold: at most one row up and one column right of (r0, c0), no wrap
 __device__ __forceinline__ bool bin_regular(const Sample &s) {
     return (s.r1 == s.r0 || s.r1 == s.r0 - 1) && (s.c1 == s.c0 || s.c1 == s.c0 + 1) &&
@@ -175,14 +190,14 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     FaceAgg face_agg;
     // BINNED: block-level slot reservation.  Pass 1 counts the block's records per bin in a small LDS hash table, one global
     // cursor atomic per (block, bin) reserves the range, pass 2 writes the records -- a single atomic round trip per block.
-    int *s_key = nullptr, *s_cnt = nullptr, *s_base = nullptr, *s_ent = nullptr;
+    int *s_key = nullptr, *s_cnt = nullptr, *s_base = nullptr, *s_room = nullptr, *s_ent = nullptr;
     {
         char *nxt = (char *)(s_layers + (long long)KK * NT);
         if (use_lds) { tex_agg.bind(nxt); nxt += TexAgg::BYTES; tex_agg.clear(threadIdx.x, NT); }          // block-uniform
         if (lds_alpha) { alpha_agg.bind(nxt); nxt += AlphaAgg::BYTES; alpha_agg.clear(threadIdx.x, NT); }
         if (FUSED) { face_agg.bind(nxt); face_agg.clear(threadIdx.x, NT); nxt += FaceAgg::BYTES; }
         if (BINNED) {
-            s_key = (int *)nxt; s_cnt = s_key + BIN_SLOTS; s_base = s_cnt + BIN_SLOTS; s_ent = s_base + BIN_SLOTS + threadIdx.x;
+            s_key = (int *)nxt; s_cnt = s_key + BIN_SLOTS; s_base = s_cnt + BIN_SLOTS; s_room = s_base + BIN_SLOTS; s_ent = s_room + BIN_SLOTS + threadIdx.x;
             if (threadIdx.x < BIN_SLOTS) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
         }
     }
@@ -283,8 +298,14 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
     }
     if (BINNED) {
         __syncthreads();
-        if (threadIdx.x < BIN_SLOTS && s_key[threadIdx.x] >= 0)
-            s_base[threadIdx.x] = atomicAdd(A.bin_cursor + s_key[threadIdx.x] * BIN_SUB + (blockIdx.x & (BIN_SUB - 1)), s_cnt[threadIdx.x]);
+        if (threadIdx.x < BIN_SLOTS && s_key[threadIdx.x] >= 0) {
+            // -> first record of the block's reservation in the record array, and the room left behind it in the sub-range
+            const int sub = blockIdx.x & (BIN_SUB - 1), ci = s_key[threadIdx.x] * BIN_SUB + sub;
+            const int b0 = atomicAdd(A.bin_cursor + ci, s_cnt[threadIdx.x]);
+            const SubRange sr = sub_range(A, s_key[threadIdx.x], sub);
+            s_base[threadIdx.x] = (int)(sr.first + (unsigned)b0);
+            s_room[threadIdx.x] = sr.cap - b0;
+        }
         __syncthreads();
     }
     PROF_T(t_p1);
@@ -376,11 +397,11 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
                 // borders leaving the halo), hash-table misses and bin overflow fall through to the atomic path below
                 const int ent = s_ent[k * NT];
                 if (tex && ent >= 0) {
-                    const int h = ent >> 16, slot = s_base[h] + (ent & 0xffff), sub_cap = A.bin_cap / BIN_SUB;
-                    if (slot < sub_cap) {
+                    const int h = ent >> 16, rank = ent & 0xffff;
+                    if (rank < s_room[h]) {
                         const unsigned packed = (unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) |
                                                 ((unsigned)(s.c1 - s.c0) << 11);
-                        int4 *dst = A.bin_records + ((long long)s_key[h] * A.bin_cap + (long long)(blockIdx.x & (BIN_SUB - 1)) * sub_cap + slot) * 2;
+                        int4 *dst = A.bin_records + (long long)((unsigned)s_base[h] + (unsigned)rank) * 2;
                         dst[0] = make_int4((int)packed, __float_as_int(s.wx1), __float_as_int(s.wy1), __float_as_int(gc[0]));
                         dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
                         pending = false;
@@ -512,8 +533,11 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
 //  * the tile index is wave-uniform: fragment planes are addressed as scalar base + lane;
 //  * the distance backward picks the closest edge with selects and differentiates that one edge (the generic form runs the three
 //    candidate branches under divergence).
+#ifndef DBW_FACE_LOG2
+#define DBW_FACE_LOG2 7
+#endif
 struct FaceAlphaAgg {      // key = clipped face id -> 6 vertex xy-gradients + 1 opacity gradient (destination index in `aux`)
-    static constexpr int LOG2 = 7, NSLOT = 1 << LOG2, NV = 7;
+    static constexpr int LOG2 = DBW_FACE_LOG2, NSLOT = 1 << LOG2, NV = 7;
     static constexpr size_t BYTES = (size_t)NSLOT * (NV * 8 + 8);
     int *keys, *aux;
     double *vals;
@@ -579,6 +603,7 @@ __device__ __forceinline__ float seg_dist_t(f2 p, f2 a, f2 b, float &tt) {
 struct BinRes {            // reservation of one fragment's record: bin, rank among the wave's records of that bin, the lane that holds
     int bin, rank, leader, base, packed;   // `base` (it issued the atomic), and the footprint in the record's packed form
     float wx1, wy1;
+    unsigned first; int cap;               // (leader only) the sub-range the reservation was made in
 };
 
 constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
@@ -721,10 +746,10 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     };
     // BINNED: footprint of a fragment in record form + the slot reservation of the wave's records of its layer (in the sub-range
     // `sub` of the bin: neighbouring tiles, which hit the same bins at the same time, use different cursors)
-    const int sub = tile & (BIN_SUB - 1), sub_cap = BINNED ? A.bin_cap / BIN_SUB : 0;
+    const int sub = tile & (BIN_SUB - 1);
     auto reserve = [&](const Raw &r, bool ok) {
         BinRes R;
-        R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f;
+        R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f; R.first = 0u; R.cap = 0;
         const float wgt = r.T * r.a;
         const bool tex = ok && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f) && !(A.dbg & (1 << 19));      // (1 << 19: ablation of the whole record path)
         if (__ballot(tex) == 0ull) return R;
@@ -748,7 +773,11 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             const bool mine = on && R.bin == b;
             const unsigned long long mm = __ballot(mine);
             if (mine) { R.rank = __popcll(mm & below); R.leader = L; }
-            if (lane == L && !(A.dbg & (1 << 18))) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));     // (1 << 18: ablation, tools/diag)
+            if (lane == L) {
+                if (!(A.dbg & (1 << 18))) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));     // (1 << 18: ablation, tools/diag)
+                const SubRange sr = sub_range(A, b, sub);
+                R.first = sr.first; R.cap = sr.cap;
+            }
             rem &= ~mm;
         }
         return R;
@@ -756,7 +785,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     Raw nxt = load(kmax > 0 ? kmax - 1 : 0, kmax > 0 && kmax - 1 < cnt);
     Raw nxt2 = nxt;
     BinRes nres;
-    nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f;
+    nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f; nres.first = 0u; nres.cap = 0;
     FaceXY nxtq;
     nxtq.v0 = nxtq.v1 = nxtq.v2 = make_float2(0.f, 0.f);
     constexpr bool PIPE = BINNED;      // the two-deep memory schedule (for decimated maps it measures 0.366 against 0.355 ms: not used there)
@@ -795,12 +824,13 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             // colour -> one record in the fragment's texture bin; irregular footprints (circular wrap, clamped borders leaving the
             // bin's halo) and bin overflow take the atomic path, so the result is exact either way
             if (__ballot(tex) != 0ull) {
-                const int base = __shfl(cres.base, cres.leader, 64);
+                // the leader's reservation: its first record in the record array, and the room left behind it in the sub-range
+                const unsigned start = (unsigned)__shfl((int)(cres.first + (unsigned)cres.base), cres.leader, 64);
+                const int room = __shfl(cres.cap - cres.base, cres.leader, 64);
                 bool pending = tex;
                 if (tex && cres.bin >= 0) {
-                    const int slot = base + cres.rank;
-                    if (slot < sub_cap) {
-                        int4 *dst = A.bin_records + ((long long)cres.bin * A.bin_cap + (long long)sub * sub_cap + slot) * 2;
+                    if (cres.rank < room) {
+                        int4 *dst = A.bin_records + (long long)(start + (unsigned)cres.rank) * 2;
                         if (!(A.dbg & (1 << 17))) {                    // (1 << 17: ablation of the record stores, tools/diag)
                             st_stream4(dst, make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0])));
                             st_stream4(dst + 1, make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0));
@@ -948,20 +978,29 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 #endif
 constexpr int BIN_STAGE = DBW_BIN_STAGE, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
 __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restrict__ bin_info, const int *__restrict__ cursor,
-                                                            const int4 *__restrict__ records, int cap, float *__restrict__ gmaps) {
+                                                            const int4 *__restrict__ records, int cap, const unsigned *__restrict__ layout,
+                                                            float *__restrict__ gmaps) {
     __shared__ double tile[33 * 33 * 3];
     __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
     const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG, sub_cap = cap / BIN_SUB;
     int n_sub[BIN_SUB_PER_WG], total = 0;
+    unsigned first[BIN_SUB_PER_WG];
 #pragma unroll
-    for (int g = 0; g < BIN_SUB_PER_WG; ++g) { n_sub[g] = min(cursor[bin * BIN_SUB + sub0 + g], sub_cap); total += n_sub[g]; }
+    for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
+        const int ci = bin * BIN_SUB + sub0 + g;
+        int room = sub_cap;
+        first[g] = (unsigned)bin * (unsigned)cap + (unsigned)(sub0 + g) * (unsigned)sub_cap;
+        if (layout) { first[g] = layout[ci * 2]; room = (int)layout[ci * 2 + 1]; }
+        n_sub[g] = min(cursor[ci], room);
+        total += n_sub[g];
+    }
     if (total == 0) return;
     for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0.0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll 1
     for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
     const int n = n_sub[g];
-    const int4 *rec = records + ((long long)bin * cap + (long long)(sub0 + g) * sub_cap) * 2;
+    const int4 *rec = records + (long long)first[g] * 2;
     for (int sb = 0; sb < n; sb += BIN_STAGE) {
         const int m = min(n - sb, BIN_STAGE);
         __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
@@ -1044,7 +1083,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.dbg = g_dbg_flags;
     A.agg = 0;
     A.tiled = 0;
-    A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0;
+    A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0; A.bin_layout = nullptr;
     A.gscale = nullptr; A.geom_begin = 0; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
     A.img_tiled = 0;
     return DBW_OK;
@@ -1228,7 +1267,7 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     if (A.agg & 1) lds += TexAgg::BYTES;
     if (A.agg & 2) lds += AlphaAgg::BYTES;
     if (fused) lds += FaceAgg::BYTES;
-    if (fused && A.bin_records) lds += (size_t)(3 * BIN_SLOTS + K * NT) * sizeof(int);
+    if (fused && A.bin_records) lds += (size_t)(4 * BIN_SLOTS + K * NT) * sizeof(int);
     static bool raised = false;
     if (!raised) {
         if (hipFuncSetAttribute((const void *)shade_blend_bwd_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -1305,8 +1344,8 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     const float *face_verts_c, int perspective_correct, int detach_bary,
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
                                     int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
-                                    void *bin_records, int bin_cap, int const_geometry_faces, const float *grad_scale,
-                                    int image_layout, dbw_stream_t stream) {
+                                    void *bin_records, int bin_cap, const uint32_t *bin_layout, int const_geometry_faces,
+                                    const float *grad_scale, int image_layout, dbw_stream_t stream) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -1325,20 +1364,64 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     A.geom_begin = const_geometry_faces;
     DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap >= DBW_BIN_SUBCURSORS) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none (bin_cap >= DBW_BIN_SUBCURSORS)");
     if (bin_records && !lds_aggregate) {
-        A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap;
+        A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap; A.bin_layout = bin_layout;
     }
+    DBW_REQUIRE(!bin_layout || bin_records, "bin_layout without texture bins");
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
 }
 
 extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
-                                 int nbins, float *grad_maps, dbw_stream_t stream) {
+                                 const uint32_t *bin_layout, int nbins, float *grad_maps, dbw_stream_t stream) {
     DBW_REQUIRE(bin_info && bin_cursor && bin_records && grad_maps, "null pointer");
     DBW_REQUIRE(bin_cap >= DBW_BIN_SUBCURSORS && nbins >= 0, "bad size");
+    DBW_REQUIRE((long long)nbins * bin_cap < (1LL << 32), "the record array is indexed with 32 bits: nbins * bin_cap must stay below 2^32 (128 GB of records)");
     if (nbins == 0) return DBW_OK;
     hipLaunchKernelGGL(texbin_reduce_kernel, dim3(nbins, BIN_SUB / BIN_SUB_PER_WG), dim3(256), 0, (hipStream_t)stream, bin_info, bin_cursor,
-                       (const int4 *)bin_records, bin_cap, grad_maps);
+                       (const int4 *)bin_records, bin_cap, bin_layout, grad_maps);
     return dbw_check_launch("texbin_reduce_kernel");
+}
+
+// Record sub-ranges by demand (include/dbw_hip.h: dbw_bin_layout): one workgroup, every thread a contiguous piece of the table --
+// wanted = max(asked, min) * 1.25, scaled so that the pieces add up to `total`, prefix sums through LDS.  Deterministic, no atomics.
+__global__ __launch_bounds__(1024) void bin_layout_kernel(const int *__restrict__ asked, long long n, double total, int min_records,
+                                                          unsigned *__restrict__ layout) {
+    __shared__ double s_sum[1024];
+    const int t = threadIdx.x;
+    const long long per = (n + 1023) / 1024, i0 = min(n, t * per), i1 = min(n, i0 + per);
+    double mine = 0.0;
+    for (long long i = i0; i < i1; ++i) mine += (double)max(asked[i], min_records) * 1.25;
+    s_sum[t] = mine;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) s_sum[t] += s_sum[t + o]; __syncthreads(); }
+    const double scale = total / s_sum[0];
+    __syncthreads();
+    double caps = 0.0;
+    for (long long i = i0; i < i1; ++i) caps += max(floor((double)max(asked[i], min_records) * 1.25 * scale), 1.0);
+    s_sum[t] = caps;
+    __syncthreads();
+    // exclusive scan of the 1024 piece totals (Hillis-Steele in place, double buffered by the barrier pairs)
+    for (int o = 1; o < 1024; o <<= 1) {
+        const double v = t >= o ? s_sum[t - o] : 0.0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    double first = s_sum[t] - caps;
+    for (long long i = i0; i < i1; ++i) {
+        const double c = max(floor((double)max(asked[i], min_records) * 1.25 * scale), 1.0);
+        layout[i * 2] = (unsigned)(long long)first;
+        layout[i * 2 + 1] = (unsigned)(long long)c;
+        first += c;
+    }
+}
+extern "C" int dbw_bin_layout(const int32_t *asked, int64_t n, double total_records, int min_records, uint32_t *layout, dbw_stream_t stream) {
+    DBW_REQUIRE(asked && layout, "null pointer");
+    DBW_REQUIRE(n >= 0 && min_records >= 1 && total_records >= 1.0 && total_records < 4294967296.0, "bad size (records are indexed with 32 bits)");
+    DBW_REQUIRE((double)n * 1.0 <= total_records, "fewer records than sub-ranges");
+    if (n == 0) return DBW_OK;
+    hipLaunchKernelGGL(bin_layout_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, asked, (long long)n, total_records, min_records, layout);
+    return dbw_check_launch("bin_layout_kernel");
 }
 
 // test hook: lane_merge on caller-supplied keys / values (tests/test_gpu_parity.py)

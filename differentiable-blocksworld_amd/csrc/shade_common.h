@@ -8,9 +8,9 @@
 namespace dbw {
 
 #ifndef DBW_TEX_LOG2
-#define DBW_TEX_LOG2 9
-#endif
-typedef LdsAgg<3, DBW_TEX_LOG2> TexAgg;      // 512 texels x (key + fp64 rgb) = 14 KB
+#define DBW_TEX_LOG2 8       // 128 / 256 / 512 / 1024 slots: uv backward 0.49 / 0.323 / 0.353 / 0.54 ms at config 2 (round 3, after the lane merge:
+#endif                       // 19 instead of 26 KB of LDS per workgroup = 8 instead of 5-6 waves per SIMD; 128 slots overflow into memory atomics)
+typedef LdsAgg<3, DBW_TEX_LOG2> TexAgg;      // 256 texels x (key + fp64 rgb) = 7 KB
 typedef LdsAgg<1, 8> AlphaAgg;    // 256 faces x (key + fp64)       =  3 KB
 typedef LdsAgg<9, 7> FaceAgg;     // 128 faces x (key + fp64 3x3)   = 9.5 KB
 
@@ -30,6 +30,7 @@ struct ShadeArgs {
     int *bin_cursor;       // (nbins) append cursors
     int4 *bin_records;     // (nbins, bin_cap, 2)
     int bin_cap;
+    const unsigned *bin_layout;   // optional (nbins * DBW_BIN_SUBCURSORS, 2): {first record, capacity} of every sub-range; NULL = bin_cap / SUB each
     int dbg;   // ablation switches (dbw_debug_set_flags): 1 = no texel atomics, 2 = no opacity atomics, 4 = no wave aggregation
     // backward: device scalar every incoming image gradient is multiplied by (the upstream gradient of the loss node), NULL = 1
     const float *gscale;

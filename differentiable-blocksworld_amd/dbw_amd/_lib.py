@@ -13,6 +13,7 @@ c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_f = ctypes.c_float
 c_i64 = ctypes.c_int64
+c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
 
 
@@ -46,8 +47,9 @@ SIGNATURES = {
     'dbw_render_fwd_fused_mse': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i, c_i, c_i, c_i, c_f, c_f,
                                  c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p],
     'dbw_render_bwd_fused': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
-                             c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
-    'dbw_texbin_reduce': [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+                             c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p],
+    'dbw_texbin_reduce': [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
+    'dbw_bin_layout': [c_p, c_i64, c_d, c_i, c_p, c_p],
     'dbw_texture_prep_fwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_texture_prep_bwd': [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     'dbw_sq_blocks_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],

@@ -405,31 +405,85 @@ class _RenderScene(torch.autograd.Function):
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
 
 
-def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale, after_kernel=None, img_tiled=False):
+class BinDemand:
+    """Record sub-ranges of the texture bins sized by demand (include/dbw_hip.h: bin_layout, dbw_bin_layout).  After a backward pass
+    bin_cursor holds how many records every sub-range was asked for; a caller that runs the same pass step after step
+    (native_step.py) keeps one of these per pass, and the next launch divides the SAME total -- texbin_capacity(...) records per bin on
+    average -- in proportion to that demand (+ 25 %, at least MIN records each) instead of in equal shares.  One small kernel on the
+    device, no host read, the record buffer keeps its size.  With equal shares the hot bins of a large scene overflow into the atomic
+    fallback: config 5's backward took 56 ms at full resolution, 9.6 ms with four times the memory.
+    Two cursor arrays are kept and used in turn (this launch's cursors are the next launch's demand); they are never reallocated, so a
+    captured hipGraph that replays one launch keeps reading a valid -- if frozen -- demand."""
+    MIN = 64
+
+    def __init__(self):
+        self.key, self.cursors, self.layouts, self.turn, self.ready = None, None, None, 0, False
+
+    def _fit(self, nbins, device):
+        n = nbins * bin_subcursors()
+        if self.key != (n, device):
+            self.key = (n, device)
+            self.cursors = [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(2)]
+            self.layouts = [torch.zeros(n, 2, dtype=torch.int32, device=device) for _ in range(2)]
+            self.turn, self.ready = 0, False
+        return n
+
+    def prepare(self, nbins, cap, device):
+        """Enqueue, on the current stream, the layout of the NEXT launch from the cursors of the previous one (call it early in the
+        step, off the critical path; begin() does it itself otherwise)."""
+        n = self._fit(nbins, device)
+        if not self.ready:
+            return None
+        lay = self.layouts[self.turn]
+        _lib.call('dbw_bin_layout', _ptr(self.cursors[1 - self.turn]), n, float(nbins) * float(cap), self.MIN, _ptr(lay),
+                  torch.cuda.current_stream(device).cuda_stream)
+        self.prepared = (nbins, cap, lay)
+        return lay
+
+    def begin(self, nbins, cap, device):
+        """-> (zeroed cursors of this launch, layout or None for the first launch / after a change of geometry)."""
+        self._fit(nbins, device)
+        lay = None
+        if self.ready:
+            pre = getattr(self, 'prepared', None)
+            lay = pre[2] if (pre is not None and pre[:2] == (nbins, cap) and pre[2] is self.layouts[self.turn]) else self.prepare(nbins, cap, device)
+        self.prepared = None
+        cur = self.cursors[self.turn]
+        cur.zero_()
+        self.turn, self.ready = 1 - self.turn, True
+        return cur, lay
+
+
+def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, tiled, g_img, B, gscale, after_kernel=None, img_tiled=False,
+               bin_demand=None):
     """dbw_render_bwd_fused (+ dbw_texbin_reduce when the texel gradients go through texture-space bins) of one pass.
-    gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c."""
+    gscale: device scalar multiplying g_img inside the kernel (or None).  -> grad maps, grad faces_alpha (or None), grad face_verts_c.
+    bin_demand: a BinDemand kept by the caller across steps -> the bins' record sub-ranges follow the previous step's demand."""
     fvc = cl['face_verts'].view(-1, 3, 3)
     per_map = fa is not None and _alpha_len(fa, map_desc, cfg.F) < 0        # then 64 partial sums per opacity (include/dbw_hip.h)
     g_maps = ARENA.zeros_like(maps)
     g_alpha = None if fa is None else (ARENA.zeros(fa.numel() * ALPHA_SPREAD, torch.float32, fa.device) if per_map else ARENA.zeros_like(fa))
     g_fvc = ARENA.zeros_like(fvc)
     bins = cfg.texbins if (TEXTURE_BINS and not cfg.lds_aggregate) else None
-    bin_base = cursor = records = None
+    bin_base = cursor = records = layout = None
     cap = 0
     if bins is not None and bins[2] > 0:
         bin_base, bin_info, nbins = bins
         cap = texbin_capacity(B, cfg.H, cfg.W, cfg.K, nbins)
-        cursor = ARENA.zeros(nbins * bin_subcursors(), torch.int32, fvc.device)
+        if bin_demand is not None:
+            cursor, layout = bin_demand.begin(nbins, cap, fvc.device)
+        else:
+            cursor = ARENA.zeros(nbins * bin_subcursors(), torch.int32, fvc.device)
         records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
     _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                    (B, cfg.H, cfg.W, cfg.K)),
               _ptr(g_img), _ptr(fvc), int(cfg.persp), int(cfg.detach_bary), _ptr(g_maps), _ptr(g_alpha), _ptr(g_fvc),
-              int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, int(cfg.const_faces), _ptr(gscale),
-              int(img_tiled), _stream(fvc))
+              int(cfg.lds_aggregate), int(tiled), _ptr(bin_base), _ptr(cursor), _ptr(records), cap, _ptr(layout), int(cfg.const_faces),
+              _ptr(gscale), int(img_tiled), _stream(fvc))
     if after_kernel is not None:
         after_kernel()            # (the big kernel is enqueued; the bin reduction, a low-occupancy kernel, may share the GPU with other work)
     if records is not None:
-        _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, nbins, _ptr(g_maps), _stream(fvc))
+        _lib.call('dbw_texbin_reduce', _ptr(bin_info), _ptr(cursor), _ptr(records), cap, _ptr(layout), nbins, _ptr(g_maps), _stream(fvc))
     return g_maps, g_alpha, g_fvc
 
 

@@ -216,6 +216,12 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
  * const_geometry_faces: the first that many faces of the scene (original indexing) have constant vertices -- the sky dome of the env
  * scene (dbw.py:74-76: a buffer, not a parameter) -- so nothing is propagated through their barycentrics and their rows of
  * grad_face_verts_c stay untouched; 0 = every face gets its geometry gradient.
+ * bin_layout (optional, device, (nbins * DBW_BIN_SUBCURSORS, 2) uint32): {first record, capacity} of every sub-range inside
+ * bin_records, for callers that size the sub-ranges by demand -- after a launch bin_cursor holds how many records every sub-range was
+ * ASKED for, whether they fitted or not, so the next launch can give each what it needs out of the same total (ops.py does that:
+ * with equal shares a large scene overflows its hot bins and 56 of 66 ms of config 5's backward were fallback atomics).  NULL = equal
+ * shares of bin_cap / DBW_BIN_SUBCURSORS records, bins back to back.  Both calls of a pass get the same table; records are indexed
+ * with 32 bits (nbins * bin_cap < 2^32).
  * grad_scale: DEVICE scalar every value of grad_image is multiplied by (the upstream gradient of a loss node, so that no
  * elementwise pass over the image-sized gradient is needed), NULL = 1. */
 int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,
@@ -225,10 +231,15 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
                          const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary,
                          float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate,
                          int frag_layout, const int32_t *bin_base, int32_t *bin_cursor, void *bin_records, int bin_cap,
-                         int const_geometry_faces, const float *grad_scale, int image_layout, dbw_stream_t stream);
+                         const uint32_t *bin_layout, int const_geometry_faces, const float *grad_scale, int image_layout,
+                         dbw_stream_t stream);
 /* bin_info (nbins,4) int32 = {offset of the bin's map in floats, stored width, stored height, tile_y << 16 | tile_x}. */
-int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap, int nbins,
-                      float *grad_maps, dbw_stream_t stream);
+int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
+                      const uint32_t *bin_layout, int nbins, float *grad_maps, dbw_stream_t stream);
+/* bin_layout by demand: asked (n = nbins * DBW_BIN_SUBCURSORS) = the bin_cursor of an earlier launch of the same pass -> layout (n, 2):
+ * capacity_i = floor(max(asked_i, min_records) * 1.25 * scale) (at least 1), scale such that the capacities add up to at most
+ * total_records (< 2^32; a caller passes nbins * bin_cap: the memory of the equal shares); first_i = sum of the capacities before i. */
+int dbw_bin_layout(const int32_t *asked, int64_t n, double total_records, int min_records, uint32_t *layout, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Texture preparation: maps = sigmoid(texture) (dbw.py:273,288,306), optionally "decimated"

@@ -10,7 +10,7 @@ from conftest import ROOT
 from dbw_amd import _lib
 
 HEADER = os.path.join(ROOT, 'include', 'dbw_hip.h')
-CTYPE = {'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t,
+CTYPE = {'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t,
          'dbw_stream_t': ctypes.c_void_p}
 
 
@@ -35,14 +35,14 @@ def parse_header():
 def test_library_builds_and_loads_without_gpu():
     lib = _lib.load()
     assert os.path.exists(_lib.LIB_PATH)
-    assert lib.dbw_abi_version() == 2
+    assert lib.dbw_abi_version() == 3
     assert lib.dbw_last_error() is not None
 
 
 def test_every_declared_symbol_is_exported_with_matching_signature():
     lib = _lib.load()
     protos = parse_header()
-    assert len(protos) == 36
+    assert len(protos) == 37
     for name, (ret, types) in protos.items():
         assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
         if name in _lib.SIGNATURES:

@@ -734,3 +734,51 @@ def test_lane_merge_preserves_the_per_key_sums(steps):
     assert int(a_out[:16 * 64].sum()) == 16 * 64 // run                 # aligned runs: one lane left per run
     assert int(a_out[16 * 64:24 * 64].sum()) == 8 * 64 // min(run, 16)  # (a wave of one key: 2^steps lanes into one, 16 at most)
     assert int(a_out.sum()) < int(active.sum())
+
+
+def test_bin_layout_by_demand_is_a_partition_and_gives_the_same_gradients(monkeypatch):
+    """Record sub-ranges sized by the previous launch's demand (ops.BinDemand, dbw_bin_layout): the layout is a partition of the record
+    array -- sub-ranges back to back, none empty, their sum within the total -- proportional to the demand, and a backward pass that
+    uses it gives the gradients of the atomic scatter (a tiny total forces overflow into the exact fallback as well)."""
+    from dbw_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n = 16 * 37
+    asked = torch.randint(0, 5000, (n,), generator=g).int()
+    asked[::5] = 0
+    total = 400000.0
+    lay = torch.zeros(n, 2, dtype=torch.int32, device=DEV)
+    assert lib.dbw_bin_layout(asked.to(DEV).data_ptr(), n, total, 64, lay.data_ptr(), 0) == 0, lib.dbw_last_error()
+    first, caps = (lay.cpu().long() & 0xffffffff).unbind(1)
+    assert int(first[0]) == 0 and bool((first[1:] == (first + caps)[:-1]).all()) and int(caps.min()) >= 1
+    assert total - n <= float(first[-1] + caps[-1]) <= total
+    want = asked.clamp(min=64).double() * 1.25
+    assert float(((caps.double() - want * (total / want.sum())).abs()).max()) <= 1.0
+    # the same gradients with and without it (two launches: the second one runs on the first one's demand)
+    m, R, T, Km = _model(seed=29, ts=64, hw=(72, 96), fpp=8)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    pl, pr = m.txt_padding
+    unpadded = [mp[:, pl:mp.shape[1] - pr] for mp in scene['maps']]
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    ps = _packed(dict(scene, maps=unpadded), pads=[(pl, pr)] * len(unpadded))
+    bins = PackedScene.describe_bins([(64, 64)] * len(unpadded), DEV)
+    B, H, W, K = 3, 72, 96, 8
+    cfg = ops.RenderCfg(H, W, K, 1e-4, 0.001, True, True, scene['faces'].shape[0], lds_aggregate=False, texbins=bins)
+    cl = ops.project_clip(ps.verts, ps.faces, *args, cfg.eps, cfg.z_clip, cfg.persp)
+    fvc = cl['face_verts'].view(-1, 3, 3)
+    p2f, bary, dists, img = ops._render_fwd_fused(fvc, cl, B, cfg, ps.face_uvs, ps.face_map, ps.map_desc, ps.maps, None, None, 2)
+    g_img = torch.rand(img.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    outs = []
+    for capacity in (None, 4096, 32):
+        if capacity is not None:
+            monkeypatch.setattr(ops, 'texbin_capacity', lambda *a, _c=capacity: _c)
+        for demand in ((None,) if capacity is None else (ops.BinDemand(),)):
+            for launch in range(1 if demand is None else 3):
+                gm, _, gv = ops._fused_bwd(p2f, bary, dists, cl, ps.face_uvs, ps.face_map, ps.map_desc, ps.maps, None, cfg, None, 2, g_img, B, None,
+                                           bin_demand=demand)
+                outs.append((gm.clone(), gv.clone()))
+            if demand is not None:
+                assert demand.ready and int(demand.cursors[1 - demand.turn].sum()) > 0
+    for gm, gv in outs[1:]:
+        assert rel_err(gm, outs[0][0]) < 1e-5 and rel_err(gv, outs[0][1]) < 1e-5

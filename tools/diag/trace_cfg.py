@@ -9,7 +9,7 @@ args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = [int(x
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.sync_free = True
-model.set_cur_epoch(0)
+model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
 step = ShardedTrainStep(model, seed=1)
 for _ in range(int(sys.argv[7]) if len(sys.argv) > 7 else 4):
     step(inp)

@@ -28,7 +28,7 @@ for tiled in (1, 0):
         g_maps, g_fvc, g_alpha = torch.zeros_like(maps), torch.zeros_like(fvc), torch.zeros_like(alpha)
         def bwd():
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
-                      cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), 1, 1, g_maps.data_ptr(), g_alpha.data_ptr(), g_fvc.data_ptr(), 1, tiled, 0, 0, 0, 0, 0, 0, 0, ops._stream(fvc))
+                      cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), 1, 1, g_maps.data_ptr(), g_alpha.data_ptr(), g_fvc.data_ptr(), 1, tiled, 0, 0, 0, 0, 0, 0, 0, 0, ops._stream(fvc))        # (no texture bins, no layout, const faces 0, no grad scale, image_layout 0)
         bwd(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
