@@ -468,6 +468,10 @@ def main():
                 }
                 out['configs']['c4']['what'] = 'BASELINE config 4 (BlendedMVS-like, 31 views, 768x576, K=20, fpp 16, 4 GPUs): the 8 views of one GPU'
                 out['configs']['c5']['what'] = 'BASELINE config 5 (Nerfstudio-like, 200 views, 1080x1920, K=50, 512^2 textures, fpp 16, 8 GPUs): the 25 views of one GPU'
+                # ... and their full-resolution phase (epoch 800: texel gradients through the texture bins, sub-ranges sized by demand)
+                for name, cfg_, st_ in (('c4', (8, 576, 768, 20, 16, 256), 20), ('c5', (25, 1080, 1920, 50, 16, 512), 5)):
+                    r = measure_other(*cfg_, dev, steps=st_, warmup=3, epoch=800)
+                    out['configs'][name]['full_resolution_phase'] = {k: r[k] for k in ('ms_per_step', 'views_per_s', 'whole_path_frac', 'steps')}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
