@@ -31,7 +31,6 @@ class NativeStep:
         self._target, self._target_key = None, None
         self._side, self.overlap_regularisers, self.side_priority = None, True, True
         self.regularisers_behind_fg = True
-        self._bin_demand = ops.BinDemand()    # full-resolution phases: the texture bins' record sub-ranges follow the previous step's demand
         self.binned_concurrent = None         # full-resolution phases: env backward chain next to the fg backward kernel instead of
                                               # behind it (None: on one GPU; 1.655 -> 1.635 and 1.017 -> 1.007 ms per step)
         # None: by configuration -- one after the other when the blocks' gradients are worth announcing early (data parallel: their
@@ -212,7 +211,7 @@ class NativeStep:
             torch.cuda.set_stream(side)
             st = st_side
             if cfg_f.texbins is not None:          # (full-resolution maps: the record sub-ranges of this step's backward, from the last step's demand)
-                self._bin_demand.prepare(cfg_f.texbins[2], ops.texbin_capacity(B, cfg_f.H, cfg_f.W, cfg_f.K, cfg_f.texbins[2]), dev)
+                cfg_f.bin_demand.prepare(cfg_f.texbins[2], ops.texbin_capacity(B, cfg_f.H, cfg_f.W, cfg_f.K, cfg_f.texbins[2]), dev)
             g_alpha_full = ops.ARENA.zeros(nb, torch.float32, dev)                                  # d / d alpha_full (parsimony, overlap)
             if 'parsimony' in w and coarse:
                 _lib.call('dbw_sqrt_mean', _p(alpha_full), nb, 1e-6, float(w['parsimony']) * rs, vals.data_ptr() + 4, _p(g_alpha_full), st)
@@ -244,7 +243,7 @@ class NativeStep:
 
         def fg_backward(st, after_kernel=None, with_textures=True):
             g_blk_maps, g_fa, g_fvc = ops._fused_bwd(p2f, bary, dists, cl_f, m._block_face_uvs_all, m._block_face_map_all, desc_f, blk_maps, fa,
-                                                     cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel, img_tiled=True, bin_demand=self._bin_demand)
+                                                     cfg_f, renderer._bg, 2, g_fg, B, None, after_kernel, img_tiled=True)
             fg_out.update(g_blk_maps=g_blk_maps, g_fa=g_fa)
             g_blk_verts = ops.project_clip_bwd(blk_verts, m._block_faces_all, R, T, Kmat, cl_f, g_fvc, cfg_f.eps, cfg_f.z_clip, cfg_f.persp)
             _lib.call('dbw_sq_blocks_bwd', _p(m.sq_eps), _p(m.S), _p(m.R_6d), _p(m.T), _p(m._trig), keep_p, 0, nb, nv, float(m.ratio_block_scene),

@@ -276,12 +276,13 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 # The whole Renderer.forward as ONE autograd node: verts/maps/faces_alpha -> (B,4,H,W)
 # ---------------------------------------------------------------------------------------------------------------------
 class RenderCfg:
-    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins', 'const_faces')
+    __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins', 'const_faces', 'bin_demand')
 
     def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None, const_faces=0):
         self.lds_aggregate = lds_aggregate
         self.const_faces = int(const_faces)   # the first that many faces have constant vertices (sky dome): no geometry gradient for them
         self.texbins = texbins          # (bin_base, bin_info, nbins): texture-space binning of texel gradients when not aggregating
+        self.bin_demand = None          # optional BinDemand of the caller (one per pass, kept across steps): record sub-ranges by demand
         self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
         self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
@@ -470,6 +471,8 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
     if bins is not None and bins[2] > 0:
         bin_base, bin_info, nbins = bins
         cap = texbin_capacity(B, cfg.H, cfg.W, cfg.K, nbins)
+        if bin_demand is None:
+            bin_demand = cfg.bin_demand
         if bin_demand is not None:
             cursor, layout = bin_demand.begin(nbins, cap, fvc.device)
         else:

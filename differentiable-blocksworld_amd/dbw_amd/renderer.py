@@ -99,8 +99,13 @@ class Renderer(nn.Module):
         H, W = self.img_size
         if viz:   # exact anti-aliased rendering for visualisation (renderer.py:56-60): 4x res, sigma 0, 1 face per pixel
             return ops.RenderCfg(H * 4, W * 4, 1, 0.0, self.z_clip, self.perspective_correct, False, n_faces, EPS)
-        return ops.RenderCfg(H, W, self.faces_per_pixel, self.sigma, self.z_clip, self.perspective_correct, self.detach_bary,
-                             n_faces, EPS, lds_aggregate, texbins, const_faces)
+        cfg = ops.RenderCfg(H, W, self.faces_per_pixel, self.sigma, self.z_clip, self.perspective_correct, self.detach_bary,
+                            n_faces, EPS, lds_aggregate, texbins, const_faces)
+        if texbins is not None:         # the texture bins' record sub-ranges follow the demand of this renderer's previous backward (ops.BinDemand)
+            if getattr(self, '_bin_demand', None) is None:
+                self._bin_demand = ops.BinDemand()
+            cfg.bin_demand = self._bin_demand
+        return cfg
 
     def render_packed(self, scene, R, T, faces_alpha=None, viz_purpose=False, lds_aggregate=False):
         """scene: PackedScene shared by the len(R) views.  lds_aggregate: hint for the backward pass (pays when neighbouring
