@@ -144,7 +144,7 @@ constexpr int BIN_SUB = DBW_BIN_SUBCURSORS;                 // sub-ranges (each 
                                                           // ~2000 reservations per launch, and returning atomics on ONE address serialise at
                                                           // ~0.2 us each (0.43 ms of a 0.86 ms kernel); 16 addresses per bin make that 16 chains
 #ifndef DBW_BIN_SUB_PER_WG
-#define DBW_BIN_SUB_PER_WG 4
+#define DBW_BIN_SUB_PER_WG 2
 #endif
 constexpr int BIN_SUB_PER_WG = DBW_BIN_SUB_PER_WG;                         // sub-ranges one texbin_reduce workgroup accumulates
 
@@ -974,8 +974,8 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 // patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
 // transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
 #ifndef DBW_BIN_STAGE
-#define DBW_BIN_STAGE 1024
-#endif
+#define DBW_BIN_STAGE 512       // (round 3: 1024 -> 512 records per batch and 4 -> 2 sub-ranges per workgroup: 43 instead of 60 KB of LDS, three
+#endif                          // workgroups per CU instead of two, eight per bin: 0.268 -> 0.236 ms at config 2; 256 records: 0.234)
 constexpr int BIN_STAGE = DBW_BIN_STAGE, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
 __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restrict__ bin_info, const int *__restrict__ cursor,
                                                             const int4 *__restrict__ records, int cap, const unsigned *__restrict__ layout,
