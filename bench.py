@@ -166,7 +166,7 @@ def kernel_breakdown(model, inp, reps=5):
         if alpha is not None and ops._alpha_len(alpha, scene.map_desc, cfg.F) < 0:     # one opacity per map: 64 partial sums each
             g_alpha = torch.zeros(alpha.numel() * ops.ALPHA_SPREAD, device=alpha.device)
         bins = scene.texbins if (ops.TEXTURE_BINS and not agg and scene.texbins is not None and scene.texbins[2] > 0) else None
-        bin_base = cursor = records = 0
+        bin_base = cursor = records = layout = 0
         cap = 0
         if bins is not None:                                               # same sizing as ops._RenderScene.backward
             nbins = bins[2]
@@ -174,6 +174,7 @@ def kernel_breakdown(model, inp, reps=5):
             cursor_t = torch.zeros(nbins * ops.BIN_SUBCURSORS, dtype=torch.int32, device=fvc.device)   # one cursor per record sub-range
             records_t = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
             bin_base, cursor, records = bins[0].data_ptr(), cursor_t.data_ptr(), records_t.data_ptr()
+            layout = ops.uniform_bin_layout(nbins, cap, fvc.device).data_ptr()            # equal shares (the step sizes them by demand)
 
         def bwd():
             if bins is not None:
@@ -181,11 +182,11 @@ def kernel_breakdown(model, inp, reps=5):
             _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps,
                                                                alpha, cfg.F, cfg.sigma, r._bg, (B, H, W, K)),
                       g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap, 0,
+                      0 if g_alpha is None else g_alpha.data_ptr(), g_fvc.data_ptr(), int(agg), mode, bin_base, cursor, records, cap, layout,
                       int(getattr(scene, 'const_faces', 0)), 0, 1, ops._stream(fvc))          # image_layout 1: the step's tiled images
 
         def reduce():
-            _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, 0, bins[2], g_maps.data_ptr(), ops._stream(fvc))
+            _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cursor, records, cap, layout, bins[2], g_maps.data_ptr(), ops._stream(fvc))
 
         def t(fn):
             fn()

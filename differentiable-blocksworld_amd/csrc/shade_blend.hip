@@ -148,18 +148,15 @@ constexpr int BIN_SUB = DBW_BIN_SUBCURSORS;                 // sub-ranges (each 
 #endif
 constexpr int BIN_SUB_PER_WG = DBW_BIN_SUB_PER_WG;                         // sub-ranges one texbin_reduce workgroup accumulates
 
-// the record sub-range (bin, sub): its first record in the record array and its capacity -- from the caller's layout table when there
-// is one (capacities that follow the demand of the previous launch, ops.py), else bin_cap / BIN_SUB records each, bins back to back
+// the record sub-range (bin, sub): its first record in the record array and its capacity, from the caller's layout table (equal shares
+// or capacities that follow the demand of the previous launch, ops.py).  ONE load and no alternative: a second way to the same two
+// values would put the wait for the load where the two meet, i.e. right here, and drain every load the layer loop has in flight
+// (0.467 -> 0.51 ms when the table was optional)
 struct SubRange { unsigned first; int cap; };
 __device__ __forceinline__ SubRange sub_range(const ShadeArgs &A, int bin, int sub) {
+    const uint2 l = *(const uint2 *)(A.bin_layout + ((long long)bin * BIN_SUB + sub) * 2);
     SubRange r;
-    if (A.bin_layout) {
-        const uint2 l = *(const uint2 *)(A.bin_layout + ((long long)bin * BIN_SUB + sub) * 2);
-        r.first = l.x; r.cap = (int)l.y;
-    } else {
-        const int sub_cap = A.bin_cap / BIN_SUB;
-        r.first = (unsigned)bin * (unsigned)A.bin_cap + (unsigned)sub * (unsigned)sub_cap; r.cap = sub_cap;
-    }
+    r.first = l.x; r.cap = (int)l.y;
     return r;
 }
 
@@ -603,7 +600,7 @@ __device__ __forceinline__ float seg_dist_t(f2 p, f2 a, f2 b, float &tt) {
 struct BinRes {            // reservation of one fragment's record: bin, rank among the wave's records of that bin, the lane that holds
     int bin, rank, leader, base, packed;   // `base` (it issued the atomic), and the footprint in the record's packed form
     float wx1, wy1;
-    unsigned first; int cap;               // (leader only) the sub-range the reservation was made in
+    uint2 lay;                             // (leader only) {first record, capacity} of the sub-range the reservation was made in
 };
 
 constexpr int ALPHA_DIRECT_MAPS = 64, ALPHA_DIRECT_SPREAD = 8;
@@ -616,6 +613,9 @@ constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_S
 #endif
 #ifndef DBW_FACE_MERGE
 #define DBW_FACE_MERGE 1
+#endif
+#ifndef DBW_FACE_MERGE_BINNED
+#define DBW_FACE_MERGE_BINNED 1
 #endif
 constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
 #ifndef DBW_UVB_WAVES
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     const int sub = tile & (BIN_SUB - 1);
     auto reserve = [&](const Raw &r, bool ok) {
         BinRes R;
-        R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f; R.first = 0u; R.cap = 0;
+        R.bin = -1; R.rank = 0; R.leader = 0; R.base = 0; R.packed = 0; R.wx1 = R.wy1 = 0.f; R.lay = make_uint2(0u, 0u);
         const float wgt = r.T * r.a;
         const bool tex = ok && (wgt * gr != 0.f || wgt * gg != 0.f || wgt * gbl != 0.f) && !(A.dbg & (1 << 19));      // (1 << 19: ablation of the whole record path)
         if (__ballot(tex) == 0ull) return R;
@@ -773,19 +773,18 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             const bool mine = on && R.bin == b;
             const unsigned long long mm = __ballot(mine);
             if (mine) { R.rank = __popcll(mm & below); R.leader = L; }
-            if (lane == L) {
-                if (!(A.dbg & (1 << 18))) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));     // (1 << 18: ablation, tools/diag)
-                const SubRange sr = sub_range(A, b, sub);
-                R.first = sr.first; R.cap = sr.cap;
-            }
+            if (lane == L && !(A.dbg & (1 << 18))) R.base = atomicAdd(A.bin_cursor + b * BIN_SUB + sub, __popcll(mm));     // (1 << 18: ablation, tools/diag)
             rem &= ~mm;
         }
+        // the leaders' sub-ranges: ONE masked load behind the loop, straight into the reservation's registers (inside the loop the
+        // compiler reuses those registers for the atomic's address and waits for the pending load first: vmcnt(0) per bin)
+        if (on && R.leader == lane) R.lay = *(const uint2 *)(A.bin_layout + ((long long)R.bin * BIN_SUB + sub) * 2);
         return R;
     };
     Raw nxt = load(kmax > 0 ? kmax - 1 : 0, kmax > 0 && kmax - 1 < cnt);
     Raw nxt2 = nxt;
     BinRes nres;
-    nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f; nres.first = 0u; nres.cap = 0;
+    nres.bin = -1; nres.rank = nres.leader = nres.base = nres.packed = 0; nres.wx1 = nres.wy1 = 0.f; nres.lay = make_uint2(0u, 0u);
     FaceXY nxtq;
     nxtq.v0 = nxtq.v1 = nxtq.v2 = make_float2(0.f, 0.f);
     constexpr bool PIPE = BINNED;      // the two-deep memory schedule (for decimated maps it measures 0.366 against 0.355 ms: not used there)
@@ -825,8 +824,8 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             // bin's halo) and bin overflow take the atomic path, so the result is exact either way
             if (__ballot(tex) != 0ull) {
                 // the leader's reservation: its first record in the record array, and the room left behind it in the sub-range
-                const unsigned start = (unsigned)__shfl((int)(cres.first + (unsigned)cres.base), cres.leader, 64);
-                const int room = __shfl(cres.cap - cres.base, cres.leader, 64);
+                const unsigned start = (unsigned)__shfl((int)(cres.lay.x + (unsigned)cres.base), cres.leader, 64);
+                const int room = __shfl((int)cres.lay.y - cres.base, cres.leader, 64);
                 bool pending = tex;
                 if (tex && cres.bin >= 0) {
                     if (cres.rank < room) {
@@ -928,7 +927,8 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
         }
 #endif
         bool f_on = valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2);
-        if (FACE_MERGE > 0 && __ballot(f_on) != 0ull) lane_merge<7, FACE_MERGE>(cur.fc, f_on, g7);
+        constexpr int FM = BINNED ? DBW_FACE_MERGE_BINNED : FACE_MERGE;
+        if (FM > 0 && __ballot(f_on) != 0ull) lane_merge<7, FM>(cur.fc, f_on, g7);
         if (f_on) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
@@ -982,16 +982,14 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                                                             float *__restrict__ gmaps) {
     __shared__ double tile[33 * 33 * 3];
     __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
-    const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG, sub_cap = cap / BIN_SUB;
+    const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG;
     int n_sub[BIN_SUB_PER_WG], total = 0;
     unsigned first[BIN_SUB_PER_WG];
 #pragma unroll
     for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
         const int ci = bin * BIN_SUB + sub0 + g;
-        int room = sub_cap;
-        first[g] = (unsigned)bin * (unsigned)cap + (unsigned)(sub0 + g) * (unsigned)sub_cap;
-        if (layout) { first[g] = layout[ci * 2]; room = (int)layout[ci * 2 + 1]; }
-        n_sub[g] = min(cursor[ci], room);
+        first[g] = layout[ci * 2];
+        n_sub[g] = min(cursor[ci], (int)layout[ci * 2 + 1]);
         total += n_sub[g];
     }
     if (total == 0) return;
@@ -1366,14 +1364,14 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     if (bin_records && !lds_aggregate) {
         A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap; A.bin_layout = bin_layout;
     }
-    DBW_REQUIRE(!bin_layout || bin_records, "bin_layout without texture bins");
+    DBW_REQUIRE(!bin_records || bin_layout, "texture bins need their layout table (bin_layout: dbw_bin_layout; equal shares: all counts 0)");
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
 }
 
 extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
                                  const uint32_t *bin_layout, int nbins, float *grad_maps, dbw_stream_t stream) {
-    DBW_REQUIRE(bin_info && bin_cursor && bin_records && grad_maps, "null pointer");
+    DBW_REQUIRE(bin_info && bin_cursor && bin_records && bin_layout && grad_maps, "null pointer");
     DBW_REQUIRE(bin_cap >= DBW_BIN_SUBCURSORS && nbins >= 0, "bad size");
     DBW_REQUIRE((long long)nbins * bin_cap < (1LL << 32), "the record array is indexed with 32 bits: nbins * bin_cap must stay below 2^32 (128 GB of records)");
     if (nbins == 0) return DBW_OK;

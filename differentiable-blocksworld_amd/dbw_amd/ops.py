@@ -406,6 +406,25 @@ class _RenderScene(torch.autograd.Function):
         return g_verts, g_maps, g_alpha, None, None, None, None, None, None, None, None, None
 
 
+_UNIFORM_LAYOUTS = {}
+
+
+def uniform_bin_layout(nbins, cap, device):
+    """The layout table of equal shares (include/dbw_hip.h: bin_layout): nbins * cap records divided evenly over the sub-ranges;
+    computed once per geometry (dbw_bin_layout on an all-zero demand) and kept."""
+    device = torch.device(device)
+    key = (nbins, cap, device)
+    lay = _UNIFORM_LAYOUTS.get(key)
+    if lay is None:
+        n = nbins * bin_subcursors()
+        lay = torch.zeros(n, 2, dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.call('dbw_bin_layout', _ptr(torch.zeros(n, dtype=torch.int32, device=device)), n, float(nbins) * float(cap), 1, _ptr(lay),
+                      torch.cuda.current_stream(device).cuda_stream)
+        _UNIFORM_LAYOUTS[key] = lay
+    return lay
+
+
 class BinDemand:
     """Record sub-ranges of the texture bins sized by demand (include/dbw_hip.h: bin_layout, dbw_bin_layout).  After a backward pass
     bin_cursor holds how many records every sub-range was asked for; a caller that runs the same pass step after step
@@ -477,6 +496,8 @@ def _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg
             cursor, layout = bin_demand.begin(nbins, cap, fvc.device)
         else:
             cursor = ARENA.zeros(nbins * bin_subcursors(), torch.int32, fvc.device)
+        if layout is None:
+            layout = uniform_bin_layout(nbins, cap, fvc.device)         # (first launch, or a caller that keeps no demand: equal shares)
         records = torch.empty(nbins * cap * 8, dtype=torch.int32, device=fvc.device)
     _lib.call('dbw_render_bwd_fused', *_shade_args(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg.F, cfg.sigma, bg,
                                                    (B, cfg.H, cfg.W, cfg.K)),

@@ -216,12 +216,11 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
  * const_geometry_faces: the first that many faces of the scene (original indexing) have constant vertices -- the sky dome of the env
  * scene (dbw.py:74-76: a buffer, not a parameter) -- so nothing is propagated through their barycentrics and their rows of
  * grad_face_verts_c stay untouched; 0 = every face gets its geometry gradient.
- * bin_layout (optional, device, (nbins * DBW_BIN_SUBCURSORS, 2) uint32): {first record, capacity} of every sub-range inside
- * bin_records, for callers that size the sub-ranges by demand -- after a launch bin_cursor holds how many records every sub-range was
+ * bin_layout (device, (nbins * DBW_BIN_SUBCURSORS, 2) uint32; required with texture bins): {first record, capacity} of every sub-range
+ * inside bin_records, from dbw_bin_layout -- equal shares (all-zero demand) or sized by demand: after a launch bin_cursor holds how many records every sub-range was
  * ASKED for, whether they fitted or not, so the next launch can give each what it needs out of the same total (ops.py does that:
- * with equal shares a large scene overflows its hot bins and 56 of 66 ms of config 5's backward were fallback atomics).  NULL = equal
- * shares of bin_cap / DBW_BIN_SUBCURSORS records, bins back to back.  Both calls of a pass get the same table; records are indexed
- * with 32 bits (nbins * bin_cap < 2^32).
+ * with equal shares a large scene overflows its hot bins and 56 of 66 ms of config 5's backward were fallback atomics).  Both calls of
+ * a pass get the same table; records are indexed with 32 bits (nbins * bin_cap < 2^32).
  * grad_scale: DEVICE scalar every value of grad_image is multiplied by (the upstream gradient of a loss node, so that no
  * elementwise pass over the image-sized gradient is needed), NULL = 1. */
 int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o,

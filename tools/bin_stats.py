@@ -29,7 +29,7 @@ cap = ops.texbin_capacity(B, H, W, K, nbins)
 cursor = torch.zeros(nbins * ops.BIN_SUBCURSORS, dtype=torch.int32, device=dev); records = torch.zeros(nbins * cap * 8, dtype=torch.int32, device=dev)
 _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
           cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-          g_alpha.data_ptr(), g_fvc.data_ptr(), 0, 2, bins[0].data_ptr(), cursor.data_ptr(), records.data_ptr(), cap, 0, 0, 0, 0, ops._stream(fvc))
+          g_alpha.data_ptr(), g_fvc.data_ptr(), 0, 2, bins[0].data_ptr(), cursor.data_ptr(), records.data_ptr(), cap, ops.uniform_bin_layout(nbins, cap, dev).data_ptr(), 0, 0, 0, ops._stream(fvc))
 torch.cuda.synchronize()
 c = cursor.view(nbins, -1).clamp(max=cap // ops.BIN_SUBCURSORS).sum(1).cpu()        # (records sit in BIN_SUBCURSORS sub-ranges of each bin)
 print('records', int(c.sum()), 'max', int(c.max()), 'nonempty bins', int((c > 0).sum()), 'top10', sorted(c.tolist())[-10:])

@@ -30,6 +30,7 @@ g_alpha = torch.zeros(alpha.numel() * ops.ALPHA_SPREAD, device=dev)
 bins = scene.texbins; nbins = bins[2]
 cap = ops.texbin_capacity(B, H, W, K, nbins)
 sets = [(torch.zeros(nbins * ops.BIN_SUBCURSORS, dtype=torch.int32, device=dev), torch.empty(nbins * cap * 8, dtype=torch.int32, device=dev)) for _ in range(2)]
+LAY = ops.uniform_bin_layout(nbins, cap, dev)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
 def bwd(i, stream):
@@ -38,12 +39,12 @@ def bwd(i, stream):
         cur.zero_()
         _lib.call('dbw_render_bwd_fused', *ops._shade_args(p2f, bary, dists, cl, scene.face_uvs, scene.face_map, scene.map_desc, maps, alpha, cfg.F,
                   cfg.sigma, r._bg, (B, H, W, K)), g_img.data_ptr(), fvc.data_ptr(), int(cfg.persp), int(cfg.detach_bary), g_maps.data_ptr(),
-                  g_alpha.data_ptr(), g_fvc.data_ptr(), 0, 2, bins[0].data_ptr(), cur.data_ptr(), rec.data_ptr(), cap, 0, 0, 0, 0, stream.cuda_stream)
+                  g_alpha.data_ptr(), g_fvc.data_ptr(), 0, 2, bins[0].data_ptr(), cur.data_ptr(), rec.data_ptr(), cap, LAY.data_ptr(), 0, 0, 0, stream.cuda_stream)
 
 def reduce(i, stream):
     cur, rec = sets[i]
     with torch.cuda.stream(stream):
-        _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cur.data_ptr(), rec.data_ptr(), cap, 0, nbins, g_maps.data_ptr(), stream.cuda_stream)
+        _lib.call('dbw_texbin_reduce', bins[1].data_ptr(), cur.data_ptr(), rec.data_ptr(), cap, LAY.data_ptr(), nbins, g_maps.data_ptr(), stream.cuda_stream)
 
 def timed(fn, reps=5):
     fn(); torch.cuda.synchronize()
