@@ -596,7 +596,8 @@ __device__ __forceinline__ float seg_dist_t(f2 p, f2 a, f2 b, float &tt) {
 // returning atomic per distinct bin (an 8x8-pixel patch of one layer touches one to four 32x32-texel bins), software-pipelined one
 // layer ahead of its use: the fragments are loaded two layers ahead, the reservation for layer k - 1 is issued at the top of
 // iteration k and its result is first looked at in iteration k - 1.  A fragment carries T and its blend opacity, so whether it emits a
-// record at all (weight * pixel gradient != 0) is known without the back-to-front recurrences.
+// record at all (weight * pixel gradient != 0) is known without the back-to-front recurrences.  Where a sub-range lies in the record
+// array and how much it holds comes from the caller's layout table (include/dbw_hip.h: bin_layout -- equal shares or by demand).
 struct BinRes {            // reservation of one fragment's record: bin, rank among the wave's records of that bin, the lane that holds
     int bin, rank, leader, base, packed;   // `base` (it issued the atomic), and the footprint in the record's packed form
     float wx1, wy1;
