@@ -2,6 +2,8 @@
 # round-3 evidence: per-kernel rocprofv3 stats of the three training phases and of configs 4 / 5, one step's kernel sequence, the bench
 # line, SQ / HBM counters (separate --pmc passes), cycle accounting of the fused forward.  Run on the GPU box; copies go to profiles/.
 O=gpurun_out/r03; mkdir -p $O; export TMPDIR=/tmp
+# (the cycle-accounting build must be of the same sources as the library: rebuild it when it is older)
+[ tools/variants/fprof.so -nt differentiable-blocksworld_amd/dbw_amd/libdbw_hip.so ] || tools/variants.sh fprof "-DDBW_PROFILE_FWD" > /dev/null 2>&1
 for e in 0 800 1600; do
   rocprofv3 --kernel-trace -d $O/t$e -o p --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --epoch $e > $O/t$e.log 2>&1
   csv=$(find $O/t$e -name "*kernel_trace.csv" | head -1)
