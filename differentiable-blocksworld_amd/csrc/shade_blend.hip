@@ -1393,10 +1393,12 @@ __global__ __launch_bounds__(1024) void bin_layout_kernel(const int *__restrict_
     s_sum[t] = mine;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) { if (t < o) s_sum[t] += s_sum[t + o]; __syncthreads(); }
-    const double scale = total / s_sum[0];
+    // one record per sub-range is set aside before the rest is divided in proportion: the floor of a share below 1 used to be raised
+    // to 1 AFTER scaling, so the capacities of a very skewed demand could add up to more than `total`
+    const double scale = (total - (double)n) / s_sum[0];
     __syncthreads();
     double caps = 0.0;
-    for (long long i = i0; i < i1; ++i) caps += max(floor((double)max(asked[i], min_records) * 1.25 * scale), 1.0);
+    for (long long i = i0; i < i1; ++i) caps += 1.0 + floor((double)max(asked[i], min_records) * 1.25 * scale);
     s_sum[t] = caps;
     __syncthreads();
     // exclusive scan of the 1024 piece totals (Hillis-Steele in place, double buffered by the barrier pairs)
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(1024) void bin_layout_kernel(const int *__restrict_
     }
     double first = s_sum[t] - caps;
     for (long long i = i0; i < i1; ++i) {
-        const double c = max(floor((double)max(asked[i], min_records) * 1.25 * scale), 1.0);
+        const double c = 1.0 + floor((double)max(asked[i], min_records) * 1.25 * scale);
         layout[i * 2] = (unsigned)(long long)first;
         layout[i * 2 + 1] = (unsigned)(long long)c;
         first += c;

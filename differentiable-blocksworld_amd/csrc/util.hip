@@ -25,4 +25,4 @@ int dbw_check_launch(const char *what) {
 
 extern "C" const char *dbw_last_error(void) { return g_err; }
 extern "C" int dbw_bin_subcursors(void) { return DBW_BIN_SUBCURSORS; }
-extern "C" int dbw_abi_version(void) { return 3; }      // 2: image_layout argument of the fused render entry points; 3: bin_layout
+extern "C" int dbw_abi_version(void) { return DBW_ABI_VERSION; }      // (history: include/dbw_hip.h)

@@ -9,6 +9,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdbw_hip.so')
 _lib = None
 
+
+def _header_abi_version():
+    """DBW_ABI_VERSION of include/dbw_hip.h: the one place the revision is written down (csrc/util.hip returns it, tests/test_abi.py and
+    __graft_entry__.build() compare the loaded library with it)."""
+    import re
+    with open(os.path.join(_HERE, '..', '..', 'include', 'dbw_hip.h')) as f:
+        return int(re.search(r'#define DBW_ABI_VERSION (\d+)', f.read()).group(1))
+
+
+ABI_VERSION = _header_abi_version()
+
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_f = ctypes.c_float
@@ -95,6 +106,9 @@ def load():
     lib = ctypes.CDLL(os.environ.get('DBW_HIP_LIB') or LIB_PATH)
     lib.dbw_last_error.restype = ctypes.c_char_p
     lib.dbw_abi_version.restype = c_i
+    if not os.environ.get('DBW_HIP_LIB') and lib.dbw_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'{LIB_PATH} was built for ABI {lib.dbw_abi_version()}, include/dbw_hip.h declares {ABI_VERSION}: rebuild '
+                           '(python differentiable-blocksworld_amd/build.py --force)')
     if hasattr(lib, 'dbw_bin_subcursors'):      # (absent from tuning builds of older sources, tools/variants.sh: 16 there)
         lib.dbw_bin_subcursors.restype = c_i
     lib.dbw_rasterize_workspace_bytes.restype = c_sz

@@ -404,6 +404,29 @@ class DifferentiableBlocksWorld(nn.Module):
             torch.cuda.current_stream().wait_stream(self._side_stream)
         return fg, env
 
+    def _host_packed_rebuild(self):
+        """Context of a visualisation-only rebuild of the scene with the kept blocks packed on the host (sync_free off): the per-step state
+        the last forward cached (`_alpha`, `_alpha_full`, the maps, the keep mask -- a later compute_losses reads them) is put back
+        afterwards, and the opacity noise of the rebuild is the forward's or none: the shared default generator, which the data-parallel
+        ranks advance in lock step, is not touched."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            names = ('_alpha', '_alpha_full', '_blocks_maps', '_bkg_maps', '_ground_maps', '_keep_mask', '_blocks_decimated')
+            saved = {n: getattr(self, n) for n in names if hasattr(self, n)}
+            sf, nz, on = self.sync_free, self._noise_override, self.opacity_noise
+            self.sync_free = False
+            if self._noise_override is None:
+                self.opacity_noise = False
+            try:
+                yield
+            finally:
+                self.sync_free, self._noise_override, self.opacity_noise = sf, nz, on
+                for n, v in saved.items():
+                    setattr(self, n, v)
+        return ctx()
+
     def predict(self, inp, labels=None, w_edges=False, filter_transparent=False):
         if self.decouple_rendering:
             fg, env = self.render_layers(inp, filter_transparent)
@@ -416,11 +439,8 @@ class DifferentiableBlocksWorld(nn.Module):
             with torch.no_grad():
                 # host-packed scene (only the kept blocks): the colour table below has one row per KEPT face, while the sync-free
                 # scene of the training path keeps all n_blocks blocks (culled ones collapsed to a point) and its face ids run over all
-                sf, self.sync_free = self.sync_free, False
-                try:
+                with self._host_packed_rebuild():
                     scene = self.build_scene(filter_transparent=filter_tsp)
-                finally:
-                    self.sync_free = sf
                 colors = self.get_scene_face_colors(filter_transparent=filter_tsp).repeat(len(inp['R']), 1)
                 renderer = self.renderer_fine if fine else self.renderer
                 rec = renderer.draw_edges(rec, scene, inp['R'], inp['T'], colors=colors)
@@ -433,11 +453,8 @@ class DifferentiableBlocksWorld(nn.Module):
         self._ensure_cameras(inp)
         was_training = self.training
         self.eval()
-        sf, self.sync_free = self.sync_free, False         # host-packed: `colors` / `desc` below hold the kept blocks only
-        try:
+        with self._host_packed_rebuild():                  # host-packed: `colors` / `desc` below hold the kept blocks only
             blocks = self.build_blocks_scene(filter_transparent=True)
-        finally:
-            self.sync_free = sf
         self.train(was_training)
         if blocks is None:
             return torch.ones_like(inp['imgs'])

@@ -310,7 +310,7 @@ def tile_image(img):
     ty, tx = (H + 7) // 8, (W + 7) // 8
     if (H, W) != (ty * 8, tx * 8):
         img = torch.nn.functional.pad(img, (0, tx * 8 - W, 0, ty * 8 - H))
-    return img.view(B, C, ty, 8, tx, 8).permute(0, 2, 4, 1, 3, 5).reshape(B, ty, tx, C, 64).contiguous()
+    return img.reshape(B, C, ty, 8, tx, 8).permute(0, 2, 4, 1, 3, 5).reshape(B, ty, tx, C, 64).contiguous()      # (reshape: imgs may be a strided view)
 
 
 def untile_image(t, H, W):

@@ -25,6 +25,10 @@
                                  * built with: dbw_bin_subcursors() */
 #endif
 
+/* ABI revision of this header (dbw_abi_version() returns the value the library was built with).  2: image_layout argument of the fused
+ * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry) */
+#define DBW_ABI_VERSION 3
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -236,7 +240,7 @@ int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const fl
 int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
                       const uint32_t *bin_layout, int nbins, float *grad_maps, dbw_stream_t stream);
 /* bin_layout by demand: asked (n = nbins * DBW_BIN_SUBCURSORS) = the bin_cursor of an earlier launch of the same pass -> layout (n, 2):
- * capacity_i = floor(max(asked_i, min_records) * 1.25 * scale) (at least 1), scale such that the capacities add up to at most
+ * capacity_i = 1 + floor(max(asked_i, min_records) * 1.25 * scale), scale = (total_records - n) / sum: the capacities add up to at most
  * total_records (< 2^32; a caller passes nbins * bin_cap: the memory of the equal shares); first_i = sum of the capacities before i. */
 int dbw_bin_layout(const int32_t *asked, int64_t n, double total_records, int min_records, uint32_t *layout, dbw_stream_t stream);
 

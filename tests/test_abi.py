@@ -35,7 +35,7 @@ def parse_header():
 def test_library_builds_and_loads_without_gpu():
     lib = _lib.load()
     assert os.path.exists(_lib.LIB_PATH)
-    assert lib.dbw_abi_version() == 3
+    assert lib.dbw_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define DBW_ABI_VERSION (\d+)', open(HEADER).read()).group(1))
     assert lib.dbw_last_error() is not None
 
 
@@ -73,3 +73,14 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'null pointer' in lib.dbw_last_error()
     with pytest.raises(RuntimeError, match='null pointer'):
         _lib.call('dbw_tv_l2sq', 0, 1, 4, 4, 0, 1.0, 0, 0, 0)
+
+
+def test_graft_entry_build_runs_on_the_committed_tree():
+    """The driver's "does it build" check: __graft_entry__.build() compiles (or finds up to date) every HIP source and the CPU oracle and
+    returns the library; it used to assert a stale ABI literal."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_graft_entry_under_test', os.path.join(ROOT, '__graft_entry__.py'))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    so = ge.build()
+    assert os.path.exists(so) and so.endswith('libdbw_hip.so')
