@@ -26,12 +26,15 @@ struct Proj {
     f3 ndc;             // x,y NDC, z = view depth
 };
 
+// view depth of a world point: the one quantity near-plane clipping classifies a vertex by (clip_emit_count)
+DBW_HD float view_z(const float *X, const Cam &c) { return X[0] * c.R[2] + X[1] * c.R[5] + X[2] * c.R[8] + c.T[2]; }
+
 DBW_HD Proj project(const float *X, const Cam &c, float eps) {
     Proj o;
     const float x = X[0], y = X[1], z = X[2];
     o.vx = x * c.R[0] + y * c.R[3] + z * c.R[6] + c.T[0];
     o.vy = x * c.R[1] + y * c.R[4] + z * c.R[7] + c.T[1];
-    o.vz = x * c.R[2] + y * c.R[5] + z * c.R[8] + c.T[2];
+    o.vz = view_z(X, c);
     o.px = o.vx * c.K[0] + o.vy * c.K[1] + o.vz * c.K[2] + c.K[3];
     o.py = o.vx * c.K[4] + o.vy * c.K[5] + o.vz * c.K[6] + c.K[7];
     o.pw = o.vx * c.K[12] + o.vy * c.K[13] + o.vz * c.K[14] + c.K[15];
@@ -92,6 +95,12 @@ DBW_HD void clip_face(const f3 p[3], int zc_on, float zc, int persp, ClippedFace
         o.t1[0] = p5; o.t1[1] = p2; o.t1[2] = p3;
         o.code0 = i1 | (1 << 2); o.code1 = i1 | (2 << 2);
     }
+}
+
+// number of triangles clip_face emits for a face whose vertices have view depths z0, z1, z2 (its `emit`, without the rest)
+DBW_HD int clip_emit_count(float z0, float z1, float z2, int zc_on, float zc) {
+    const int nbh = (zc_on && z0 < zc ? 1 : 0) + (zc_on && z1 < zc ? 1 : 0) + (zc_on && z2 < zc ? 1 : 0);
+    return nbh == 0 ? 1 : (nbh == 3 ? 0 : (nbh == 2 ? 1 : 2));
 }
 
 // d(ndc vertex)/d(world vertex): the world-space gradient of one vertex of one view

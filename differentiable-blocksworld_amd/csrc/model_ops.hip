@@ -6,6 +6,9 @@
 // (~0.1 MFLOP per step, matrix cores do not pay).
 #include "dbw_common.h"
 #include "model_math.h"
+#include "rng_math.h"
+#include "texture_body.h"
+#include "step_kernels.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -102,13 +105,15 @@ struct BlockP {
     float e1, e2, sr[3], R[9], T[3], alpha;   // sr = S*ratio
 };
 
-__global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, const float *sq_eps, const float *S,
-                                                      const float *R6, const float *T, const float *alpha, int Kb,
-                                                      float ratio, float scale_min, float inv_temp, float thresh,
-                                                      float scale_over_P, float *loss, float *ws) {
-    __shared__ BlockP s_b[MAX_KB];
-    __shared__ float s_g[MAX_KB * NG];
-    __shared__ float s_red[4];
+// one workgroup of the overlap term: 256 sample points against every block.  u == nullptr: the samples are drawn in registers
+// (rng_math.h: stream 1 of (seed, rng_step), index = the point) instead of being read from a caller's torch.rand buffer
+struct OverlapShared { BlockP b[MAX_KB]; float g[MAX_KB * NG]; float red[4]; };
+__device__ __forceinline__ void overlap_block(const float *u, unsigned long long seed, unsigned long long rng_step, int npts, const float *sq_eps,
+                                              const float *S, const float *R6, const float *T, const float *alpha, int Kb, float ratio,
+                                              float scale_min, float inv_temp, float thresh, float scale_over_P, float *loss, float *ws,
+                                              OverlapShared &sh) {
+    BlockP *s_b = sh.b;
+    float *s_g = sh.g, *s_red = sh.red;
     for (int j = threadIdx.x; j < Kb; j += blockDim.x) {
         Pose p;
         load_pose(sq_eps, S, R6, T, j, scale_min, p);
@@ -125,7 +130,13 @@ __global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, 
         const int k = (int)(pi / npts);
         const BlockP &bk = s_b[k];
         float l[3], pt[3];
-        for (int i = 0; i < 3; ++i) l[i] = (u[pi * 3 + i] * 2.f - 1.f) * bk.sr[i];
+        float u3[3];
+        if (u) { u3[0] = u[pi * 3]; u3[1] = u[pi * 3 + 1]; u3[2] = u[pi * 3 + 2]; }
+        else {
+            const Philox4 r = step_random(seed, rng_step, 1u, (uint32_t)pi);
+            u3[0] = uniform01(r.x); u3[1] = uniform01(r.y); u3[2] = uniform01(r.z);
+        }
+        for (int i = 0; i < 3; ++i) l[i] = (u3[i] * 2.f - 1.f) * bk.sr[i];
         for (int c = 0; c < 3; ++c) pt[c] = l[0] * bk.R[c] + l[1] * bk.R[3 + c] + l[2] * bk.R[6 + c] + bk.T[c];
         float sum = 0.f;
         for (int pass = 0; pass < 2; ++pass) {
@@ -175,6 +186,52 @@ __global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, 
     }
     for (int i = threadIdx.x; i < Kb * NG; i += blockDim.x)
         if (s_g[i] != 0.f) unsafeAtomicAdd(ws + i, s_g[i]);
+}
+
+__global__ __launch_bounds__(256) void overlap_kernel(const float *u, int npts, const float *sq_eps, const float *S,
+                                                      const float *R6, const float *T, const float *alpha, int Kb,
+                                                      float ratio, float scale_min, float inv_temp, float thresh,
+                                                      float scale_over_P, float *loss, float *ws) {
+    __shared__ OverlapShared sh;
+    overlap_block(u, 0ull, 0ull, npts, sq_eps, S, R6, T, alpha, Kb, ratio, scale_min, inv_temp, thresh, scale_over_P, loss, ws, sh);
+}
+
+// The regularisers of a training step in ONE launch: the overlap term, then -- in the workgroup that finishes last -- its per-block
+// finish (raw accumulators -> parameter gradients) and the parsimony term; both add into g_alpha_full, one after the other in one thread.
+__global__ __launch_bounds__(256) void regularisers_kernel(const RegulariserArgs A) {
+    __shared__ OverlapShared sh;
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const bool overlap = A.overlap_scale != 0.f;
+    if (overlap) {
+        const long long P = (long long)A.nb * A.npts;
+        overlap_block(A.u, A.seed, A.rng_step, A.npts, A.sq_eps, A.S, A.R6, A.T, A.alpha_full, A.nb, A.ratio, A.scale_min, A.inv_temp, A.thresh,
+                      A.overlap_scale / (float)P, A.loss_overlap, A.ws, sh);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (overlap && tid < A.nb) {
+        Pose p;
+        load_pose(A.sq_eps, A.S, A.R6, A.T, tid, A.scale_min, p);
+        finish_pose_grads(p, A.S, tid, A.ws + tid * NG, A.g_sq_eps, A.g_S, A.g_R6, A.g_T);
+        A.g_alpha_full[tid] += A.ws[tid * NG + 17];
+    }
+    __syncthreads();
+    if (A.pars_scale != 0.f && tid < 64) {          // (sqrt_mean_kernel: loss += scale * mean(max(x, eps)^0.5))
+        float acc = 0.f;
+        for (int i = tid; i < A.nb; i += 64) {
+            const float v = A.alpha_full[i], c = v > A.pars_eps ? v : A.pars_eps, r = sqrtf(c);
+            acc += r;
+            if (v > A.pars_eps) A.g_alpha_full[i] += A.pars_scale * 0.5f / r / (float)A.nb;
+        }
+        acc = dbw::wave_sum(acc);
+        if (tid == 0) unsafeAtomicAdd(A.loss_parsimony, A.pars_scale * acc / (float)A.nb);
+    }
+    if (tid == 0) *A.ticket = 0u;
 }
 
 __global__ void overlap_finish_kernel(const float *sq_eps, const float *S, const float *R6, const float *T, int Kb,
@@ -227,7 +284,79 @@ __global__ void sqrt_mean_kernel(const float *x, int n, float eps, float scale, 
     if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, scale * acc / (float)n);
 }
 
+// The head of a training step in ONE launch (step_kernels.h): blockIdx.y < nsets -> sigmoid / decimation of texture set y (grid-stride
+// over x); blockIdx.y == nsets -> x < nb: opacity + vertices of block x, x == nb: the ground's vertices and the clearing of the small
+// gradient accumulators.  The same device functions as the stand-alone kernels, so the same bits.
+__global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P) {
+    if ((int)blockIdx.y < P.nsets) {
+        const dbw_texture_set &t = P.tex.s[blockIdx.y];
+        texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig);
+        return;
+    }
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (k < P.nb) {
+        // dbw.py:297-311 (block_alpha_fwd_kernel); every thread evaluates the block's mask, thread 0 writes
+        const float lg = P.alpha_logit[k];
+        float nz = 0.f;
+        if (P.noise_scale != 0.f) {
+            if (P.noise) nz = P.noise[k];
+            else { const Philox4 r = step_random(P.seed, P.rng_step, 0u, (uint32_t)k); nz = normal01(r.x, r.y); }
+        }
+        const float x = lg + (P.noise_scale != 0.f ? P.noise_scale * nz : 0.f);
+        const float a = 1.f / (1.f + expf(-x));
+        int m = 1;
+        if (P.thresh >= 0.f) m = (1.f / (1.f + expf(-lg))) > P.thresh ? 1 : 0;
+        if (tid == 0) { P.alpha[k] = a; P.alpha_full[k] = m ? a : 0.f; P.keep[k] = m; }
+        if (!m) {            // a dead block collapses to one point: zero-area faces, dropped by the rasteriser (sq_blocks_fwd_kernel, dense = 0)
+            for (int v = tid; v < P.nv * 3; v += blockDim.x) P.blk_verts[(long long)k * P.nv * 3 + v] = 0.f;
+            return;
+        }
+        Pose p;
+        load_pose(P.sq_eps, P.S, P.R6, P.T, k, P.scale_min, p);
+        const long long plane = (long long)P.nb * P.nv;
+        for (int v = tid; v < P.nv; v += blockDim.x) {
+            const long long o = (long long)k * P.nv + v;
+            float loc[3], de1[3], de2[3];
+            parametric_sq_point(P.trig[o], P.trig[plane + o], P.trig[2 * plane + o], P.trig[3 * plane + o], p.e1, p.e2, P.ratio, loc, de1, de2);
+            pose_fwd(p, loc, P.S_world, P.Rw, P.Tw, P.blk_verts + o * 3);
+        }
+    } else if (k == P.nb) {
+        Pose p;
+        load_pose(nullptr, nullptr, P.R6g, P.Tg, 0, 0.f, p);
+        for (int v = tid; v < P.ngv; v += blockDim.x) pose_fwd(p, P.ground_base + (long long)v * 3, P.S_world, P.Rw, P.Tw, P.ground_verts + (long long)v * 3);
+        for (int i = tid; i < P.nzero0; i += blockDim.x) P.zero0[i] = 0.f;
+    }
+}
+
 }  // namespace
+
+int dbw::launch_step_prologue(const PrologueArgs &P, hipStream_t s) {
+    DBW_REQUIRE(P.nsets >= 0 && P.nsets <= STEP_MAX_SETS && P.nb > 0 && P.nb <= MAX_KB && P.nv > 0 && P.ngv > 0, "bad size");
+    long long work = (long long)(P.nb + 1) * 256;
+    for (int i = 0; i < P.nsets; ++i) {
+        const dbw_texture_set &t = P.tex.s[i];
+        DBW_REQUIRE(t.texture && t.maps && t.n > 0 && t.h > 1 && t.w > 1 && t.decim >= 1 && (t.decim == 1 || (t.sig && t.h % t.decim == 0 && t.w % t.decim == 0)),
+                    "bad texture set");
+        const long long wk = t.decim > 1 ? (long long)t.n * (t.h / t.decim) * (t.w / t.decim) * 64 : (long long)t.n * t.h * t.w * 3;
+        work = wk > work ? wk : work;
+    }
+    long long gx = (work + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    if (gx < P.nb + 1) gx = P.nb + 1;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)gx, (unsigned)(P.nsets + 1)), dim3(256), 0, s, P);
+    return dbw_check_launch("step_prologue_kernel");
+}
+
+int dbw::launch_regularisers(const RegulariserArgs &A, hipStream_t s) {
+    DBW_REQUIRE(A.nb > 0 && A.nb <= MAX_KB && A.ticket && A.g_alpha_full && A.alpha_full, "bad argument");
+    const bool overlap = A.overlap_scale != 0.f;
+    if (!overlap && A.pars_scale == 0.f) return DBW_OK;
+    DBW_REQUIRE(!overlap || (A.npts > 0 && A.ws && A.loss_overlap && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.inv_temp > 0.f), "bad overlap argument");
+    DBW_REQUIRE(A.pars_scale == 0.f || A.loss_parsimony, "bad parsimony argument");
+    const long long P = (long long)A.nb * A.npts;
+    hipLaunchKernelGGL(regularisers_kernel, dim3(overlap ? (unsigned)((P + 255) / 256) : 1u), dim3(256), 0, s, A);
+    return dbw_check_launch("regularisers_kernel");
+}
 
 extern "C" int dbw_block_alpha_fwd(const float *alpha_logit, const float *noise, float noise_scale, float mask_threshold, int Kb,
                                    float *alpha, float *alpha_full, int32_t *keep, dbw_stream_t stream) {

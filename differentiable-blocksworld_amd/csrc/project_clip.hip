@@ -9,6 +9,10 @@
 // or 2 triangles) assigns output slots in original face order, and each thread writes its own triangles.
 #include "dbw_common.h"
 #include "camera_math.h"
+#include "model_math.h"
+#include "shade_common.h"
+#include "raster_bin.h"
+#include "step_kernels.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -79,12 +83,11 @@ __global__ __launch_bounds__(NT) void project_clip_fwd_kernel(
 // (env pass: 395 k atomics on 730 addresses, 30 us); now they meet in LDS and each workgroup flushes every touched component once.
 constexpr int BWD_SLOTS = 8;           // clipped-face slots per workgroup (LDS_TABLE)
 template <bool LDS_TABLE>
-__global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
+__device__ __forceinline__ void project_clip_bwd_body(
     const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
     const float *__restrict__ T, const float *__restrict__ Kmat, int B, int V, int F, float eps, float zc, int persp,
     const int *__restrict__ num_faces, const int *__restrict__ c2o, const int *__restrict__ code,
-    const float *__restrict__ cw, const float *__restrict__ gfvc, float *__restrict__ gverts) {
-    extern __shared__ float s_acc[];   // LDS_TABLE: V * 3
+    const float *__restrict__ cw, const float *__restrict__ gfvc, float *gverts, float *s_acc, int blk) {
     const int lane = threadIdx.x & 63;
     if (LDS_TABLE) {
         for (int i = threadIdx.x; i < V * 3; i += NT) s_acc[i] = 0.f;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     }
     constexpr int WAVES = NT / DBW_WAVE, ITERS = LDS_TABLE ? BWD_SLOTS / WAVES : 1;
     for (int it = 0; it < ITERS; ++it) {
-    const int j = LDS_TABLE ? blockIdx.x * BWD_SLOTS + it * WAVES + (threadIdx.x >> 6) : blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int j = LDS_TABLE ? blk * BWD_SLOTS + it * WAVES + (threadIdx.x >> 6) : blk * WAVES + (threadIdx.x >> 6);
     if (j >= 2 * F) break;
     for (int b0 = 0; b0 < B; b0 += DBW_WAVE) {
         const int b = b0 + lane;
@@ -185,7 +188,199 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     }
 }
 
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
+    const float *__restrict__ verts, const int *__restrict__ faces, const float *__restrict__ R,
+    const float *__restrict__ T, const float *__restrict__ Kmat, int B, int V, int F, float eps, float zc, int persp,
+    const int *__restrict__ num_faces, const int *__restrict__ c2o, const int *__restrict__ code,
+    const float *__restrict__ cw, const float *__restrict__ gfvc, float *__restrict__ gverts) {
+    extern __shared__ float s_acc[];   // LDS_TABLE: V * 3
+    project_clip_bwd_body<LDS_TABLE>(verts, faces, R, T, Kmat, B, V, F, eps, zc, persp, num_faces, c2o, code, cw, gfvc, gverts, s_acc, blockIdx.x);
+}
+
+// ---- training step: backward of projection + clipping of one scene, then, in the workgroup that finishes last, what used to be the
+// next launches of the chain: the backward of the pose / shape parameters (step_kernels.h: SceneTailArgs) --------------------------------
+__global__ __launch_bounds__(NT) void scene_tail_kernel(const SceneTailArgs A) {
+    extern __shared__ float s_acc[];   // V * 3
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    project_clip_bwd_body<true>(A.verts, A.faces, A.camR, A.camT, A.Kmat, A.B, A.V, A.F, A.cam_eps, A.zc, A.persp, A.num_faces, A.c2o, A.code, A.cw,
+                                A.gfvc, A.g_verts, s_acc, blockIdx.x);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                   // every workgroup's flush is visible: g_verts is final
+    const float *gverts = A.g_verts;
+    if (A.mode == 0) {
+        // sq_blocks_bwd_kernel: one wave per block (dense = 0: every block keeps its slot)
+        for (int k = wv; k < A.nb; k += NT / DBW_WAVE) {
+            if (A.keep && !A.keep[k]) continue;
+            Pose p;
+            load_pose(A.sq_eps, A.S, A.R6, A.T, k, A.scale_min, p);
+            const long long plane = (long long)A.nb * A.nv;
+            float acc[17];
+#pragma unroll
+            for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+            for (int v = lane; v < A.nv; v += 64) {
+                const long long o = (long long)k * A.nv + v;
+                float loc[3], de1[3], de2[3];
+                parametric_sq_point(A.trig[o], A.trig[plane + o], A.trig[2 * plane + o], A.trig[3 * plane + o], p.e1, p.e2, A.ratio, loc, de1, de2);
+                float gv[3];
+                pose_bwd(p, loc, A.S_world, A.Rw, gverts + o * 3, acc, gv);
+                acc[0] += gv[0] * de1[0] + gv[1] * de1[1] + gv[2] * de1[2];
+                acc[1] += gv[0] * de2[0] + gv[1] * de2[1] + gv[2] * de2[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
+            if (lane == 0) finish_pose_grads(p, A.S, k, acc, A.g_sq_eps, A.g_S, A.g_R6, A.g_T);
+        }
+        // block_alpha_bwd_kernel
+        if (tid < A.nb) {
+            const float a = A.alpha[tid];
+            float g = 0.f;
+            if (A.g_alpha_parts)
+                for (int i = 0; i < A.alpha_parts; ++i) g += A.g_alpha_parts[tid * A.alpha_parts + i];
+            if (A.g_alpha_full && (!A.keep || A.keep[tid])) g += A.g_alpha_full[tid];
+            A.g_logit[tid] = g * a * (1.f - a);
+        }
+    } else if (wv == 0) {
+        // posed_mesh_bwd_kernel
+        Pose p;
+        load_pose(nullptr, nullptr, A.R6, A.T, 0, 0.f, p);
+        float acc[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+        for (int v = lane; v < A.nv; v += 64) {
+            float gv[3];
+            pose_bwd(p, A.base + (long long)v * 3, A.S_world, A.Rw, gverts + (long long)(A.v_begin + v) * 3, acc, gv);
+        }
+#pragma unroll
+        for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0) finish_pose_grads(p, nullptr, 0, acc, nullptr, nullptr, A.g_R6, A.g_T);
+    }
+    if (tid == 0) *A.ticket = 0u;
+}
+
+// ---- training step: camera transform + near-plane clipping + per-face raster records (+ shading records) of both scenes -----------------
+// One workgroup per (chunk of 256 faces, view, scene).  The slots of a view's clipped faces are assigned in face order (a face emits 0,
+// 1 or 2 triangles): a workgroup first COUNTS what the faces in front of its chunk emit -- a face's count follows from the view depths
+// of its three vertices alone (clip_emit_count) -- then works on its own 256 faces exactly like project_clip_fwd_kernel does on its
+// current iteration, and goes straight on to what face_setup_kernel (raster.hip) and shade_setup_kernel (render_fused.hip) compute from
+// the values it holds in registers.  Same device functions, same bits.
+__global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A) {
+    __shared__ int s_wcnt[NT / DBW_WAVE];
+    const SceneGeom &G = A.sc[blockIdx.z];
+    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int F = G.F, nchunks = (F + NT - 1) / NT;
+    if (chunk >= nchunks) return;
+    if (G.hdr && chunk == 0 && b == 0)
+        for (int i = tid; i < G.nhdr; i += NT) G.hdr[i] = 0;
+    Cam cam;
+    load_cam(A.R, A.T, A.Kmat, b, cam);
+    const long long base_out = (long long)b * 2 * F;
+    // triangles emitted by the faces in front of this chunk
+    int before = 0;
+    for (int f = tid; f < chunk * NT; f += NT) {
+        const float z0 = view_z(G.verts + (long long)G.faces[f * 3] * 3, cam), z1 = view_z(G.verts + (long long)G.faces[f * 3 + 1] * 3, cam),
+                    z2 = view_z(G.verts + (long long)G.faces[f * 3 + 2] * 3, cam);
+        before += clip_emit_count(z0, z1, z2, G.zc_on, G.zc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) s_wcnt[wv] = before;
+    __syncthreads();
+    int running = 0;
+#pragma unroll
+    for (int w = 0; w < NT / DBW_WAVE; ++w) running += s_wcnt[w];
+    __syncthreads();
+    const int f = chunk * NT + tid;
+    ClippedFace cf;
+    cf.emit = 0;
+    if (f < F) {
+        f3 p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = project(G.verts + (long long)G.faces[f * 3 + i] * 3, cam, G.cam_eps).ndc;
+        clip_face(p, G.zc_on, G.zc, G.persp, cf);
+    }
+    const int emit = cf.emit;
+    const unsigned long long m1 = __ballot(emit >= 1), m2 = __ballot(emit == 2);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const int prefix = __popcll(m1 & lower) + __popcll(m2 & lower);
+    if (lane == 0) s_wcnt[wv] = __popcll(m1) + __popcll(m2);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / DBW_WAVE; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
+    const int slot = running + woff + prefix;
+    FaceRec *recs = (FaceRec *)G.recs;
+    ShadeRec *srec = (ShadeRec *)G.srec;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {          // (unrolled: which triangle is a compile-time choice, nothing of `cf` is indexed at run time)
+        if (t >= emit) break;
+        const long long o = base_out + slot + t;
+        const f3 a = t == 0 ? cf.t0[0] : cf.t1[0], bq = t == 0 ? cf.t0[1] : cf.t1[1], cq = t == 0 ? cf.t0[2] : cf.t1[2];
+        const float p9[9] = {a.x, a.y, a.z, bq.x, bq.y, bq.z, cq.x, cq.y, cq.z};
+        const int nbr = emit == 2 ? (int)(t == 0 ? o + 1 : o - 1) : -1, cd = t == 0 ? cf.code0 : cf.code1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) G.fvc[o * 9 + i] = p9[i];
+        G.c2o[o] = f; G.neighbor[o] = nbr; G.code[o] = cd; G.cw[o * 2] = cf.w2; G.cw[o * 2 + 1] = cf.w3;
+        FaceRec r;
+        float box[4];
+        make_face_rec(p9, G.margin, 0, nbr, r, box);
+        G.bbox[o] = make_float4(box[0], box[1], box[2], box[3]);
+        recs[o] = r;
+        if (srec) {
+            ShadeRec sr;
+            const float *uv = G.face_uvs + (long long)f * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sr.uv[i] = uv[i];
+            sr.j = f; sr.cd = cd; sr.w2 = cf.w2; sr.w3 = cf.w3;
+            sr.map = G.face_map[f];
+            sr.fa = G.map_alpha ? G.map_alpha[sr.map] : 1.f;
+            const int *md = G.map_desc + sr.map * 8;
+            sr.off = md[0]; sr.hw = (md[1] << 16) | md[2]; sr.pads = (md[3] << 16) | md[4]; sr.sh = md[5];
+            srec[o] = sr;
+        }
+    }
+    if (chunk == nchunks - 1 && tid == 0) {
+        G.first_idx[b] = (int)base_out;
+        G.num_faces[b] = running + tot;
+        if (srec && b == 0 && running + tot == 0) {      // record 0 is what an empty slot of the shading loop fetches through: keep it benign
+            ShadeRec sr;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sr.uv[i] = 0.f;
+            sr.j = 0; sr.cd = -1; sr.w2 = sr.w3 = 0.f; sr.map = 0; sr.fa = 0.f; sr.off = 0; sr.hw = (1 << 16) | 1; sr.pads = 0; sr.sh = 0;
+            srec[0] = sr;
+        }
+    }
+}
+
 }  // namespace
+
+int dbw::launch_scene_setup(const SceneSetupArgs &A, hipStream_t s) {
+    DBW_REQUIRE(A.R && A.T && A.Kmat && A.B > 0, "bad argument");
+    int chunks = 0;
+    for (int i = 0; i < 2; ++i) {
+        const SceneGeom &G = A.sc[i];
+        DBW_REQUIRE(G.verts && G.faces && G.fvc && G.first_idx && G.num_faces && G.c2o && G.neighbor && G.code && G.cw && G.bbox && G.recs, "null pointer");
+        DBW_REQUIRE(G.V > 0 && G.F > 0 && (long long)A.B * 2 * G.F < 0x7fffffffLL && (!G.zc_on || G.zc > 0.f), "bad size / z_clip");
+        DBW_REQUIRE(!G.srec || (G.face_uvs && G.face_map && G.map_desc), "null pointer");
+        chunks = max(chunks, (G.F + NT - 1) / NT);
+    }
+    hipLaunchKernelGGL(scene_setup_kernel, dim3((unsigned)chunks, (unsigned)A.B, 2u), dim3(NT), 0, s, A);
+    return dbw_check_launch("scene_setup_kernel");
+}
+
+int dbw::launch_scene_tail(const SceneTailArgs &A, hipStream_t s) {
+    DBW_REQUIRE(A.verts && A.faces && A.camR && A.camT && A.Kmat && A.num_faces && A.c2o && A.code && A.cw && A.gfvc && A.g_verts && A.ticket, "null pointer");
+    DBW_REQUIRE(A.B > 0 && A.V > 0 && A.F > 0 && (size_t)A.V * 3 * sizeof(float) <= 48 * 1024, "bad size (the vertex table must fit 48 KB of LDS)");
+    if (A.mode == 0) DBW_REQUIRE(A.sq_eps && A.S && A.R6 && A.T && A.trig && A.Rw && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.alpha && A.g_logit && A.nb > 0 && A.nb <= NT && A.nv > 0, "bad argument (blocks)");
+    else DBW_REQUIRE(A.base && A.R6 && A.T && A.Rw && A.g_R6 && A.g_T && A.nv > 0 && A.v_begin >= 0 && A.v_begin + A.nv <= A.V, "bad argument (posed mesh)");
+    hipLaunchKernelGGL(scene_tail_kernel, dim3((2 * A.F + BWD_SLOTS - 1) / BWD_SLOTS), dim3(NT), (size_t)A.V * 3 * sizeof(float), s, A);
+    return dbw_check_launch("scene_tail_kernel");
+}
 
 extern "C" int dbw_project_clip_fwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,
                                     const float *Kmat, int B, int V, int F, float eps, int z_clip_enabled,

@@ -17,6 +17,8 @@
 //    rows stay in that XCD's L2;
 //  * measured (profiles/): the kernel is instruction-issue bound, not HBM bound -- see DESIGN.md section 4.
 #include "raster_common.h"
+#include "raster_bin.h"
+#include "step_kernels.h"
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
@@ -43,88 +45,17 @@ __global__ void face_setup_kernel(const float *__restrict__ fv, const int *__res
     recs[i] = r;
 }
 
-// Coarse level of the two-level binning: one workgroup per (view, COARSE x COARSE pixel bin) compacts the faces whose box touches the
-// bin, in face order (wave ballots), so that tiles see the same candidate sequence as a full scan.  An entry packs the face index
-// with the range of 8x8-pixel cells of the bin the box reaches (pixel-centre extents, the same comparisons a tile would make),
-// so that a tile decides from the entry alone -- no second, dependent load of the box -- and the bin also gets a 64-bit mask of its
-// occupied cells: a tile none of whose cells is occupied exits before its prologue.
+// The two levels of the binning (raster_bin.h) as stand-alone kernels: one workgroup per (view, COARSE x COARSE pixel bin).
 __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restrict__ bbox, const int *__restrict__ first_idx,
                                                          const int *__restrict__ num_faces, int H, int W, int nx, int ny,
                                                          int *__restrict__ list, int *__restrict__ count, unsigned *__restrict__ mask) {
-    __shared__ int s_wcnt[4];
-    __shared__ float s_cmin[2][8], s_cmax[2][8];
-    __shared__ unsigned s_mask[2];
+    __shared__ BinShared S;
     const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb;
-    const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
-    const int x1 = min(x0 + COARSE - 1, W - 1), y1 = min(y0 + COARSE - 1, H - 1);
-    const float bxmax = pix_to_ndc(W - 1 - x0, W, H), bxmin = pix_to_ndc(W - 1 - x1, W, H);
-    const float bymax = pix_to_ndc(H - 1 - y0, H, W), bymin = pix_to_ndc(H - 1 - y1, H, W);
-    if (threadIdx.x < 16) {          // NDC extents of the pixel centres of cell column / row c (empty beyond the image)
-        const int axis = threadIdx.x >> 3, c = threadIdx.x & 7;
-        const int S1 = axis ? H : W, S2 = axis ? W : H, p0 = (axis ? y0 : x0) + 8 * c, p1 = min(p0 + 7, S1 - 1);
-        s_cmax[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p0, S1, S2) : -INFINITY;
-        s_cmin[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p1, S1, S2) : INFINITY;
-    }
-    if (threadIdx.x < 2) s_mask[threadIdx.x] = 0u;
+    bin_cell_extents(S, H, W, (bin % nx) * COARSE, (bin / nx) * COARSE);
     __syncthreads();
-    const int f_begin = first_idx[n], nf = num_faces[n];
-    int *out = list + (long long)f_begin * nb + (long long)bin * nf;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int cnt = 0;
-    for (int base = 0; base < nf; base += 256) {
-        const int j = base + threadIdx.x;
-        bool hit = false;
-        int entry = 0;
-        if (j < nf) {
-            const float4 bb = bbox[f_begin + j];
-            if (!(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w)) {
-                int cx0 = 8, cx1 = -1, cy0 = 8, cy1 = -1;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (!(s_cmax[0][c] < bb.x || s_cmin[0][c] > bb.y)) { cx0 = min(cx0, c); cx1 = c; }
-                    if (!(s_cmax[1][c] < bb.z || s_cmin[1][c] > bb.w)) { cy0 = min(cy0, c); cy1 = c; }
-                }
-                hit = cx1 >= 0 && cy1 >= 0;        // a box that slips between the pixel centres of two cells touches no pixel at all
-                if (hit) {
-                    entry = j | (cx0 << 20) | (cx1 << 23) | (cy0 << 26) | (cy1 << 29);
-                    const unsigned row = ((1u << (cx1 - cx0 + 1)) - 1u) << cx0;
-                    unsigned lo = 0u, hi = 0u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r >= cy0 && r <= cy1) lo |= row << (8 * r);
-                        if (r + 4 >= cy0 && r + 4 <= cy1) hi |= row << (8 * r);
-                    }
-                    if (lo) atomicOr(&s_mask[0], lo);
-                    if (hi) atomicOr(&s_mask[1], hi);
-                }
-            }
-        }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = s_wcnt[w]; if (w < wv) woff += c; tot += c; }
-        if (hit) out[cnt + woff + __popcll(m & ((1ull << lane) - 1ull))] = entry;
-        cnt += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) count[n * nb + bin] = cnt;
-    if (threadIdx.x < 2) mask[(n * nb + bin) * 2 + threadIdx.x] = s_mask[threadIdx.x];
+    coarse_bin_block(bbox, first_idx, num_faces, H, W, nx, ny, list, count, mask, n, bin, S);
 }
 
-// Launch order of the tiles of a render pass: the tile count is fixed by the image, the work per tile is not -- a tile of a soft pass
-// costs about as many microseconds as it has faces, two thirds of the tiles have none, and the tiles that were started last with
-// dozens of faces used to keep a handful of waves busy for 80 us after everything else had drained.  Inside every XCD segment of the
-// XCD-aware grid (the tiles xcd_remap gives that XCD: same tiles, same L2 locality) the tiles are ordered by face-count class,
-// heaviest first, and the empty tiles -- whose composite + loss epilogue is pure memory traffic -- are spread evenly between the
-// occupied ones, so that the streaming work hides behind the arithmetic instead of piling up at the end.
-//   cell_bin_kernel: class + rank inside (segment, class) of every tile (returning atomics on hdr[1 + segment * 16 + class])
-//   work_scatter_kernel: thread = tile: work[position] = view * tiles + tile
-constexpr int WORK_CLASSES = 10;
-__device__ __forceinline__ int work_class(int c) {
-    return c < 0 ? 0 : c == 0 ? 9 : c >= 64 ? 0 : c >= 48 ? 1 : c >= 32 ? 2 : c >= 24 ? 3 : c >= 16 ? 4 : c >= 12 ? 5 : c >= 8 ? 6 : c >= 4 ? 7 : 8;
-}
 __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restrict__ cell, const int *__restrict__ rank, const int *__restrict__ hdr,
                                                            long long total, int *__restrict__ work) {
     const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,123 +82,30 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
     work[seg0 + p] = (int)L;
 }
 
-// Fine level: one workgroup per (view, coarse bin) splits the bin's ordered list into the ordered lists of its 64 cells (8x8 pixels =
-// the tile of one wave of the soft passes), so that a render wave reads exactly the faces it has to evaluate -- no list walk, no
-// compaction, no staging in LDS, no tile-vs-edge test per (tile, face) at render time -- and so that the number of faces of every
-// tile is known before the render kernel starts (work_scatter_kernel).
-//   masks:     thread = list entry: the 64-bit mask of the cells of the entry's box range that the blur-expanded triangle can touch
-//              (tile_culled, conservative)
-//   transpose: 64 ballots per chunk of 64 entries: the column of a cell = bit i set where entry i of the chunk touches the cell
-//   reserve:   one atomic on the pool cursor per bin; a bin whose lists do not fit (or with more than CELL_ENTRY_CAP entries) marks
-//              its cells "walk the coarse list" (count -1)
-//   fill:      thread = (cell, chunk): the set bits of its column, in order, behind the entries of the chunks before it -- every
-//              loop runs over entries that exist, not over the whole list
-constexpr int CELL_ENTRY_CAP = 1024, CELL_CHUNKS = CELL_ENTRY_CAP / 64;
 __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
                                                        const int *__restrict__ num_faces, int N, int H, int W, int nx, int ny,
                                                        const int *__restrict__ clist, const int *__restrict__ ccount, int2 *__restrict__ cell,
                                                        int *__restrict__ pool, int pool_cap, int *__restrict__ hdr, int *__restrict__ rank) {
-    __shared__ float s_cmin[2][8], s_cmax[2][8];
-    __shared__ unsigned long long s_col[CELL_CHUNKS][64];
-    __shared__ int s_j[CELL_ENTRY_CAP];
-    __shared__ int s_pre[CELL_CHUNKS][64];
-    __shared__ int s_base;
-    const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
-    if (tid < 16) {          // NDC extents of the pixel centres of cell column / row c (as coarse_bin_kernel)
-        const int axis = tid >> 3, c = tid & 7;
-        const int S1 = axis ? H : W, S2 = axis ? W : H, p0 = (axis ? y0 : x0) + 8 * c, p1 = min(p0 + 7, S1 - 1);
-        s_cmax[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p0, S1, S2) : -INFINITY;
-        s_cmin[axis][c] = p0 < S1 ? pix_to_ndc(S1 - 1 - p1, S1, S2) : INFINITY;
-    }
+    __shared__ BinShared S;
+    const int nb = nx * ny, n = blockIdx.x / nb, bin = blockIdx.x % nb;
+    bin_cell_extents(S, H, W, (bin % nx) * COARSE, (bin / nx) * COARSE);
     __syncthreads();
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3, tiles = tiles_x * tiles_y;
-    const int f_begin = first_idx[n], cnt_all = ccount[n * nb + bin];
-    const bool too_long = cnt_all > CELL_ENTRY_CAP;
-    const int cnt = too_long ? 0 : cnt_all, chunks = (cnt + 63) >> 6;
-    const int *lst = clist + (long long)f_begin * nb + (long long)bin * num_faces[n];
-    for (int ch = wv; ch < chunks; ch += 4) {
-        const int idx = ch * 64 + lane;
-        unsigned mlo = 0u, mhi = 0u;
-        if (idx < cnt) {
-            const int e = lst[idx];
-            const int j = e & 0xfffff, ex0 = (e >> 20) & 7, ex1 = (e >> 23) & 7, ey0 = (e >> 26) & 7, ey1 = (e >> 29) & 7;
-            s_j[idx] = j;
-            // (by value, through 128-bit loads: every field the tile test reads sits in registers before the loop over the cells starts --
-            // a reference left a dependent global load per edge test inside it)
-            FaceRec r;
-            {
-                const uint4 *src = (const uint4 *)(recs + f_begin + j);
-                uint4 *dst = (uint4 *)&r;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) dst[w] = src[w];
-            }
-            for (int cy = ey0; cy <= ey1; ++cy)
-                for (int cx = ex0; cx <= ex1; ++cx)
-                    if (!tile_culled(r, s_cmin[0][cx], s_cmax[0][cx], s_cmin[1][cy], s_cmax[1][cy])) {
-                        if (cy < 4) mlo |= 1u << (8 * cy + cx); else mhi |= 1u << (8 * (cy - 4) + cx);
-                    }
-        }
-        unsigned long long col = 0ull;          // lane c: the entries of this chunk that touch cell c
-#pragma unroll 2
-        for (int c = 0; c < 32; ++c) {
-            const unsigned long long b0 = __ballot((mlo >> c) & 1u), b1 = __ballot((mhi >> c) & 1u);
-            if (lane == c) col = b0;
-            if (lane == c + 32) col = b1;
-        }
-        s_col[ch][lane] = col;
-    }
+    const int *lst = clist + (long long)first_idx[n] * nb + (long long)bin * num_faces[n];
+    cell_bin_block<false>(recs, first_idx, N, H, W, nx, ny, lst, ccount[n * nb + bin], cell, pool, pool_cap, hdr, rank, n, bin, S);
+}
+
+// Training step: both levels of the binning of both scenes in one launch (step_kernels.h): one workgroup per (bin, view, scene) runs the
+// coarse level and, where the scene's pass reads per-tile lists, goes straight on to the fine level with the bin's list still in LDS.
+__global__ __launch_bounds__(256) void scene_bins_kernel(const SceneBinsArgs A) {
+    __shared__ BinShared S;
+    const SceneBinsArgs::One &G = A.sc[blockIdx.z];
+    const int bin = blockIdx.x, n = blockIdx.y;
+    bin_cell_extents(S, A.H, A.W, (bin % A.nx) * COARSE, (bin / A.nx) * COARSE);
     __syncthreads();
-    // per cell (wave 0, lane = cell): entries per chunk -> exclusive prefix over the chunks, total; then over the cells
-    const int px = x0 + 8 * (lane & 7), py = y0 + 8 * (lane >> 3);
-    const bool in_img = px < W && py < H;
-    const int tile = (py >> 3) * tiles_x + (px >> 3);
-    if (wv == 0) {
-        int all = 0;
-        for (int ch = 0; ch < chunks; ++ch) { s_pre[ch][lane] = all; all += __popcll(s_col[ch][lane]); }
-        int incl = all;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        const int total = __shfl(incl, 63, 64);
-        int base_off = 0;
-        if (lane == 0 && total > 0) base_off = atomicAdd(&hdr[0], total);
-        base_off = __shfl(base_off, 0, 64);
-        const bool overflow = too_long || (total > 0 && (long long)base_off + total > (long long)pool_cap);
-        const int off = base_off + (incl - all);
-        for (int ch = 0; ch < chunks; ++ch) s_pre[ch][lane] += off;
-        if (lane == 0) s_base = (overflow || total == 0) ? -1 : 0;
-        const int count = overflow ? -1 : all;
-        const long long L = (long long)n * tiles + tile;
-        if (in_img) cell[L] = make_int2(overflow ? 0 : off, count);
-        // rank of the tile inside its (XCD segment, face-count class): one returning atomic per distinct key of the wave
-        // (work_scatter_kernel turns class + rank into the tile's place in the launch order)
-        const long long per = ((long long)N * tiles + 7) / 8;
-        const int key = in_img ? (int)(L / per) * 16 + work_class(count) : -1;
-        unsigned long long rem = __ballot(key >= 0);
-        int r = 0;
-        while (rem) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const int k0 = __shfl(key, leader, 64);
-            const unsigned long long m = __ballot(key == k0);
-            int b0 = 0;
-            if (lane == leader) b0 = atomicAdd(&hdr[1 + k0], __popcll(m));
-            b0 = __shfl(b0, leader, 64);
-            if (key == k0) r = b0 + __popcll(m & ((1ull << lane) - 1ull));
-            rem &= ~m;
-        }
-        if (in_img) rank[L] = r;
-    }
-    __syncthreads();
-    if (s_base < 0) return;
-    for (int ch = wv; ch < chunks; ch += 4) {
-        unsigned long long bits = s_col[ch][lane];
-        int o = s_pre[ch][lane];
-        while (bits) {
-            const int i = __ffsll((long long)bits) - 1;
-            pool[o++] = s_j[ch * 64 + i];
-            bits &= bits - 1ull;
-        }
-    }
+    const int cnt = coarse_bin_block(G.bbox, G.first_idx, G.num_faces, A.H, A.W, A.nx, A.ny, G.list, G.count, G.mask, n, bin, S);
+    if (!G.cells) return;
+    // (coarse_bin_block ends its last round with a barrier: S.ent is complete)
+    cell_bin_block<true>((const FaceRec *)G.recs, G.first_idx, A.B, A.H, A.W, A.nx, A.ny, nullptr, cnt, G.cell, G.pool, G.pool_cap, G.hdr, G.rank, n, bin, S);
 }
 
 template <int KMAX, int TW, int TH>
@@ -389,7 +227,6 @@ extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) {
 
 // ... [coarse-bin lists][cell-list header: pool cursor, 8 x 16 class cursors][cell table (N, tiles) int2][work list (N * tiles)]
 //     [tile ranks (N * tiles)][cell-list pool]
-constexpr int CELL_HDR_INTS = 1 + 8 * 16;
 static size_t coarse_bytes(int64_t F_total, int N, int H, int W) {
     const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
     return align256((size_t)(N > 0 ? N : 1) * nb * 3 * sizeof(int)) + align256((size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int));
@@ -416,13 +253,9 @@ void *dbw_workspace_shade_recs(void *workspace, long long F_total) {
     return (char *)workspace + align256(F * sizeof(float4)) + align256(F * sizeof(FaceRec));
 }
 
-// Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
-int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
-                       long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
-                       dbw::CoarseBins &cb, hipStream_t s, bool launch, bool want_cells) {
-    // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass); only `cb` is rebuilt
-    cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
-    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
+int dbw_raster_workspace_layout(void *workspace, size_t workspace_bytes, long long F_total, long long max_faces_per_view, int N, int H, int W,
+                                bool want_cells, dbw::RasterWorkspace &L) {
+    L = dbw::RasterWorkspace{};
     if (F_total <= 0) return DBW_OK;
     if (F_total >= (1LL << TOPK_ID_BITS) - 1) {
         dbw_set_error("rasteriser: %lld packed faces, the per-pixel list keys hold face ids below 2^%d - 1", F_total, TOPK_ID_BITS);
@@ -432,51 +265,90 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
         dbw_set_error("rasteriser: the workspace must be 128-byte aligned");
         return DBW_ERR_INVALID;
     }
-    int rc = DBW_OK;
+    L.bbox = (float4 *)workspace;
+    L.recs = (FaceRec *)dbw_workspace_recs(workspace, F_total);
+    L.shade_recs = dbw_workspace_shade_recs(workspace, F_total);
     // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
-    const bool binned = workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20);
-    const bool cells = binned && want_cells && !(g_raster_dbg & 4096) && DBW_CELL_LISTS;
+    L.binned = workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20);
+    L.cells = L.binned && want_cells && !(g_raster_dbg & 4096) && DBW_CELL_LISTS;
     char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
-    int *hdr = (int *)(p + coarse_bytes(F_total, N, H, W));
-    if (launch) {
-        hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
-                           (float4 *)workspace, (FaceRec *)dbw_workspace_recs(workspace, F_total), cells ? hdr : nullptr, cells ? CELL_HDR_INTS : 0);
-        rc = dbw_check_launch("face_setup_kernel");
-        if (rc) return rc;
-    }
-    if (binned) {
-        const int nx = (W + COARSE - 1) / COARSE, ny = (H + COARSE - 1) / COARSE;
-        int *count = (int *)p;
-        unsigned *mask = (unsigned *)(count + (size_t)N * nx * ny);
-        int *list = (int *)(p + align256((size_t)N * nx * ny * 3 * sizeof(int)));
-        if (launch) {
-            hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, (const float4 *)workspace, first_idx,
-                               num_faces, H, W, nx, ny, list, count, mask);
-            rc = dbw_check_launch("coarse_bin_kernel");
-            if (rc) return rc;
-        }
-        cb.list = list; cb.count = count; cb.mask = mask; cb.nx = nx; cb.ny = ny;
-        if (cells) {
+    L.hdr = (int *)(p + coarse_bytes(F_total, N, H, W));
+    if (L.binned) {
+        L.nx = (W + COARSE - 1) / COARSE; L.ny = (H + COARSE - 1) / COARSE;
+        L.count = (int *)p;
+        L.mask = (unsigned *)(L.count + (size_t)N * L.nx * L.ny);
+        L.list = (int *)(p + align256((size_t)N * L.nx * L.ny * 3 * sizeof(int)));
+        if (L.cells) {
             const size_t t = cell_tiles(H, W);
-            int2 *cell = (int2 *)((char *)hdr + align256(CELL_HDR_INTS * sizeof(int)));
-            int *work = (int *)((char *)cell + align256((size_t)N * t * sizeof(int2)));
-            int *rank = (int *)((char *)work + align256((size_t)N * t * sizeof(int)));
-            int *pool = (int *)((char *)rank + align256((size_t)N * t * sizeof(int)));
-            const size_t cap = cell_pool_entries(F_total, N, H, W);
-            if (launch) {
-                hipLaunchKernelGGL(cell_bin_kernel, dim3((unsigned)(N * nx * ny)), dim3(256), 0, s, dbw_workspace_recs(workspace, F_total), first_idx,
-                                   num_faces, N, H, W, nx, ny, list, count, cell, pool, (int)cap, hdr, rank);
-                rc = dbw_check_launch("cell_bin_kernel");
-                if (rc) return rc;
-                const long long total = (long long)N * (long long)t;
-                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cell, rank, hdr, total, work);
-                rc = dbw_check_launch("work_scatter_kernel");
-                if (rc) return rc;
-            }
-            cb.cell = cell; cb.pool = pool; cb.work = work;
+            L.cell = (int2 *)((char *)L.hdr + align256(CELL_HDR_INTS * sizeof(int)));
+            L.work = (int *)((char *)L.cell + align256((size_t)N * t * sizeof(int2)));
+            L.rank = (int *)((char *)L.work + align256((size_t)N * t * sizeof(int)));
+            L.pool = (int *)((char *)L.rank + align256((size_t)N * t * sizeof(int)));
+            L.pool_cap = (int)cell_pool_entries(F_total, N, H, W);
         }
     }
     return DBW_OK;
+}
+
+// Face boxes + records, then (when the workspace has room for it) the coarse bins.  boxes = workspace.
+int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int *num_faces, const int *neighbor, int N, long long F_total,
+                       long long max_faces_per_view, int H, int W, float margin, int cull, void *workspace, size_t workspace_bytes,
+                       dbw::CoarseBins &cb, hipStream_t s, bool launch, bool want_cells) {
+    // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass, or the fused set-up
+    // kernels of the training step); only `cb` is rebuilt
+    cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
+    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
+    if (F_total <= 0) return DBW_OK;
+    dbw::RasterWorkspace L;
+    int rc = dbw_raster_workspace_layout(workspace, workspace_bytes, F_total, max_faces_per_view, N, H, W, want_cells, L);
+    if (rc) return rc;
+    if (launch) {
+        hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)((F_total + 255) / 256)), dim3(256), 0, s, face_verts, neighbor, F_total, margin, cull,
+                           L.bbox, L.recs, L.cells ? L.hdr : nullptr, L.cells ? CELL_HDR_INTS : 0);
+        rc = dbw_check_launch("face_setup_kernel");
+        if (rc) return rc;
+    }
+    if (L.binned) {
+        if (launch) {
+            hipLaunchKernelGGL(coarse_bin_kernel, dim3((unsigned)(N * L.nx * L.ny)), dim3(256), 0, s, (const float4 *)L.bbox, first_idx,
+                               num_faces, H, W, L.nx, L.ny, L.list, L.count, L.mask);
+            rc = dbw_check_launch("coarse_bin_kernel");
+            if (rc) return rc;
+        }
+        cb.list = L.list; cb.count = L.count; cb.mask = L.mask; cb.nx = L.nx; cb.ny = L.ny;
+        if (L.cells) {
+            if (launch) {
+                hipLaunchKernelGGL(cell_bin_kernel, dim3((unsigned)(N * L.nx * L.ny)), dim3(256), 0, s, (const FaceRec *)L.recs, first_idx,
+                                   num_faces, N, H, W, L.nx, L.ny, L.list, L.count, L.cell, L.pool, L.pool_cap, L.hdr, L.rank);
+                rc = dbw_check_launch("cell_bin_kernel");
+                if (rc) return rc;
+                const long long total = (long long)N * (long long)cell_tiles(H, W);
+                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work);
+                rc = dbw_check_launch("work_scatter_kernel");
+                if (rc) return rc;
+            }
+            cb.cell = L.cell; cb.pool = L.pool; cb.work = L.work;
+        }
+    }
+    return DBW_OK;
+}
+
+int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
+    DBW_REQUIRE(A.B > 0 && A.H > 0 && A.W > 0 && A.nx == (A.W + COARSE - 1) / COARSE && A.ny == (A.H + COARSE - 1) / COARSE, "bad size");
+    for (int i = 0; i < 2; ++i) {
+        const SceneBinsArgs::One &G = A.sc[i];
+        DBW_REQUIRE(G.bbox && G.recs && G.first_idx && G.num_faces && G.list && G.count && G.mask, "null pointer");
+        DBW_REQUIRE(!G.cells || (G.cell && G.pool && G.hdr && G.rank && G.pool_cap > 0), "null pointer (cell lists)");
+    }
+    hipLaunchKernelGGL(scene_bins_kernel, dim3((unsigned)(A.nx * A.ny), (unsigned)A.B, 2u), dim3(256), 0, s, A);
+    return dbw_check_launch("scene_bins_kernel");
+}
+
+// the launch-order kernel alone (the training step's fused set-up fills cell / rank / hdr itself)
+int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s) {
+    const long long total = (long long)N * (long long)cell_tiles(H, W);
+    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work);
+    return dbw_check_launch("work_scatter_kernel");
 }
 
 extern "C" int dbw_rasterize_fwd(const float *face_verts, const int32_t *first_idx, const int32_t *num_faces,

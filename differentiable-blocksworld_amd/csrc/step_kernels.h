@@ -1,0 +1,110 @@
+// Fused small kernels of the training step (train_step.hip enqueues them): each replaces a chain of dependent 5-20 us launches of the
+// operator-level path -- a dependent launch costs a gap of 5-9 us on the GPU whatever it computes, and at the reference's batch size
+// (4 views, configs/dtu/default.yml:28) those gaps were the step.  The kernels live next to the kernels they fuse (same device
+// functions, same arithmetic, bit-identical results); this header is their host-side interface.  Internal: not part of the C ABI.
+//
+//   step_prologue     (model_ops.hip)     sigmoid / decimation of the three texture tensors, block opacities (+ their noise), blocks'
+//                                         vertices, ground vertices, clearing of the small gradients      [was 7 launches]
+//   scene_setup       (project_clip.hip)  camera transform + near-plane clipping + per-face raster records + shading records of BOTH
+//                                         scenes (env: sky + ground, fg: blocks)                          [was 5]
+//   scene_bins        (raster.hip)        coarse bins of both scenes + per-tile face lists of the fg pass [was 3]
+//   regularisers      (model_ops.hip)     parsimony + overlap (samples drawn in registers) + its finish   [was 4]
+//   scene_tail        (project_clip.hip)  backward of projection / clipping, then -- by the workgroup that finishes last -- the
+//                                         backward of the pose / shape (blocks: + opacities; env: ground) [was 3 / 2]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dbw_hip.h"
+
+namespace dbw {
+struct RasterWorkspace;
+
+constexpr int STEP_MAX_SETS = 4;
+struct StepTextureSets { dbw_texture_set s[STEP_MAX_SETS]; };
+
+struct PrologueArgs {
+    StepTextureSets tex; int nsets;                 // texture preparation (blockIdx.y < nsets)
+    // block opacities (dbw.py:297-311): alpha = sigmoid(logit + noise_scale * noise), keep = sigmoid(logit) > thresh
+    const float *alpha_logit, *noise;               // noise: caller's draw (n_blocks) or NULL -> Philox (seed, rng_step, stream 0)
+    float noise_scale, thresh;
+    int nb;
+    float *alpha, *alpha_full;
+    int *keep;
+    unsigned long long seed, rng_step;
+    // blocks' vertices (dbw.py:343-352)
+    const float *sq_eps, *S, *R6, *T, *trig;
+    int nv;
+    float ratio, scale_min, S_world;
+    const float *Rw, *Tw;
+    float *blk_verts;
+    // ground (dbw.py:282-287)
+    const float *ground_base; int ngv;
+    const float *R6g, *Tg;
+    float *ground_verts;
+    // floats cleared by the launch (the accumulated pose / shape / opacity gradients)
+    float *zero0; int nzero0;
+};
+int launch_step_prologue(const PrologueArgs &P, hipStream_t s);
+
+// one scene of the set-up kernels
+struct SceneGeom {
+    const float *verts; const int *faces; int V, F;
+    float cam_eps; int zc_on; float zc; int persp;
+    // clipped faces (B, 2F, ...)
+    float *fvc; int *first_idx, *num_faces, *c2o, *neighbor, *code; float *cw;
+    // raster records
+    float margin;                                   // sqrt(blur_radius)
+    float4 *bbox; void *recs;                       // FaceRec
+    int *hdr; int nhdr;                             // cell-list header to clear (or NULL)
+    // shading records of the soft pass (NULL: none)
+    void *srec; const float *face_uvs; const int *face_map, *map_desc; const float *map_alpha;    // one opacity per map, or NULL
+};
+struct SceneSetupArgs { SceneGeom sc[2]; const float *R, *T, *Kmat; int B; };
+int launch_scene_setup(const SceneSetupArgs &A, hipStream_t s);
+
+struct SceneBinsArgs {
+    struct One {
+        const float4 *bbox; const void *recs; const int *first_idx, *num_faces;
+        int *list, *count; unsigned *mask;
+        int cells; int2 *cell; int *pool; int pool_cap; int *hdr; int *rank;
+    } sc[2];
+    int B, H, W, nx, ny;
+};
+int launch_scene_bins(const SceneBinsArgs &A, hipStream_t s);
+int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s);
+
+struct RegulariserArgs {
+    // overlap (dbw.py:389-405): scale = 0 -> off
+    const float *u; int npts;                       // caller's samples (nb, npts, 3) or NULL -> Philox (seed, rng_step, stream 1)
+    unsigned long long seed, rng_step;
+    const float *sq_eps, *S, *R6, *T, *alpha_full;
+    int nb;
+    float ratio, scale_min, inv_temp, thresh, overlap_scale;
+    // parsimony (dbw.py:373-377): scale = 0 -> off
+    float pars_eps, pars_scale;
+    float *loss_parsimony, *loss_overlap;
+    float *g_sq_eps, *g_S, *g_R6, *g_T, *g_alpha_full;
+    float *ws;                                      // nb * 18 floats, zero
+    unsigned *ticket;                               // zero; left zero
+};
+int launch_regularisers(const RegulariserArgs &A, hipStream_t s);
+
+struct SceneTailArgs {
+    // backward of projection + clipping: grad_face_verts_c (B, 2F, 3, 3) -> g_verts (V, 3) (zero on entry)
+    const float *verts; const int *faces; const float *camR, *camT, *Kmat;
+    int B, V, F; float cam_eps, zc; int persp;
+    const int *num_faces, *c2o, *code; const float *cw; const float *gfvc;
+    float *g_verts;
+    unsigned *ticket;                               // zero; left zero
+    int mode;                                       // 0: blocks (pose / shape of nb superquadrics + opacities), 1: one posed mesh (the ground)
+    // mode 0
+    const float *sq_eps, *S, *R6, *T, *trig; const int *keep; int nb, nv; float ratio, scale_min, S_world; const float *Rw;
+    float *g_sq_eps, *g_S, *g_R6, *g_T;
+    const float *alpha, *g_alpha_parts, *g_alpha_full; int alpha_parts; float *g_logit;      // g_alpha_parts may be NULL (fine phase)
+    // mode 1: vertices [v_begin, v_begin + nv) of the scene are base (nv, 3) posed by (R6, T)
+    const float *base; int v_begin;
+};
+int launch_scene_tail(const SceneTailArgs &A, hipStream_t s);
+
+}  // namespace dbw

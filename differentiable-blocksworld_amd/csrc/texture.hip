@@ -3,6 +3,7 @@
 // All are streaming, HBM-bound passes over O(10 MB) per optimisation step (not per view).
 #include "dbw_common.h"
 #include "loss_math.h"
+#include "texture_body.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -23,45 +24,6 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threa
 #pragma unroll
     for (int w = 0; w < NT / DBW_WAVE; ++w) t += s_red[w];
     return t;
-}
-
-// d == 1: elementwise.  d > 1: one WAVE per (d x d) cell (lane <-> texel, wave-sum for the cell mean); `maps` is written
-// at CELL resolution (n, h/d, w/d, 3).
-__device__ __forceinline__ void texture_prep_fwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
-                                                      float *__restrict__ maps, float *__restrict__ sig) {
-    if (d <= 1) {
-        const long long total = (long long)n * h * w * 3;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-            const float s = sigmoidf(tex[i]);
-            maps[i] = s;
-            if (sig) sig[i] = s;
-        }
-        return;
-    }
-    const int ch_ = h / d, cw_ = w / d, lane = threadIdx.x & 63;
-    const long long cells = (long long)n * ch_ * cw_;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long c = wave; c < cells; c += nwaves) {
-        const int m = (int)(c / (ch_ * cw_));
-        const int r = (int)(c % (ch_ * cw_));
-        const int cy = r / cw_, cx = r % cw_;
-        float acc[3] = {0.f, 0.f, 0.f};
-        for (int t = lane; t < d * d; t += 64) {
-            const long long o = (((long long)m * h + cy * d + t / d) * w + cx * d + t % d) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float s = sigmoidf(tex[o + k]);
-                sig[o + k] = s;
-                acc[k] += s;
-            }
-        }
-        const float inv = 1.f / (float)(d * d);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float tot = wave_sum(acc[k]);
-            if (lane == 0) maps[c * 3 + k] = tot * inv;
-        }
-    }
 }
 
 __global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,

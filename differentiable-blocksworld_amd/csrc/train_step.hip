@@ -1,0 +1,597 @@
+// The whole optimisation iteration of the training path behind one entry point (include/dbw_hip.h: dbw_train_step_*).
+//
+// Replaces one pass of src/trainer.py:137-147 (zero_grad -> model(images) -> total.backward() -> optimizer.step()) for the decoupled
+// training render (src/model/dbw.py:198-223, 361-408; src/model/renderer.py:84-98) with MSE + parsimony + TV + overlap.  This file is
+// host-side orchestration: which kernel goes on which of the two streams, in which order, with which event between them -- plus two
+// small kernels of its own (tiling of the target images, reduction of the loss values).  The arithmetic lives in the kernels it
+// launches, each of which is the kernel the operator-level path uses or a fusion of several of them out of the same device functions
+// (step_kernels.h), so a step computes what dbw_amd/native_step.py computes through ~33 launches -- tests/test_gpu_model.py holds the
+// two (and every fuse mask in between) to each other.
+//
+// Schedule (M = stream_main, S = stream_side; `|` = an event):
+//   M: prologue -> scene set-up -> bins | env pass ............ | fg pass + MSE | env backward -> ground tail -> env textures ...... | Adam
+//   S: tile targets, bin layout ...... | launch order | regularisers, TV ...... | fg backward [-> bin reduction] -> blocks' textures
+//                                                                                  -> blocks' tail -> loss values ................. |
+// (backward_order 1: the env backward waits for the fg backward KERNEL -- two kernels that each fill the GPU gain nothing from sharing
+// it, and the blocks' texture gradient, 83 % of the gradient bytes, is then final early enough for a data-parallel caller to reduce it
+// next to the env chain.)
+#include "dbw_common.h"
+#include "raster_bin.h"
+#include "step_kernels.h"
+#include "../../include/dbw_hip.h"
+
+#include <math.h>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace dbw;
+
+namespace {
+
+// ---- the two kernels of this file ---------------------------------------------------------------------------------------------------
+// (B, 3, H, W) -> the 8x8-tile planar layout [B][ceil(H/8)][ceil(W/8)][3][64] (include/dbw_hip.h: image_layout 1); pixels beyond the
+// image are zero.  One thread per element of the tiled image: the writes are coalesced, the reads are 32 B row pieces.
+__global__ __launch_bounds__(256) void tile_target_kernel(const float *__restrict__ img, int B, int C, int H, int W, float *__restrict__ out) {
+    const int tx = (W + 7) >> 3, ty = (H + 7) >> 3;
+    const long long total = (long long)B * ty * tx * C * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int c = (int)(r % C); r /= C;
+        const int tix = (int)(r % tx); r /= tx;
+        const int tiy = (int)(r % ty);
+        const int n = (int)(r / ty);
+        const int y = tiy * 8 + (lane >> 3), x = tix * 8 + (lane & 7);
+        out[i] = (y < H && x < W) ? img[(((long long)n * C + c) * H + y) * W + x] : 0.f;
+    }
+}
+
+// vals (device: parsimony, tv, overlap accumulated by their kernels in slots 1..3) + the per-tile sums of squared differences of the fg
+// pass -> out5 = rgb, parsimony, tv, overlap, total (what compute_losses returns, dbw.py:361-408)
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float *__restrict__ part, long long nparts, float scale, const float *__restrict__ vals,
+                                                           float *__restrict__ out5) {
+    __shared__ float s_red[16];
+    float acc = 0.f;
+    for (long long i = threadIdx.x; i < nparts; i += 1024) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_red[w];
+        const float rgb = t * scale;
+        out5[0] = rgb; out5[1] = vals[1]; out5[2] = vals[2]; out5[3] = vals[3];
+        out5[4] = ((rgb + vals[1]) + vals[2]) + vals[3];
+    }
+}
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SceneBuf { size_t fvc, first, num, c2o, nbr, code, cw, rws, rws_bytes; };
+
+struct Layout {
+    SceneBuf e, f;
+    size_t p2f_e, bary_e, dists_e, img_e, p2f, bary, dists, part, g_fg, g_env;
+    size_t env_maps, blk_maps, sig[3], g_sig[3];
+    size_t alpha, alpha_full, keep, blk_verts, losses, target;
+    size_t records, cursor[2], layout[2], layout_uniform;
+    size_t arena_begin, g_alpha_full, ovl_ws, vals, tickets, g_blk_maps, g_fa, g_fvc_f, g_blk_verts, g_env_maps, g_fvc_e, g_env_verts, arena_end;
+    size_t total;
+    // derived sizes
+    int Fe, Ff, Ve, Vf, tiles, bin_cap;
+    size_t ce, cb_, n_env_maps, n_blk_maps;
+};
+
+bool tv_on(const dbw_step_desc &d) { return d.w_tv_bkg != 0.f || d.w_tv_blocks != 0.f || d.w_tv_ground != 0.f; }
+bool bins_on(const dbw_step_desc &d) { return d.decim_blocks == 1 && d.n_bins > 0 && d.block_bin_base && d.block_bin_info; }
+
+int texbin_capacity(int B, int H, int W, int K, int nbins) {
+    // records per texture bin: room for max(K / 2, 2) fragments per pixel spread evenly over the bins (a soft K-layer render fills ~20 %
+    // of its slots; what does not fit falls back to atomics), at most 16 GiB, a multiple of the cursors per bin (dbw_amd/ops.py: the same)
+    long long cap = (long long)B * H * W * (K > 4 ? K : 4) / (2LL * nbins);
+    if (cap < 256) cap = 256;
+    const long long hi = (16LL << 30) / (32LL * nbins);
+    if (cap > hi) cap = hi;
+    return (int)((cap + DBW_BIN_SUBCURSORS - 1) / DBW_BIN_SUBCURSORS * DBW_BIN_SUBCURSORS);
+}
+
+void scene_layout(SceneBuf &s, size_t &o, int B, int F, int H, int W) {
+    const size_t n = (size_t)B * 2 * F;
+    s.fvc = o; o += al(n * 9 * 4);
+    s.first = o; o += al((size_t)B * 4);
+    s.num = o; o += al((size_t)B * 4);
+    s.c2o = o; o += al(n * 4);
+    s.nbr = o; o += al(n * 4);
+    s.code = o; o += al(n * 4);
+    s.cw = o; o += al(n * 8);
+    s.rws_bytes = dbw_rasterize_workspace_bytes_binned((int64_t)n, B, H, W);
+    s.rws = o; o += al(s.rws_bytes);
+}
+
+void make_layout(const dbw_step_desc &d, Layout &L) {
+    memset(&L, 0, sizeof(L));
+    const int B = d.max_views, K = d.faces_per_pixel;
+    L.Fe = d.n_sky_faces + d.n_ground_faces; L.Ff = d.n_blocks * d.block_nf;
+    L.Ve = d.n_sky_verts + d.n_ground_verts; L.Vf = d.n_blocks * d.block_nv;
+    L.tiles = ((d.H + 7) / 8) * ((d.W + 7) / 8);
+    const size_t bt = (size_t)B * L.tiles;
+    L.ce = (size_t)(d.env_txt_size / d.decim_env) * (d.env_txt_size / d.decim_env) * 3;
+    L.cb_ = (size_t)(d.txt_size / d.decim_blocks) * (d.txt_size / d.decim_blocks) * 3;
+    L.n_env_maps = 2 * L.ce; L.n_blk_maps = (size_t)d.n_blocks * L.cb_;
+    size_t o = 0;
+    scene_layout(L.e, o, B, L.Fe, d.H, d.W);
+    scene_layout(L.f, o, B, L.Ff, d.H, d.W);
+    L.p2f_e = o; o += al(bt * 64 * 4);
+    L.bary_e = o; o += al(bt * 64 * 3 * 4);
+    L.dists_e = o; o += al(bt * 64 * 4);
+    L.img_e = o; o += al(bt * 256 * 4);
+    L.p2f = o; o += al(bt * K * 64 * 4);
+    L.bary = o; o += al(bt * K * 64 * 8 * 4);
+    L.dists = o; o += al(bt * K * 64 * 4);
+    L.part = o; o += al(bt * 4);
+    L.g_fg = o; o += al(bt * 256 * 4);
+    L.g_env = o; o += al(bt * 256 * 4);
+    L.env_maps = o; o += al(L.n_env_maps * 4);
+    L.blk_maps = o; o += al(L.n_blk_maps * 4);
+    const size_t full[3] = {(size_t)d.env_txt_size * d.env_txt_size * 3, (size_t)d.n_blocks * d.txt_size * d.txt_size * 3, (size_t)d.env_txt_size * d.env_txt_size * 3};
+    const int dec[3] = {d.decim_env, d.decim_blocks, d.decim_env};
+    for (int i = 0; i < 3; ++i) {
+        if (dec[i] > 1) { L.sig[i] = o; o += al(full[i] * 4); }
+        else L.sig[i] = i == 0 ? L.env_maps : (i == 1 ? L.blk_maps : L.env_maps + L.ce * 4);     // undecimated: the maps ARE the sigmoid
+        if (tv_on(d)) { L.g_sig[i] = o; o += al(full[i] * 4); }
+    }
+    L.alpha = o; o += al((size_t)d.n_blocks * 4);
+    L.alpha_full = o; o += al((size_t)d.n_blocks * 4);
+    L.keep = o; o += al((size_t)d.n_blocks * 4);
+    L.blk_verts = o; o += al((size_t)L.Vf * 12);
+    L.losses = o; o += al(8 * 4);
+    L.target = o; o += al(bt * 192 * 4);
+    if (bins_on(d)) {
+        L.bin_cap = texbin_capacity(B, d.H, d.W, K, d.n_bins);
+        const size_t nsub = (size_t)d.n_bins * DBW_BIN_SUBCURSORS;
+        L.records = o; o += al((size_t)d.n_bins * L.bin_cap * 32);
+        for (int i = 0; i < 2; ++i) { L.cursor[i] = o; o += al(nsub * 4); }
+        for (int i = 0; i < 2; ++i) { L.layout[i] = o; o += al(nsub * 8); }
+        L.layout_uniform = o; o += al(nsub * 8);
+    }
+    L.arena_begin = o;
+    L.g_alpha_full = o; o += al((size_t)d.n_blocks * 4);
+    L.ovl_ws = o; o += al((size_t)d.n_blocks * 18 * 4);
+    L.vals = o; o += al(8 * 4);
+    L.tickets = o; o += al(4 * 4);
+    L.g_blk_maps = o; o += al(L.n_blk_maps * 4);
+    L.g_fa = o; o += al((size_t)d.n_blocks * 64 * 4);
+    L.g_fvc_f = o; o += al((size_t)B * 2 * L.Ff * 9 * 4);
+    L.g_blk_verts = o; o += al((size_t)L.Vf * 12);
+    L.g_env_maps = o; o += al(L.n_env_maps * 4);
+    L.g_fvc_e = o; o += al((size_t)B * 2 * L.Fe * 9 * 4);
+    L.g_env_verts = o; o += al((size_t)L.Ve * 12);
+    L.arena_end = o;
+    L.total = o;
+}
+
+int check_desc(const dbw_step_desc *d) {
+    DBW_REQUIRE(d, "null descriptor");
+    DBW_REQUIRE(d->H > 0 && d->W > 0 && d->max_views > 0 && d->faces_per_pixel > 1 && d->faces_per_pixel <= DBW_MAX_FACES_PER_PIXEL, "bad image size / batch / faces_per_pixel (the soft pass has K > 1)");
+    DBW_REQUIRE(d->n_blocks > 0 && d->n_blocks <= 64 && d->block_nv > 0 && d->block_nf > 0, "1..64 blocks");
+    DBW_REQUIRE(d->n_blocks * d->block_nf < (1 << 20) && d->n_blocks + 2 < (1 << 11), "uv-fragments pack the face in 20 bits, the map in 11");
+    DBW_REQUIRE(d->n_sky_verts > 0 && d->n_ground_verts > 0 && d->n_sky_faces > 0 && d->n_ground_faces > 0, "bad env mesh");
+    DBW_REQUIRE(d->txt_size > 1 && d->env_txt_size > 1 && d->decim_env >= 1 && d->decim_blocks >= 1 && d->txt_size % d->decim_blocks == 0 &&
+                    d->env_txt_size % d->decim_env == 0, "texture sizes must be multiples of their decimation factor");
+    DBW_REQUIRE(d->sigma > 0.f && d->blur_radius >= 0.f && d->cam_eps > 0.f, "bad renderer constants");
+    DBW_REQUIRE(d->R_world && d->T_world && d->Kmat && d->ground_base && d->env_verts && d->env_faces && d->env_face_uvs && d->env_face_map && d->env_map_desc &&
+                    d->trig && d->block_faces && d->block_face_uvs && d->block_face_map && d->block_map_desc, "null table");
+    DBW_REQUIRE(d->sq_eps && d->S && d->R6 && d->T && d->alpha_logit && d->R6_ground && d->T_ground && d->texture_bkg && d->texture_ground && d->textures, "null parameter");
+    DBW_REQUIRE(d->g_sq_eps && d->g_S && d->g_R6 && d->g_T && d->g_alpha_logit && d->g_R6_ground && d->g_T_ground && d->g_texture_bkg && d->g_texture_ground &&
+                    d->g_textures, "null gradient");
+    DBW_REQUIRE(d->flat_param && d->flat_grad && d->exp_avg && d->exp_avg_sq && d->group_end[0] >= 0 && d->group_end[1] >= d->group_end[0], "bad Adam buffers");
+    DBW_REQUIRE(d->small_grads && d->n_small_grads > 0, "small_grads: the accumulated gradients to clear");
+    DBW_REQUIRE(d->w_rgb > 0.f && d->w_parsimony >= 0.f && d->w_overlap >= 0.f && d->w_tv_bkg >= 0.f && d->w_tv_blocks >= 0.f && d->w_tv_ground >= 0.f, "bad loss weights");
+    DBW_REQUIRE(d->w_overlap == 0.f || (d->overlap_points > 0 && d->overlap_temperature > 0.f), "bad overlap constants");
+    DBW_REQUIRE(((size_t)(d->n_sky_verts + d->n_ground_verts) * 12 <= 48 * 1024 && (size_t)d->n_blocks * d->block_nv * 12 <= 48 * 1024) || !(d->fuse & 8),
+                "fused tails keep a scene's vertex gradients in 48 KB of LDS");
+    return DBW_OK;
+}
+
+}  // namespace
+
+struct dbw_step_plan {
+    dbw_step_desc d;
+    Layout L;
+    char *ws;
+    RasterWorkspace rw_e, rw_f;         // for max_views (the pointers of a run follow from the run's own B)
+    hipEvent_t ev_fork, ev_bins, ev_scatter, ev_fg_fwd, ev_reg, ev_kernel_done, ev_blocks_ready, ev_side_done, ev_losses;
+    unsigned long long rng_step;
+    int bin_turn, bin_ready, uniform_ready;
+    bool arena_clean;
+    float *host_losses;                 // pinned
+    bool losses_pending;
+};
+
+extern "C" size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc) {
+    if (check_desc(desc)) return 0;
+    Layout L;
+    make_layout(*desc, L);
+    return L.total;
+}
+
+extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void *workspace, size_t workspace_bytes) {
+    if (check_desc(desc)) return nullptr;
+    if (!workspace || ((uintptr_t)workspace & 255)) { dbw_set_error("dbw_train_step_create: the workspace must be 256-byte aligned"); return nullptr; }
+    dbw_step_plan *p = new (std::nothrow) dbw_step_plan();
+    if (!p) { dbw_set_error("dbw_train_step_create: out of host memory"); return nullptr; }
+    p->d = *desc;
+    make_layout(p->d, p->L);
+    if (workspace_bytes < p->L.total) {
+        dbw_set_error("dbw_train_step_create: workspace of %zu bytes, %zu needed", workspace_bytes, p->L.total);
+        delete p;
+        return nullptr;
+    }
+    p->ws = (char *)workspace;
+    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_bins, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_side_done, &p->ev_losses};
+    for (hipEvent_t *e : evs)
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
+    if (hipHostMalloc((void **)&p->host_losses, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        dbw_set_error("dbw_train_step_create: hipHostMalloc failed");
+        delete p;
+        return nullptr;
+    }
+    for (int i = 0; i < 8; ++i) p->host_losses[i] = 0.f;
+    p->rng_step = 0; p->bin_turn = 0; p->bin_ready = 0; p->uniform_ready = 0; p->arena_clean = false; p->losses_pending = false;
+    return p;
+}
+
+extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
+    if (!p) return;
+    hipEvent_t evs[] = {p->ev_fork, p->ev_bins, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_kernel_done, p->ev_blocks_ready, p->ev_side_done, p->ev_losses};
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (p->host_losses) (void)hipHostFree(p->host_losses);
+    delete p;
+}
+
+extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
+    if (!p) return -1;
+    const Layout &L = p->L;
+    switch (which) {
+        case 0: return (int64_t)L.alpha;
+        case 1: return (int64_t)L.alpha_full;
+        case 2: return (int64_t)L.keep;
+        case 3: return (int64_t)L.losses;
+        case 4: return (int64_t)L.arena_begin;
+        case 5: return (int64_t)L.arena_end;
+        case 6: return (int64_t)L.g_fg;
+        case 7: return (int64_t)L.g_env;
+        case 8: return (int64_t)L.img_e;
+        case 9: return (int64_t)L.blk_verts;
+        case 10: return (int64_t)L.part;
+        default: return -1;
+    }
+}
+
+extern "C" void *dbw_train_step_blocks_ready_event(dbw_step_plan *p) { return p ? (void *)p->ev_blocks_ready : nullptr; }
+
+extern "C" int dbw_train_step_losses(dbw_step_plan *p, float *out5) {
+    DBW_REQUIRE(p && out5, "null pointer");
+    DBW_REQUIRE(p->losses_pending, "no run with read_losses != 0 to read from");
+    if (hipEventSynchronize(p->ev_losses) != hipSuccess) { dbw_set_error("dbw_train_step_losses: hipEventSynchronize failed"); return DBW_ERR_LAUNCH; }
+    for (int i = 0; i < 5; ++i) out5[i] = p->host_losses[i];
+    return DBW_OK;
+}
+
+#define HIP_OK(call)                                                              \
+    do {                                                                          \
+        const hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                                   \
+            dbw_set_error("dbw_train_step_run: %s: %s", #call, hipGetErrorString(e_)); \
+            return DBW_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+#define RC(call)                  \
+    do {                          \
+        const int rc_ = (call);   \
+        if (rc_) return rc_;      \
+    } while (0)
+
+extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side) {
+    DBW_REQUIRE(p && in, "null pointer");
+    const dbw_step_desc &d = p->d;
+    const Layout &L = p->L;
+    DBW_REQUIRE(in->imgs && in->R && in->T, "null input");
+    DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
+    DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
+    DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
+    hipStream_t M = (hipStream_t)stream_main, S = (hipStream_t)stream_side;
+    const bool two = M != S;
+    char *ws = p->ws;
+#define FP(off) ((float *)(ws + (off)))
+#define IP(off) ((int *)(ws + (off)))
+    const int B = in->B, H = d.H, W = d.W, K = d.faces_per_pixel, nb = d.n_blocks, nv = d.block_nv;
+    const int Fe = L.Fe, Ff = L.Ff, Ve = L.Ve, Vf = L.Vf;
+    const bool coarse = d.coarse != 0, bins = bins_on(d), tv = tv_on(d);
+    const float mse_scale = (float)((double)d.w_rgb / in->global_count);
+    const int zc_on = d.z_clip > 0.f ? 1 : 0;
+    const bool noise_on = coarse && d.opacity_noise != 0.f;
+    const float *fa = coarse ? FP(L.alpha) : nullptr;
+    const int alpha_len = coarse ? -nb : 0;
+    const int64_t Fte = (int64_t)B * 2 * Fe, Ftf = (int64_t)B * 2 * Ff;
+    const bool overlap_on = d.w_overlap != 0.f, pars_on = d.w_parsimony != 0.f;
+    DBW_REQUIRE((d.fuse & 1) || !noise_on || in->noise_override, "the operator-level prologue needs the caller's opacity noise (noise_override)");
+    DBW_REQUIRE((d.fuse & 4) || !overlap_on || in->overlap_u_override, "the operator-level regularisers need the caller's overlap samples (overlap_u_override)");
+
+    // the zero arena: cleared by the plan's own Adam launch at the end of a run; before the first run (and after a run whose caller ran
+    // Adam itself without clearing it) by a fill
+    if (!p->arena_clean && !(in->arena_is_clean && p->rng_step > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
+    p->arena_clean = false;
+
+    // ---- texture sets: sky, blocks, ground (dbw.py:273-293,306,331-334) ----
+    dbw_texture_set sets[3];
+    memset(sets, 0, sizeof(sets));
+    const float *tex[3] = {d.texture_bkg, d.textures, d.texture_ground};
+    float *gtex[3] = {d.g_texture_bkg, d.g_textures, d.g_texture_ground};
+    const int tn[3] = {1, nb, 1}, th[3] = {d.env_txt_size, d.txt_size, d.env_txt_size}, td[3] = {d.decim_env, d.decim_blocks, d.decim_env};
+    float *maps_out[3] = {FP(L.env_maps), FP(L.blk_maps), FP(L.env_maps) + L.ce};
+    float *gmaps[3] = {FP(L.g_env_maps), FP(L.g_blk_maps), FP(L.g_env_maps) + L.ce};
+    const float tvw[3] = {d.w_tv_bkg, d.w_tv_blocks, d.w_tv_ground};
+    for (int i = 0; i < 3; ++i) {
+        dbw_texture_set &t = sets[i];
+        t.texture = tex[i]; t.n = tn[i]; t.h = th[i]; t.w = th[i]; t.decim = td[i];
+        t.maps = maps_out[i];
+        t.sig = td[i] > 1 ? FP(L.sig[i]) : nullptr;
+        t.wrap_x = i == 1 ? 1 : 0;
+        t.tv_scale = tvw[i];
+        t.grad_texture = gtex[i];
+        t.grad_maps = gmaps[i];
+    }
+
+    if (two) { HIP_OK(hipEventRecord(p->ev_fork, M)); HIP_OK(hipStreamWaitEvent(S, p->ev_fork, 0)); }
+
+    // ---- S: targets in the tile-planar layout; texture bins: this step's cursors and record sub-ranges ----
+    const float *target = in->imgs;
+    if (!in->imgs_tiled) {
+        const long long total = (long long)B * L.tiles * 192;
+        long long g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(tile_target_kernel, dim3((unsigned)g), dim3(256), 0, S, in->imgs, B, 3, H, W, FP(L.target));
+        RC(dbw_check_launch("tile_target_kernel"));
+        target = FP(L.target);
+    }
+    int *cursor = nullptr;
+    const uint32_t *blayout = nullptr;
+    if (bins) {
+        const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
+        const double total_records = (double)d.n_bins * (double)L.bin_cap;
+        cursor = IP(L.cursor[p->bin_turn]);
+        HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, S));
+        if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
+            RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), S));
+            blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
+        } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
+            RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), S));
+            blayout = (const uint32_t *)(ws + L.layout_uniform);
+        }
+    }
+
+    // ---- M: prologue ----
+    const float thresh = d.mask_threshold;
+    if (d.fuse & 1) {
+        PrologueArgs P;
+        memset(&P, 0, sizeof(P));
+        for (int i = 0; i < 3; ++i) P.tex.s[i] = sets[i];
+        P.tex.s[3] = sets[0];
+        P.nsets = 3;
+        P.alpha_logit = d.alpha_logit; P.noise = noise_on ? in->noise_override : nullptr;
+        P.noise_scale = noise_on ? d.opacity_noise : 0.f; P.thresh = thresh; P.nb = nb;
+        P.alpha = FP(L.alpha); P.alpha_full = FP(L.alpha_full); P.keep = IP(L.keep);
+        P.seed = d.seed; P.rng_step = p->rng_step;
+        P.sq_eps = d.sq_eps; P.S = d.S; P.R6 = d.R6; P.T = d.T; P.trig = d.trig; P.nv = nv;
+        P.ratio = d.ratio_block_scene; P.scale_min = d.scale_min; P.S_world = d.S_world; P.Rw = d.R_world; P.Tw = d.T_world;
+        P.blk_verts = FP(L.blk_verts);
+        P.ground_base = d.ground_base; P.ngv = d.n_ground_verts; P.R6g = d.R6_ground; P.Tg = d.T_ground;
+        P.ground_verts = d.env_verts + (size_t)d.n_sky_verts * 3;
+        P.zero0 = d.small_grads; P.nzero0 = d.n_small_grads;
+        RC(launch_step_prologue(P, M));
+    } else {
+        RC(dbw_posed_mesh_fwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, d.T_world,
+                              d.env_verts + (size_t)d.n_sky_verts * 3, M));
+        RC(dbw_texture_prep_fwd_sets(sets, 3, M));
+        HIP_OK(hipMemsetAsync(d.small_grads, 0, (size_t)d.n_small_grads * 4, M));
+        RC(dbw_block_alpha_fwd(d.alpha_logit, noise_on ? in->noise_override : nullptr, noise_on ? d.opacity_noise : 0.f, thresh, nb, FP(L.alpha),
+                               FP(L.alpha_full), IP(L.keep), M));
+        RC(dbw_sq_blocks_fwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world,
+                             d.T_world, FP(L.blk_verts), M));
+    }
+
+    // ---- M: camera transform, clipping, per-face records, bins of both scenes ----
+    RasterWorkspace we, wf;
+    RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, /*cells: the hard pass walks its coarse bins*/ false, we));
+    RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
+    const bool fused_setup = (d.fuse & 2) && we.binned && wf.binned && wf.cells;
+    const float margin_f = (float)sqrt((double)d.blur_radius);
+    if (fused_setup) {
+        SceneSetupArgs A;
+        memset(&A, 0, sizeof(A));
+        A.R = in->R; A.T = in->T; A.Kmat = d.Kmat; A.B = B;
+        SceneGeom &e = A.sc[0], &f = A.sc[1];
+        e.verts = d.env_verts; e.faces = d.env_faces; e.V = Ve; e.F = Fe;
+        f.verts = FP(L.blk_verts); f.faces = d.block_faces; f.V = Vf; f.F = Ff;
+        const SceneBuf *sb[2] = {&L.e, &L.f};
+        RasterWorkspace *rw[2] = {&we, &wf};
+        for (int i = 0; i < 2; ++i) {
+            SceneGeom &g = A.sc[i];
+            g.cam_eps = d.cam_eps; g.zc_on = zc_on; g.zc = d.z_clip; g.persp = d.perspective_correct;
+            g.fvc = FP(sb[i]->fvc); g.first_idx = IP(sb[i]->first); g.num_faces = IP(sb[i]->num); g.c2o = IP(sb[i]->c2o); g.neighbor = IP(sb[i]->nbr);
+            g.code = IP(sb[i]->code); g.cw = FP(sb[i]->cw);
+            g.bbox = rw[i]->bbox; g.recs = rw[i]->recs;
+        }
+        e.margin = 0.f; f.margin = margin_f;
+        f.hdr = wf.hdr; f.nhdr = CELL_HDR_INTS;
+        f.srec = wf.shade_recs; f.face_uvs = d.block_face_uvs; f.face_map = d.block_face_map; f.map_desc = d.block_map_desc; f.map_alpha = fa;
+        RC(launch_scene_setup(A, M));
+        SceneBinsArgs Bn;
+        memset(&Bn, 0, sizeof(Bn));
+        Bn.B = B; Bn.H = H; Bn.W = W; Bn.nx = wf.nx; Bn.ny = wf.ny;
+        for (int i = 0; i < 2; ++i) {
+            SceneBinsArgs::One &g = Bn.sc[i];
+            g.bbox = rw[i]->bbox; g.recs = rw[i]->recs; g.first_idx = IP(sb[i]->first); g.num_faces = IP(sb[i]->num);
+            g.list = rw[i]->list; g.count = rw[i]->count; g.mask = rw[i]->mask;
+        }
+        Bn.sc[1].cells = 1; Bn.sc[1].cell = wf.cell; Bn.sc[1].pool = wf.pool; Bn.sc[1].pool_cap = wf.pool_cap; Bn.sc[1].hdr = wf.hdr; Bn.sc[1].rank = wf.rank;
+        RC(launch_scene_bins(Bn, M));
+    } else {
+        RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),
+                                IP(L.e.first), IP(L.e.num), IP(L.e.c2o), IP(L.e.nbr), IP(L.e.code), FP(L.e.cw), M));
+        RC(dbw_project_clip_fwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, zc_on, d.z_clip, d.perspective_correct,
+                                FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.c2o), IP(L.f.nbr), IP(L.f.code), FP(L.f.cw), M));
+        RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
+                                d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
+                                IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 1, 1, M));
+        RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
+                                    d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
+                                    d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, nullptr, nullptr, 0.f,
+                                    nullptr, nullptr, nullptr, 1, 1, M));
+    }
+
+    // ---- S: behind the set-up (opacities, maps, bins): the launch order of the fg pass's tiles; M waits for it (and for the tiled targets)
+    // in front of the fg pass only ----
+    if (two) { HIP_OK(hipEventRecord(p->ev_bins, M)); HIP_OK(hipStreamWaitEvent(S, p->ev_bins, 0)); }
+    if (fused_setup) RC(dbw_launch_work_scatter(wf, B, H, W, S));
+    if (two) HIP_OK(hipEventRecord(p->ev_scatter, S));
+
+    // ---- M: the env pass (hard, one face per pixel), then the fg pass ending in the composite + MSE ----
+    RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
+                            d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
+                            IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
+    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
+    RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
+                                d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
+                                d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, FP(L.img_e), target, mse_scale,
+                                FP(L.part), FP(L.g_fg), FP(L.g_env), 2, 1, M));
+    if (two) HIP_OK(hipEventRecord(p->ev_fg_fwd, M));
+
+    // ---- S: the regularisers, value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405); enqueued behind
+    // the fg pass on purpose: a stream that waits for an event of another stream was observed to wait for everything that stream had
+    // been given by then ----
+    float *vals = FP(L.vals);
+    if (d.fuse & 4) {
+        RegulariserArgs A;
+        memset(&A, 0, sizeof(A));
+        A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
+        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
+        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
+        A.overlap_scale = d.w_overlap;
+        A.pars_eps = 1e-6f; A.pars_scale = d.w_parsimony;
+        A.loss_parsimony = vals + 1; A.loss_overlap = vals + 3;
+        A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T; A.g_alpha_full = FP(L.g_alpha_full);
+        A.ws = FP(L.ovl_ws); A.ticket = (unsigned *)(ws + L.tickets);
+        RC(launch_regularisers(A, S));
+    } else {
+        if (pars_on) RC(dbw_sqrt_mean(FP(L.alpha_full), nb, 1e-6f, d.w_parsimony, vals + 1, FP(L.g_alpha_full), S));
+        if (overlap_on)
+            RC(dbw_overlap_loss(in->overlap_u_override, d.overlap_points, d.sq_eps, d.S, d.R6, d.T, FP(L.alpha_full), nb, d.ratio_block_scene, d.scale_min,
+                                d.overlap_temperature, d.overlap_n_blocks, d.w_overlap, vals + 3, d.g_sq_eps, d.g_S, d.g_R6, d.g_T, FP(L.g_alpha_full),
+                                FP(L.ovl_ws), S));
+    }
+    if (tv) {
+        for (int i = 0; i < 3; ++i) {
+            sets[i].sig = FP(L.sig[i]);
+            sets[i].grad_sig_out = FP(L.g_sig[i]);
+            sets[i].grad_sig = FP(L.g_sig[i]);
+        }
+        RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, S));
+    }
+    if (two) HIP_OK(hipEventRecord(p->ev_reg, S));
+
+    // ---- backward of the two passes, each followed by its tail ----
+    const bool seq = d.backward_order != 0 || bins;
+    const bool both = bins && d.binned_concurrent;
+    auto env_backward = [&]() -> int {
+        RC(dbw_render_bwd_fused(IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs, d.env_face_map,
+                                d.env_map_desc, FP(L.env_maps), nullptr, 0, B, H, W, 1, Fe, 0.f, d.bg_env, FP(L.g_env), FP(L.e.fvc), d.perspective_correct, 0,
+                                FP(L.g_env_maps), nullptr, FP(L.g_fvc_e), 1, 3, nullptr, nullptr, nullptr, 0, nullptr, d.n_sky_faces, nullptr, 1, M));
+        if (d.fuse & 8) {
+            SceneTailArgs A;
+            memset(&A, 0, sizeof(A));
+            A.verts = d.env_verts; A.faces = d.env_faces; A.camR = in->R; A.camT = in->T; A.Kmat = d.Kmat; A.B = B; A.V = Ve; A.F = Fe;
+            A.cam_eps = d.cam_eps; A.zc = d.z_clip; A.persp = d.perspective_correct;
+            A.num_faces = IP(L.e.num); A.c2o = IP(L.e.c2o); A.code = IP(L.e.code); A.cw = FP(L.e.cw); A.gfvc = FP(L.g_fvc_e); A.g_verts = FP(L.g_env_verts);
+            A.ticket = (unsigned *)(ws + L.tickets) + 1;
+            A.mode = 1;
+            A.base = d.ground_base; A.v_begin = d.n_sky_verts; A.nv = d.n_ground_verts; A.R6 = d.R6_ground; A.T = d.T_ground; A.S_world = d.S_world; A.Rw = d.R_world;
+            A.g_R6 = d.g_R6_ground; A.g_T = d.g_T_ground;
+            RC(launch_scene_tail(A, M));
+        } else {
+            RC(dbw_project_clip_bwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.e.num),
+                                    IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), FP(L.g_fvc_e), FP(L.g_env_verts), M));
+            RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
+                                  d.g_R6_ground, d.g_T_ground, M));
+        }
+        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));          // the TV gradients of the sky / ground maps (S)
+        dbw_texture_set env_sets[2] = {sets[0], sets[2]};
+        if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
+        RC(dbw_texture_prep_bwd_sets(env_sets, 2, M));
+        return DBW_OK;
+    };
+
+    if (two) HIP_OK(hipStreamWaitEvent(S, p->ev_fg_fwd, 0));
+    if (two && !(seq && !both)) RC(env_backward());      // both chains at once: the env chain is enqueued first, it is the one on M
+    RC(dbw_render_bwd_fused(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
+                            d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
+                            FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
+                            bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, S));
+    if (two) HIP_OK(hipEventRecord(p->ev_kernel_done, S));
+    if (two && seq && !both) {
+        HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
+        RC(env_backward());
+    }
+    if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), S));
+    {
+        dbw_texture_set blk = sets[1];
+        if (!tv) blk.grad_sig = nullptr;
+        RC(dbw_texture_prep_bwd_sets(&blk, 1, S));
+    }
+    HIP_OK(hipEventRecord(p->ev_blocks_ready, S));
+    if (d.fuse & 8) {
+        SceneTailArgs A;
+        memset(&A, 0, sizeof(A));
+        A.verts = FP(L.blk_verts); A.faces = d.block_faces; A.camR = in->R; A.camT = in->T; A.Kmat = d.Kmat; A.B = B; A.V = Vf; A.F = Ff;
+        A.cam_eps = d.cam_eps; A.zc = d.z_clip; A.persp = d.perspective_correct;
+        A.num_faces = IP(L.f.num); A.c2o = IP(L.f.c2o); A.code = IP(L.f.code); A.cw = FP(L.f.cw); A.gfvc = FP(L.g_fvc_f); A.g_verts = FP(L.g_blk_verts);
+        A.ticket = (unsigned *)(ws + L.tickets) + 2;
+        A.mode = 0;
+        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.trig = d.trig; A.keep = IP(L.keep); A.nb = nb; A.nv = nv;
+        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world;
+        A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T;
+        A.alpha = FP(L.alpha); A.g_alpha_parts = coarse ? FP(L.g_fa) : nullptr; A.alpha_parts = 64; A.g_alpha_full = FP(L.g_alpha_full); A.g_logit = d.g_alpha_logit;
+        RC(launch_scene_tail(A, S));
+    } else {
+        RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
+                                IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), S));
+        RC(dbw_sq_blocks_bwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world, FP(L.g_blk_verts),
+                             d.g_sq_eps, d.g_S, d.g_R6, d.g_T, S));
+        RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, S));
+    }
+    if (!two) RC(env_backward());
+    // ---- S: the loss values (nothing is differentiated through them) ----
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, S, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
+    RC(dbw_check_launch("loss_finish_kernel"));
+    if (in->read_losses) {
+        HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, S));
+        HIP_OK(hipEventRecord(p->ev_losses, S));
+        p->losses_pending = true;
+    }
+    if (two) { HIP_OK(hipEventRecord(p->ev_side_done, S)); HIP_OK(hipStreamWaitEvent(M, p->ev_side_done, 0)); }
+
+    // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----
+    if (in->with_adam) {
+        RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
+                                ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+        p->arena_clean = true;
+    }
+    if (bins) { p->bin_turn = 1 - p->bin_turn; p->bin_ready = 1; }
+    p->rng_step += 1;
+    return DBW_OK;
+#undef FP
+#undef IP
+}

@@ -35,6 +35,32 @@ class TextureSet(ctypes.Structure):
                 ('tv_scale', c_f), ('grad_sig_out', c_p), ('grad_maps', c_p), ('grad_sig', c_p), ('grad_texture', c_p)]
 
 
+class StepDesc(ctypes.Structure):
+    """dbw_step_desc of include/dbw_hip.h (field order = the header's; tests/test_abi.py compares the two)."""
+    _fields_ = ([(n, c_i) for n in ('H', 'W', 'faces_per_pixel', 'max_views', 'n_blocks', 'block_nv', 'block_nf', 'n_sky_verts', 'n_ground_verts',
+                                    'n_sky_faces', 'n_ground_faces', 'txt_size', 'env_txt_size', 'decim_env', 'decim_blocks', 'coarse')]
+                + [(n, c_f) for n in ('sigma', 'blur_radius', 'z_clip', 'cam_eps')] + [('perspective_correct', c_i)]
+                + [('bg_fg', c_f * 3), ('bg_env', c_f * 3)]
+                + [(n, c_f) for n in ('S_world', 'ratio_block_scene', 'scale_min', 'opacity_noise', 'mask_threshold', 'w_rgb', 'w_parsimony', 'w_tv_bkg',
+                                      'w_tv_blocks', 'w_tv_ground', 'w_overlap')]
+                + [('overlap_points', c_i), ('overlap_temperature', c_f), ('overlap_n_blocks', c_f)]
+                + [(n, c_p) for n in ('R_world', 'T_world', 'Kmat', 'ground_base', 'env_verts', 'env_faces', 'env_face_uvs', 'env_face_map', 'env_map_desc',
+                                      'trig', 'block_faces', 'block_face_uvs', 'block_face_map', 'block_map_desc', 'block_bin_base', 'block_bin_info')]
+                + [('n_bins', c_i)]
+                + [(n, c_p) for n in ('sq_eps', 'S', 'R6', 'T', 'alpha_logit', 'R6_ground', 'T_ground', 'texture_bkg', 'texture_ground', 'textures',
+                                      'g_sq_eps', 'g_S', 'g_R6', 'g_T', 'g_alpha_logit', 'g_R6_ground', 'g_T_ground', 'g_texture_bkg', 'g_texture_ground',
+                                      'g_textures', 'flat_param', 'flat_grad', 'exp_avg', 'exp_avg_sq')]
+                + [('group_end', c_i64 * 2), ('small_grads', c_p), ('n_small_grads', c_i), ('fuse', c_i), ('backward_order', c_i),
+                   ('binned_concurrent', c_i), ('seed', ctypes.c_uint64)])
+
+
+class StepInputs(ctypes.Structure):
+    """dbw_step_inputs of include/dbw_hip.h."""
+    _fields_ = [('imgs', c_p), ('imgs_tiled', c_i), ('R', c_p), ('T', c_p), ('B', c_i), ('global_count', c_d), ('noise_override', c_p),
+                ('overlap_u_override', c_p), ('with_adam', c_i), ('adam_step', c_i), ('lr', c_f * 2), ('beta1', c_f), ('beta2', c_f), ('adam_eps', c_f),
+                ('read_losses', c_i), ('arena_is_clean', c_i)]
+
+
 def texture_sets(sets):
     """list of dicts (missing fields = 0 / NULL) -> (ctypes array, count)"""
     arr = (TextureSet * len(sets))()
@@ -81,6 +107,16 @@ SIGNATURES = {
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p],
+    'dbw_train_step_run': [c_p, c_p, c_p, c_p],
+    'dbw_train_step_losses': [c_p, c_p],
+}
+# entry points that do not return an error code: name -> (restype, argtypes)
+OTHER_SIGNATURES = {
+    'dbw_train_step_workspace_bytes': (c_sz, [c_p]),
+    'dbw_train_step_create': (c_p, [c_p, c_p, c_sz]),
+    'dbw_train_step_destroy': (None, [c_p]),
+    'dbw_train_step_offset': (c_i64, [c_p, c_i]),
+    'dbw_train_step_blocks_ready_event': (c_p, [c_p]),
 }
 
 
@@ -116,9 +152,15 @@ def load():
     lib.dbw_rasterize_workspace_bytes_binned.restype = c_sz
     lib.dbw_rasterize_workspace_bytes_binned.argtypes = [c_i64, c_i, c_i, c_i]
     for name, argtypes in SIGNATURES.items():
+        if name.startswith('dbw_train_step') and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_i
+    for name, (restype, argtypes) in OTHER_SIGNATURES.items():
+        if hasattr(lib, name):                  # (absent from tuning builds of older sources)
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argtypes, restype
     _lib = lib
     return lib
 

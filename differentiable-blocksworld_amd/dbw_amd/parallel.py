@@ -53,7 +53,8 @@ class ShardedTrainStep:
     launch stay outside the graph."""
 
     def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
-                 use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures'):
+                 use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures', use_c_step=True,
+                 fuse=None):
         self.model, self.pg = model, process_group
         self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
         self._graph_key = None
@@ -75,6 +76,13 @@ class ShardedTrainStep:
             from .native_step import NativeStep
             self.native = NativeStep(model, self.params)
             self.native.on_block_grads_ready = self.start_early_allreduce
+        # ... and the same iteration behind ONE call into the library (c_step.py: ~16 launches enqueued from C, fused set-up / tail
+        # kernels, the random numbers drawn inside them, Adam inside the call on one GPU) where the library has it; the launch-by-launch
+        # native step stays as the form the C step is tested against
+        self.cstep = None
+        if use_c_step and self.native is not None and self.params.flat.is_cuda and not use_graph:
+            from .c_step import CStep, FUSE_ALL
+            self.cstep = CStep(model, self.params, (self.exp_avg, self.exp_avg_sq), fuse=FUSE_ALL if fuse is None else fuse)
         # Overlapped all-reduce: the blocks' texture gradient (`early_param`: 83 % of the buffer at config 2) is final long before the
         # step ends -- the env chain finishes last -- so its slice is reduced on the communicator's own stream while the env backward
         # still runs, and only the rest (1.6 MB) after the step.  Same collectives in the same order on every rank, whatever path a
@@ -93,6 +101,7 @@ class ShardedTrainStep:
                 s = s.to(self.params.flat.device if dist.get_backend(process_group) == 'nccl' else 'cpu')
                 dist.broadcast(s, src=0, group=process_group)
             torch.manual_seed(int(s.item()))
+            model._rng_seed = int(s.item())           # the C step's counter-based generator: the same key on every rank
 
     def _global_count(self, imgs, global_count):
         """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367).  Callers that
@@ -113,6 +122,9 @@ class ShardedTrainStep:
         view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
         self.model._global_count = self._global_count(inp['imgs'], global_count)
         dirty = None
+        if (self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported()
+                and self.native.supported()):
+            return self._c_iteration(inp)
         if self.use_graph and self.n_steps >= self.graph_warmup and self._native_graph_ok(inp):
             losses = self._native_graph_iteration(inp)
         elif self.use_graph and self.n_steps >= self.graph_warmup:
@@ -148,6 +160,33 @@ class ShardedTrainStep:
             if b > a:
                 self.adam_fn(self.params.flat[a:b], self.params.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr, self.n_steps,
                              self.betas, self.eps)
+        return losses
+
+    def _c_iteration(self, inp):
+        """The iteration through the C step.  One GPU: everything, Adam included, in the one call.  Data parallel: the call stops in front
+        of Adam; the blocks' texture gradient is reduced as soon as the step's side stream has it (its queue ends with the fg tail, the
+        env chain is still running on the main stream), the rest behind the step; then the fused Adam, which also clears the step's
+        zero arena."""
+        cs = self.cstep
+        distributed = self.world_size > 1 or self.overlap_allreduce
+        with torch.no_grad():
+            if not distributed:
+                losses = cs(inp, self.model._global_count, adam=(self.n_steps + 1, self.lrs, self.betas, self.eps))
+                self.n_steps += 1
+                return losses
+            losses = cs(inp, self.model._global_count, adam=None)
+            if self.overlap_allreduce:
+                dev = self.params.flat.device
+                from .c_step import side_stream
+                side = side_stream(dev, cs.side_priority) if cs.use_side_stream else torch.cuda.current_stream(dev)
+                with torch.cuda.stream(side):
+                    self.start_early_allreduce()
+                torch.cuda.current_stream(dev).wait_stream(side)      # (a synchronous backend -- gloo through a host copy -- wrote on `side`)
+            self.allreduce_gradients()
+            self.n_steps += 1
+            ops.adam_step_groups_(self.params.flat, self.params.grad, self.exp_avg, self.exp_avg_sq, [b for _, b in self.params.bounds],
+                                  self.lrs, self.n_steps, self.betas, self.eps, zero=cs.arena())
+            cs._arena_cleaned_by_caller = True
         return losses
 
     def _fused_adam(self):

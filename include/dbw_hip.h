@@ -27,7 +27,7 @@
 
 /* ABI revision of this header (dbw_abi_version() returns the value the library was built with).  2: image_layout argument of the fused
  * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry) */
-#define DBW_ABI_VERSION 3
+#define DBW_ABI_VERSION 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -359,6 +359,103 @@ int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
                          const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
                          int64_t zero_bytes, dbw_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The whole optimisation iteration of the training path behind ONE entry point (ABI 4).
+ * Replaces one pass of src/trainer.py:137-147 -- optimizer.zero_grad(); loss = model(images, labels) (src/model/dbw.py:198-408: the
+ * decoupled render of dbw.py:213-223 through src/model/renderer.py:84-98, compute_losses dbw.py:361-408 without the perceptual term);
+ * loss['total'].backward(); optimizer.step() (Adam, two learning-rate groups, src/optimizer.py:9-15) -- for the configuration every
+ * shipped config trains in (decouple_rendering, detach_bary, perspective cameras, MSE + parsimony + TV + overlap).
+ *
+ * Why an entry of its own: at the reference's batch size (4 views, configs/dtu/default.yml:28) the kernels of an iteration take ~0.1 ms
+ * and 33 launches issued one by one from the host took 0.5 ms.  Here the host makes ONE call; the library enqueues ~16 launches on two
+ * streams (the dependent 5-20 us kernels of the operator-level path are fused into a prologue, one set-up kernel and one binning kernel
+ * for both scenes, one regulariser kernel and one tail kernel per scene: csrc/step_kernels.h), draws the opacity noise and the overlap
+ * samples from a counter-based generator inside those kernels, and leaves the loss values in host-visible memory with one copy.
+ *
+ * Ownership: every pointer of dbw_step_desc / dbw_step_inputs is caller-owned DEVICE memory that stays valid while the plan lives
+ * (inputs: until the call's work has finished).  `workspace` (dbw_train_step_workspace_bytes bytes, 256-byte aligned) is caller-owned
+ * scratch the plan carves everything else out of: clipped faces, raster workspaces, fragments, images, maps, gradient accumulators, the
+ * records of the texture bins.  The plan is the one object of this ABI that holds state between calls: its events, the step counter of
+ * its random numbers, and which of the two demand tables of the texture bins is current.  Not thread-safe; one plan per
+ * (model, training phase, device).
+ */
+typedef struct dbw_step_desc {
+    /* ---- sizes ---- */
+    int H, W, faces_per_pixel, max_views;       /* image size, K, the largest batch a run may bring */
+    int n_blocks, block_nv, block_nf;           /* blocks, vertices and faces per block (42 / 80 for the icosphere-1 superquadric) */
+    int n_sky_verts, n_ground_verts, n_sky_faces, n_ground_faces;
+    int txt_size, env_txt_size;                 /* texture side of a block / of the sky and ground maps */
+    int decim_env, decim_blocks;                /* decimation factor in force for the env maps / the blocks' maps (1 = none; dbw.py:276-278,331-334) */
+    int coarse;                                 /* 1: coarse phase -- one learned opacity per block (+ noise); 0: fine -- opaque faces */
+    /* ---- renderer constants (src/model/renderer.py:25-60) ---- */
+    float sigma, blur_radius;                   /* of the soft pass */
+    float z_clip, cam_eps;                      /* z_clip <= 0: no near-plane clipping */
+    int perspective_correct;
+    float bg_fg[3], bg_env[3];
+    float S_world, ratio_block_scene, scale_min;
+    float opacity_noise;                        /* std of the opacity noise (0 = none) */
+    float mask_threshold;                       /* a block is kept while sigmoid(alpha_logit) > mask_threshold; < 0: all kept */
+    /* ---- loss weights, phase factors and 1 / world_size folded in (dbw.py:361-408); 0 = term off ---- */
+    float w_rgb, w_parsimony, w_tv_bkg, w_tv_blocks, w_tv_ground, w_overlap;
+    int overlap_points;                         /* samples per block (dbw.py:33) */
+    float overlap_temperature, overlap_n_blocks;
+    /* ---- constant tables ---- */
+    const float *R_world, *T_world, *Kmat;      /* (3,3), (3), (4,4) */
+    const float *ground_base;                   /* (n_ground_verts, 3) */
+    float *env_verts;                           /* (n_sky_verts + n_ground_verts, 3): the sky part filled by the caller, the ground part by the step */
+    const int32_t *env_faces; const float *env_face_uvs; const int32_t *env_face_map, *env_map_desc;
+    const float *trig;                          /* (4, n_blocks, block_nv), see dbw_sq_blocks_fwd */
+    const int32_t *block_faces; const float *block_face_uvs; const int32_t *block_face_map, *block_map_desc;
+    const int32_t *block_bin_base, *block_bin_info; int n_bins;       /* texture bins (decim_blocks == 1), see dbw_render_bwd_fused */
+    /* ---- parameters and their gradients (the gradients: views of one flat buffer, see flat_*) ---- */
+    const float *sq_eps, *S, *R6, *T, *alpha_logit, *R6_ground, *T_ground, *texture_bkg, *texture_ground, *textures;
+    float *g_sq_eps, *g_S, *g_R6, *g_T, *g_alpha_logit, *g_R6_ground, *g_T_ground, *g_texture_bkg, *g_texture_ground, *g_textures;
+    /* ---- Adam over the flat parameter buffer: group 0 = [0, group_end[0]) pose / shape / opacity, group 1 = textures ---- */
+    float *flat_param, *flat_grad, *exp_avg, *exp_avg_sq;
+    int64_t group_end[2];
+    float *small_grads; int n_small_grads;      /* the accumulated (not fully written) gradients: cleared at the head of every run */
+    /* ---- options ---- */
+    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: tails; 0 = the operator-level kernels */
+    int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel / texture bins) */
+    int binned_concurrent;                      /* texture bins: the env chain starts next to the fg kernel */
+    uint64_t seed;                              /* of the step's random numbers: the same on every data-parallel rank */
+} dbw_step_desc;
+
+typedef struct dbw_step_inputs {
+    const float *imgs;                          /* targets: (B,3,H,W), or the 8x8-tile planar layout when imgs_tiled != 0 */
+    int imgs_tiled;
+    const float *R, *T;                         /* (B,3,3), (B,3) */
+    int B;                                      /* 1 <= B <= max_views */
+    double global_count;                        /* elements of the GLOBAL batch's images: the MSE is a mean over them (dbw.py:367) */
+    const float *noise_override, *overlap_u_override;   /* caller's draws instead of the plan's (n_blocks), (n_blocks, overlap_points, 3); NULL */
+    int with_adam;                              /* 0: stop in front of Adam (data parallel: the caller all-reduces flat_grad first) */
+    int adam_step; float lr[2], beta1, beta2, adam_eps;
+    int read_losses;                            /* != 0: copy the loss values to host memory (dbw_train_step_losses) */
+    int arena_is_clean;                         /* != 0: the caller cleared the zero arena (dbw_train_step_offset 4 / 5) since the last run --
+                                                 * it does when it runs Adam itself through dbw_adam_step_groups(zero_buf = the arena);
+                                                 * otherwise a run that does not follow a run with_adam clears the arena with a fill of its own */
+} dbw_step_inputs;
+
+typedef struct dbw_step_plan dbw_step_plan;
+size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc);
+/* returns NULL on error (dbw_last_error) */
+dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void *workspace, size_t workspace_bytes);
+void dbw_train_step_destroy(dbw_step_plan *plan);
+/* Enqueues one iteration: stream_main carries the critical path and ends with Adam (or, with_adam == 0, with everything the caller's
+ * all-reduce has to wait for); stream_side (a different stream; may equal stream_main: everything then runs in order on one stream)
+ * carries what runs next to it.  On return nothing has been waited for. */
+int dbw_train_step_run(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side);
+/* Blocks until the loss values of the last run with read_losses != 0 are in host memory: out5 = rgb, parsimony, tv, overlap, total */
+int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
+/* Byte offset inside the workspace of one of the plan's buffers (tests, diagnostics, host-side views of per-step state):
+ * which = 0 alpha (n_blocks), 1 alpha_full, 2 keep (int32), 3 loss values on the device (5 floats, valid after a run), 4 / 5 begin / end of
+ * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
+ * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials; -1 for an unknown name */
+int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
+/* Enqueued on the side stream of a run right after the blocks' texture gradient is final (data parallel: the caller reduces that
+ * slice while the env chain still runs): the event's handle as a hipEvent_t, for hipStreamWaitEvent */
+void *dbw_train_step_blocks_ready_event(dbw_step_plan *plan);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // compiles) for the host: tests/test_host_model_math.py compares it, without a GPU, with golden vectors of the reference's own
 // parametric_sq / implicit_sq / safe_pow / signed_pow and with torch autograd of the oracle's posing.  Test infrastructure only.
 #include "../differentiable-blocksworld_amd/csrc/model_math.h"
+#include "../differentiable-blocksworld_amd/csrc/rng_math.h"
 
 using namespace dbw;
 
@@ -70,4 +71,22 @@ int host_pose(const float *S_raw, const float *R6, const float *T, float scale_m
     return 0;
 }
 
+
+// rng_math.h: the raw Philox4x32-10 block, and the step's draws (stream 0: opacity noise, stream 1: overlap samples)
+int host_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *out4) {
+    const Philox4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+    return 0;
+}
+int host_step_noise(unsigned long long seed, unsigned long long step, int n, float *out) {
+    for (int k = 0; k < n; ++k) { const Philox4 r = step_random(seed, step, 0u, (unsigned)k); out[k] = normal01(r.x, r.y); }
+    return 0;
+}
+int host_step_uniform(unsigned long long seed, unsigned long long step, int n, float *out3) {
+    for (int i = 0; i < n; ++i) {
+        const Philox4 r = step_random(seed, step, 1u, (unsigned)i);
+        out3[3 * i] = uniform01(r.x); out3[3 * i + 1] = uniform01(r.y); out3[3 * i + 2] = uniform01(r.z);
+    }
+    return 0;
+}
 }  // extern "C"

@@ -18,7 +18,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
-    for ret, name, args in re.findall(r'\b(int|size_t|void|const char \*)\s*(dbw_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+    for ret, name, args in re.findall(r'\b(int64_t|int|size_t|void \*|void|const char \*|dbw_step_plan \*)\s*(dbw_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
         args = ' '.join(args.split())
         types = []
         if args and args != 'void':
@@ -42,14 +42,20 @@ def test_library_builds_and_loads_without_gpu():
 def test_every_declared_symbol_is_exported_with_matching_signature():
     lib = _lib.load()
     protos = parse_header()
-    assert len(protos) == 37
+    assert len(protos) == 44
     for name, (ret, types) in protos.items():
         assert hasattr(lib, name), f'{name} declared in dbw_hip.h but not exported'
         if name in _lib.SIGNATURES:
             assert _lib.SIGNATURES[name] == types, f'{name}: ctypes signature differs from the header'
     missing = set(_lib.SIGNATURES) - set(protos)
     assert not missing, f'bound but not declared: {missing}'
-    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES} - {'dbw_abi_version', 'dbw_bin_subcursors', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_rasterize_workspace_bytes_binned', 'dbw_debug_set_flags', 'dbw_debug_set_raster_flags'}
+    RET = {'int': ctypes.c_int, 'size_t': ctypes.c_size_t, 'int64_t': ctypes.c_int64, 'void': None, 'void *': ctypes.c_void_p, 'dbw_step_plan *': ctypes.c_void_p}
+    for name, (restype, argtypes) in _lib.OTHER_SIGNATURES.items():
+        assert name in protos, f'{name} bound but not declared'
+        assert protos[name] == ([k for k, v in RET.items() if k == protos[name][0]][0], argtypes) and RET[protos[name][0]] == restype, name
+        fn = getattr(lib, name)
+        assert fn.restype == restype and fn.argtypes == argtypes, name
+    undeclared_compute = {n for n in protos if n not in _lib.SIGNATURES and n not in _lib.OTHER_SIGNATURES} - {'dbw_abi_version', 'dbw_bin_subcursors', 'dbw_last_error', 'dbw_rasterize_workspace_bytes', 'dbw_rasterize_workspace_bytes_binned', 'dbw_debug_set_flags', 'dbw_debug_set_raster_flags'}
     assert not undeclared_compute, f'declared but not bound: {undeclared_compute}'
 
 
@@ -84,3 +90,46 @@ def test_graft_entry_build_runs_on_the_committed_tree():
     spec.loader.exec_module(ge)
     so = ge.build()
     assert os.path.exists(so) and so.endswith('libdbw_hip.so')
+
+
+def _parse_struct(name):
+    """[(field, ctype)] of `typedef struct name { ... } name;` in the header: plain declarations only (scalars, pointers, small arrays)."""
+    src = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), src, flags=re.S).group(1)
+    base = dict(CTYPE, uint64_t=ctypes.c_uint64, int32_t=ctypes.c_int32)
+    fields = []
+    for decl in body.split(';'):
+        decl = ' '.join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r'(const )?(\w+) (.*)', decl)
+        t = base[m.group(2)]
+        for item in m.group(3).split(','):
+            item = item.strip()
+            arr = re.match(r'(\w+)\[(\d+)\]', item)
+            if item.startswith('*'):
+                fields.append((item.lstrip('* '), ctypes.c_void_p))
+            elif arr:
+                fields.append((arr.group(1), t * int(arr.group(2))))
+            else:
+                fields.append((item, t))
+    return fields
+
+
+def test_step_structures_match_the_header_field_by_field():
+    """dbw_step_desc / dbw_step_inputs are filled through ctypes.Structure mirrors: same fields, same order, same types, or the library
+    reads garbage."""
+    for cname, cls in (('dbw_step_desc', _lib.StepDesc), ('dbw_step_inputs', _lib.StepInputs)):
+        want = _parse_struct(cname)
+        got = list(cls._fields_)
+        assert [n for n, _ in want] == [n for n, _ in got], cname
+        for (n, a), (_, b) in zip(want, got):
+            assert ctypes.sizeof(a) == ctypes.sizeof(b) and (a is b or a._type_ == b._type_ or {a, b} <= {ctypes.c_int, ctypes.c_int32}), (cname, n, a, b)
+
+
+def test_train_step_rejects_a_bad_descriptor_without_a_gpu():
+    lib = _lib.load()
+    d = _lib.StepDesc()
+    assert lib.dbw_train_step_workspace_bytes(ctypes.byref(d)) == 0 and b'dbw' not in lib.dbw_last_error()[:0]
+    assert not lib.dbw_train_step_create(ctypes.byref(d), 0, 0)
+    assert lib.dbw_train_step_offset(None, 0) == -1

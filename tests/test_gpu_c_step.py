@@ -1,0 +1,202 @@
+"""GPU: the optimisation iteration behind one C-ABI call (dbw_train_step_*, csrc/train_step.hip) against the launch-by-launch native step
+(dbw_amd/native_step.py, itself held to the autograd iteration and through it to the oracle): same loss values, same flat gradient, same
+parameters after Adam -- for the operator-level kernels enqueued from C (fuse = 0), for each fused kernel alone (1, 2, 4, 8) and for all
+of them (15), in the three training phases; the step's own random numbers against the host build of the same generator; the loss values
+the step copies to host memory; fresh mini-batches; the reference's own operating point (4 views).  `-m gpu`."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O                                              # noqa: E402  (checker only)
+import dbw_amd                                                  # noqa: E402
+from dbw_amd import _lib, ops                                   # noqa: E402
+from dbw_amd.parallel import ShardedTrainStep                   # noqa: E402
+
+DEV = 'cuda:0'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cfg(n_blocks=4, ts=32, fpp=6):
+    return {'model': {'name': 'dbw', 'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},
+                      'renderer': {'faces_per_pixel': fpp, 'cameras': {'name': 'perspective'}, 'detach_bary': True, 'z_clip': 0.001},
+                      'rend_optim': {'coarse_learning': 1500, 'decimate_txt': 750, 'decimate_factor': 8, 'kill_blocks': True,
+                                     'decouple_rendering': True, 'opacity_noise': True},
+                      'loss': {'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1, 'overlap_weight': 1}}}
+
+
+def _inputs(n_views, H, W, seed=2):
+    R, T, Km = O.synthetic_cameras(n_views, R_world=O.world_rotation(115, 0, 0))
+    imgs = torch.rand(n_views, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    return {k: v.to(DEV) for k, v in dict(imgs=imgs, R=R, T=T, K=Km).items()}
+
+
+def _model(epoch, nb=4, ts=32, fpp=6, H=48, W=64, kill=True):
+    torch.manual_seed(227391)
+    model = dbw_amd.create_model(_cfg(nb, ts, fpp), (H, W)).to(DEV).train()
+    with torch.no_grad():
+        model.T.mul_(0.5)
+        if kill:
+            model.alpha_logit.add_(torch.tensor(([1.0, -6.0, 0.3, 2.0] * nb)[:nb], device=DEV))       # block 1 is killed / filtered
+    model.set_cur_epoch(epoch)
+    model.sync_free = True
+    return model
+
+
+def _run(model, inp, steps, noise, u, **kw):
+    model._noise_override, model._overlap_u_override = noise, u
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, **kw)
+    out = step(inp)
+    torch.cuda.synchronize()
+    vals = {k: float(v) for k, v in out.items()}
+    grad1 = step.params.grad.clone()
+    for _ in range(steps - 1):
+        step(inp)
+    torch.cuda.synchronize()
+    return step, vals, grad1, step.params.flat.clone()
+
+
+def _compare(a, b, names):
+    (_, va, ga, pa), (_, vb, gb, pb) = a, b
+    assert set(va) == set(vb)
+    for k in va:
+        assert abs(va[k] - vb[k]) <= 2e-6 * max(abs(vb[k]), 1e-3), (k, va[k], vb[k])
+    for n, off, k in names:
+        x, y = ga[off:off + k], gb[off:off + k]
+        assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-12, (n, float((x - y).abs().max()), float(y.abs().max()))
+    diff = (pa - pb).abs()
+    # (Adam divides by sqrt(v): an element whose gradient is at the rounding noise of the float atomics moves by +-lr whatever the noise
+    # was; see test_gpu_model.py::test_native_step_equals_autograd_step)
+    assert float((diff > 1e-4).float().mean()) < 1e-2 and float(diff.max()) < 0.02, (float((diff > 1e-4).float().mean()), float(diff.max()))
+
+
+@pytest.mark.parametrize('epoch', [0, 800, 1600])
+@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 8, 15])
+def test_c_step_equals_native_step(epoch, fuse):
+    inp = _inputs(3, 48, 64)
+    noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ref = _run(_model(epoch), inp, 3, noise, u, use_c_step=False)
+    assert ref[0].cstep is None and ref[0].native is not None
+    got = _run(_model(epoch), inp, 3, noise, u, use_c_step=True, fuse=fuse)
+    assert got[0].cstep is not None and got[0].cstep.supported() and got[0].cstep._cur is not None, 'the C step did not run'
+    _compare(got, ref, ref[0].params.names)
+
+
+@pytest.mark.parametrize('epoch', [0, 800])
+def test_c_step_at_the_benchmark_geometry_fused_equals_operator_level_kernels(epoch):
+    """Config-2 geometry (300x400, K = 10, 10 blocks of 80 faces: four chunks of faces per view in the set-up kernel, per-tile lists of real
+    density, the ground plane crossing the near plane in every view) on 5 views: every fused kernel against the kernels it replaces, and
+    against the launch-by-launch native step."""
+    inp = _inputs(5, 300, 400)
+    nb = 10
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    mk = lambda: _model(epoch, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
+    ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
+    for fuse in (0, 15):
+        got = _run(mk(), inp, 2, noise, u, use_c_step=True, fuse=fuse)
+        _compare(got, ref, ref[0].params.names)
+
+
+def test_c_step_draws_its_noise_and_samples_from_the_counter_based_generator():
+    """Without the caller's draws the step makes its own (rng_math.h): the opacities of step t are sigmoid(logit + std * normal(seed, t, k))
+    of the HOST build of the same generator, identical on a second replica (what data-parallel ranks need), different from step to
+    step; and the overlap term over the step's own samples is the overlap term over torch's samples up to Monte-Carlo noise."""
+    import test_host_model_math as HM
+    L = HM.lib()
+    L.host_step_noise.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+    inp = _inputs(2, 48, 64)
+    alphas = []
+    for rep in range(2):
+        model = _model(0, kill=False)
+        step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=1234)
+        logit = model.alpha_logit.detach().cpu().clone()
+        got = []
+        for t in range(3):
+            out = step(inp)
+            torch.cuda.synchronize()
+            got.append(step.cstep.view('alpha', numel=4).cpu().clone())
+            z = torch.empty(4)
+            L.host_step_noise(1234, t, 4, ctypes.c_void_p(z.data_ptr()))
+            want = torch.sigmoid(logit + float(model.opacity_noise) * z)
+            assert float((got[-1] - want).abs().max()) < 2e-6, (t, got[-1], want)
+        assert not torch.equal(got[0], got[1])
+        alphas.append(torch.stack(got))
+        ov = float(out['overlap'])
+    assert torch.equal(alphas[0], alphas[1])
+    # overlap with torch's samples (the launch-by-launch step): same scene, frozen parameters
+    model = _model(0, kill=False)
+    model._noise_override = torch.zeros(4, device=DEV)
+    ref = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=1234, use_c_step=False)
+    ovs = [float(ref(inp)['overlap']) for _ in range(8)]
+    mean, spread = sum(ovs) / len(ovs), max(ovs) - min(ovs)
+    assert abs(ov - mean) <= max(3 * spread, 0.1 * abs(mean)) + 1e-6, (ov, ovs)
+
+
+def test_c_step_copies_the_loss_values_to_host_memory_itself():
+    """read_losses: the step leaves rgb / parsimony / tv / overlap / total in pinned host memory with ONE copy (src/trainer.py:143 reads six
+    scalars one by one); they are the values on the device, and total is their sum."""
+    inp = _inputs(3, 48, 64)
+    model = _model(0)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=7)
+    step.cstep.read_losses = True
+    for _ in range(3):
+        out = step(inp)
+        host = out.host()
+        dev = {k: float(v) for k, v in out.items()}
+        assert set(host) == set(dev) == {'rgb', 'parsimony', 'tv', 'overlap', 'total'}
+        for k in host:
+            assert host[k] == dev[k], (k, host[k], dev[k])
+        assert abs(host['total'] - (host['rgb'] + host['parsimony'] + host['tv'] + host['overlap'])) < 1e-6 * abs(host['total'])
+        assert host['rgb'] > 0 and host['tv'] > 0
+
+
+def test_c_step_on_fresh_minibatches_of_the_reference_batch_size():
+    """configs/dtu/default.yml:28: batch_size 4, a different set of views every iteration (src/trainer.py:137-147).  The step tiles a fresh
+    mini-batch's targets itself and sizes nothing by the first batch it saw: a plan made for 4 views runs 4, then a ragged last batch of
+    2, then 4 again -- each equal to the launch-by-launch step on the same views."""
+    H, W = 48, 64
+    allv = _inputs(10, H, W, seed=5)
+    nz = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for c in (True, False):
+        model = _model(0)
+        model._noise_override, model._overlap_u_override = nz, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=7, use_c_step=c)
+        grads = []
+        for a, b in ((0, 4), (4, 8), (8, 10), (2, 6)):
+            inp = {k: (v[a:b].clone() if k != 'K' else v[a:b]) for k, v in allv.items()}
+            out = step(inp)
+            torch.cuda.synchronize()
+            grads.append((step.params.grad.clone(), float(out['total'])))
+        res.append(grads)
+    for (ga, la), (gb, lb) in zip(*res):
+        assert abs(la - lb) <= 2e-6 * abs(lb), (la, lb)
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
+
+
+def test_c_step_single_stream_equals_two_streams():
+    """stream_side == stream_main: everything in order on one stream (no events) gives the same step."""
+    inp = _inputs(3, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for side in (True, False):
+        model = _model(800)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        step.cstep.use_side_stream = side
+        out = step(inp)
+        torch.cuda.synchronize()
+        vals = {k: float(v) for k, v in out.items()}
+        grad1 = step.params.grad.clone()
+        step(inp)
+        torch.cuda.synchronize()
+        res.append((step, vals, grad1, step.params.flat.clone()))
+    _compare(res[0], res[1], res[0][0].params.names)

@@ -697,8 +697,9 @@ def test_native_step_equals_autograd_step(epoch):
             model.alpha_logit.add_(torch.tensor([1.0, -6.0, 0.3, 2.0], device=DEV))       # block 1 is killed / filtered
         model.set_cur_epoch(epoch)
         model.sync_free = True
-        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, use_native=native)
-        assert (step.native is not None) == native and (not native or step.native.supported())
+        # (the launch-by-launch form of the native step: use_c_step=False; the C step is held to it in tests/test_gpu_c_step.py)
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, use_native=native, use_c_step=False)
+        assert (step.native is not None) == native and (not native or step.native.supported()) and step.cstep is None
         out = step(inp)
         grad1 = step.params.grad.clone()
         vals = {k: float(v) for k, v in out.items()}

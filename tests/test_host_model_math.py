@@ -24,7 +24,7 @@ def lib():
         os.makedirs(out, exist_ok=True)
         so = os.path.join(out, 'libhost_model_math.so')
         csrc = os.path.join(HERE, '..', 'differentiable-blocksworld_amd', 'csrc')
-        srcs = [os.path.join(HERE, 'host_model_math.cpp'), os.path.join(csrc, 'model_math.h'), os.path.join(csrc, 'raster_math.h')]
+        srcs = [os.path.join(HERE, 'host_model_math.cpp'), os.path.join(csrc, 'model_math.h'), os.path.join(csrc, 'raster_math.h'), os.path.join(csrc, 'rng_math.h')]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', srcs[0], '-o', so])
         _LIB = ctypes.CDLL(so)
@@ -121,3 +121,54 @@ def test_rotation_6d_and_posing_match_autograd_of_the_oracle():
         (ref * g).sum().backward()
         for got, leaf in ((gS, s_), (gR6, a_), (gT, t_), (gv, v_)):
             assert float((got - leaf.grad).abs().max()) <= 1e-4 * float(leaf.grad.abs().max()) + 1e-6
+
+
+# ---- rng_math.h: the counter-based generator of the training step --------------------------------------------------------------------
+def _philox_py(ctr, key):
+    """Independent restatement of Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xffffffff
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & mask, p1 & mask, ((p0 >> 32) ^ c[3] ^ k[1]) & mask, p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return c
+
+
+def test_philox_matches_the_published_known_answers_and_an_independent_restatement():
+    L = lib()
+    out = (ctypes.c_uint32 * 4)()
+    # known-answer vectors of Random123 (kat_vectors: philox4x32 10)
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        L.host_philox(*[ctypes.c_uint32(x) for x in ctr + key], out)
+        assert tuple(out) == want == tuple(_philox_py(ctr, key)), (ctr, [hex(x) for x in out])
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        v = [int(x) for x in rng.integers(0, 2 ** 32, 6)]
+        L.host_philox(*[ctypes.c_uint32(x) for x in v], out)
+        assert list(out) == _philox_py(v[:4], v[4:])
+
+
+def test_step_draws_have_the_distributions_the_reference_draws_from():
+    """dbw.py:301 draws the opacity noise from N(0, 1) (randn_like), dbw.py:393 the overlap samples from U[0, 1) (torch.rand): moments and
+    range of the step's own draws, their dependence on (seed, step) and nothing else."""
+    L = lib()
+    L.host_step_noise.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+    L.host_step_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+    n = 200000
+    z = torch.empty(n)
+    L.host_step_noise(227391, 5, n, _p(z))
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01 and abs(float((z ** 4).mean()) - 3) < 0.1 and torch.isfinite(z).all()
+    u = torch.empty(n, 3)
+    L.host_step_uniform(227391, 5, n, _p(u))
+    assert float(u.min()) >= 0 and float(u.max()) < 1 and abs(float(u.mean()) - 0.5) < 0.005 and abs(float(u.var()) - 1 / 12) < 0.002
+    assert abs(float(torch.corrcoef(u.T)[0, 1])) < 0.01
+    z2, z3 = torch.empty(16), torch.empty(16)
+    L.host_step_noise(227391, 5, 16, _p(z2))
+    L.host_step_noise(227391, 6, 16, _p(z3))
+    assert torch.equal(z2, z[:16]) and not torch.equal(z3, z2)          # a function of (seed, step, index): reproducible, fresh every step
+    L.host_step_noise(227392, 5, 16, _p(z3))
+    assert not torch.equal(z3, z2)
