@@ -219,14 +219,15 @@ __global__ __launch_bounds__(NT) void scene_tail_kernel(const SceneTailArgs A) {
             if (A.keep && !A.keep[k]) continue;
             Pose p;
             load_pose(A.sq_eps, A.S, A.R6, A.T, k, A.scale_min, p);
-            const long long plane = (long long)A.nb * A.nv;
             float acc[17];
 #pragma unroll
             for (int i = 0; i < 17; ++i) acc[i] = 0.f;
             for (int v = lane; v < A.nv; v += 64) {
                 const long long o = (long long)k * A.nv + v;
-                float loc[3], de1[3], de2[3];
-                parametric_sq_point(A.trig[o], A.trig[plane + o], A.trig[2 * plane + o], A.trig[3 * plane + o], p.e1, p.e2, A.ratio, loc, de1, de2);
+                // (the block-frame point and its exponent derivatives as the prologue of this step computed them: the last workgroup runs
+                // the blocks one after the other, and 8 powf / logf per vertex were most of its time)
+                const float *q = A.sq_local + o * 9;
+                const float loc[3] = {q[0], q[1], q[2]}, de1[3] = {q[3], q[4], q[5]}, de2[3] = {q[6], q[7], q[8]};
                 float gv[3];
                 pose_bwd(p, loc, A.S_world, A.Rw, gverts + o * 3, acc, gv);
                 acc[0] += gv[0] * de1[0] + gv[1] * de1[1] + gv[2] * de1[2];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(NT) void scene_tail_kernel(const SceneTailArgs A) {
 // the values it holds in registers.  Same device functions, same bits.
 __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A) {
     __shared__ int s_wcnt[NT / DBW_WAVE];
-    const SceneGeom &G = A.sc[blockIdx.z];
+    const SceneGeom &G = A.sc[A.scene0 + blockIdx.z];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int F = G.F, nchunks = (F + NT - 1) / NT;
     if (chunk >= nchunks) return;
@@ -362,21 +363,22 @@ __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A)
 int dbw::launch_scene_setup(const SceneSetupArgs &A, hipStream_t s) {
     DBW_REQUIRE(A.R && A.T && A.Kmat && A.B > 0, "bad argument");
     int chunks = 0;
-    for (int i = 0; i < 2; ++i) {
+    DBW_REQUIRE(A.scene0 >= 0 && A.nscenes >= 1 && A.scene0 + A.nscenes <= 2, "bad scene range");
+    for (int i = A.scene0; i < A.scene0 + A.nscenes; ++i) {
         const SceneGeom &G = A.sc[i];
         DBW_REQUIRE(G.verts && G.faces && G.fvc && G.first_idx && G.num_faces && G.c2o && G.neighbor && G.code && G.cw && G.bbox && G.recs, "null pointer");
         DBW_REQUIRE(G.V > 0 && G.F > 0 && (long long)A.B * 2 * G.F < 0x7fffffffLL && (!G.zc_on || G.zc > 0.f), "bad size / z_clip");
         DBW_REQUIRE(!G.srec || (G.face_uvs && G.face_map && G.map_desc), "null pointer");
         chunks = max(chunks, (G.F + NT - 1) / NT);
     }
-    hipLaunchKernelGGL(scene_setup_kernel, dim3((unsigned)chunks, (unsigned)A.B, 2u), dim3(NT), 0, s, A);
+    hipLaunchKernelGGL(scene_setup_kernel, dim3((unsigned)chunks, (unsigned)A.B, (unsigned)A.nscenes), dim3(NT), 0, s, A);
     return dbw_check_launch("scene_setup_kernel");
 }
 
 int dbw::launch_scene_tail(const SceneTailArgs &A, hipStream_t s) {
     DBW_REQUIRE(A.verts && A.faces && A.camR && A.camT && A.Kmat && A.num_faces && A.c2o && A.code && A.cw && A.gfvc && A.g_verts && A.ticket, "null pointer");
     DBW_REQUIRE(A.B > 0 && A.V > 0 && A.F > 0 && (size_t)A.V * 3 * sizeof(float) <= 48 * 1024, "bad size (the vertex table must fit 48 KB of LDS)");
-    if (A.mode == 0) DBW_REQUIRE(A.sq_eps && A.S && A.R6 && A.T && A.trig && A.Rw && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.alpha && A.g_logit && A.nb > 0 && A.nb <= NT && A.nv > 0, "bad argument (blocks)");
+    if (A.mode == 0) DBW_REQUIRE(A.sq_eps && A.S && A.R6 && A.T && A.sq_local && A.Rw && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.alpha && A.g_logit && A.nb > 0 && A.nb <= NT && A.nv > 0, "bad argument (blocks)");
     else DBW_REQUIRE(A.base && A.R6 && A.T && A.Rw && A.g_R6 && A.g_T && A.nv > 0 && A.v_begin >= 0 && A.v_begin + A.nv <= A.V, "bad argument (posed mesh)");
     hipLaunchKernelGGL(scene_tail_kernel, dim3((2 * A.F + BWD_SLOTS - 1) / BWD_SLOTS), dim3(NT), (size_t)A.V * 3 * sizeof(float), s, A);
     return dbw_check_launch("scene_tail_kernel");

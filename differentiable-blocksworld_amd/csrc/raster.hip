@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict
 // coarse level and, where the scene's pass reads per-tile lists, goes straight on to the fine level with the bin's list still in LDS.
 __global__ __launch_bounds__(256) void scene_bins_kernel(const SceneBinsArgs A) {
     __shared__ BinShared S;
-    const SceneBinsArgs::One &G = A.sc[blockIdx.z];
+    const SceneBinsArgs::One &G = A.sc[A.scene0 + blockIdx.z];
     const int bin = blockIdx.x, n = blockIdx.y;
     bin_cell_extents(S, A.H, A.W, (bin % A.nx) * COARSE, (bin / A.nx) * COARSE);
     __syncthreads();
@@ -335,12 +335,13 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
 
 int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
     DBW_REQUIRE(A.B > 0 && A.H > 0 && A.W > 0 && A.nx == (A.W + COARSE - 1) / COARSE && A.ny == (A.H + COARSE - 1) / COARSE, "bad size");
-    for (int i = 0; i < 2; ++i) {
+    DBW_REQUIRE(A.scene0 >= 0 && A.nscenes >= 1 && A.scene0 + A.nscenes <= 2, "bad scene range");
+    for (int i = A.scene0; i < A.scene0 + A.nscenes; ++i) {
         const SceneBinsArgs::One &G = A.sc[i];
         DBW_REQUIRE(G.bbox && G.recs && G.first_idx && G.num_faces && G.list && G.count && G.mask, "null pointer");
         DBW_REQUIRE(!G.cells || (G.cell && G.pool && G.hdr && G.rank && G.pool_cap > 0), "null pointer (cell lists)");
     }
-    hipLaunchKernelGGL(scene_bins_kernel, dim3((unsigned)(A.nx * A.ny), (unsigned)A.B, 2u), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(scene_bins_kernel, dim3((unsigned)(A.nx * A.ny), (unsigned)A.B, (unsigned)A.nscenes), dim3(256), 0, s, A);
     return dbw_check_launch("scene_bins_kernel");
 }
 

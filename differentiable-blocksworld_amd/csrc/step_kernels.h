@@ -38,6 +38,7 @@ struct PrologueArgs {
     float ratio, scale_min, S_world;
     const float *Rw, *Tw;
     float *blk_verts;
+    float *sq_local;                                // (nb, nv, 9): block-frame point, d / d eps1, d / d eps2 of every vertex, kept for the tail kernel
     // ground (dbw.py:282-287)
     const float *ground_base; int ngv;
     const float *R6g, *Tg;
@@ -60,7 +61,7 @@ struct SceneGeom {
     // shading records of the soft pass (NULL: none)
     void *srec; const float *face_uvs; const int *face_map, *map_desc; const float *map_alpha;    // one opacity per map, or NULL
 };
-struct SceneSetupArgs { SceneGeom sc[2]; const float *R, *T, *Kmat; int B; };
+struct SceneSetupArgs { SceneGeom sc[2]; const float *R, *T, *Kmat; int B; int scene0, nscenes; };     // scenes [scene0, scene0 + nscenes) of sc
 int launch_scene_setup(const SceneSetupArgs &A, hipStream_t s);
 
 struct SceneBinsArgs {
@@ -70,6 +71,7 @@ struct SceneBinsArgs {
         int cells; int2 *cell; int *pool; int pool_cap; int *hdr; int *rank;
     } sc[2];
     int B, H, W, nx, ny;
+    int scene0, nscenes;
 };
 int launch_scene_bins(const SceneBinsArgs &A, hipStream_t s);
 int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s);
@@ -99,7 +101,7 @@ struct SceneTailArgs {
     unsigned *ticket;                               // zero; left zero
     int mode;                                       // 0: blocks (pose / shape of nb superquadrics + opacities), 1: one posed mesh (the ground)
     // mode 0
-    const float *sq_eps, *S, *R6, *T, *trig; const int *keep; int nb, nv; float ratio, scale_min, S_world; const float *Rw;
+    const float *sq_eps, *S, *R6, *T, *sq_local; const int *keep; int nb, nv; float scale_min, S_world; const float *Rw;
     float *g_sq_eps, *g_S, *g_R6, *g_T;
     const float *alpha, *g_alpha_parts, *g_alpha_full; int alpha_parts; float *g_logit;      // g_alpha_parts may be NULL (fine phase)
     // mode 1: vertices [v_begin, v_begin + nv) of the scene are base (nv, 3) posed by (R6, T)

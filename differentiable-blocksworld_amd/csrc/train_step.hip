@@ -75,7 +75,7 @@ struct Layout {
     SceneBuf e, f;
     size_t p2f_e, bary_e, dists_e, img_e, p2f, bary, dists, part, g_fg, g_env;
     size_t env_maps, blk_maps, sig[3], g_sig[3];
-    size_t alpha, alpha_full, keep, blk_verts, losses, target;
+    size_t alpha, alpha_full, keep, blk_verts, sq_local, losses, target;
     size_t records, cursor[2], layout[2], layout_uniform;
     size_t arena_begin, g_alpha_full, ovl_ws, vals, tickets, g_blk_maps, g_fa, g_fvc_f, g_blk_verts, g_env_maps, g_fvc_e, g_env_verts, arena_end;
     size_t total;
@@ -146,6 +146,7 @@ void make_layout(const dbw_step_desc &d, Layout &L) {
     L.alpha_full = o; o += al((size_t)d.n_blocks * 4);
     L.keep = o; o += al((size_t)d.n_blocks * 4);
     L.blk_verts = o; o += al((size_t)L.Vf * 12);
+    L.sq_local = o; o += al((size_t)L.Vf * 36);
     L.losses = o; o += al(8 * 4);
     L.target = o; o += al(bt * 192 * 4);
     if (bins_on(d)) {
@@ -202,7 +203,8 @@ struct dbw_step_plan {
     Layout L;
     char *ws;
     RasterWorkspace rw_e, rw_f;         // for max_views (the pointers of a run follow from the run's own B)
-    hipEvent_t ev_fork, ev_bins, ev_scatter, ev_fg_fwd, ev_reg, ev_kernel_done, ev_blocks_ready, ev_side_done, ev_losses;
+    hipEvent_t ev_prologue, ev_scatter, ev_fg_fwd, ev_reg, ev_kernel_done, ev_blocks_ready, ev_side_done, ev_losses;
+    hipStream_t stream_r;               // the regularisers run here, next to the set-up and the passes of M and S
     unsigned long long rng_step;
     int bin_turn, bin_ready, uniform_ready;
     bool arena_clean;
@@ -230,9 +232,10 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
         return nullptr;
     }
     p->ws = (char *)workspace;
-    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_bins, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_side_done, &p->ev_losses};
+    hipEvent_t *evs[] = {&p->ev_prologue, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_side_done, &p->ev_losses};
     for (hipEvent_t *e : evs)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
+    if (hipStreamCreateWithFlags(&p->stream_r, hipStreamNonBlocking) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipStreamCreate failed"); delete p; return nullptr; }
     if (hipHostMalloc((void **)&p->host_losses, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         dbw_set_error("dbw_train_step_create: hipHostMalloc failed");
         delete p;
@@ -245,8 +248,9 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
 
 extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     if (!p) return;
-    hipEvent_t evs[] = {p->ev_fork, p->ev_bins, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_kernel_done, p->ev_blocks_ready, p->ev_side_done, p->ev_losses};
+    hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_kernel_done, p->ev_blocks_ready, p->ev_side_done, p->ev_losses};
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
     delete p;
 }
@@ -345,32 +349,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         t.grad_maps = gmaps[i];
     }
 
-    if (two) { HIP_OK(hipEventRecord(p->ev_fork, M)); HIP_OK(hipStreamWaitEvent(S, p->ev_fork, 0)); }
+    hipStream_t Rg = two ? p->stream_r : M;         // the regularisers' stream (plan-owned)
 
-    // ---- S: targets in the tile-planar layout; texture bins: this step's cursors and record sub-ranges ----
+    // ---- M: targets in the tile-planar layout (a fresh mini-batch; resident views come tiled) ----
     const float *target = in->imgs;
     if (!in->imgs_tiled) {
         const long long total = (long long)B * L.tiles * 192;
         long long g = (total + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(tile_target_kernel, dim3((unsigned)g), dim3(256), 0, S, in->imgs, B, 3, H, W, FP(L.target));
+        hipLaunchKernelGGL(tile_target_kernel, dim3((unsigned)g), dim3(256), 0, M, in->imgs, B, 3, H, W, FP(L.target));
         RC(dbw_check_launch("tile_target_kernel"));
         target = FP(L.target);
-    }
-    int *cursor = nullptr;
-    const uint32_t *blayout = nullptr;
-    if (bins) {
-        const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
-        const double total_records = (double)d.n_bins * (double)L.bin_cap;
-        cursor = IP(L.cursor[p->bin_turn]);
-        HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, S));
-        if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
-            RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), S));
-            blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
-        } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
-            RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), S));
-            blayout = (const uint32_t *)(ws + L.layout_uniform);
-        }
     }
 
     // ---- M: prologue ----
@@ -388,6 +377,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         P.sq_eps = d.sq_eps; P.S = d.S; P.R6 = d.R6; P.T = d.T; P.trig = d.trig; P.nv = nv;
         P.ratio = d.ratio_block_scene; P.scale_min = d.scale_min; P.S_world = d.S_world; P.Rw = d.R_world; P.Tw = d.T_world;
         P.blk_verts = FP(L.blk_verts);
+        P.sq_local = FP(L.sq_local);
         P.ground_base = d.ground_base; P.ngv = d.n_ground_verts; P.R6g = d.R6_ground; P.Tg = d.T_ground;
         P.ground_verts = d.env_verts + (size_t)d.n_sky_verts * 3;
         P.zero0 = d.small_grads; P.nzero0 = d.n_small_grads;
@@ -402,8 +392,64 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(dbw_sq_blocks_fwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world,
                              d.T_world, FP(L.blk_verts), M));
     }
+    // (an event costs the stream that records it ~7 us before its next kernel starts: the main stream records two per step, this one and
+    // the one behind the fg pass; the previous step's Adam precedes the prologue on M, so S and Rg need no other fork)
+    if (two) {
+        HIP_OK(hipEventRecord(p->ev_prologue, M));
+        HIP_OK(hipStreamWaitEvent(S, p->ev_prologue, 0));
+        HIP_OK(hipStreamWaitEvent(Rg, p->ev_prologue, 0));
+    }
 
-    // ---- M: camera transform, clipping, per-face records, bins of both scenes ----
+    // ---- Rg: texture bins: this step's cursors and record sub-ranges; the regularisers, value + gradient in one pass, weights folded into
+    // the kernels' scales (dbw.py:373-405) ----
+    int *cursor = nullptr;
+    const uint32_t *blayout = nullptr;
+    if (bins) {
+        const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
+        const double total_records = (double)d.n_bins * (double)L.bin_cap;
+        cursor = IP(L.cursor[p->bin_turn]);
+        HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, Rg));
+        if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
+            RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), Rg));
+            blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
+        } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
+            RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
+            blayout = (const uint32_t *)(ws + L.layout_uniform);
+        }
+    }
+    float *vals = FP(L.vals);
+    const bool sq_local_ready = (d.fuse & 1) != 0;
+    if (d.fuse & 4) {
+        RegulariserArgs A;
+        memset(&A, 0, sizeof(A));
+        A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
+        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
+        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
+        A.overlap_scale = d.w_overlap;
+        A.pars_eps = 1e-6f; A.pars_scale = d.w_parsimony;
+        A.loss_parsimony = vals + 1; A.loss_overlap = vals + 3;
+        A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T; A.g_alpha_full = FP(L.g_alpha_full);
+        A.ws = FP(L.ovl_ws); A.ticket = (unsigned *)(ws + L.tickets);
+        RC(launch_regularisers(A, Rg));
+    } else {
+        if (pars_on) RC(dbw_sqrt_mean(FP(L.alpha_full), nb, 1e-6f, d.w_parsimony, vals + 1, FP(L.g_alpha_full), Rg));
+        if (overlap_on)
+            RC(dbw_overlap_loss(in->overlap_u_override, d.overlap_points, d.sq_eps, d.S, d.R6, d.T, FP(L.alpha_full), nb, d.ratio_block_scene, d.scale_min,
+                                d.overlap_temperature, d.overlap_n_blocks, d.w_overlap, vals + 3, d.g_sq_eps, d.g_S, d.g_R6, d.g_T, FP(L.g_alpha_full),
+                                FP(L.ovl_ws), Rg));
+    }
+    if (tv) {
+        for (int i = 0; i < 3; ++i) {
+            sets[i].sig = FP(L.sig[i]);
+            sets[i].grad_sig_out = FP(L.g_sig[i]);
+            sets[i].grad_sig = FP(L.g_sig[i]);
+        }
+        RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
+    }
+    if (two) HIP_OK(hipEventRecord(p->ev_reg, Rg));
+
+    // ---- camera transform, clipping, per-face records, bins: the env scene on M (the env pass follows it there), the blocks on S next to
+    // the env pass, ending in the launch order of the fg pass's tiles ----
     RasterWorkspace we, wf;
     RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, /*cells: the hard pass walks its coarse bins*/ false, we));
     RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
@@ -428,7 +474,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         e.margin = 0.f; f.margin = margin_f;
         f.hdr = wf.hdr; f.nhdr = CELL_HDR_INTS;
         f.srec = wf.shade_recs; f.face_uvs = d.block_face_uvs; f.face_map = d.block_face_map; f.map_desc = d.block_map_desc; f.map_alpha = fa;
-        RC(launch_scene_setup(A, M));
         SceneBinsArgs Bn;
         memset(&Bn, 0, sizeof(Bn));
         Bn.B = B; Bn.H = H; Bn.W = W; Bn.nx = wf.nx; Bn.ny = wf.ny;
@@ -438,7 +483,14 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             g.list = rw[i]->list; g.count = rw[i]->count; g.mask = rw[i]->mask;
         }
         Bn.sc[1].cells = 1; Bn.sc[1].cell = wf.cell; Bn.sc[1].pool = wf.pool; Bn.sc[1].pool_cap = wf.pool_cap; Bn.sc[1].hdr = wf.hdr; Bn.sc[1].rank = wf.rank;
+        A.scene0 = 0; A.nscenes = 1; Bn.scene0 = 0; Bn.nscenes = 1;
+        RC(launch_scene_setup(A, M));
         RC(launch_scene_bins(Bn, M));
+        A.scene0 = 1; Bn.scene0 = 1;
+        RC(launch_scene_setup(A, S));
+        RC(launch_scene_bins(Bn, S));
+        RC(dbw_launch_work_scatter(wf, B, H, W, S));
+        if (two) HIP_OK(hipEventRecord(p->ev_scatter, S));
     } else {
         RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),
                                 IP(L.e.first), IP(L.e.num), IP(L.e.c2o), IP(L.e.nbr), IP(L.e.code), FP(L.e.cw), M));
@@ -453,59 +505,28 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                     nullptr, nullptr, nullptr, 1, 1, M));
     }
 
-    // ---- S: behind the set-up (opacities, maps, bins): the launch order of the fg pass's tiles; M waits for it (and for the tiled targets)
-    // in front of the fg pass only ----
-    if (two) { HIP_OK(hipEventRecord(p->ev_bins, M)); HIP_OK(hipStreamWaitEvent(S, p->ev_bins, 0)); }
-    if (fused_setup) RC(dbw_launch_work_scatter(wf, B, H, W, S));
-    if (two) HIP_OK(hipEventRecord(p->ev_scatter, S));
-
     // ---- M: the env pass (hard, one face per pixel), then the fg pass ending in the composite + MSE ----
     RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
                             d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
                             IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
-    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
+    if (two && fused_setup) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
     RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                 d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                 d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, FP(L.img_e), target, mse_scale,
                                 FP(L.part), FP(L.g_fg), FP(L.g_env), 2, 1, M));
     if (two) HIP_OK(hipEventRecord(p->ev_fg_fwd, M));
 
-    // ---- S: the regularisers, value + gradient in one pass, weights folded into the kernels' scales (dbw.py:373-405); enqueued behind
-    // the fg pass on purpose: a stream that waits for an event of another stream was observed to wait for everything that stream had
-    // been given by then ----
-    float *vals = FP(L.vals);
-    if (d.fuse & 4) {
-        RegulariserArgs A;
-        memset(&A, 0, sizeof(A));
-        A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
-        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
-        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
-        A.overlap_scale = d.w_overlap;
-        A.pars_eps = 1e-6f; A.pars_scale = d.w_parsimony;
-        A.loss_parsimony = vals + 1; A.loss_overlap = vals + 3;
-        A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T; A.g_alpha_full = FP(L.g_alpha_full);
-        A.ws = FP(L.ovl_ws); A.ticket = (unsigned *)(ws + L.tickets);
-        RC(launch_regularisers(A, S));
-    } else {
-        if (pars_on) RC(dbw_sqrt_mean(FP(L.alpha_full), nb, 1e-6f, d.w_parsimony, vals + 1, FP(L.g_alpha_full), S));
-        if (overlap_on)
-            RC(dbw_overlap_loss(in->overlap_u_override, d.overlap_points, d.sq_eps, d.S, d.R6, d.T, FP(L.alpha_full), nb, d.ratio_block_scene, d.scale_min,
-                                d.overlap_temperature, d.overlap_n_blocks, d.w_overlap, vals + 3, d.g_sq_eps, d.g_S, d.g_R6, d.g_T, FP(L.g_alpha_full),
-                                FP(L.ovl_ws), S));
-    }
-    if (tv) {
-        for (int i = 0; i < 3; ++i) {
-            sets[i].sig = FP(L.sig[i]);
-            sets[i].grad_sig_out = FP(L.g_sig[i]);
-            sets[i].grad_sig = FP(L.g_sig[i]);
-        }
-        RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, S));
-    }
-    if (two) HIP_OK(hipEventRecord(p->ev_reg, S));
-
     // ---- backward of the two passes, each followed by its tail ----
     const bool seq = d.backward_order != 0 || bins;
     const bool both = bins && d.binned_concurrent;
+    const bool tex_on_main = two && !bins && d.tex_bwd_on_main;       // the blocks' textures: behind the env chain on M instead of in front of the fg tail on S
+    auto blocks_textures = [&](hipStream_t st) -> int {
+        dbw_texture_set blk = sets[1];
+        if (!tv) blk.grad_sig = nullptr;
+        RC(dbw_texture_prep_bwd_sets(&blk, 1, st));
+        HIP_OK(hipEventRecord(p->ev_blocks_ready, st));
+        return DBW_OK;
+    };
     auto env_backward = [&]() -> int {
         RC(dbw_render_bwd_fused(IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs, d.env_face_map,
                                 d.env_map_desc, FP(L.env_maps), nullptr, 0, B, H, W, 1, Fe, 0.f, d.bg_env, FP(L.g_env), FP(L.e.fvc), d.perspective_correct, 0,
@@ -527,32 +548,42 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
                                   d.g_R6_ground, d.g_T_ground, M));
         }
-        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));          // the TV gradients of the sky / ground maps (S)
+        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));          // the TV gradients of the sky / ground maps, the regularisers' values (Rg)
         dbw_texture_set env_sets[2] = {sets[0], sets[2]};
         if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
         RC(dbw_texture_prep_bwd_sets(env_sets, 2, M));
+        if (tex_on_main) {
+            HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
+            RC(blocks_textures(M));
+        }
+        // the loss values (nothing is differentiated through them): behind the env chain, where M waits for the fg chain anyway
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, M, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
+        RC(dbw_check_launch("loss_finish_kernel"));
+        if (in->read_losses) {
+            HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, M));
+            HIP_OK(hipEventRecord(p->ev_losses, M));
+            p->losses_pending = true;
+        }
         return DBW_OK;
     };
 
-    if (two) HIP_OK(hipStreamWaitEvent(S, p->ev_fg_fwd, 0));
-    if (two && !(seq && !both)) RC(env_backward());      // both chains at once: the env chain is enqueued first, it is the one on M
+    if (two) {
+        HIP_OK(hipStreamWaitEvent(S, p->ev_fg_fwd, 0));
+        if (bins) HIP_OK(hipStreamWaitEvent(S, p->ev_reg, 0));        // (this step's cursors and sub-ranges come from Rg)
+    }
     RC(dbw_render_bwd_fused(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
                             d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
                             FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
                             bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, S));
-    if (two) HIP_OK(hipEventRecord(p->ev_kernel_done, S));
-    if (two && seq && !both) {
-        HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
+    if (two) {
+        HIP_OK(hipEventRecord(p->ev_kernel_done, S));
+        if (seq && !both) HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
         RC(env_backward());
     }
     if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), S));
-    {
-        dbw_texture_set blk = sets[1];
-        if (!tv) blk.grad_sig = nullptr;
-        RC(dbw_texture_prep_bwd_sets(&blk, 1, S));
-    }
-    HIP_OK(hipEventRecord(p->ev_blocks_ready, S));
-    if (d.fuse & 8) {
+    if (two) HIP_OK(hipStreamWaitEvent(S, p->ev_reg, 0));            // TV gradient of the blocks' maps, d / d alpha_full (Rg)
+    if (!tex_on_main) RC(blocks_textures(S));
+    if ((d.fuse & 8) && sq_local_ready) {
         SceneTailArgs A;
         memset(&A, 0, sizeof(A));
         A.verts = FP(L.blk_verts); A.faces = d.block_faces; A.camR = in->R; A.camT = in->T; A.Kmat = d.Kmat; A.B = B; A.V = Vf; A.F = Ff;
@@ -560,8 +591,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         A.num_faces = IP(L.f.num); A.c2o = IP(L.f.c2o); A.code = IP(L.f.code); A.cw = FP(L.f.cw); A.gfvc = FP(L.g_fvc_f); A.g_verts = FP(L.g_blk_verts);
         A.ticket = (unsigned *)(ws + L.tickets) + 2;
         A.mode = 0;
-        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.trig = d.trig; A.keep = IP(L.keep); A.nb = nb; A.nv = nv;
-        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world;
+        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.sq_local = FP(L.sq_local); A.keep = IP(L.keep); A.nb = nb; A.nv = nv;
+        A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world;
         A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T;
         A.alpha = FP(L.alpha); A.g_alpha_parts = coarse ? FP(L.g_fa) : nullptr; A.alpha_parts = 64; A.g_alpha_full = FP(L.g_alpha_full); A.g_logit = d.g_alpha_logit;
         RC(launch_scene_tail(A, S));
@@ -573,14 +604,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, S));
     }
     if (!two) RC(env_backward());
-    // ---- S: the loss values (nothing is differentiated through them) ----
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, S, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
-    RC(dbw_check_launch("loss_finish_kernel"));
-    if (in->read_losses) {
-        HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, S));
-        HIP_OK(hipEventRecord(p->ev_losses, S));
-        p->losses_pending = true;
-    }
     if (two) { HIP_OK(hipEventRecord(p->ev_side_done, S)); HIP_OK(hipStreamWaitEvent(M, p->ev_side_done, 0)); }
 
     // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----

@@ -51,7 +51,7 @@ class StepDesc(ctypes.Structure):
                                       'g_sq_eps', 'g_S', 'g_R6', 'g_T', 'g_alpha_logit', 'g_R6_ground', 'g_T_ground', 'g_texture_bkg', 'g_texture_ground',
                                       'g_textures', 'flat_param', 'flat_grad', 'exp_avg', 'exp_avg_sq')]
                 + [('group_end', c_i64 * 2), ('small_grads', c_p), ('n_small_grads', c_i), ('fuse', c_i), ('backward_order', c_i),
-                   ('binned_concurrent', c_i), ('seed', ctypes.c_uint64)])
+                   ('binned_concurrent', c_i), ('tex_bwd_on_main', c_i), ('seed', ctypes.c_uint64)])
 
 
 class StepInputs(ctypes.Structure):

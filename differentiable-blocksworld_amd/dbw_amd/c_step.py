@@ -174,6 +174,7 @@ class CStep:
         d.group_end[0], d.group_end[1] = P.bounds[0][1], P.bounds[1][1]
         d.small_grads, d.n_small_grads = _p(P.grad), P.bounds[0][1]
         d.fuse, d.backward_order, d.binned_concurrent = self.fuse, int(seq), int(bool(both))
+        d.tex_bwd_on_main = int(m.world_size == 1)
         d.seed = int(getattr(m, '_rng_seed', 227391)) & 0xffffffffffffffff
         lib = _lib.load()
         nbytes = lib.dbw_train_step_workspace_bytes(ctypes.byref(d))

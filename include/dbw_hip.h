@@ -368,16 +368,16 @@ int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float 
  * shipped config trains in (decouple_rendering, detach_bary, perspective cameras, MSE + parsimony + TV + overlap).
  *
  * Why an entry of its own: at the reference's batch size (4 views, configs/dtu/default.yml:28) the kernels of an iteration take ~0.1 ms
- * and 33 launches issued one by one from the host took 0.5 ms.  Here the host makes ONE call; the library enqueues ~16 launches on two
- * streams (the dependent 5-20 us kernels of the operator-level path are fused into a prologue, one set-up kernel and one binning kernel
+ * and 33 launches issued one by one from the host took 0.5 ms.  Here the host makes ONE call; the library enqueues ~18 launches on the
+ * caller's two streams and one of its own (the dependent 5-20 us kernels of the operator-level path are fused into a prologue, one set-up kernel and one binning kernel
  * for both scenes, one regulariser kernel and one tail kernel per scene: csrc/step_kernels.h), draws the opacity noise and the overlap
  * samples from a counter-based generator inside those kernels, and leaves the loss values in host-visible memory with one copy.
  *
  * Ownership: every pointer of dbw_step_desc / dbw_step_inputs is caller-owned DEVICE memory that stays valid while the plan lives
  * (inputs: until the call's work has finished).  `workspace` (dbw_train_step_workspace_bytes bytes, 256-byte aligned) is caller-owned
  * scratch the plan carves everything else out of: clipped faces, raster workspaces, fragments, images, maps, gradient accumulators, the
- * records of the texture bins.  The plan is the one object of this ABI that holds state between calls: its events, the step counter of
- * its random numbers, and which of the two demand tables of the texture bins is current.  Not thread-safe; one plan per
+ * records of the texture bins.  The plan is the one object of this ABI that holds state between calls: its events, a stream of its own
+ * for the regularisers, the step counter of its random numbers, and which of the two demand tables of the texture bins is current.  Not thread-safe; one plan per
  * (model, training phase, device).
  */
 typedef struct dbw_step_desc {
@@ -419,6 +419,9 @@ typedef struct dbw_step_desc {
     int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: tails; 0 = the operator-level kernels */
     int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel / texture bins) */
     int binned_concurrent;                      /* texture bins: the env chain starts next to the fg kernel */
+    int tex_bwd_on_main;                        /* the backward of the blocks' texture preparation behind the env chain on stream_main (one GPU: it
+                                                 * leaves the critical fg chain) instead of in front of the fg tail on stream_side (data parallel:
+                                                 * the blocks' texture gradient is then final as early as possible) */
     uint64_t seed;                              /* of the step's random numbers: the same on every data-parallel rank */
 } dbw_step_desc;
 

@@ -75,7 +75,7 @@ def _compare(a, b, names):
 
 
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
-@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 8, 15])
+@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 8, 9, 15])
 def test_c_step_equals_native_step(epoch, fuse):
     inp = _inputs(3, 48, 64)
     noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
