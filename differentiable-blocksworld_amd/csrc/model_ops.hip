@@ -333,7 +333,46 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P
     }
 }
 
+// Backward of the blocks' pose / shape + of their opacities (step_kernels.h: BlocksTailArgs): workgroup = block, one wave.
+__global__ __launch_bounds__(64) void blocks_tail_kernel(const BlocksTailArgs A) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const bool alive = !A.keep || A.keep[k];
+    if (lane == 0) {          // block_alpha_bwd_kernel
+        const float a = A.alpha[k];
+        float g = 0.f;
+        if (A.g_alpha_parts)
+            for (int i = 0; i < A.alpha_parts; ++i) g += A.g_alpha_parts[k * A.alpha_parts + i];
+        if (A.g_alpha_full && alive) g += A.g_alpha_full[k];
+        A.g_logit[k] = g * a * (1.f - a);
+    }
+    if (!alive) return;
+    Pose p;
+    load_pose(A.sq_eps, A.S, A.R6, A.T, k, A.scale_min, p);
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+    for (int v = lane; v < A.nv; v += 64) {
+        const long long o = (long long)k * A.nv + v;
+        const float *q = A.sq_local + o * 9;          // block-frame point, d / d eps1, d / d eps2 as this step's prologue computed them
+        const float loc[3] = {q[0], q[1], q[2]}, de1[3] = {q[3], q[4], q[5]}, de2[3] = {q[6], q[7], q[8]};
+        float gv[3];
+        pose_bwd(p, loc, A.S_world, A.Rw, A.g_verts + o * 3, acc, gv);
+        acc[0] += gv[0] * de1[0] + gv[1] * de1[1] + gv[2] * de1[2];
+        acc[1] += gv[0] * de2[0] + gv[1] * de2[1] + gv[2] * de2[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) finish_pose_grads(p, A.S, k, acc, A.g_sq_eps, A.g_S, A.g_R6, A.g_T);
+}
+
 }  // namespace
+
+int dbw::launch_blocks_tail(const BlocksTailArgs &A, hipStream_t s) {
+    DBW_REQUIRE(A.sq_eps && A.S && A.R6 && A.T && A.sq_local && A.Rw && A.g_verts && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.alpha && A.g_logit, "null pointer");
+    DBW_REQUIRE(A.nb > 0 && A.nv > 0 && A.alpha_parts >= 1, "bad size");
+    hipLaunchKernelGGL(blocks_tail_kernel, dim3((unsigned)A.nb), dim3(64), 0, s, A);
+    return dbw_check_launch("blocks_tail_kernel");
+}
 
 int dbw::launch_step_prologue(const PrologueArgs &P, hipStream_t s) {
     DBW_REQUIRE(P.nsets >= 0 && P.nsets <= STEP_MAX_SETS && P.nb > 0 && P.nb <= MAX_KB && P.nv > 0 && P.ngv > 0, "bad size");

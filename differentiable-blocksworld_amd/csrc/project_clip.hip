@@ -9,7 +9,6 @@
 // or 2 triangles) assigns output slots in original face order, and each thread writes its own triangles.
 #include "dbw_common.h"
 #include "camera_math.h"
-#include "model_math.h"
 #include "shade_common.h"
 #include "raster_bin.h"
 #include "step_kernels.h"
@@ -198,72 +197,6 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     project_clip_bwd_body<LDS_TABLE>(verts, faces, R, T, Kmat, B, V, F, eps, zc, persp, num_faces, c2o, code, cw, gfvc, gverts, s_acc, blockIdx.x);
 }
 
-// ---- training step: backward of projection + clipping of one scene, then, in the workgroup that finishes last, what used to be the
-// next launches of the chain: the backward of the pose / shape parameters (step_kernels.h: SceneTailArgs) --------------------------------
-__global__ __launch_bounds__(NT) void scene_tail_kernel(const SceneTailArgs A) {
-    extern __shared__ float s_acc[];   // V * 3
-    __shared__ int s_last;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    project_clip_bwd_body<true>(A.verts, A.faces, A.camR, A.camT, A.Kmat, A.B, A.V, A.F, A.cam_eps, A.zc, A.persp, A.num_faces, A.c2o, A.code, A.cw,
-                                A.gfvc, A.g_verts, s_acc, blockIdx.x);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                   // every workgroup's flush is visible: g_verts is final
-    const float *gverts = A.g_verts;
-    if (A.mode == 0) {
-        // sq_blocks_bwd_kernel: one wave per block (dense = 0: every block keeps its slot)
-        for (int k = wv; k < A.nb; k += NT / DBW_WAVE) {
-            if (A.keep && !A.keep[k]) continue;
-            Pose p;
-            load_pose(A.sq_eps, A.S, A.R6, A.T, k, A.scale_min, p);
-            float acc[17];
-#pragma unroll
-            for (int i = 0; i < 17; ++i) acc[i] = 0.f;
-            for (int v = lane; v < A.nv; v += 64) {
-                const long long o = (long long)k * A.nv + v;
-                // (the block-frame point and its exponent derivatives as the prologue of this step computed them: the last workgroup runs
-                // the blocks one after the other, and 8 powf / logf per vertex were most of its time)
-                const float *q = A.sq_local + o * 9;
-                const float loc[3] = {q[0], q[1], q[2]}, de1[3] = {q[3], q[4], q[5]}, de2[3] = {q[6], q[7], q[8]};
-                float gv[3];
-                pose_bwd(p, loc, A.S_world, A.Rw, gverts + o * 3, acc, gv);
-                acc[0] += gv[0] * de1[0] + gv[1] * de1[1] + gv[2] * de1[2];
-                acc[1] += gv[0] * de2[0] + gv[1] * de2[1] + gv[2] * de2[2];
-            }
-#pragma unroll
-            for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
-            if (lane == 0) finish_pose_grads(p, A.S, k, acc, A.g_sq_eps, A.g_S, A.g_R6, A.g_T);
-        }
-        // block_alpha_bwd_kernel
-        if (tid < A.nb) {
-            const float a = A.alpha[tid];
-            float g = 0.f;
-            if (A.g_alpha_parts)
-                for (int i = 0; i < A.alpha_parts; ++i) g += A.g_alpha_parts[tid * A.alpha_parts + i];
-            if (A.g_alpha_full && (!A.keep || A.keep[tid])) g += A.g_alpha_full[tid];
-            A.g_logit[tid] = g * a * (1.f - a);
-        }
-    } else if (wv == 0) {
-        // posed_mesh_bwd_kernel
-        Pose p;
-        load_pose(nullptr, nullptr, A.R6, A.T, 0, 0.f, p);
-        float acc[17];
-#pragma unroll
-        for (int i = 0; i < 17; ++i) acc[i] = 0.f;
-        for (int v = lane; v < A.nv; v += 64) {
-            float gv[3];
-            pose_bwd(p, A.base + (long long)v * 3, A.S_world, A.Rw, gverts + (long long)(A.v_begin + v) * 3, acc, gv);
-        }
-#pragma unroll
-        for (int i = 0; i < 17; ++i) acc[i] = wave_sum(acc[i]);
-        if (lane == 0) finish_pose_grads(p, nullptr, 0, acc, nullptr, nullptr, A.g_R6, A.g_T);
-    }
-    if (tid == 0) *A.ticket = 0u;
-}
-
 // ---- training step: camera transform + near-plane clipping + per-face raster records (+ shading records) of both scenes -----------------
 // One workgroup per (chunk of 256 faces, view, scene).  The slots of a view's clipped faces are assigned in face order (a face emits 0,
 // 1 or 2 triangles): a workgroup first COUNTS what the faces in front of its chunk emit -- a face's count follows from the view depths
@@ -373,15 +306,6 @@ int dbw::launch_scene_setup(const SceneSetupArgs &A, hipStream_t s) {
     }
     hipLaunchKernelGGL(scene_setup_kernel, dim3((unsigned)chunks, (unsigned)A.B, (unsigned)A.nscenes), dim3(NT), 0, s, A);
     return dbw_check_launch("scene_setup_kernel");
-}
-
-int dbw::launch_scene_tail(const SceneTailArgs &A, hipStream_t s) {
-    DBW_REQUIRE(A.verts && A.faces && A.camR && A.camT && A.Kmat && A.num_faces && A.c2o && A.code && A.cw && A.gfvc && A.g_verts && A.ticket, "null pointer");
-    DBW_REQUIRE(A.B > 0 && A.V > 0 && A.F > 0 && (size_t)A.V * 3 * sizeof(float) <= 48 * 1024, "bad size (the vertex table must fit 48 KB of LDS)");
-    if (A.mode == 0) DBW_REQUIRE(A.sq_eps && A.S && A.R6 && A.T && A.sq_local && A.Rw && A.g_sq_eps && A.g_S && A.g_R6 && A.g_T && A.alpha && A.g_logit && A.nb > 0 && A.nb <= NT && A.nv > 0, "bad argument (blocks)");
-    else DBW_REQUIRE(A.base && A.R6 && A.T && A.Rw && A.g_R6 && A.g_T && A.nv > 0 && A.v_begin >= 0 && A.v_begin + A.nv <= A.V, "bad argument (posed mesh)");
-    hipLaunchKernelGGL(scene_tail_kernel, dim3((2 * A.F + BWD_SLOTS - 1) / BWD_SLOTS), dim3(NT), (size_t)A.V * 3 * sizeof(float), s, A);
-    return dbw_check_launch("scene_tail_kernel");
 }
 
 extern "C" int dbw_project_clip_fwd(const float *verts_world, const int32_t *faces, const float *R, const float *T,

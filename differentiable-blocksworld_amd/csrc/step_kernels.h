@@ -9,8 +9,10 @@
 //                                         scenes (env: sky + ground, fg: blocks)                          [was 5]
 //   scene_bins        (raster.hip)        coarse bins of both scenes + per-tile face lists of the fg pass [was 3]
 //   regularisers      (model_ops.hip)     parsimony + overlap (samples drawn in registers) + its finish   [was 4]
-//   scene_tail        (project_clip.hip)  backward of projection / clipping, then -- by the workgroup that finishes last -- the
-//                                         backward of the pose / shape (blocks: + opacities; env: ground) [was 3 / 2]
+//   blocks_tail       (model_ops.hip)     backward of the blocks' pose / shape (from the points the prologue kept) + of their opacities [was 2]
+// (What is NOT fused, on purpose: a chain of dependent kernels on ONE stream enqueued from C runs without gaps -- measured -- so fusing it
+// buys nothing, and a "last workgroup finishes the job" epilogue serialises what separate kernels run in parallel: the tails built that
+// way were slower than the launches they replaced.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -92,21 +94,14 @@ struct RegulariserArgs {
 };
 int launch_regularisers(const RegulariserArgs &A, hipStream_t s);
 
-struct SceneTailArgs {
-    // backward of projection + clipping: grad_face_verts_c (B, 2F, 3, 3) -> g_verts (V, 3) (zero on entry)
-    const float *verts; const int *faces; const float *camR, *camT, *Kmat;
-    int B, V, F; float cam_eps, zc; int persp;
-    const int *num_faces, *c2o, *code; const float *cw; const float *gfvc;
-    float *g_verts;
-    unsigned *ticket;                               // zero; left zero
-    int mode;                                       // 0: blocks (pose / shape of nb superquadrics + opacities), 1: one posed mesh (the ground)
-    // mode 0
+// backward of the blocks' pose / shape from the gradient of their world vertices + backward of the block opacities: sq_blocks_bwd_kernel
+// reading the block-frame points the prologue kept (no powf / logf) with block_alpha_bwd_kernel in the same launch, one workgroup per block
+struct BlocksTailArgs {
     const float *sq_eps, *S, *R6, *T, *sq_local; const int *keep; int nb, nv; float scale_min, S_world; const float *Rw;
+    const float *g_verts;
     float *g_sq_eps, *g_S, *g_R6, *g_T;
     const float *alpha, *g_alpha_parts, *g_alpha_full; int alpha_parts; float *g_logit;      // g_alpha_parts may be NULL (fine phase)
-    // mode 1: vertices [v_begin, v_begin + nv) of the scene are base (nv, 3) posed by (R6, T)
-    const float *base; int v_begin;
 };
-int launch_scene_tail(const SceneTailArgs &A, hipStream_t s);
+int launch_blocks_tail(const BlocksTailArgs &A, hipStream_t s);
 
 }  // namespace dbw

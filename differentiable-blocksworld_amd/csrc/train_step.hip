@@ -203,8 +203,8 @@ struct dbw_step_plan {
     Layout L;
     char *ws;
     RasterWorkspace rw_e, rw_f;         // for max_views (the pointers of a run follow from the run's own B)
-    hipEvent_t ev_prologue, ev_scatter, ev_fg_fwd, ev_reg, ev_kernel_done, ev_blocks_ready, ev_side_done, ev_losses;
-    hipStream_t stream_r;               // the regularisers run here, next to the set-up and the passes of M and S
+    hipEvent_t ev_prologue, ev_scatter, ev_fg_fwd, ev_reg, ev_layout, ev_kernel_done, ev_blocks_ready, ev_env_done, ev_losses;
+    hipStream_t stream_r, stream_env;   // plan-owned, lowest priority: the regularisers; the env backward chain (when the caller brings no side stream)
     unsigned long long rng_step;
     int bin_turn, bin_ready, uniform_ready;
     bool arena_clean;
@@ -232,10 +232,17 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
         return nullptr;
     }
     p->ws = (char *)workspace;
-    hipEvent_t *evs[] = {&p->ev_prologue, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_side_done, &p->ev_losses};
+    hipEvent_t *evs[] = {&p->ev_prologue, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_layout, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_env_done, &p->ev_losses};
     for (hipEvent_t *e : evs)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
-    if (hipStreamCreateWithFlags(&p->stream_r, hipStreamNonBlocking) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipStreamCreate failed"); delete p; return nullptr; }
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&p->stream_r, hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipStreamCreateWithPriority(&p->stream_env, hipStreamNonBlocking, prio_least) != hipSuccess) {
+        dbw_set_error("dbw_train_step_create: hipStreamCreate failed");
+        delete p;
+        return nullptr;
+    }
     if (hipHostMalloc((void **)&p->host_losses, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         dbw_set_error("dbw_train_step_create: hipHostMalloc failed");
         delete p;
@@ -248,9 +255,10 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
 
 extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     if (!p) return;
-    hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_kernel_done, p->ev_blocks_ready, p->ev_side_done, p->ev_losses};
+    hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_layout, p->ev_kernel_done, p->ev_blocks_ready, p->ev_env_done, p->ev_losses};
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
+    if (p->stream_env) (void)hipStreamDestroy(p->stream_env);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
     delete p;
 }
@@ -274,7 +282,6 @@ extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
     }
 }
 
-extern "C" void *dbw_train_step_blocks_ready_event(dbw_step_plan *p) { return p ? (void *)p->ev_blocks_ready : nullptr; }
 
 extern "C" int dbw_train_step_losses(dbw_step_plan *p, float *out5) {
     DBW_REQUIRE(p && out5, "null pointer");
@@ -306,8 +313,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
     DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
     DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
-    hipStream_t M = (hipStream_t)stream_main, S = (hipStream_t)stream_side;
-    const bool two = M != S;
+    // M: the critical chain.  E: the env backward chain, Rg: the regularisers -- the caller's side stream, or (NULL) streams of the plan
+    // at the lowest priority, so that whatever shares the GPU with the fg chain yields to it.  stream_side == stream_main: one stream.
+    hipStream_t M = (hipStream_t)stream_main;
+    const bool two = !(stream_side && stream_side == stream_main);
+    hipStream_t E = !two ? M : (stream_side ? (hipStream_t)stream_side : p->stream_env), Rg = two ? p->stream_r : M;
     char *ws = p->ws;
 #define FP(off) ((float *)(ws + (off)))
 #define IP(off) ((int *)(ws + (off)))
@@ -348,8 +358,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         t.grad_texture = gtex[i];
         t.grad_maps = gmaps[i];
     }
-
-    hipStream_t Rg = two ? p->stream_r : M;         // the regularisers' stream (plan-owned)
 
     // ---- M: targets in the tile-planar layout (a fresh mini-batch; resident views come tiled) ----
     const float *target = in->imgs;
@@ -392,11 +400,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(dbw_sq_blocks_fwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world,
                              d.T_world, FP(L.blk_verts), M));
     }
-    // (an event costs the stream that records it ~7 us before its next kernel starts: the main stream records two per step, this one and
-    // the one behind the fg pass; the previous step's Adam precedes the prologue on M, so S and Rg need no other fork)
+    // (measured: a chain of dependent kernels enqueued from here on ONE stream runs without gaps; an event costs the stream that records or
+    // waits for it ~7 us before its next kernel, and a kernel behind an event of ANOTHER stream starts 12-26 us after that event.  So the
+    // critical chain -- set-up, passes, fg backward, its tail, Adam -- stays on M and only what is off it forks)
     if (two) {
         HIP_OK(hipEventRecord(p->ev_prologue, M));
-        HIP_OK(hipStreamWaitEvent(S, p->ev_prologue, 0));
         HIP_OK(hipStreamWaitEvent(Rg, p->ev_prologue, 0));
     }
 
@@ -416,9 +424,9 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
             blayout = (const uint32_t *)(ws + L.layout_uniform);
         }
+        if (two) HIP_OK(hipEventRecord(p->ev_layout, Rg));
     }
     float *vals = FP(L.vals);
-    const bool sq_local_ready = (d.fuse & 1) != 0;
     if (d.fuse & 4) {
         RegulariserArgs A;
         memset(&A, 0, sizeof(A));
@@ -446,15 +454,15 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         }
         RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
     }
-    if (two) HIP_OK(hipEventRecord(p->ev_reg, Rg));
 
-    // ---- camera transform, clipping, per-face records, bins: the env scene on M (the env pass follows it there), the blocks on S next to
-    // the env pass, ending in the launch order of the fg pass's tiles ----
+    // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
     RasterWorkspace we, wf;
     RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, /*cells: the hard pass walks its coarse bins*/ false, we));
     RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
     const bool fused_setup = (d.fuse & 2) && we.binned && wf.binned && wf.cells;
     const float margin_f = (float)sqrt((double)d.blur_radius);
+    // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
+    const bool setup_aside = two && fused_setup && B > d.serial_setup_max_views;
     if (fused_setup) {
         SceneSetupArgs A;
         memset(&A, 0, sizeof(A));
@@ -483,14 +491,22 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             g.list = rw[i]->list; g.count = rw[i]->count; g.mask = rw[i]->mask;
         }
         Bn.sc[1].cells = 1; Bn.sc[1].cell = wf.cell; Bn.sc[1].pool = wf.pool; Bn.sc[1].pool_cap = wf.pool_cap; Bn.sc[1].hdr = wf.hdr; Bn.sc[1].rank = wf.rank;
-        A.scene0 = 0; A.nscenes = 1; Bn.scene0 = 0; Bn.nscenes = 1;
-        RC(launch_scene_setup(A, M));
-        RC(launch_scene_bins(Bn, M));
-        A.scene0 = 1; Bn.scene0 = 1;
-        RC(launch_scene_setup(A, S));
-        RC(launch_scene_bins(Bn, S));
-        RC(dbw_launch_work_scatter(wf, B, H, W, S));
-        if (two) HIP_OK(hipEventRecord(p->ev_scatter, S));
+        if (setup_aside) {
+            HIP_OK(hipStreamWaitEvent(E, p->ev_prologue, 0));
+            A.scene0 = 0; A.nscenes = 1; Bn.scene0 = 0; Bn.nscenes = 1;
+            RC(launch_scene_setup(A, M));
+            RC(launch_scene_bins(Bn, M));
+            A.scene0 = 1; Bn.scene0 = 1;
+            RC(launch_scene_setup(A, E));
+            RC(launch_scene_bins(Bn, E));
+            RC(dbw_launch_work_scatter(wf, B, H, W, E));
+            HIP_OK(hipEventRecord(p->ev_scatter, E));
+        } else {
+            A.scene0 = 0; A.nscenes = 2; Bn.scene0 = 0; Bn.nscenes = 2;
+            RC(launch_scene_setup(A, M));
+            RC(launch_scene_bins(Bn, M));
+            RC(dbw_launch_work_scatter(wf, B, H, W, M));
+        }
     } else {
         RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),
                                 IP(L.e.first), IP(L.e.num), IP(L.e.c2o), IP(L.e.nbr), IP(L.e.code), FP(L.e.cw), M));
@@ -509,107 +525,105 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
                             d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
                             IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
-    if (two && fused_setup) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
+    if (setup_aside) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
     RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                 d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                 d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, FP(L.img_e), target, mse_scale,
                                 FP(L.part), FP(L.g_fg), FP(L.g_env), 2, 1, M));
+    const bool seq = d.backward_order != 0 || (bins && !d.binned_concurrent);     // the env chain waits for the fg backward KERNEL
     if (two) HIP_OK(hipEventRecord(p->ev_fg_fwd, M));
 
-    // ---- backward of the two passes, each followed by its tail ----
-    const bool seq = d.backward_order != 0 || bins;
-    const bool both = bins && d.binned_concurrent;
-    const bool tex_on_main = two && !bins && d.tex_bwd_on_main;       // the blocks' textures: behind the env chain on M instead of in front of the fg tail on S
-    auto blocks_textures = [&](hipStream_t st) -> int {
-        dbw_texture_set blk = sets[1];
-        if (!tv) blk.grad_sig = nullptr;
-        RC(dbw_texture_prep_bwd_sets(&blk, 1, st));
-        HIP_OK(hipEventRecord(p->ev_blocks_ready, st));
-        return DBW_OK;
-    };
-    auto env_backward = [&]() -> int {
-        RC(dbw_render_bwd_fused(IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs, d.env_face_map,
-                                d.env_map_desc, FP(L.env_maps), nullptr, 0, B, H, W, 1, Fe, 0.f, d.bg_env, FP(L.g_env), FP(L.e.fvc), d.perspective_correct, 0,
-                                FP(L.g_env_maps), nullptr, FP(L.g_fvc_e), 1, 3, nullptr, nullptr, nullptr, 0, nullptr, d.n_sky_faces, nullptr, 1, M));
-        if (d.fuse & 8) {
-            SceneTailArgs A;
-            memset(&A, 0, sizeof(A));
-            A.verts = d.env_verts; A.faces = d.env_faces; A.camR = in->R; A.camT = in->T; A.Kmat = d.Kmat; A.B = B; A.V = Ve; A.F = Fe;
-            A.cam_eps = d.cam_eps; A.zc = d.z_clip; A.persp = d.perspective_correct;
-            A.num_faces = IP(L.e.num); A.c2o = IP(L.e.c2o); A.code = IP(L.e.code); A.cw = FP(L.e.cw); A.gfvc = FP(L.g_fvc_e); A.g_verts = FP(L.g_env_verts);
-            A.ticket = (unsigned *)(ws + L.tickets) + 1;
-            A.mode = 1;
-            A.base = d.ground_base; A.v_begin = d.n_sky_verts; A.nv = d.n_ground_verts; A.R6 = d.R6_ground; A.T = d.T_ground; A.S_world = d.S_world; A.Rw = d.R_world;
-            A.g_R6 = d.g_R6_ground; A.g_T = d.g_T_ground;
-            RC(launch_scene_tail(A, M));
-        } else {
-            RC(dbw_project_clip_bwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.e.num),
-                                    IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), FP(L.g_fvc_e), FP(L.g_env_verts), M));
-            RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
-                                  d.g_R6_ground, d.g_T_ground, M));
-        }
-        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));          // the TV gradients of the sky / ground maps, the regularisers' values (Rg)
-        dbw_texture_set env_sets[2] = {sets[0], sets[2]};
-        if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
-        RC(dbw_texture_prep_bwd_sets(env_sets, 2, M));
-        if (tex_on_main) {
-            HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
-            RC(blocks_textures(M));
-        }
-        // the loss values (nothing is differentiated through them): behind the env chain, where M waits for the fg chain anyway
-        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, M, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
+    // ---- Rg: the loss values (nothing is differentiated through them) ----
+    if (two) HIP_OK(hipStreamWaitEvent(Rg, p->ev_fg_fwd, 0));
+    auto loss_values = [&](hipStream_t st) -> int {
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
         RC(dbw_check_launch("loss_finish_kernel"));
         if (in->read_losses) {
-            HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, M));
-            HIP_OK(hipEventRecord(p->ev_losses, M));
+            HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipEventRecord(p->ev_losses, st));
             p->losses_pending = true;
         }
         return DBW_OK;
     };
+    if (two) { RC(loss_values(Rg)); HIP_OK(hipEventRecord(p->ev_reg, Rg)); }
 
-    if (two) {
-        HIP_OK(hipStreamWaitEvent(S, p->ev_fg_fwd, 0));
-        if (bins) HIP_OK(hipStreamWaitEvent(S, p->ev_reg, 0));        // (this step's cursors and sub-ranges come from Rg)
+    // ---- E: backward of the env pass and its tail ----
+    const bool tex_in_adam = in->with_adam && (d.fuse & 16);
+    auto env_backward = [&](hipStream_t st) -> int {
+        RC(dbw_render_bwd_fused(IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs, d.env_face_map,
+                                d.env_map_desc, FP(L.env_maps), nullptr, 0, B, H, W, 1, Fe, 0.f, d.bg_env, FP(L.g_env), FP(L.e.fvc), d.perspective_correct, 0,
+                                FP(L.g_env_maps), nullptr, FP(L.g_fvc_e), 1, 3, nullptr, nullptr, nullptr, 0, nullptr, d.n_sky_faces, nullptr, 1, st));
+        RC(dbw_project_clip_bwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.e.num),
+                                IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), FP(L.g_fvc_e), FP(L.g_env_verts), st));
+        RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
+                              d.g_R6_ground, d.g_T_ground, st));
+        if (!tex_in_adam) {
+            if (two) HIP_OK(hipStreamWaitEvent(st, p->ev_reg, 0));      // the TV gradients of the sky / ground maps (Rg)
+            dbw_texture_set env_sets[2] = {sets[0], sets[2]};
+            if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
+            RC(dbw_texture_prep_bwd_sets(env_sets, 2, st));
+        }
+        return DBW_OK;
+    };
+    if (two && !seq) {
+        HIP_OK(hipStreamWaitEvent(E, p->ev_fg_fwd, 0));
+        RC(env_backward(E));
+        HIP_OK(hipEventRecord(p->ev_env_done, E));
     }
+
+    // ---- M: backward of the fg pass and its tail ----
+    if (bins && two) HIP_OK(hipStreamWaitEvent(M, p->ev_layout, 0));      // (this step's cursors and sub-ranges come from Rg)
     RC(dbw_render_bwd_fused(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
                             d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
                             FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
-                            bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, S));
-    if (two) {
-        HIP_OK(hipEventRecord(p->ev_kernel_done, S));
-        if (seq && !both) HIP_OK(hipStreamWaitEvent(M, p->ev_kernel_done, 0));
-        RC(env_backward());
+                            bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, M));
+    if (two && seq) {
+        HIP_OK(hipEventRecord(p->ev_kernel_done, M));
+        HIP_OK(hipStreamWaitEvent(E, p->ev_kernel_done, 0));
+        RC(env_backward(E));
+        HIP_OK(hipEventRecord(p->ev_env_done, E));
     }
-    if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), S));
-    if (two) HIP_OK(hipStreamWaitEvent(S, p->ev_reg, 0));            // TV gradient of the blocks' maps, d / d alpha_full (Rg)
-    if (!tex_on_main) RC(blocks_textures(S));
-    if ((d.fuse & 8) && sq_local_ready) {
-        SceneTailArgs A;
+    if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), M));
+    bool waited_reg = !two;
+    if (!tex_in_adam) {
+        // the backward of the blocks' texture preparation as a launch of its own, first in the tail: a data-parallel caller reduces the
+        // blocks' texture gradient -- 83 % of the gradient bytes -- as soon as ev_blocks_ready says so, next to everything below
+        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));            // TV gradient of the blocks' maps (Rg)
+        waited_reg = true;
+        dbw_texture_set blk = sets[1];
+        if (!tv) blk.grad_sig = nullptr;
+        RC(dbw_texture_prep_bwd_sets(&blk, 1, M));
+        HIP_OK(hipEventRecord(p->ev_blocks_ready, M));
+    }
+    RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
+                            IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
+    if (!waited_reg) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));        // d / d alpha_full, the pose gradients of the overlap term, TV gradients (Rg)
+    if ((d.fuse & 8) && (d.fuse & 1)) {
+        BlocksTailArgs A;
         memset(&A, 0, sizeof(A));
-        A.verts = FP(L.blk_verts); A.faces = d.block_faces; A.camR = in->R; A.camT = in->T; A.Kmat = d.Kmat; A.B = B; A.V = Vf; A.F = Ff;
-        A.cam_eps = d.cam_eps; A.zc = d.z_clip; A.persp = d.perspective_correct;
-        A.num_faces = IP(L.f.num); A.c2o = IP(L.f.c2o); A.code = IP(L.f.code); A.cw = FP(L.f.cw); A.gfvc = FP(L.g_fvc_f); A.g_verts = FP(L.g_blk_verts);
-        A.ticket = (unsigned *)(ws + L.tickets) + 2;
-        A.mode = 0;
         A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.sq_local = FP(L.sq_local); A.keep = IP(L.keep); A.nb = nb; A.nv = nv;
-        A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world;
+        A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world; A.g_verts = FP(L.g_blk_verts);
         A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T;
         A.alpha = FP(L.alpha); A.g_alpha_parts = coarse ? FP(L.g_fa) : nullptr; A.alpha_parts = 64; A.g_alpha_full = FP(L.g_alpha_full); A.g_logit = d.g_alpha_logit;
-        RC(launch_scene_tail(A, S));
+        RC(launch_blocks_tail(A, M));
     } else {
-        RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
-                                IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), S));
         RC(dbw_sq_blocks_bwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world, FP(L.g_blk_verts),
-                             d.g_sq_eps, d.g_S, d.g_R6, d.g_T, S));
-        RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, S));
+                             d.g_sq_eps, d.g_S, d.g_R6, d.g_T, M));
+        RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, M));
     }
-    if (!two) RC(env_backward());
-    if (two) { HIP_OK(hipEventRecord(p->ev_side_done, S)); HIP_OK(hipStreamWaitEvent(M, p->ev_side_done, 0)); }
+    if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
+    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_env_done, 0));
 
     // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----
     if (in->with_adam) {
-        RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
-                                ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+        if (tex_in_adam) {
+            if (!tv) for (int i = 0; i < 3; ++i) sets[i].grad_sig = nullptr;
+            const int64_t begin[3] = {(int64_t)(d.texture_bkg - d.flat_param), (int64_t)(d.textures - d.flat_param), (int64_t)(d.texture_ground - d.flat_param)};
+            RC(dbw_adam_step_groups_textures(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps,
+                                             in->adam_step, sets, begin, 3, ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+        } else
+            RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
+                                    ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
         p->arena_clean = true;
     }
     if (bins) { p->bin_turn = 1 - p->bin_turn; p->bin_ready = 1; }
@@ -617,4 +631,10 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     return DBW_OK;
 #undef FP
 #undef IP
+}
+
+extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t stream) {
+    DBW_REQUIRE(p, "null pointer");
+    HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0));
+    return DBW_OK;
 }

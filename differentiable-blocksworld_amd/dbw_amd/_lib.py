@@ -51,7 +51,7 @@ class StepDesc(ctypes.Structure):
                                       'g_sq_eps', 'g_S', 'g_R6', 'g_T', 'g_alpha_logit', 'g_R6_ground', 'g_T_ground', 'g_texture_bkg', 'g_texture_ground',
                                       'g_textures', 'flat_param', 'flat_grad', 'exp_avg', 'exp_avg_sq')]
                 + [('group_end', c_i64 * 2), ('small_grads', c_p), ('n_small_grads', c_i), ('fuse', c_i), ('backward_order', c_i),
-                   ('binned_concurrent', c_i), ('tex_bwd_on_main', c_i), ('seed', ctypes.c_uint64)])
+                   ('binned_concurrent', c_i), ('serial_setup_max_views', c_i), ('seed', ctypes.c_uint64)])
 
 
 class StepInputs(ctypes.Structure):
@@ -107,8 +107,10 @@ SIGNATURES = {
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p],
+    'dbw_adam_step_groups_textures': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_i, c_p, c_i64, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
+    'dbw_train_step_wait_blocks_ready': [c_p, c_p],
 }
 # entry points that do not return an error code: name -> (restype, argtypes)
 OTHER_SIGNATURES = {
@@ -116,7 +118,6 @@ OTHER_SIGNATURES = {
     'dbw_train_step_create': (c_p, [c_p, c_p, c_sz]),
     'dbw_train_step_destroy': (None, [c_p]),
     'dbw_train_step_offset': (c_i64, [c_p, c_i]),
-    'dbw_train_step_blocks_ready_event': (c_p, [c_p]),
 }
 
 
@@ -152,7 +153,7 @@ def load():
     lib.dbw_rasterize_workspace_bytes_binned.restype = c_sz
     lib.dbw_rasterize_workspace_bytes_binned.argtypes = [c_i64, c_i, c_i, c_i]
     for name, argtypes in SIGNATURES.items():
-        if name.startswith('dbw_train_step') and not hasattr(lib, name):
+        if (name.startswith('dbw_train_step') or name == 'dbw_adam_step_groups_textures') and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -17,7 +17,7 @@ from . import _lib, ops
 from .dbw import OVERLAP_N_BLOCKS, OVERLAP_N_POINTS, OVERLAP_TEMPERATURE
 
 _p = ops._ptr
-FUSE_ALL = 15
+FUSE_ALL = 31          # include/dbw_hip.h: dbw_step_desc.fuse
 _SIDE_STREAMS = {}
 _OFF = {'alpha': 0, 'alpha_full': 1, 'keep': 2, 'losses': 3, 'arena_begin': 4, 'arena_end': 5, 'g_fg': 6, 'g_env': 7, 'env_img': 8, 'blk_verts': 9,
         'loss_part': 10}
@@ -64,7 +64,9 @@ class CStep:
         self.side_priority = True
         self.backward_order = None          # None: by configuration (see _plan_for), 0 / 1 force
         self.binned_concurrent = None
-        self.use_side_stream = True
+        self.use_side_stream = True         # False: everything in order on the caller's stream
+        self.own_side_stream = False        # True: the env chain on a (high-priority) torch stream of the caller instead of the plan's own
+        self.serial_setup_max_views = 12    # include/dbw_hip.h: up to that many views the blocks' set-up stays on the main stream
         self.read_losses = False            # copy the five loss values to host memory in every step (StepLosses.host())
         self._plans = {}                    # key -> (handle, workspace tensor, keep-alive list)
         self._cur = None
@@ -115,7 +117,8 @@ class CStep:
         max_views = max(int(self.max_views or 0), B)
         key = (coarse, decim, decim_blocks, max_views, m.world_size, self.fuse, int(seq), int(bool(both)), Kt.data_ptr(), m.R_world.data_ptr(),
                m.R_world._version, m.T_world._version, float(m.S_world),
-               self.params.flat.data_ptr(), tuple(sorted(m.loss_weights.items())), float(m.opacity_noise or 0.0), bool(m.kill_blocks))
+               self.params.flat.data_ptr(), tuple(sorted(m.loss_weights.items())), float(m.opacity_noise or 0.0), bool(m.kill_blocks),
+               int(self.serial_setup_max_views))
         if key in self._plans:
             self._cur = self._plans[key]
             return self._cur
@@ -174,7 +177,7 @@ class CStep:
         d.group_end[0], d.group_end[1] = P.bounds[0][1], P.bounds[1][1]
         d.small_grads, d.n_small_grads = _p(P.grad), P.bounds[0][1]
         d.fuse, d.backward_order, d.binned_concurrent = self.fuse, int(seq), int(bool(both))
-        d.tex_bwd_on_main = int(m.world_size == 1)
+        d.serial_setup_max_views = int(self.serial_setup_max_views)
         d.seed = int(getattr(m, '_rng_seed', 227391)) & 0xffffffffffffffff
         lib = _lib.load()
         nbytes = lib.dbw_train_step_workspace_bytes(ctypes.byref(d))
@@ -202,8 +205,10 @@ class CStep:
         lib = _lib.load()
         return wsb[lib.dbw_train_step_offset(handle, 4):lib.dbw_train_step_offset(handle, 5)]
 
-    def blocks_ready_event(self):
-        return _lib.load().dbw_train_step_blocks_ready_event(self._cur[0])
+    def wait_blocks_ready(self, stream):
+        """`stream` (a torch stream) waits until the blocks' texture gradient of the last step is final (data parallel: the early slice of
+        the all-reduce)."""
+        _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------
     def __call__(self, inp, global_count=None, adam=None, tiled_target=True):
@@ -242,9 +247,10 @@ class CStep:
         a.arena_is_clean = int(self._arena_cleaned_by_caller)
         self._arena_cleaned_by_caller = False
         cur = torch.cuda.current_stream(dev)
-        side = side_stream(dev, self.side_priority) if self.use_side_stream else cur
+        # the env chain and the regularisers: streams of the plan (NULL), a torch stream of this process, or the caller's own stream
+        side = cur.cuda_stream if not self.use_side_stream else (side_stream(dev, self.side_priority).cuda_stream if self.own_side_stream else 0)
         with torch.cuda.device(dev):
-            _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side.cuda_stream)
+            _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
         self._keep = (imgs, R, T, nz, u)            # inputs stay referenced until the next call has been enqueued behind this one
         w = m.loss_weights
         names = [k for k in w if k in StepLosses.NAMES]

@@ -164,9 +164,9 @@ class ShardedTrainStep:
 
     def _c_iteration(self, inp):
         """The iteration through the C step.  One GPU: everything, Adam included, in the one call.  Data parallel: the call stops in front
-        of Adam; the blocks' texture gradient is reduced as soon as the step's side stream has it (its queue ends with the fg tail, the
-        env chain is still running on the main stream), the rest behind the step; then the fused Adam, which also clears the step's
-        zero arena."""
+        of Adam; the blocks' texture gradient is reduced as soon as the step has it (it records an event behind the backward of the
+        blocks' texture preparation, the first kernel of the fg tail), the rest behind the step; then the fused Adam, which also clears
+        the step's zero arena."""
         cs = self.cstep
         distributed = self.world_size > 1 or self.overlap_allreduce
         with torch.no_grad():
@@ -176,9 +176,12 @@ class ShardedTrainStep:
                 return losses
             losses = cs(inp, self.model._global_count, adam=None)
             if self.overlap_allreduce:
+                # the blocks' texture gradient is final long before the step ends (the step says when): its slice is reduced from a
+                # stream of its own next to the rest of the fg tail and the env chain
                 dev = self.params.flat.device
                 from .c_step import side_stream
-                side = side_stream(dev, cs.side_priority) if cs.use_side_stream else torch.cuda.current_stream(dev)
+                side = side_stream(dev, cs.side_priority)
+                cs.wait_blocks_ready(side)
                 with torch.cuda.stream(side):
                     self.start_early_allreduce()
                 torch.cuda.current_stream(dev).wait_stream(side)      # (a synchronous backend -- gloo through a host copy -- wrote on `side`)

@@ -360,6 +360,14 @@ int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float 
                          const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
                          int64_t zero_bytes, dbw_stream_t stream);
 
+/* The same launch with the backward of the texture preparation (dbw_texture_prep_bwd) folded in: for the elements of up to three texture
+ * tensors -- sets[k] describes one: texture = param + set_begin[k] (n, h, w, 3), decim, grad_maps (cell resolution), grad_sig (or NULL) --
+ * the gradient is formed on the spot as (grad_maps[cell] / decim^2 + grad_sig) * s (1 - s), s = sigmoid(param), and also written to `grad`;
+ * every other element takes its gradient from `grad` as dbw_adam_step_groups does. */
+int dbw_adam_step_groups_textures(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end, const float *lr,
+                                  int ngroups, float beta1, float beta2, float eps, int step, const dbw_texture_set *sets,
+                                  const int64_t *set_begin, int nsets, void *zero_buf, int64_t zero_bytes, dbw_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * The whole optimisation iteration of the training path behind ONE entry point (ABI 4).
  * Replaces one pass of src/trainer.py:137-147 -- optimizer.zero_grad(); loss = model(images, labels) (src/model/dbw.py:198-408: the
@@ -416,12 +424,12 @@ typedef struct dbw_step_desc {
     int64_t group_end[2];
     float *small_grads; int n_small_grads;      /* the accumulated (not fully written) gradients: cleared at the head of every run */
     /* ---- options ---- */
-    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: tails; 0 = the operator-level kernels */
-    int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel / texture bins) */
-    int binned_concurrent;                      /* texture bins: the env chain starts next to the fg kernel */
-    int tex_bwd_on_main;                        /* the backward of the blocks' texture preparation behind the env chain on stream_main (one GPU: it
-                                                 * leaves the critical fg chain) instead of in front of the fg tail on stream_side (data parallel:
-                                                 * the blocks' texture gradient is then final as early as possible) */
+    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail, 4: the backward of the
+                                                 * texture preparation inside the Adam launch (runs with_adam only); 0 = the operator-level kernels */
+    int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel) */
+    int binned_concurrent;                      /* texture bins (which otherwise imply order 1): the env chain starts next to the fg kernel */
+    int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);
+                                                 * larger ones run it next to the env pass on the env stream */
     uint64_t seed;                              /* of the step's random numbers: the same on every data-parallel rank */
 } dbw_step_desc;
 
@@ -445,9 +453,10 @@ size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc);
 /* returns NULL on error (dbw_last_error) */
 dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void *workspace, size_t workspace_bytes);
 void dbw_train_step_destroy(dbw_step_plan *plan);
-/* Enqueues one iteration: stream_main carries the critical path and ends with Adam (or, with_adam == 0, with everything the caller's
- * all-reduce has to wait for); stream_side (a different stream; may equal stream_main: everything then runs in order on one stream)
- * carries what runs next to it.  On return nothing has been waited for. */
+/* Enqueues one iteration.  stream_main carries the critical chain -- set-up, the two passes, the fg backward and its tail, Adam (or,
+ * with_adam == 0, everything the caller's all-reduce has to wait for) -- and is the only stream the caller has to order against.  The env
+ * backward chain and the regularisers run next to it: on stream_side if the caller brings one, else (NULL) on lowest-priority streams
+ * of the plan; stream_side == stream_main: everything in order on one stream.  On return nothing has been waited for. */
 int dbw_train_step_run(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side);
 /* Blocks until the loss values of the last run with read_losses != 0 are in host memory: out5 = rgb, parsimony, tv, overlap, total */
 int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
@@ -456,9 +465,10 @@ int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
  * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
  * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials; -1 for an unknown name */
 int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
-/* Enqueued on the side stream of a run right after the blocks' texture gradient is final (data parallel: the caller reduces that
- * slice while the env chain still runs): the event's handle as a hipEvent_t, for hipStreamWaitEvent */
-void *dbw_train_step_blocks_ready_event(dbw_step_plan *plan);
+/* Makes `stream` wait until the blocks' texture gradient of the last run is final (runs whose Adam does not fold the texture backward in:
+ * with_adam == 0 or fuse bit 4 clear).  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
+ * own while the rest of the step still runs. */
+int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -752,8 +752,14 @@ def test_bin_layout_by_demand_is_a_partition_and_gives_the_same_gradients(monkey
     first, caps = (lay.cpu().long() & 0xffffffff).unbind(1)
     assert int(first[0]) == 0 and bool((first[1:] == (first + caps)[:-1]).all()) and int(caps.min()) >= 1
     assert total - n <= float(first[-1] + caps[-1]) <= total
-    want = asked.clamp(min=64).double() * 1.25
-    assert float(((caps.double() - want * (total / want.sum())).abs()).max()) <= 1.0
+    want = asked.clamp(min=64).double() * 1.25      # one record each, the rest in proportion (so that the sum can never exceed the total)
+    assert float(((caps.double() - 1 - want * ((total - n) / want.sum())).abs()).max()) <= 1.0
+    # a demand so skewed that most shares round to nothing: still a partition inside the total (it used to overrun it)
+    skew = torch.zeros(n, dtype=torch.int32)
+    skew[0] = 2 ** 30
+    assert lib.dbw_bin_layout(skew.to(DEV).data_ptr(), n, float(4 * n), 1, lay.data_ptr(), 0) == 0, lib.dbw_last_error()
+    first, caps = (lay.cpu().long() & 0xffffffff).unbind(1)
+    assert int(caps.min()) >= 1 and int(first[-1] + caps[-1]) <= 4 * n and bool((first[1:] == (first + caps)[:-1]).all())
     # the same gradients with and without it (two launches: the second one runs on the first one's demand)
     m, R, T, Km = _model(seed=29, ts=64, hw=(72, 96), fpp=8)
     with torch.no_grad():

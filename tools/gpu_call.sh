@@ -1,10 +1,11 @@
 #!/bin/bash
 # One gpurun session of round 4 (everything lands under gpurun_out/r04/<tag>): usage: tools/gpu_call.sh <tag> <stage>...
-# stages: cstep_tests | all_tests | times [epoch] | trace <views> <epoch> | bench
+# stages: cstep_tests | tests '<pytest args>' | all_tests | times [epoch] | trace <views> <epoch> | bench
 O=gpurun_out/r04/$1; shift; mkdir -p $O; export TMPDIR=/tmp
 while [ $# -gt 0 ]; do
   case $1 in
     cstep_tests) timeout 1500 python -m pytest tests/test_gpu_c_step.py -x -q > $O/cstep_tests.log 2>&1; tail -15 $O/cstep_tests.log;;
+    tests) timeout 1500 python -m pytest $2 -x -q > $O/tests.log 2>&1; tail -40 $O/tests.log; shift;;
     all_tests) timeout 2400 python -m pytest tests -m gpu -q > $O/all_tests.log 2>&1; tail -15 $O/all_tests.log;;
     times) timeout 900 python tools/diag/cstep_times.py $2 > $O/times_$2.log 2>&1; cat $O/times_$2.log; shift;;
     trace) v=$2; e=$3; shift 2
