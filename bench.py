@@ -28,6 +28,22 @@ sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
 import torch                                                            # noqa: E402
 import torch.distributed as dist                                        # noqa: E402
 
+PMC_FILE = 'r04_pmc_counters.json'
+
+
+def csrc_sha16():
+    """Hash of the kernel sources + build flags of the library: committed counter files are keyed on it (a later kernel change must not ship
+    the counters of the old kernels)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'differentiable-blocksworld_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'differentiable-blocksworld_amd', 'build.py'), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -65,7 +81,8 @@ def build_workload(args, dev):
 BIN_STATS = {}
 
 
-def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0, use_graph=False):
+def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0, use_graph=False,
+                  c_step=True):
     """One more workload measured like the headline (same step, same launch path, inputs resident), outside its timed region:
     -> ms per step, views / s and the share of the HBM roofline the WHOLE-PATH algorithmic bytes (64 P K + 140 P per view)
     reach.  read_losses: every loss value is read on the host after every step, as the reference's trainer does
@@ -79,11 +96,18 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
     model, inp = build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391, use_graph=use_graph, graph_warmup=2)
+    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391, use_graph=use_graph, graph_warmup=2,
+                            use_c_step=c_step)
+    if step.cstep is not None:
+        step.cstep.read_losses = bool(read_losses)        # the step copies its five loss values to host memory itself
+
+    def read(out):
+        # every loss value on the host after every step (trainer.py:143): one wait for the step's own copy (C step), or six scalar reads
+        return out.host() if hasattr(out, 'host') else {k: float(v) for k, v in out.items()}
     for _ in range(warmup):
         out = step(inp)
         if read_losses:
-            _ = {k: float(v) for k, v in out.items()}
+            read(out)
     torch.cuda.synchronize()
     st0 = torch.cuda.memory_stats(dev)
     n, t0 = 0, time.perf_counter()
@@ -91,7 +115,7 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
         for _ in range(steps):
             out = step(inp)
             if read_losses:
-                vals = {k: float(v) for k, v in out.items()}          # six scalars, one device -> host read each (trainer.py:143)
+                vals = read(out)
         n += steps
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -105,7 +129,8 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
     res = {'workload': f'{views} views/step, {W}x{H}, {blocks} blocks, faces_per_pixel={fpp}, {txt}^2 textures', 'steps': n,
            'ms_per_step': dt / n * 1e3, 'views_per_s': vps, 'whole_path_frac': vps * (64 * P * fpp + 140 * P) / 1e9 / HBM_PEAK_GBS,
            # device allocations (hipMalloc) inside the timed region: must be 0 -- every buffer of a step comes out of torch's cache
-           'device_allocs_in_timed_region': int(st1.get('num_device_alloc', 0) - st0.get('num_device_alloc', 0))}
+           'device_allocs_in_timed_region': int(st1.get('num_device_alloc', 0) - st0.get('num_device_alloc', 0)),
+           'step': 'one C-ABI call per iteration (dbw_train_step_run)' if step.cstep is not None else 'launch by launch from Python'}
     del step, model, inp
     torch.cuda.empty_cache()
     return res
@@ -269,8 +294,9 @@ def main():
     ap.add_argument('--txt', type=int, default=256)
     ap.add_argument('--epoch', type=int, default=0, help='training phase to measure: 0 = coarse+decimated textures (default, the '
                     'configuration at the start of training), 800 = coarse, 1600 = fine (dbw.py:210-219, default.yml:15-16)')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak', help='weak: --views per GPU (default); strong: --views in total, '
-                    'sharded over the ranks (BASELINE config 3: 49 views -> 7,6,...,6)')
+    ap.add_argument('--scaling', choices=['auto', 'weak', 'strong'], default='auto', help='strong (default when --gpus > 1): --views in total, sharded '
+                    'over the ranks = BASELINE config 3 as written (49 views -> 7,6,...,6), the weak form measured next to it in the same run; '
+                    'weak: --views per GPU')
     ap.add_argument('--no-phases', action='store_true', help='skip the measurement of the two other training phases')
     ap.add_argument('--no-extras', action='store_true', help='skip the measurements reported next to the headline at N = 1: the reference\'s own '
                     'operating point (batch 4, loss values read every step), BASELINE configs 4 and 5 (per-GPU share) and the sustained run')
@@ -280,7 +306,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='(default) eager launches')
     ap.add_argument('--backward-order', choices=['auto', 'sequential', 'concurrent'], default='auto', help='debug: the two backward kernels')
     ap.add_argument('--no-side-priority', action='store_true', help='debug: the side stream of the native step at normal priority')
-    ap.add_argument('--no-overlap', action='store_true', help='run the env pass on the main stream instead of a side stream')
+    ap.add_argument('--no-overlap', action='store_true', help='everything in order on ONE stream: every kernel alone on the GPU (per-kernel averages of a '
+                    'trace are then exact)')
+    ap.add_argument('--launch-by-launch', action='store_true', help='the round-3 form of the step: ~33 launches issued one by one from Python '
+                    '(dbw_amd/native_step.py) instead of one C-ABI call per iteration (dbw_train_step_run)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -306,10 +335,13 @@ def main():
         assert dist.get_world_size() == args.gpus and dist.get_rank() == rank, (dist.get_world_size(), args.gpus, dist.get_rank(), rank)
 
     from dbw_amd.parallel import ShardedTrainStep, shard_views
+    if args.scaling == 'auto':
+        args.scaling = 'strong' if world > 1 else 'weak'
     model, inp = build_workload(args, dev)
     model.set_cur_epoch(args.epoch)
     model.sync_free = True
     model.overlap_passes = not args.no_overlap
+    inp_all = inp
     if args.scaling == 'strong':            # BASELINE config 3: the SAME views, split 7,6,...,6 over the ranks
         a, b = shard_views(args.views, world, rank)
         global_count = inp['imgs'].numel()
@@ -318,7 +350,7 @@ def main():
     else:
         global_count = inp['imgs'].numel() * world
         views_total = args.views * world
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391, use_c_step=not args.launch_by_launch)
     # every phase below is measured from the SAME state (freshly initialised parameters + its own warm-up), not from whatever the
     # previously measured phase left behind (opacities drift, blocks get filtered: the workload would change)
     if step.native is not None and args.backward_order != 'auto':
@@ -327,6 +359,11 @@ def main():
         step.native.side_priority = False
     if step.native is not None and args.no_overlap:
         step.native.overlap_regularisers = False      # every kernel alone on one stream: per-kernel averages of a trace are then exact
+    if step.cstep is not None:
+        if args.no_overlap:
+            step.cstep.use_side_stream = False
+        if args.backward_order != 'auto':
+            step.cstep.backward_order = int(args.backward_order == 'sequential')
     snapshot = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone(), step.n_steps)
 
     def restore():
@@ -338,7 +375,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n):
+    def timed(n, inp=inp, global_count=global_count):
         """n steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
         sync()
         t0 = time.perf_counter()
@@ -392,6 +429,33 @@ def main():
         allreduce_ms = e0.elapsed_time(e1) / 5
         step.params.zero_grad()
 
+    # ---- N > 1: the other scaling form in the same run, and what the early slice of the all-reduce buys ----
+    other_scaling, overlap_off_ms = None, None
+    if world > 1 and not args.graph:
+        restore()
+        model.set_cur_epoch(args.epoch)
+        if args.scaling == 'strong':
+            o_inp, o_count, o_views, o_name = inp_all, inp_all['imgs'].numel() * world, args.views * world, 'weak'
+        else:
+            a, b = shard_views(args.views, world, rank)
+            o_inp, o_count, o_views, o_name = {k: v[a:b].contiguous() for k, v in inp_all.items()}, inp_all['imgs'].numel(), args.views, 'strong'
+        for _ in range(max(args.warmup, 3)):
+            step(o_inp, global_count=o_count)
+        k = max(5, min(args.steps, 10))
+        d, _ = timed(k, o_inp, o_count)
+        other_scaling = {'scaling': o_name, 'value': o_views * k / d, 'unit': 'views/s', 'ms_per_step': d / k * 1e3, 'views_per_step': o_views,
+                         'views_on_rank0': int(o_inp['R'].shape[0])}
+        if step.overlap_allreduce:
+            restore()
+            step.overlap_allreduce = False
+            for _ in range(max(args.warmup, 3)):
+                step(inp, global_count=global_count)
+            d, _ = timed(k)
+            overlap_off_ms = d / k * 1e3
+            step.overlap_allreduce = True
+        restore()
+        step(inp, global_count=global_count)
+
     if rank == 0:
         phase = ('coarse phase (sigma=1e-4, opacity noise, decimated textures)' if model.is_live('decimate_txt') else
                  'coarse phase (sigma=1e-4, opacity noise, full-resolution textures)' if model.is_live('coarse_learning') else
@@ -405,13 +469,26 @@ def main():
         achieved = nbytes / (ms * 1e-3) / 1e9
         # counter evidence for the dominant kernel from the rocprofv3 PMC passes of this same workload (profiles/, see its _how):
         # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE with the gfx950 correction) and the SQ issue counters
-        traffic, counters = None, None
+        traffic, counters, counters_note = None, None, None
+        sha = csrc_sha16()
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_counters.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
             if inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0) and dom in pmc:
-                traffic, counters = pmc[dom].get('hbm_bytes'), {k: v for k, v in pmc[dom].items() if k != 'hbm_bytes'}
+                if pmc.get('_csrc_sha16') == sha:
+                    traffic, counters = pmc[dom].get('hbm_bytes'), {k: v for k, v in pmc[dom].items() if k != 'hbm_bytes'}
+                else:       # counters of another build of the kernels say nothing about this one
+                    counters_note = f'profiles/{PMC_FILE} was collected on csrc {pmc.get("_csrc_sha16")}, this library is built from {sha}: not reported'
         except (OSError, ValueError, KeyError):
             pass
+        # the same kernels INSIDE a step: HIP events recorded by the step on the streams they run on, everything that shares the GPU with
+        # them running next to them (dbw_train_step_profile)
+        in_step = None
+        if step.cstep is not None and world == 1:
+            restore()
+            kt = step.cstep.kernel_times(inp, global_count)
+            name_of = {'env_fwd': 'render_fwd_fused K=1 (env pass)', 'fg_fwd': f'render_fwd_fused K={args.fpp} (fg pass)',
+                       'fg_bwd': f'render_bwd_fused K={args.fpp} (fg pass)', 'env_bwd': 'render_bwd_fused K=1 (env pass)'}
+            in_step = {name_of[k]: round(v, 4) for k, v in kt.items()}
         local_views = inp['R'].shape[0]
         out = {
             'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
@@ -424,24 +501,31 @@ def main():
                                    f'MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
                        'views_per_gpu': local_views, 'views_per_step': views_total, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks,
                        'faces_per_pixel': args.fpp, 'txt_size': args.txt,
-                       'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else 'eager, no host sync in the iteration') +
-                                 ('' if args.no_overlap else ', small kernels on a side stream') + ('' if step.native is None else ', native step (no autograd)'),
+                       'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else
+                                  'one C-ABI call per iteration (dbw_train_step_run: ~18 launches enqueued from C)' if step.cstep is not None else
+                                  'launch by launch from Python, no host sync in the iteration') +
+                                 ('' if args.no_overlap else ', env backward chain and regularisers on side streams') +
+                                 ('' if step.native is None else ', native step (no autograd)'),
                        'parallelism': f'view-sharded dp{world}, {step.params.flat.numel() * 4 / 1e6:.1f} MB of gradients all-reduced per step over RCCL'
                                       + (' (blocks\' textures overlapped with the env backward, the rest after it)' if step.overlap_allreduce else ''),
                        'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
+                         # frac: the kernel launched alone (HIP events around back-to-back launches); frac_in_step: the same kernel where it
+                         # runs, sharing the GPU with the env backward chain and the regularisers (events recorded by the step itself)
+                         'frac_in_step': None if not in_step or dom not in in_step else nbytes / (in_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'all_kernels_ms_in_step': in_step,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS,
-                         'counters': counters,
-                         'counters_source': None if counters is None else 'profiles/r03_pmc_counters.json: separate rocprofv3 --pmc passes of this '
+                         'counters': counters, 'csrc_sha16': sha,
+                         'counters_source': counters_note if counters is None else f'profiles/{PMC_FILE}: separate rocprofv3 --pmc passes of this '
                                             'workload on this build (tools/pmc_sq.sh), committed -- NOT measured in this run (a counter pass '
                                             'serialises the kernels); avg_ms_per_launch, achieved and frac ARE measured in this run (HIP events)',
                          'limiter': 'instruction issue and latency, not HBM: see `counters` (share of the SIMD time the VALU is busy, lane '
-                                    'utilisation, HBM traffic per launch; profiles/r03_pmc_counters.json) and DESIGN.md section 4; frac is the '
+                                    f'utilisation, HBM traffic per launch; profiles/{PMC_FILE}) and DESIGN.md section 4; frac is the '
                                     'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
-            'phases': phases, 'allreduce_ms': allreduce_ms,
+            'phases': phases, 'allreduce_ms': allreduce_ms, 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms,
             'final_loss': total_loss,
         }
         if world == 1 and not args.no_extras and not args.graph:
@@ -451,14 +535,14 @@ def main():
                 torch.cuda.empty_cache()
                 # the reference's operating point: configs/dtu/default.yml:28 trains with batch_size 4 and src/trainer.py:143 reads every
                 # loss value on the host each iteration
-                out['batch4'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True)
-                out['batch4']['what'] = ('batch_size 4 (configs/dtu/default.yml:28), the loss values read on the host after every step '
-                                         '(src/trainer.py:143): launch-bound, ~31 launches per step')
-                out['batch4_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=False)
-                # the same with the step replayed from a hipGraph (ShardedTrainStep(use_graph=True): one host call per step + the Adam launch)
-                out['batch4_graph'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True, use_graph=True)
-                out['batch4_graph']['what'] = 'batch_size 4, loss values read every step, the native step replayed from a hipGraph'
-                out['batch4_graph_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, use_graph=True)
+                out['batch4'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
+                out['batch4']['what'] = ('batch_size 4 (configs/dtu/default.yml:28), the loss values on the host after every step '
+                                         '(src/trainer.py:143): one C-ABI call per iteration, the step copies its loss values itself')
+                out['batch4_no_reads'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=False)
+                out['batch7'] = measure_other(7, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
+                out['batch7']['what'] = 'the largest per-rank batch of BASELINE config 3 (49 views over 8 ranks: 7,6,...,6), loss values read every step'
+                # the round-3 form of the same step for comparison: ~33 launches issued one by one from Python, six scalar reads
+                out['batch4_launch_by_launch'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True, c_step=False)
                 # >= 2 s of steps from the initial scene with frozen parameters (learning rates 0: Adam runs, the workload does not drift)
                 out['sustained'] = measure_other(49, 300, 400, 10, 10, 256, dev, steps=200, warmup=10, lr_scale=0.0, min_seconds=2.0)
                 out['sustained']['what'] = '>= 2 s of steps of the headline workload with both learning rates 0 (the scene does not drift)'

@@ -178,51 +178,6 @@ __global__ void adam_groups_kernel(float *__restrict__ p, const float *__restric
         zero_buf[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// The same Adam launch with the backward of the texture preparation folded in (training step, one GPU): for the elements of up to three
-// texture tensors the gradient is not read from `g` but formed on the spot from what the render / TV kernels left --
-// (grad_maps[cell of the texel] / d^2 + grad_sig) * s (1 - s) with s = sigmoid(p), p being the value Adam reads anyway -- and written to
-// `g` on the way (callers read .grad): two launches and one 9.4 MB round trip per step less than texture_prep_bwd + Adam.
-struct AdamTex { long long begin[3], end[3]; const float *gmaps[3], *gsig[3]; int h[3], w[3], d[3]; int nsets; };
-__global__ void adam_groups_tex_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                                       long long n, const AdamGroups G, const AdamTex X, float beta1, float beta2, float eps, float bc2_sqrt,
-                                       uint4 *__restrict__ zero_buf, long long zero_vec) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float step_size = G.step_size[0];
-#pragma unroll
-        for (int k = 1; k < MAX_SETS; ++k) step_size = i >= G.end[k - 1] ? G.step_size[k] : step_size;
-        float pi = p[i], gi;
-        int set = -1;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) set = (k < X.nsets && i >= X.begin[k] && i < X.end[k]) ? k : set;
-        if (set < 0) gi = g[i];
-        else {
-            // (texture_prep_bwd_body: same expressions, same order)
-            const long long li = i - (set == 0 ? X.begin[0] : set == 1 ? X.begin[1] : X.begin[2]);
-            const float *gm = set == 0 ? X.gmaps[0] : set == 1 ? X.gmaps[1] : X.gmaps[2], *gs = set == 0 ? X.gsig[0] : set == 1 ? X.gsig[1] : X.gsig[2];
-            const int h = set == 0 ? X.h[0] : set == 1 ? X.h[1] : X.h[2], w = set == 0 ? X.w[0] : set == 1 ? X.w[1] : X.w[2];
-            const int d = set == 0 ? X.d[0] : set == 1 ? X.d[1] : X.d[2];
-            const float s = sigmoidf(pi);
-            float gr;
-            if (d <= 1) gr = gm[li];
-            else {
-                const float inv = 1.f / (float)(d * d);
-                const int ch_ = h / d, cw_ = w / d;
-                const int k = (int)(li % 3);
-                const long long t = li / 3;
-                const int x = (int)(t % w), y = (int)((t / w) % h), mm = (int)(t / ((long long)w * h));
-                gr = gm[(((long long)mm * ch_ + y / d) * cw_ + x / d) * 3 + k] * inv;
-            }
-            if (gs) gr += gs[li];
-            gi = gr * s * (1.f - s);
-            g[i] = gi;
-        }
-        adam_update(pi, gi, m[i], v[i], step_size, beta1, beta2, eps, bc2_sqrt);
-        p[i] = pi;
-    }
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += (long long)gridDim.x * blockDim.x)
-        zero_buf[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 inline unsigned grid_for(long long work) {
     long long b = (work + NT - 1) / NT;
     if (b < 1) b = 1;
@@ -346,39 +301,6 @@ extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_
     hipLaunchKernelGGL(adam_groups_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, G,
                        beta1, beta2, eps, (float)sqrt(bc2), (uint4 *)zero_buf, (long long)(zero_bytes / 16));
     return dbw_check_launch("adam_groups_kernel");
-}
-
-extern "C" int dbw_adam_step_groups_textures(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end, const float *lr,
-                                             int ngroups, float beta1, float beta2, float eps, int step, const dbw_texture_set *sets,
-                                             const int64_t *set_begin, int nsets, void *zero_buf, int64_t zero_bytes, dbw_stream_t stream) {
-    DBW_REQUIRE(param && grad && exp_avg && exp_avg_sq && group_end && lr, "null pointer");
-    DBW_REQUIRE(zero_bytes >= 0 && (zero_bytes == 0 || (zero_buf && zero_bytes % 16 == 0 && ((uintptr_t)zero_buf & 15) == 0)),
-                "zero_buf: 16-byte aligned, a multiple of 16 bytes");
-    DBW_REQUIRE(ngroups >= 1 && ngroups <= MAX_SETS && step >= 1, "1..4 groups, step >= 1");
-    DBW_REQUIRE(nsets >= 0 && nsets <= 3 && (nsets == 0 || (sets && set_begin)), "0..3 texture sets");
-    for (int k = 0; k < ngroups; ++k) DBW_REQUIRE(group_end[k] >= (k ? group_end[k - 1] : 0), "group ends must not decrease");
-    const long long n = group_end[ngroups - 1];
-    if (n == 0) return DBW_OK;
-    AdamTex X;
-    memset(&X, 0, sizeof(X));
-    X.nsets = nsets;
-    for (int k = 0; k < nsets; ++k) {
-        const dbw_texture_set &t = sets[k];
-        DBW_REQUIRE(t.texture && t.grad_maps && t.n > 0 && t.h > 0 && t.w > 0 && t.decim >= 1 && t.h % t.decim == 0 && t.w % t.decim == 0, "bad texture set");
-        const long long cnt = (long long)t.n * t.h * t.w * 3;
-        DBW_REQUIRE(set_begin[k] >= 0 && set_begin[k] + cnt <= n && t.texture == param + set_begin[k], "a texture set must be a slice of the flat parameter buffer");
-        X.begin[k] = set_begin[k]; X.end[k] = set_begin[k] + cnt;
-        X.gmaps[k] = t.grad_maps; X.gsig[k] = t.grad_sig; X.h[k] = t.h; X.w[k] = t.w; X.d[k] = t.decim;
-    }
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    AdamGroups G;
-    for (int k = 0; k < MAX_SETS; ++k) {
-        G.end[k] = k < ngroups ? group_end[k] : n;
-        G.step_size[k] = (float)(lr[k < ngroups ? k : ngroups - 1] / bc1);
-    }
-    hipLaunchKernelGGL(adam_groups_tex_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, G, X, beta1, beta2,
-                       eps, (float)sqrt(bc2), (uint4 *)zero_buf, (long long)(zero_bytes / 16));
-    return dbw_check_launch("adam_groups_tex_kernel");
 }
 
 extern "C" int dbw_composite_mse(const float *fg, const float *env, const float *imgs, int N, int H, int W,

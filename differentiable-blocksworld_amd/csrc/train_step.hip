@@ -47,21 +47,28 @@ __global__ __launch_bounds__(256) void tile_target_kernel(const float *__restric
     }
 }
 
-// vals (device: parsimony, tv, overlap accumulated by their kernels in slots 1..3) + the per-tile sums of squared differences of the fg
-// pass -> out5 = rgb, parsimony, tv, overlap, total (what compute_losses returns, dbw.py:361-408)
-__global__ __launch_bounds__(1024) void loss_finish_kernel(const float *__restrict__ part, long long nparts, float scale, const float *__restrict__ vals,
-                                                           float *__restrict__ out5) {
-    __shared__ float s_red[16];
+// vals (device: parsimony, tv, overlap accumulated by their kernels in slots 1..3; slot 0 = this kernel's running sum, slot 5 its ticket)
+// + the per-tile sums of squared differences of the fg pass -> out5 = rgb, parsimony, tv, overlap, total (what compute_losses returns,
+// dbw.py:361-408); the workgroup that finishes last writes them
+constexpr int LOSS_BLOCKS = 32;
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restrict__ part, long long nparts, float scale, float *vals, float *__restrict__ out5) {
+    __shared__ float s_red[4];
+    __shared__ int s_last;
     float acc = 0.f;
-    for (long long i = threadIdx.x; i < nparts; i += 1024) acc += part[i];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nparts; i += (long long)gridDim.x * 256) acc += part[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += s_red[w];
-        const float rgb = t * scale;
+        const float t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (t != 0.f) unsafeAtomicAdd(vals, t);
+        __threadfence();
+        s_last = atomicAdd((unsigned *)(vals + 5), 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        const float rgb = atomicAdd(vals, 0.f) * scale;          // (through the L2: the other workgroups' adds)
         out5[0] = rgb; out5[1] = vals[1]; out5[2] = vals[2]; out5[3] = vals[3];
         out5[4] = ((rgb + vals[1]) + vals[2]) + vals[3];
     }
@@ -210,6 +217,8 @@ struct dbw_step_plan {
     bool arena_clean;
     float *host_losses;                 // pinned
     bool losses_pending;
+    bool profile, profiled;             // dbw_train_step_profile: timing events around the four big kernels of a run
+    hipEvent_t ev_t[8];
 };
 
 extern "C" size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc) {
@@ -249,6 +258,9 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
         return nullptr;
     }
     for (int i = 0; i < 8; ++i) p->host_losses[i] = 0.f;
+    p->profile = p->profiled = false;
+    for (hipEvent_t &e : p->ev_t)
+        if (hipEventCreate(&e) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
     p->rng_step = 0; p->bin_turn = 0; p->bin_ready = 0; p->uniform_ready = 0; p->arena_clean = false; p->losses_pending = false;
     return p;
 }
@@ -257,6 +269,7 @@ extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     if (!p) return;
     hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_layout, p->ev_kernel_done, p->ev_blocks_ready, p->ev_env_done, p->ev_losses};
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_t) (void)hipEventDestroy(e);
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     if (p->stream_env) (void)hipStreamDestroy(p->stream_env);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
@@ -522,21 +535,26 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     }
 
     // ---- M: the env pass (hard, one face per pixel), then the fg pass ending in the composite + MSE ----
+#define PROF(i, st) do { if (p->profile) HIP_OK(hipEventRecord(p->ev_t[i], st)); } while (0)
+    PROF(0, M);
     RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
                             d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
                             IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
+    PROF(1, M);
     if (setup_aside) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
+    PROF(2, M);
     RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                 d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                 d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, FP(L.img_e), target, mse_scale,
                                 FP(L.part), FP(L.g_fg), FP(L.g_env), 2, 1, M));
+    PROF(3, M);
     const bool seq = d.backward_order != 0 || (bins && !d.binned_concurrent);     // the env chain waits for the fg backward KERNEL
     if (two) HIP_OK(hipEventRecord(p->ev_fg_fwd, M));
 
     // ---- Rg: the loss values (nothing is differentiated through them) ----
     if (two) HIP_OK(hipStreamWaitEvent(Rg, p->ev_fg_fwd, 0));
     auto loss_values = [&](hipStream_t st) -> int {
-        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
         RC(dbw_check_launch("loss_finish_kernel"));
         if (in->read_losses) {
             HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -548,21 +566,21 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     if (two) { RC(loss_values(Rg)); HIP_OK(hipEventRecord(p->ev_reg, Rg)); }
 
     // ---- E: backward of the env pass and its tail ----
-    const bool tex_in_adam = in->with_adam && (d.fuse & 16);
     auto env_backward = [&](hipStream_t st) -> int {
+        PROF(6, st);
         RC(dbw_render_bwd_fused(IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs, d.env_face_map,
                                 d.env_map_desc, FP(L.env_maps), nullptr, 0, B, H, W, 1, Fe, 0.f, d.bg_env, FP(L.g_env), FP(L.e.fvc), d.perspective_correct, 0,
                                 FP(L.g_env_maps), nullptr, FP(L.g_fvc_e), 1, 3, nullptr, nullptr, nullptr, 0, nullptr, d.n_sky_faces, nullptr, 1, st));
+        PROF(7, st);
         RC(dbw_project_clip_bwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.e.num),
                                 IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), FP(L.g_fvc_e), FP(L.g_env_verts), st));
         RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
                               d.g_R6_ground, d.g_T_ground, st));
-        if (!tex_in_adam) {
-            if (two) HIP_OK(hipStreamWaitEvent(st, p->ev_reg, 0));      // the TV gradients of the sky / ground maps (Rg)
-            dbw_texture_set env_sets[2] = {sets[0], sets[2]};
-            if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
-            RC(dbw_texture_prep_bwd_sets(env_sets, 2, st));
-        }
+        // (Rg: the TV gradients of the sky / ground maps -- and, for M behind this chain: d / d alpha_full, the pose gradients of the overlap term)
+        if (two) HIP_OK(hipStreamWaitEvent(st, p->ev_reg, 0));
+        dbw_texture_set env_sets[2] = {sets[0], sets[2]};
+        if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
+        RC(dbw_texture_prep_bwd_sets(env_sets, 2, st));
         return DBW_OK;
     };
     if (two && !seq) {
@@ -573,10 +591,12 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // ---- M: backward of the fg pass and its tail ----
     if (bins && two) HIP_OK(hipStreamWaitEvent(M, p->ev_layout, 0));      // (this step's cursors and sub-ranges come from Rg)
+    PROF(4, M);
     RC(dbw_render_bwd_fused(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
                             d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
                             FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
                             bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, M));
+    PROF(5, M);
     if (two && seq) {
         HIP_OK(hipEventRecord(p->ev_kernel_done, M));
         HIP_OK(hipStreamWaitEvent(E, p->ev_kernel_done, 0));
@@ -584,20 +604,27 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         HIP_OK(hipEventRecord(p->ev_env_done, E));
     }
     if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), M));
-    bool waited_reg = !two;
-    if (!tex_in_adam) {
-        // the backward of the blocks' texture preparation as a launch of its own, first in the tail: a data-parallel caller reduces the
-        // blocks' texture gradient -- 83 % of the gradient bytes -- as soon as ev_blocks_ready says so, next to everything below
-        if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));            // TV gradient of the blocks' maps (Rg)
-        waited_reg = true;
+    // the backward of the blocks' texture preparation, first in the tail: a data-parallel caller reduces the blocks' texture gradient -- 83 %
+    // of the gradient bytes -- as soon as ev_blocks_ready says so, next to everything below.  It needs the TV gradient of the blocks' maps
+    // (Rg): data parallel M waits for it here; on one GPU the launch moves behind the join with the env chain (which has waited for Rg), so
+    // that M pays for one wait instead of two
+    auto blocks_textures = [&]() -> int {
         dbw_texture_set blk = sets[1];
         if (!tv) blk.grad_sig = nullptr;
         RC(dbw_texture_prep_bwd_sets(&blk, 1, M));
         HIP_OK(hipEventRecord(p->ev_blocks_ready, M));
+        return DBW_OK;
+    };
+    const bool early_textures = two && !in->with_adam;
+    if (early_textures) {
+        HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));
+        RC(blocks_textures());
     }
     RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
                             IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
-    if (!waited_reg) HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));        // d / d alpha_full, the pose gradients of the overlap term, TV gradients (Rg)
+    if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
+    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_env_done, 0));           // the env chain, and through it the regularisers (E waited for Rg)
+    if (!early_textures) RC(blocks_textures());
     if ((d.fuse & 8) && (d.fuse & 1)) {
         BlocksTailArgs A;
         memset(&A, 0, sizeof(A));
@@ -611,24 +638,18 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                              d.g_sq_eps, d.g_S, d.g_R6, d.g_T, M));
         RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, M));
     }
-    if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
-    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_env_done, 0));
 
     // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----
     if (in->with_adam) {
-        if (tex_in_adam) {
-            if (!tv) for (int i = 0; i < 3; ++i) sets[i].grad_sig = nullptr;
-            const int64_t begin[3] = {(int64_t)(d.texture_bkg - d.flat_param), (int64_t)(d.textures - d.flat_param), (int64_t)(d.texture_ground - d.flat_param)};
-            RC(dbw_adam_step_groups_textures(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps,
-                                             in->adam_step, sets, begin, 3, ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
-        } else
-            RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
-                                    ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+        RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
+                                ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
         p->arena_clean = true;
     }
     if (bins) { p->bin_turn = 1 - p->bin_turn; p->bin_ready = 1; }
     p->rng_step += 1;
+    p->profiled = p->profile;
     return DBW_OK;
+#undef PROF
 #undef FP
 #undef IP
 }
@@ -636,5 +657,22 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t stream) {
     DBW_REQUIRE(p, "null pointer");
     HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0));
+    return DBW_OK;
+}
+
+extern "C" int dbw_train_step_profile(dbw_step_plan *p, int on) {
+    DBW_REQUIRE(p, "null pointer");
+    p->profile = on != 0;
+    p->profiled = false;
+    return DBW_OK;
+}
+
+extern "C" int dbw_train_step_kernel_times(dbw_step_plan *p, float *out4_ms) {
+    DBW_REQUIRE(p && out4_ms, "null pointer");
+    DBW_REQUIRE(p->profiled, "no profiled run: dbw_train_step_profile(plan, 1), then a run");
+    for (int k = 0; k < 4; ++k) {
+        HIP_OK(hipEventSynchronize(p->ev_t[2 * k + 1]));
+        HIP_OK(hipEventElapsedTime(out4_ms + k, p->ev_t[2 * k], p->ev_t[2 * k + 1]));
+    }
     return DBW_OK;
 }

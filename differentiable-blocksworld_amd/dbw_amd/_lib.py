@@ -107,10 +107,11 @@ SIGNATURES = {
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p],
-    'dbw_adam_step_groups_textures': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_i, c_p, c_i64, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
+    'dbw_train_step_profile': [c_p, c_i],
+    'dbw_train_step_kernel_times': [c_p, c_p],
 }
 # entry points that do not return an error code: name -> (restype, argtypes)
 OTHER_SIGNATURES = {
@@ -153,7 +154,7 @@ def load():
     lib.dbw_rasterize_workspace_bytes_binned.restype = c_sz
     lib.dbw_rasterize_workspace_bytes_binned.argtypes = [c_i64, c_i, c_i, c_i]
     for name, argtypes in SIGNATURES.items():
-        if (name.startswith('dbw_train_step') or name == 'dbw_adam_step_groups_textures') and not hasattr(lib, name):
+        if name.startswith('dbw_train_step') and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -17,7 +17,7 @@ from . import _lib, ops
 from .dbw import OVERLAP_N_BLOCKS, OVERLAP_N_POINTS, OVERLAP_TEMPERATURE
 
 _p = ops._ptr
-FUSE_ALL = 31          # include/dbw_hip.h: dbw_step_desc.fuse
+FUSE_ALL = 15          # include/dbw_hip.h: dbw_step_desc.fuse
 _SIDE_STREAMS = {}
 _OFF = {'alpha': 0, 'alpha_full': 1, 'keep': 2, 'losses': 3, 'arena_begin': 4, 'arena_end': 5, 'g_fg': 6, 'g_env': 7, 'env_img': 8, 'blk_verts': 9,
         'loss_part': 10}
@@ -204,6 +204,23 @@ class CStep:
         handle, wsb, _ = self._cur
         lib = _lib.load()
         return wsb[lib.dbw_train_step_offset(handle, 4):lib.dbw_train_step_offset(handle, 5)]
+
+    def kernel_times(self, inp, global_count=None, reps=5):
+        """ms of the four big kernels INSIDE a step (env pass, fg pass, fg backward, env backward), everything that shares the GPU with them
+        in a real step running next to them: HIP events recorded by the step itself on the streams the kernels run on; averaged over
+        `reps` steps without Adam (the parameters do not move).  -> {'env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'}"""
+        self(inp, global_count)
+        _lib.call('dbw_train_step_profile', self._cur[0], 1)
+        acc = [0.0] * 4
+        out = (ctypes.c_float * 4)()
+        try:
+            for _ in range(reps):
+                self(inp, global_count)
+                _lib.call('dbw_train_step_kernel_times', self._cur[0], ctypes.cast(out, ctypes.c_void_p))
+                acc = [a + float(o) for a, o in zip(acc, out)]
+        finally:
+            _lib.call('dbw_train_step_profile', self._cur[0], 0)
+        return dict(zip(('env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'), [a / reps for a in acc]))
 
     def wait_blocks_ready(self, stream):
         """`stream` (a torch stream) waits until the blocks' texture gradient of the last step is final (data parallel: the early slice of

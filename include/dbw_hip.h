@@ -360,14 +360,6 @@ int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float 
                          const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
                          int64_t zero_bytes, dbw_stream_t stream);
 
-/* The same launch with the backward of the texture preparation (dbw_texture_prep_bwd) folded in: for the elements of up to three texture
- * tensors -- sets[k] describes one: texture = param + set_begin[k] (n, h, w, 3), decim, grad_maps (cell resolution), grad_sig (or NULL) --
- * the gradient is formed on the spot as (grad_maps[cell] / decim^2 + grad_sig) * s (1 - s), s = sigmoid(param), and also written to `grad`;
- * every other element takes its gradient from `grad` as dbw_adam_step_groups does. */
-int dbw_adam_step_groups_textures(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end, const float *lr,
-                                  int ngroups, float beta1, float beta2, float eps, int step, const dbw_texture_set *sets,
-                                  const int64_t *set_begin, int nsets, void *zero_buf, int64_t zero_bytes, dbw_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------------------------------
  * The whole optimisation iteration of the training path behind ONE entry point (ABI 4).
  * Replaces one pass of src/trainer.py:137-147 -- optimizer.zero_grad(); loss = model(images, labels) (src/model/dbw.py:198-408: the
@@ -424,8 +416,7 @@ typedef struct dbw_step_desc {
     int64_t group_end[2];
     float *small_grads; int n_small_grads;      /* the accumulated (not fully written) gradients: cleared at the head of every run */
     /* ---- options ---- */
-    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail, 4: the backward of the
-                                                 * texture preparation inside the Adam launch (runs with_adam only); 0 = the operator-level kernels */
+    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail; 0 = the operator-level kernels */
     int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel) */
     int binned_concurrent;                      /* texture bins (which otherwise imply order 1): the env chain starts next to the fg kernel */
     int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);
@@ -465,10 +456,16 @@ int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
  * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
  * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials; -1 for an unknown name */
 int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
-/* Makes `stream` wait until the blocks' texture gradient of the last run is final (runs whose Adam does not fold the texture backward in:
- * with_adam == 0 or fuse bit 4 clear).  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
+/* Makes `stream` wait until the blocks' texture gradient of the last run is final.  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
  * own while the rest of the step still runs. */
 int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
+
+/* Measurement aid (bench.py): on != 0 makes every following run record HIP timing events around its four big kernels, on the streams they
+ * run on and with everything that shares the GPU with them in a real step running next to them (the events themselves cost each
+ * stream a few microseconds per record: profiled runs are not the timed ones).  dbw_train_step_kernel_times waits for the last profiled run
+ * and returns out4_ms = env pass, fg pass (+ composite + MSE), fg backward, env backward. */
+int dbw_train_step_profile(dbw_step_plan *plan, int on);
+int dbw_train_step_kernel_times(dbw_step_plan *plan, float *out4_ms);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """GPU: the optimisation iteration behind one C-ABI call (dbw_train_step_*, csrc/train_step.hip) against the launch-by-launch native step
 (dbw_amd/native_step.py, itself held to the autograd iteration and through it to the oracle): same loss values, same flat gradient, same
-parameters after Adam -- for the operator-level kernels enqueued from C (fuse = 0), for each fused kernel alone (1, 2, 4, 1 + 8, 16) and for all
-of them (31), in the three training phases; the step's own random numbers against the host build of the same generator; the loss values
+parameters after Adam -- for the operator-level kernels enqueued from C (fuse = 0), for each fused kernel alone (1, 2, 4, 1 + 8) and for all
+of them (15), in the three training phases; the step's own random numbers against the host build of the same generator; the loss values
 the step copies to host memory; fresh mini-batches; the reference's own operating point (4 views).  `-m gpu`."""
 import ctypes
 import os
@@ -75,7 +75,7 @@ def _compare(a, b, names):
 
 
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
-@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 16, 31])
+@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 15])
 def test_c_step_equals_native_step(epoch, fuse):
     inp = _inputs(3, 48, 64)
     noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -98,7 +98,7 @@ def test_c_step_at_the_benchmark_geometry_fused_equals_operator_level_kernels(ep
     u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
     mk = lambda: _model(epoch, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
     ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
-    for fuse in (0, 31):
+    for fuse in (0, 15):
         got = _run(mk(), inp, 2, noise, u, use_c_step=True, fuse=fuse)
         _compare(got, ref, ref[0].params.names)
 

@@ -23,15 +23,13 @@ def measure(B, variant, reads, steps):
     model, inp = bench.build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c31': dict(fuse=31), 'c31_1s': dict(fuse=31), 'c31_ts': dict(fuse=31)}[variant]
+    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c15_1s': dict(fuse=15)}[variant]
     if variant == 'c0':          # the operator-level kernels need the caller's draws
         model._noise_override = torch.randn(10, device=dev)
         model._overlap_u_override = torch.rand(10, 1000, 3, device=dev)
     step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=227391, **kw)
-    if variant == 'c31_1s':
+    if variant == 'c15_1s':
         step.cstep.use_side_stream = False
-    if variant == 'c31_ts':          # the env chain on a high-priority torch stream instead of the plan's own low-priority one
-        step.cstep.own_side_stream = True
     if step.cstep is not None:
         step.cstep.read_losses = reads
 
@@ -58,7 +56,7 @@ def measure(B, variant, reads, steps):
 
 for B in batches:
     steps = 200 if B <= 8 else 50
-    for variant in ('py', 'c0', 'c31', 'c31_1s', 'c31_ts'):
+    for variant in ('py', 'c0', 'c15', 'c15_1s'):
         row = []
         for reads in (False, True):
             for rep in range(2):

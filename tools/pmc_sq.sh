@@ -12,4 +12,8 @@ for grp in "$A" "$B" "$C" "$D"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/g$i -o p --output-format csv -- python tools/pmc_target.py > $OUT/g$i.log 2>&1
 done
+# calibration of the byte counters on 4 B/lane plane traffic of known size (tools/ubench/plane_rw.hip)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/calib_$c -o p --output-format csv -- tools/ubench/plane_rw > $OUT/calib_$c.log 2>&1
+done
 python tools/pmc_sq_summary.py $OUT

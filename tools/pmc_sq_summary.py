@@ -12,6 +12,22 @@ for f in glob.glob(os.path.join(out, 'g*', '**', '*counter_collection.csv'), rec
         vals.setdefault(n, {}).setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
         vals[n][r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
 med = lambda xs: sorted(xs)[len(xs) // 2]
+# calibration of the byte counters on this access pattern (tools/ubench/plane_rw.hip under the same counters: calib/ next to the groups):
+# known bytes / reported bytes for 4 B/lane plane reads and writes
+calib = {'fetch': 2.0, 'write': 1.0, 'source': 'MI355X_MICROARCH.md (x2 for 16 B/lane streaming reads; 4 B/lane uncalibrated)'}
+KNOWN = {'plane_read_kernel': ('FETCH_SIZE', 2 * 1024 ** 3), 'plane_write_kernel': ('WRITE_SIZE', 1024 ** 3)}
+got = {}
+for f in glob.glob(os.path.join(out, 'calib*', '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r['Kernel_Name'].split('(')[0].strip()
+        if n in KNOWN and r['Counter_Name'] == KNOWN[n][0]:
+            got.setdefault(n, {}).setdefault(r['Dispatch_Id'], 0.0)
+            got[n][r['Dispatch_Id']] += float(r['Counter_Value'])
+if len(got) == 2:
+    rep = {n: med(list(d.values())) * 1024 for n, d in got.items()}            # the counters are in KB
+    calib = {'fetch': KNOWN['plane_read_kernel'][1] / rep['plane_read_kernel'], 'write': KNOWN['plane_write_kernel'][1] / rep['plane_write_kernel'],
+             'source': 'tools/ubench/plane_rw.hip: 2 GiB read / 1 GiB written 4 B per lane under the same counters (known bytes / reported bytes)'}
+print('byte-counter calibration:', calib)
 res = {}
 for n, cs in sorted(vals.items()):
     row = {}
@@ -19,7 +35,8 @@ for n, cs in sorted(vals.items()):
         v = med(list(d.values()))
         row[c] = round(v / 1024, 2) if c in ('FETCH_SIZE', 'WRITE_SIZE') else round(v / 1e6, 3)
     if 'FETCH_SIZE' in row and 'WRITE_SIZE' in row:
-        row['hbm_mb'] = round(2 * row['FETCH_SIZE'] + row['WRITE_SIZE'], 1)
+        row['hbm_mb'] = round(calib['fetch'] * row['FETCH_SIZE'] + calib['write'] * row['WRITE_SIZE'], 1)
+        row['hbm_mb_guide_x2'] = round(2 * row['FETCH_SIZE'] + row['WRITE_SIZE'], 1)
     if 'SQ_THREAD_CYCLES_VALU' in row and 'SQ_ACTIVE_INST_VALU' in row and row['SQ_ACTIVE_INST_VALU']:
         row['valu_lane_utilisation'] = round(row['SQ_THREAD_CYCLES_VALU'] / (64 * row['SQ_ACTIVE_INST_VALU']), 3)
     res[n] = row
@@ -45,8 +62,14 @@ LABEL = {'render_fwd_kernel<10, 8, 8, 2, true>': 'render_fwd_fused K=10 (fg pass
          'render_fwd_kernel<1, 16, 16, 2, false>': 'render_fwd_fused K=1 (env pass)', 'render_fwd_kernel<1, 16, 16, 1, false>': 'render_fwd_fused K=1 (env pass)',
          'render_bwd_hard_kernel': 'render_bwd_fused K=1 (env pass)',
          'shade_blend_bwd_kernel<true, false, true>': 'render_bwd_fused K=1 (env pass)', 'texbin_reduce_kernel': 'texbin_reduce_kernel (fg pass)'}
-bench = {'_how': 'rocprofv3 --kernel-trace --pmc <group> -- python tools/pmc_target.py, one run per counter group (tools/pmc_sq.sh); medians over the '
-                 'dispatches; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; '
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench as _bench
+bench = {'_csrc_sha16': _bench.csrc_sha16(),
+         '_calibration': calib,
+         '_how': 'rocprofv3 --kernel-trace --pmc <group> -- python tools/pmc_target.py, one run per counter group (tools/pmc_sq.sh); medians over the '
+                 'dispatches; hbm_bytes = (fetch x FETCH_SIZE + write x WRITE_SIZE) KB with the factors of _calibration: the guide prescribes x2 for '
+                 'FETCH_SIZE on 16 B/lane streaming reads and calls other widths uncalibrated -- these kernels read and write planes 4 B per lane, so '
+                 'the factors are measured on exactly that pattern (tools/ubench/plane_rw.hip, known byte counts, same counters, same session); '
                  'valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (kernel duration * 2.4 GHz * 1024 SIMDs); valu_lane_utilisation = '
                  'SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)'}
 for n, lab in LABEL.items():
