@@ -608,14 +608,14 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // of the gradient bytes -- as soon as ev_blocks_ready says so, next to everything below.  It needs the TV gradient of the blocks' maps
     // (Rg): data parallel M waits for it here; on one GPU the launch moves behind the join with the env chain (which has waited for Rg), so
     // that M pays for one wait instead of two
+    const bool early_textures = two && !in->with_adam;
     auto blocks_textures = [&]() -> int {
         dbw_texture_set blk = sets[1];
         if (!tv) blk.grad_sig = nullptr;
         RC(dbw_texture_prep_bwd_sets(&blk, 1, M));
-        HIP_OK(hipEventRecord(p->ev_blocks_ready, M));
+        if (early_textures) HIP_OK(hipEventRecord(p->ev_blocks_ready, M));      // (an event costs M ~7 us: only where somebody waits for it)
         return DBW_OK;
     };
-    const bool early_textures = two && !in->with_adam;
     if (early_textures) {
         HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));
         RC(blocks_textures());

@@ -181,7 +181,10 @@ class ShardedTrainStep:
                 dev = self.params.flat.device
                 from .c_step import side_stream
                 side = side_stream(dev, cs.side_priority)
-                cs.wait_blocks_ready(side)
+                if cs.use_side_stream:
+                    cs.wait_blocks_ready(side)
+                else:
+                    side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     self.start_early_allreduce()
                 torch.cuda.current_stream(dev).wait_stream(side)      # (a synchronous backend -- gloo through a host copy -- wrote on `side`)
