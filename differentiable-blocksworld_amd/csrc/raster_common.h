@@ -92,9 +92,12 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 // records arrive in SGPRs (two s_load_dwordx16 per face), lanes are pixels.  Shared by the cell-list path and the legacy staging path.
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
-                                                  int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false) {
+                                                  int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false,
+                                                  unsigned long long mask = ~0ull) {
+    // (mask: the lanes of `jl` that hold faces of the chunk, in order)
 #pragma unroll 1
     for (int i = 0; i < mcnt; ++i) {
+        if (!((mask >> i) & 1ull)) continue;
         const int j = __builtin_amdgcn_readlane(jl, i);
         const FaceRec r = load_rec_uniform(recs + f_begin + j);
         const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
@@ -133,11 +136,14 @@ __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ re
 // (keys in `q`, payloads in the LDS array `home`, stride TW * TH, lane threadIdx.x).  Returns false for the padding blocks of the
 // XCD-aware grid.  All threads of the block must call it.  dbg: bit 0 = plain IEEE divisions, bit 1 = no tile culling (parity tests
 // run every variant against the oracle), bit 3 = hard pass whose distances are only read for their sign (eval_pair's sign_only).
-template <int KMAX, int TW, int TH, int GROUP = 2, bool PAY3 = false>
+// (PRE: a callable run once the tile's view and pixel are known and BEFORE the tile's own list is built -- the fused forward evaluates the
+// hard env layer of its pixel there, while nothing of the soft pass is live in registers yet)
+struct NoPre { __device__ __forceinline__ void operator()(int, int, int, bool) const {} };
+template <int KMAX, int TW, int TH, int GROUP = 2, bool PAY3 = false, class PRE = NoPre>
 __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                             const int *__restrict__ first_idx, const int *__restrict__ num_faces, int H, int W, int K,
                                             float blur, int persp, int clipb, long long total_blocks, const CoarseBins &cb, int dbg,
-                                            int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home, bool *known_empty = nullptr) {
+                                            int &n, int &xi, int &yi, TopK<KMAX, PAY3> &q, pay4 *&home, bool *known_empty = nullptr, PRE pre = PRE()) {
     static_assert(COARSE % TW == 0 && COARSE % TH == 0, "a tile must lie inside one coarse bin");
     // 8x8 tiles read the cell lists of cell_bin_kernel; walking the coarse bin (below) is their fallback -- a bin whose cell lists did
     // not fit the pool, or a caller without a binned workspace -- and gets by with the smallest staging area
@@ -179,6 +185,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     const int x0 = tx * TW, y0 = ty * TH;
     const int x1 = min(x0 + TW - 1, W - 1), y1 = min(y0 + TH - 1, H - 1);
 
+    pre(n, xi, yi, in_img);
     if (known_empty) *known_empty = empty_tile;
     if (known_empty && empty_tile) return true;        // (the caller has a path of its own for tiles without faces: no list to set up)
     q.init();

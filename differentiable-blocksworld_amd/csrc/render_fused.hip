@@ -5,6 +5,8 @@
 #include "raster_common.h"
 #include "shade_common.h"
 #include "loss_math.h"
+#include "raster_bin.h"
+#include "step_kernels.h"
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
@@ -189,9 +191,101 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
     return s;
 }
 
+// ---- the env layer folded into the soft pass (training step) ---------------------------------------------------------------------------
+// The decoupled render (dbw.py:213-223) draws sky + ground in a pass of their own -- hard, one face per pixel -- whose image the fg pass
+// composites over.  As a kernel of its own that pass sat on the step's critical path in front of the fg pass (0.16 ms of 1.03 at config 2)
+// and its image made a round trip through memory.  Folded: every 8x8 tile of the fg pass first rasterises ITS pixel of the env scene from
+// the env scene's per-tile face list (2-3 large faces: the same eval_pair / TopK<1> / sibling rule the env pass runs, so the same face, the
+// same barycentrics), shades it through the face's ShadeRec and keeps the colour in three registers for the composite; what the env
+// BACKWARD needs -- the hard uv-fragment (frag_layout 3: clipped face, u, v, face | map) -- is stored exactly as the env pass stores it.
+struct EnvFold {
+    const FaceRec *recs;            // nullptr: not folded (the epilogue reads env_img)
+    const int *first_idx;
+    const int2 *cell; const int *pool;                  // per-tile face lists of the env scene (cell_bin_block)
+    const int *clist, *ccount; int nx, ny;              // its coarse bins: what a tile whose list did not fit the pool walks
+    const int *num_faces;
+    const ShadeRec *srec;
+    const float *maps;
+    float bg[3];
+    int *p2f; float *uvj;                               // hard uv-fragments out: [tile][64], [tile][3][64]
+    int persp, dbg;
+};
+
+__device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, int n_, int xi, int yi, bool in_img, float (&rgb)[3]) {
+    const int lane = threadIdx.x;
+    const int n = __builtin_amdgcn_readfirstlane(n_);          // (the tile's view: wave-uniform, and the record loads below need to know)
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int L = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
+    const NdcAxis ax = ndc_axis(W, H), ay = ndc_axis(H, W);
+    f2 p;
+    p.x = pix_to_ndc_fast(W - 1 - xi, ax);
+    p.y = pix_to_ndc_fast(H - 1 - yi, ay);
+    TopK<1, false> q;
+    q.init();
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(E.dbg & 1);
+    const int fb = __builtin_amdgcn_readfirstlane(E.first_idx[n]);
+    const int2 c = E.cell[L];
+    // the tile's own list; or, where the bin's lists did not fit the pool (count < 0), the bin's coarse list: its entries in order, those
+    // whose cell range covers this tile.  ONE evaluation site for both (everything wave-uniform, and said so: the record loads inside
+    // want scalar addresses under uniform control flow)
+    const bool walk = c.y < 0;
+    int total = c.y > 0 ? c.y : 0, cx = 0, cy = 0;
+    const int *__restrict__ lst = E.pool + c.x;
+    if (walk) {
+        const int x0 = __builtin_amdgcn_readfirstlane(xi & ~7), y0 = __builtin_amdgcn_readfirstlane(yi & ~7);
+        const int nb = E.nx * E.ny, bin = (y0 / COARSE) * E.nx + (x0 / COARSE);
+        total = __builtin_amdgcn_readfirstlane(E.ccount[n * nb + bin]);
+        lst = E.clist + (long long)fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(E.num_faces[n]);
+        cx = (x0 & (COARSE - 1)) >> 3; cy = (y0 & (COARSE - 1)) >> 3;
+    }
+#pragma unroll 1
+    for (int cb0 = 0; cb0 < total; cb0 += DBW_WAVE) {
+        const bool have = cb0 + lane < total;
+        const int e = have ? lst[cb0 + lane] : 0;
+        const bool hit = have && (!walk || !(cx < ((e >> 20) & 7) || cx > ((e >> 23) & 7) || cy < ((e >> 26) & 7) || cy > ((e >> 29) & 7)));
+        const unsigned long long m = __ballot(hit);
+        eval_staged_chunk<1, false>(E.recs, fb, e & 0xfffff, min(DBW_WAVE, total - cb0), in_img, p, 1, 0.f, E.persp, 1, fastdiv, true, q, nullptr, DBW_WAVE,
+                                    lane, false, false, m);
+    }
+    float pz = 0.f;
+    int fi = 0;
+    pay4 v{0.f, 0.f, 0.f, 0.f};
+    const bool valid = q.get(0, nullptr, DBW_WAVE, lane, pz, fi, v) && in_img;
+    if (!valid) fi = 0;
+    const ShadeRec sr = E.srec[fi];
+    const float bc[3] = {v.y, v.z, v.w};
+    float bo[3], u, vv;
+    convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
+    interp_uv(bo, sr.uv, u, vv);
+    Sample s;
+    footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+    float col[3];
+    fetch(E.maps, s, col);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = valid ? col[k] : E.bg[k];
+    if (in_img) {
+        const long long o = ((long long)L << 6) + lane;
+#if DBW_NT_STORES
+        __builtin_nontemporal_store(valid ? fi : -1, E.p2f + o);
+#else
+        E.p2f[o] = valid ? fi : -1;
+#endif
+        if (valid) {
+            float *bp = E.uvj + ((long long)L * 3 << 6) + lane;
+#if DBW_NT_STORES
+            __builtin_nontemporal_store(u, bp); __builtin_nontemporal_store(vv, bp + 64);
+            __builtin_nontemporal_store(__int_as_float(sr.j | (sr.map << 20)), bp + 128);
+#else
+            bp[0] = u; bp[64] = vv; bp[128] = __int_as_float(sr.j | (sr.map << 20));
+#endif
+        }
+    }
+}
+
 // the pixel's blended colour -> the image, or (training) the composite + MSE partials and the two image gradients
+// (env_rgb: the env layer's colour of this pixel when the env pass is folded into this one, else nullptr: read from A.env_img)
 __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
-                                             float *__restrict__ image) {
+                                             float *__restrict__ image, const float *env_rgb = nullptr) {
     const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
     const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
     if (A.target) {
@@ -200,8 +294,11 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
         // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
         float sq = 0.f;
         if (in_img) {
-            const float *ev = A.env_img + i4.base, *tg = A.target + i3.base;
-            const float fc3[3] = {f0, f1, f2}, ec3[3] = {ev[0], ev[i4.cstride], ev[2 * i4.cstride]}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
+            const float *tg = A.target + i3.base;
+            float ec3[3];
+            if (env_rgb) { ec3[0] = env_rgb[0]; ec3[1] = env_rgb[1]; ec3[2] = env_rgb[2]; }
+            else { const float *ev = A.env_img + i4.base; ec3[0] = ev[0]; ec3[1] = ev[i4.cstride]; ec3[2] = ev[2 * i4.cstride]; }
+            const float fc3[3] = {f0, f1, f2}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
             float rec3[3], gf3[3], ge3[3], gmask;
             sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
             float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
@@ -230,7 +327,8 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
 
 // a tile no face reaches (cell list of length 0): every pixel is the background; the fragment record is the count 0
 template <int KMAX>
-__device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image) {
+__device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image,
+                                                const float *env_rgb = nullptr) {
     const int lane = threadIdx.x;
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
@@ -240,13 +338,13 @@ __device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int x
     blend_front_init(bl);
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
 }
 
 template <int KMAX>
 __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
-                                          float *__restrict__ image, int dbg) {
+                                          float *__restrict__ image, int dbg, const float *env_rgb = nullptr) {
     // dbg (tools/diag ablations, dbw_debug_set_flags): 32 = no fragment stores (flags 8192), 64 = no layer loop at all (16384)
     const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
     const bool in_img = xi < A.W && yi < A.H;
@@ -329,7 +427,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     }
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
 }
 
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
@@ -340,7 +438,7 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
                                                              float blur, int persp, int dbg,
                                                              long long total_blocks, ShadeArgs A, CoarseBins cb, const ShadeRec *__restrict__ srec,
                                                              int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
-                                                             float *__restrict__ image) {
+                                                             float *__restrict__ image, const EnvFold E) {
     static_assert(!UV || (TW == 8 && TH == 8), "shade_uv8 needs one wave per 8x8 tile");
     int n, xi, yi;
     TopK<KMAX, UV> q;
@@ -348,13 +446,18 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     FPROF_T(t_k0);
     FPROF_ADD(13, wall_clock64());            // (100 MHz, common to the XCDs: the wave's place on the kernel's time line)
     bool empty = false;
+    float env_rgb[3] = {0.f, 0.f, 0.f};
+    const bool fold = UV && E.recs != nullptr;
+    auto env_layer = [&](int n_, int xi_, int yi_, bool in_img_) {
+        if constexpr (UV) { if (fold) env_fold_pixel(E, A.H, A.W, n_, xi_, yi_, in_img_, env_rgb); }
+    };
     if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb,
                                               (dbg & (3 | 128)) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home,
-                                              UV ? &empty : nullptr)) return;
+                                              UV ? &empty : nullptr, env_layer)) return;
     FPROF_T(t_k1);
     if constexpr (UV) {
-        if (empty) shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, image);
-        else shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg);
+        if (empty) shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, image, fold ? env_rgb : nullptr);
+        else shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg, fold ? env_rgb : nullptr);
     }
     else {
         if (xi >= A.W || yi >= A.H) return;
@@ -368,18 +471,20 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
 
 template <int KMAX, int TW, int TH, int GROUP, bool UV>
 int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
-             int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
+             int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
+             hipStream_t s) {
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
     DBW_REQUIRE(total < (1LL << 31) - 8, "more than 2^31 tiles in one pass");
     hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP, UV>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
-                       num_faces, blur, persp, g_render_dbg, total, A, cb, srec, p2f, bary, dists, image);
+                       num_faces, blur, persp, g_render_dbg, total, A, cb, srec, p2f, bary, dists, image, E);
     return dbw_check_launch("render_fwd_kernel");
 }
 
 template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
-           int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, hipStream_t s) {
-#define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, s)
+           int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
+           hipStream_t s) {
+#define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, E, s)
     if constexpr (KMAX == 1) {                                 // hard K=1 pass: large faces (sky dome, ground); the single payload stays in registers
         if (g_render_variant == 1) return DBW_V(8, 8, 2, false);
         if (g_render_variant == 2) return DBW_V(16, 8, 2, false);
@@ -407,7 +512,8 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int N, int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius,
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
-                                    int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream) {
+                                    int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream,
+                                    const dbw::EnvFoldHost *fold = nullptr) {
     DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
@@ -426,7 +532,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     A.img_tiled = image_layout;
     if (mse) {
         DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
-        DBW_REQUIRE(stage == 1 || (mse->env_img && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
+        DBW_REQUIRE(stage == 1 || ((mse->env_img || fold) && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
         A.env_img = mse->env_img; A.target = mse->target; A.mse_scale = mse->scale; A.loss_part = mse->loss_part; A.g_fg = mse->g_fg; A.g_env = mse->g_env;
     }
     if (K > DBW_MAX_FACES_PER_PIXEL) {
@@ -452,7 +558,18 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
         }
     }
     if (stage == 1) return DBW_OK;
-#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, s)
+    EnvFold E;
+    memset(&E, 0, sizeof(E));
+    if (fold) {
+        DBW_REQUIRE(mse && frag_layout == 2 && K > 1, "the env layer folds into the soft pass with the loss epilogue");
+        DBW_REQUIRE(fold->ws && fold->ws->cells && fold->ws->shade_recs && fold->first_idx && fold->num_faces && fold->maps && fold->p2f && fold->uvj, "null pointer (env fold)");
+        const dbw::RasterWorkspace &w = *fold->ws;
+        E.recs = w.recs; E.first_idx = fold->first_idx; E.cell = w.cell; E.pool = w.pool; E.clist = w.list; E.ccount = w.count; E.nx = w.nx; E.ny = w.ny;
+        E.num_faces = fold->num_faces; E.srec = (const ShadeRec *)w.shade_recs; E.maps = fold->maps;
+        for (int i = 0; i < 3; ++i) E.bg[i] = fold->bg[i];
+        E.p2f = fold->p2f; E.uvj = fold->uvj; E.persp = perspective_correct; E.dbg = g_render_dbg;
+    }
+#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);
@@ -487,4 +604,19 @@ extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
                            bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stage, image_layout, stream);
+}
+
+// the fg pass of the training step with the env layer folded in (step_kernels.h): stage 2 only -- the step's fused set-up kernels have
+// filled both workspaces
+int dbw::render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces, const int32_t *neighbor,
+                                   const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                                   const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len, int N,
+                                   int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
+                                   const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
+                                   const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
+                                   hipStream_t stream) {
+    const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env};
+    return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
+                           faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold);
 }

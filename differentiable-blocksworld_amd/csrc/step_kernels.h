@@ -104,4 +104,18 @@ struct BlocksTailArgs {
 };
 int launch_blocks_tail(const BlocksTailArgs &A, hipStream_t s);
 
+// the env layer folded into the fg pass (render_fused.hip): the env scene's workspace (per-tile lists and shading records filled by the
+// set-up kernels), its maps and background, and where its hard uv-fragments go (frag_layout 3: what the env backward reads)
+struct EnvFoldHost {
+    const RasterWorkspace *ws; const int *first_idx, *num_faces; const float *maps; float bg[3];
+    int *p2f; float *uvj;
+};
+int render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces, const int32_t *neighbor,
+                              const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride, const float *face_uvs,
+                              const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha, int alpha_len, int N,
+                              int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
+                              const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
+                              const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
+                              hipStream_t stream);
+
 }  // namespace dbw

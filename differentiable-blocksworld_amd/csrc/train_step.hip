@@ -203,6 +203,29 @@ int check_desc(const dbw_step_desc *d) {
     return DBW_OK;
 }
 
+// The two side streams of the training step: ONE pair per process and device, shared by every plan, created on first use and never
+// destroyed.  HIP multiplexes a process's streams onto a handful of hardware queues round-robin: when every plan made its own pair, the
+// second plan of a process (the next training phase) got streams that share a queue with the caller's stream -- false dependencies
+// between "concurrent" chains, 1.6 -> 2.2 ms per step at the full-resolution phase.  Lowest priority: whatever shares the GPU with the
+// critical chain on the caller's stream yields to it.
+constexpr int MAX_DEVICES = 64;
+hipStream_t g_stream_r[MAX_DEVICES], g_stream_env[MAX_DEVICES];
+int step_streams(hipStream_t &r, hipStream_t &e) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { dbw_set_error("dbw_train_step_create: no current device"); return DBW_ERR_LAUNCH; }
+    if (!g_stream_r[dev]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&g_stream_r[dev], hipStreamNonBlocking, least) != hipSuccess ||
+            hipStreamCreateWithPriority(&g_stream_env[dev], hipStreamNonBlocking, least) != hipSuccess) {
+            dbw_set_error("dbw_train_step_create: hipStreamCreate failed");
+            return DBW_ERR_LAUNCH;
+        }
+    }
+    r = g_stream_r[dev]; e = g_stream_env[dev];
+    return DBW_OK;
+}
+
 }  // namespace
 
 struct dbw_step_plan {
@@ -211,7 +234,7 @@ struct dbw_step_plan {
     char *ws;
     RasterWorkspace rw_e, rw_f;         // for max_views (the pointers of a run follow from the run's own B)
     hipEvent_t ev_prologue, ev_scatter, ev_fg_fwd, ev_reg, ev_layout, ev_kernel_done, ev_blocks_ready, ev_env_done, ev_losses;
-    hipStream_t stream_r, stream_env;   // plan-owned, lowest priority: the regularisers; the env backward chain (when the caller brings no side stream)
+    hipStream_t stream_r, stream_env;   // the library's two side streams of this device (step_streams): the regularisers; the env backward chain
     unsigned long long rng_step;
     int bin_turn, bin_ready, uniform_ready;
     bool arena_clean;
@@ -244,14 +267,7 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
     hipEvent_t *evs[] = {&p->ev_prologue, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_layout, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_env_done, &p->ev_losses};
     for (hipEvent_t *e : evs)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&p->stream_r, hipStreamNonBlocking, prio_least) != hipSuccess ||
-        hipStreamCreateWithPriority(&p->stream_env, hipStreamNonBlocking, prio_least) != hipSuccess) {
-        dbw_set_error("dbw_train_step_create: hipStreamCreate failed");
-        delete p;
-        return nullptr;
-    }
+    if (step_streams(p->stream_r, p->stream_env)) { delete p; return nullptr; }
     if (hipHostMalloc((void **)&p->host_losses, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         dbw_set_error("dbw_train_step_create: hipHostMalloc failed");
         delete p;
@@ -270,8 +286,6 @@ extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_layout, p->ev_kernel_done, p->ev_blocks_ready, p->ev_env_done, p->ev_losses};
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_t) (void)hipEventDestroy(e);
-    if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
-    if (p->stream_env) (void)hipStreamDestroy(p->stream_env);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
     delete p;
 }
@@ -291,6 +305,8 @@ extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
         case 8: return (int64_t)L.img_e;
         case 9: return (int64_t)L.blk_verts;
         case 10: return (int64_t)L.part;
+        case 11: return (int64_t)L.p2f_e;
+        case 12: return (int64_t)L.bary_e;
         default: return -1;
     }
 }
@@ -470,12 +486,14 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
     RasterWorkspace we, wf;
-    RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, /*cells: the hard pass walks its coarse bins*/ false, we));
+    // (fuse bit 4: the env layer is evaluated inside the fg pass, from per-tile lists of its own; else the hard pass walks its coarse bins)
+    RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, (d.fuse & 16) != 0, we));
     RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
     const bool fused_setup = (d.fuse & 2) && we.binned && wf.binned && wf.cells;
+    const bool fold = fused_setup && (d.fuse & 16) && we.cells;
     const float margin_f = (float)sqrt((double)d.blur_radius);
     // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
-    const bool setup_aside = two && fused_setup && B > d.serial_setup_max_views;
+    const bool setup_aside = two && fused_setup && !fold && B > d.serial_setup_max_views;
     if (fused_setup) {
         SceneSetupArgs A;
         memset(&A, 0, sizeof(A));
@@ -504,6 +522,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             g.list = rw[i]->list; g.count = rw[i]->count; g.mask = rw[i]->mask;
         }
         Bn.sc[1].cells = 1; Bn.sc[1].cell = wf.cell; Bn.sc[1].pool = wf.pool; Bn.sc[1].pool_cap = wf.pool_cap; Bn.sc[1].hdr = wf.hdr; Bn.sc[1].rank = wf.rank;
+        if (fold) {          // the env scene gets shading records and per-tile lists too
+            e.hdr = we.hdr; e.nhdr = CELL_HDR_INTS;
+            e.srec = we.shade_recs; e.face_uvs = d.env_face_uvs; e.face_map = d.env_face_map; e.map_desc = d.env_map_desc; e.map_alpha = nullptr;
+            Bn.sc[0].cells = 1; Bn.sc[0].cell = we.cell; Bn.sc[0].pool = we.pool; Bn.sc[0].pool_cap = we.pool_cap; Bn.sc[0].hdr = we.hdr; Bn.sc[0].rank = we.rank;
+        }
         if (setup_aside) {
             HIP_OK(hipStreamWaitEvent(E, p->ev_prologue, 0));
             A.scene0 = 0; A.nscenes = 1; Bn.scene0 = 0; Bn.nscenes = 1;
@@ -537,12 +560,24 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // ---- M: the env pass (hard, one face per pixel), then the fg pass ending in the composite + MSE ----
 #define PROF(i, st) do { if (p->profile) HIP_OK(hipEventRecord(p->ev_t[i], st)); } while (0)
     PROF(0, M);
-    RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
-                            d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
-                            IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
+    if (!fold)
+        RC(dbw_render_fwd_fused(FP(L.e.fvc), IP(L.e.first), IP(L.e.num), IP(L.e.nbr), IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), 2 * Fe, d.env_face_uvs,
+                                d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
+                                IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
     PROF(1, M);
     if (setup_aside) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
     PROF(2, M);
+    if (fold) {
+        // the fg pass with the env layer inside it: no env pass, no env image; the env scene's hard uv-fragments leave from here
+        EnvFoldHost fh;
+        fh.ws = &we; fh.first_idx = IP(L.e.first); fh.num_faces = IP(L.e.num); fh.maps = FP(L.env_maps);
+        for (int i = 0; i < 3; ++i) fh.bg[i] = d.bg_env[i];
+        fh.p2f = IP(L.p2f_e); fh.uvj = FP(L.bary_e);
+        RC(render_fwd_fused_mse_fold(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
+                                     d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
+                                     d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, target, mse_scale,
+                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, M));
+    } else
     RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                 d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                 d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, FP(L.img_e), target, mse_scale,

@@ -376,8 +376,10 @@ int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float 
  * Ownership: every pointer of dbw_step_desc / dbw_step_inputs is caller-owned DEVICE memory that stays valid while the plan lives
  * (inputs: until the call's work has finished).  `workspace` (dbw_train_step_workspace_bytes bytes, 256-byte aligned) is caller-owned
  * scratch the plan carves everything else out of: clipped faces, raster workspaces, fragments, images, maps, gradient accumulators, the
- * records of the texture bins.  The plan is the one object of this ABI that holds state between calls: its events, a stream of its own
- * for the regularisers, the step counter of its random numbers, and which of the two demand tables of the texture bins is current.  Not thread-safe; one plan per
+ * records of the texture bins.  The plan is the one object of this ABI that holds state between calls: its events, the step counter of its
+ * random numbers, and which of the two demand tables of the texture bins is current.  (The library also keeps ONE pair of lowest-priority
+ * side streams per process and device, shared by all plans: HIP multiplexes streams onto a few hardware queues, a pair per plan ends up
+ * sharing a queue with the caller's stream.)  Not thread-safe; one plan per
  * (model, training phase, device).
  */
 typedef struct dbw_step_desc {
@@ -416,7 +418,8 @@ typedef struct dbw_step_desc {
     int64_t group_end[2];
     float *small_grads; int n_small_grads;      /* the accumulated (not fully written) gradients: cleared at the head of every run */
     /* ---- options ---- */
-    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail; 0 = the operator-level kernels */
+    int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail, 4: the env layer inside the
+                                                 * fg pass (no env pass, no env image; needs bit 1); 0 = the operator-level kernels */
     int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel) */
     int binned_concurrent;                      /* texture bins (which otherwise imply order 1): the env chain starts next to the fg kernel */
     int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);
@@ -446,15 +449,16 @@ dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void *workspace,
 void dbw_train_step_destroy(dbw_step_plan *plan);
 /* Enqueues one iteration.  stream_main carries the critical chain -- set-up, the two passes, the fg backward and its tail, Adam (or,
  * with_adam == 0, everything the caller's all-reduce has to wait for) -- and is the only stream the caller has to order against.  The env
- * backward chain and the regularisers run next to it: on stream_side if the caller brings one, else (NULL) on lowest-priority streams
- * of the plan; stream_side == stream_main: everything in order on one stream.  On return nothing has been waited for. */
+ * backward chain and the regularisers run next to it: on stream_side if the caller brings one, else (NULL) on the library's own
+ * lowest-priority streams; stream_side == stream_main: everything in order on one stream.  On return nothing has been waited for. */
 int dbw_train_step_run(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side);
 /* Blocks until the loss values of the last run with read_losses != 0 are in host memory: out5 = rgb, parsimony, tv, overlap, total */
 int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
 /* Byte offset inside the workspace of one of the plan's buffers (tests, diagnostics, host-side views of per-step state):
  * which = 0 alpha (n_blocks), 1 alpha_full, 2 keep (int32), 3 loss values on the device (5 floats, valid after a run), 4 / 5 begin / end of
  * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
- * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials; -1 for an unknown name */
+ * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials, 11 / 12 the env scene's hard uv-fragments (face ids;
+ * u, v, face | map); -1 for an unknown name */
 int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 /* Makes `stream` wait until the blocks' texture gradient of the last run is final.  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
  * own while the rest of the step still runs. */

@@ -1,7 +1,7 @@
 """GPU: the optimisation iteration behind one C-ABI call (dbw_train_step_*, csrc/train_step.hip) against the launch-by-launch native step
 (dbw_amd/native_step.py, itself held to the autograd iteration and through it to the oracle): same loss values, same flat gradient, same
 parameters after Adam -- for the operator-level kernels enqueued from C (fuse = 0), for each fused kernel alone (1, 2, 4, 1 + 8) and for all
-of them (15), in the three training phases; the step's own random numbers against the host build of the same generator; the loss values
+of them (15), and with the env layer folded into the fg pass (31), in the three training phases; the step's own random numbers against the host build of the same generator; the loss values
 the step copies to host memory; fresh mini-batches; the reference's own operating point (4 views).  `-m gpu`."""
 import ctypes
 import os
@@ -75,7 +75,7 @@ def _compare(a, b, names):
 
 
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
-@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 15])
+@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 15, 31])
 def test_c_step_equals_native_step(epoch, fuse):
     inp = _inputs(3, 48, 64)
     noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -98,7 +98,7 @@ def test_c_step_at_the_benchmark_geometry_fused_equals_operator_level_kernels(ep
     u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
     mk = lambda: _model(epoch, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
     ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
-    for fuse in (0, 15):
+    for fuse in (0, 15, 31):
         got = _run(mk(), inp, 2, noise, u, use_c_step=True, fuse=fuse)
         _compare(got, ref, ref[0].params.names)
 
@@ -200,3 +200,38 @@ def test_c_step_single_stream_equals_two_streams():
         torch.cuda.synchronize()
         res.append((step, vals, grad1, step.params.flat.clone()))
     _compare(res[0], res[1], res[0][0].params.names)
+
+
+@pytest.mark.parametrize('epoch', [0, 800])
+def test_env_layer_folded_into_the_fg_pass_leaves_the_fragments_of_the_env_pass(epoch):
+    """fuse bit 4: every 8x8 tile of the fg pass rasterises and shades its pixel of the env scene itself (per-tile lists of the env faces,
+    the env pass's own per-pair arithmetic) instead of reading the image of a separate env pass.  What the env backward consumes -- the
+    hard uv-fragments: clipped face id, u, v, face | map per pixel -- must be what the env pass writes, bit for bit; config-2 geometry, the
+    ground plane crossing the near plane (split quads: the sibling rule)."""
+    inp = _inputs(5, 300, 400)
+    nb = 10
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    frags = []
+    for fuse in (15, 31):
+        model = _model(epoch, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=99, fuse=fuse)
+        out = step(inp)
+        torch.cuda.synchronize()
+        tiles = 5 * ((300 + 7) // 8) * ((400 + 7) // 8)
+        p2f = step.cstep.view('p2f_env', torch.int32, tiles * 64).clone()
+        uvj = step.cstep.view('uvj_env', torch.int32, tiles * 192).view(tiles, 3, 64).clone()
+        frags.append((p2f, uvj, {k: float(v) for k, v in out.items()}, step.params.grad.clone()))
+    (pa, ua, la, ga), (pb, ub, lb, gb) = frags
+    # rows / columns of the last tiles that lie beyond the image are never written: compare the pixels of the image
+    ty, tx = (300 + 7) // 8, (400 + 7) // 8
+    yy = (torch.arange(ty, device=DEV)[:, None, None] * 8 + torch.arange(64, device=DEV)[None, None, :] // 8).expand(ty, tx, 64)
+    xx = (torch.arange(tx, device=DEV)[None, :, None] * 8 + torch.arange(64, device=DEV)[None, None, :] % 8).expand(ty, tx, 64)
+    inside = ((yy < 300) & (xx < 400)).reshape(1, ty * tx, 64).expand(5, -1, -1).reshape(-1)
+    assert torch.equal(pa[inside], pb[inside]) and int((pa[inside] >= 0).sum()) > 0.9 * int(inside.sum())
+    valid = (inside & (pa >= 0)).view(-1, 1, 64).expand(-1, 3, -1)
+    assert torch.equal(ua[valid], ub[valid])
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-6 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())

@@ -23,13 +23,11 @@ def measure(B, variant, reads, steps):
     model, inp = bench.build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c15_1s': dict(fuse=15)}[variant]
+    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c31': dict(fuse=31)}[variant]
     if variant == 'c0':          # the operator-level kernels need the caller's draws
         model._noise_override = torch.randn(10, device=dev)
         model._overlap_u_override = torch.rand(10, 1000, 3, device=dev)
     step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=227391, **kw)
-    if variant == 'c15_1s':
-        step.cstep.use_side_stream = False
     if step.cstep is not None:
         step.cstep.read_losses = reads
 
@@ -56,7 +54,7 @@ def measure(B, variant, reads, steps):
 
 for B in batches:
     steps = 200 if B <= 8 else 50
-    for variant in ('py', 'c0', 'c15', 'c15_1s'):
+    for variant in ('py', 'c15', 'c31'):
         row = []
         for reads in (False, True):
             for rep in range(2):
