@@ -62,12 +62,24 @@ __device__ __forceinline__ int coarse_bin_block(const float4 *__restrict__ bbox,
     int *out = list + (long long)f_begin * nb + (long long)bin * nf;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int cnt = 0;
-    for (int base = 0; base < nf; base += 256) {
+    // (the boxes of four rounds are requested together: a round used to start with a load every thread then waited for, and the rounds
+    // of a bin are a chain -- the workgroup's latency, not its work, is what the step pays for at small batches)
+    for (int base0 = 0; base0 < nf; base0 += 1024) {
+    float4 bbs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = base0 + r * 256 + threadIdx.x;
+        bbs[r] = j < nf ? bbox[f_begin + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int base = base0 + r * 256;
+        if (base >= nf) break;
         const int j = base + threadIdx.x;
         bool hit = false;
         int entry = 0;
         if (j < nf) {
-            const float4 bb = bbox[f_begin + j];
+            const float4 bb = bbs[r];
             if (!(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w)) {
                 int cx0 = 8, cx1 = -1, cy0 = 8, cy1 = -1;
 #pragma unroll
@@ -81,9 +93,9 @@ __device__ __forceinline__ int coarse_bin_block(const float4 *__restrict__ bbox,
                     const unsigned row = ((1u << (cx1 - cx0 + 1)) - 1u) << cx0;
                     unsigned lo = 0u, hi = 0u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r >= cy0 && r <= cy1) lo |= row << (8 * r);
-                        if (r + 4 >= cy0 && r + 4 <= cy1) hi |= row << (8 * r);
+                    for (int q = 0; q < 4; ++q) {
+                        if (q >= cy0 && q <= cy1) lo |= row << (8 * q);
+                        if (q + 4 >= cy0 && q + 4 <= cy1) hi |= row << (8 * q);
                     }
                     if (lo) atomicOr(&S.mask[0], lo);
                     if (hi) atomicOr(&S.mask[1], hi);
@@ -103,6 +115,7 @@ __device__ __forceinline__ int coarse_bin_block(const float4 *__restrict__ bbox,
         }
         cnt += tot;
         __syncthreads();
+    }
     }
     if (threadIdx.x == 0) count[n * nb + bin] = cnt;
     if (threadIdx.x < 2) mask[(n * nb + bin) * 2 + threadIdx.x] = S.mask[threadIdx.x];
@@ -175,32 +188,48 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
         const int total = __shfl(incl, 63, 64);
+        // The bin's returning atomics -- its share of the pool, and one per distinct (XCD segment, face-count class) of its tiles for their
+        // ranks -- are ISSUED TOGETHER and read afterwards: one round trip instead of up to eleven in a row (they were a third of the
+        // workgroup's latency).  The class of a tile needs its count, which needs to know whether the pool overflowed, which needs the pool
+        // atomic's answer: so the rank atomics are issued for the no-overflow classes, and a bin that does overflow (never, at the pool
+        // sizes in use) hands its ranks back and takes new ones for class 0.
         int base_off = 0;
         if (lane == 0 && total > 0) base_off = atomicAdd(&hdr[0], total);
+        const long long per = ((long long)N * tiles + 7) / 8;
+        const long long L = (long long)n * tiles + tile;
+        const int seg16 = in_img ? (int)(L / per) * 16 : 0;
+        auto ranks = [&](int key, int &r_out, int &leader_out, int &gcount_out) {
+            unsigned long long rem = __ballot(key >= 0);
+            int leader = lane, gcount = 0, grank = 0;
+            while (rem) {
+                const int l0 = __ffsll((long long)rem) - 1;
+                const int k0 = __builtin_amdgcn_readlane(key, l0);
+                const unsigned long long m = __ballot(key == k0);
+                if (key == k0) { leader = l0; gcount = __popcll(m); grank = __popcll(m & ((1ull << lane) - 1ull)); }
+                rem &= ~m;
+            }
+            int b0 = 0;
+            if (key >= 0 && lane == leader) b0 = atomicAdd(&hdr[1 + key], gcount);
+            r_out = __shfl(b0, leader, 64) + grank;
+            leader_out = leader; gcount_out = gcount;
+        };
+        int key = in_img ? seg16 + work_class(too_long ? -1 : all) : -1;
+        int r = 0, leader = lane, gcount = 0;
+        ranks(key, r, leader, gcount);
         base_off = __shfl(base_off, 0, 64);
         const bool overflow = too_long || (total > 0 && (long long)base_off + total > (long long)pool_cap);
+        if (overflow && !too_long) {          // (wave-uniform) the pool was full: the tiles walk the coarse list -> class 0
+            if (key >= 0 && lane == leader) atomicAdd(&hdr[1 + key], -gcount);
+            key = in_img ? seg16 + work_class(-1) : -1;
+            ranks(key, r, leader, gcount);
+        }
         const int off = base_off + (incl - all);
         for (int ch = 0; ch < chunks; ++ch) S.pre[ch][lane] += off;
         if (lane == 0) S.base = (overflow || total == 0) ? -1 : 0;
         const int count = overflow ? -1 : all;
-        const long long L = (long long)n * tiles + tile;
         if (in_img) cell[L] = make_int2(overflow ? 0 : off, count);
-        // rank of the tile inside its (XCD segment, face-count class): one returning atomic per distinct key of the wave
-        // (work_scatter_kernel turns class + rank into the tile's place in the launch order)
-        const long long per = ((long long)N * tiles + 7) / 8;
-        const int key = in_img ? (int)(L / per) * 16 + work_class(count) : -1;
-        unsigned long long rem = __ballot(key >= 0);
-        int r = 0;
-        while (rem) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const int k0 = __shfl(key, leader, 64);
-            const unsigned long long m = __ballot(key == k0);
-            int b0 = 0;
-            if (lane == leader) b0 = atomicAdd(&hdr[1 + k0], __popcll(m));
-            b0 = __shfl(b0, leader, 64);
-            if (key == k0) r = b0 + __popcll(m & ((1ull << lane) - 1ull));
-            rem &= ~m;
-        }
+        // (rank of the tile inside its (XCD segment, face-count class): work_scatter_kernel turns class + rank into the tile's place in the
+        // launch order)
         if (in_img) rank[L] = r;
     }
     __syncthreads();

@@ -285,7 +285,7 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
 // the pixel's blended colour -> the image, or (training) the composite + MSE partials and the two image gradients
 // (env_rgb: the env layer's colour of this pixel when the env pass is folded into this one, else nullptr: read from A.env_img)
 __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
-                                             float *__restrict__ image, const float *env_rgb = nullptr) {
+                                             float *__restrict__ image, const float *env_rgb = nullptr, bool no_fragments = false) {
     const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
     const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
     if (A.target) {
@@ -304,10 +304,12 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
             float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
             const long long cs = i4.cstride;
 #if DBW_NT_STORES
-            __builtin_nontemporal_store(gf3[0], gf); __builtin_nontemporal_store(gf3[1], gf + cs); __builtin_nontemporal_store(gf3[2], gf + 2 * cs);
-            __builtin_nontemporal_store(gmask, gf + 3 * cs);
+            if (!(A.lean_grads && no_fragments)) {
+                __builtin_nontemporal_store(gf3[0], gf); __builtin_nontemporal_store(gf3[1], gf + cs); __builtin_nontemporal_store(gf3[2], gf + 2 * cs);
+                __builtin_nontemporal_store(gmask, gf + 3 * cs);
+            }
             __builtin_nontemporal_store(ge3[0], ge); __builtin_nontemporal_store(ge3[1], ge + cs); __builtin_nontemporal_store(ge3[2], ge + 2 * cs);
-            __builtin_nontemporal_store(0.f, ge + 3 * cs);
+            if (!A.lean_grads) __builtin_nontemporal_store(0.f, ge + 3 * cs);
 #else
             gf[0] = gf3[0]; gf[cs] = gf3[1]; gf[2 * cs] = gf3[2];
             gf[3 * cs] = gmask;
@@ -338,7 +340,7 @@ __device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int x
     blend_front_init(bl);
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, true);
 }
 
 template <int KMAX>
@@ -568,6 +570,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
         E.num_faces = fold->num_faces; E.srec = (const ShadeRec *)w.shade_recs; E.maps = fold->maps;
         for (int i = 0; i < 3; ++i) E.bg[i] = fold->bg[i];
         E.p2f = fold->p2f; E.uvj = fold->uvj; E.persp = perspective_correct; E.dbg = g_render_dbg;
+        A.lean_grads = 1;          // (the training step: its two backward kernels are the only readers of the gradient images)
     }
 #define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s)
     if (K == 1) return DBW_RF(1);

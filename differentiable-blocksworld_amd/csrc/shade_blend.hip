@@ -685,7 +685,8 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
     const long long plane = (long long)A.H * A.W;
     float gr = 0.f, gg = 0.f, gbl = 0.f, gA = 0.f;
-    if (in_img) {
+    if (in_img && cnt > 0) {          // (a pixel without fragments passes nothing on: its gradient is not read -- the forward of the training
+                                      // step does not even write it for a tile without fragments, ShadeArgs::lean_grads)
         const ImgAddr ia = img_addr(A, n, yi, xi, 4);
         const float *gi = gimg + ia.base;
         const float gs = A.gscale ? *A.gscale : 1.f;
@@ -1085,6 +1086,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.bin_base = nullptr; A.bin_cursor = nullptr; A.bin_records = nullptr; A.bin_cap = 0; A.bin_layout = nullptr;
     A.gscale = nullptr; A.geom_begin = 0; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
     A.img_tiled = 0;
+    A.lean_grads = 0;
     return DBW_OK;
 }
 

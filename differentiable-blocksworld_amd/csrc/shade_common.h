@@ -45,6 +45,10 @@ struct ShadeArgs {
     // images of the loss epilogue): 0 = (N, C, H, W) planes as torch holds them; 1 = 8x8-tile planar [n][tile_y][tile_x][C][64], the
     // layout of the fragments -- a wave's access to one plane of its tile is then ONE 256 B line instead of eight 32 B row pieces
     int img_tiled;
+    // forward with the loss epilogue, training step: write only what the two backward kernels read of the gradient images -- no alpha plane of
+    // g_env (identically zero; the hard backward reads the colour planes), no g_fg for a tile without a single fragment (the soft backward
+    // only loads the gradient of pixels that hold fragments): 90 of the 376 MB the epilogue wrote per step at config 2
+    int lean_grads;
 };
 
 // The map descriptors of a pass in LDS.  A fragment's footprint starts with its map's six descriptor ints; read from memory that is
