@@ -299,8 +299,11 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
             if (env_rgb) { ec3[0] = env_rgb[0]; ec3[1] = env_rgb[1]; ec3[2] = env_rgb[2]; }
             else { const float *ev = A.env_img + i4.base; ec3[0] = ev[0]; ec3[1] = ev[i4.cstride]; ec3[2] = ev[2 * i4.cstride]; }
             const float fc3[3] = {f0, f1, f2}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
-            float rec3[3], gf3[3], ge3[3], gmask;
-            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask);      // loss_math.h
+            float rec3[3], gf3[3], ge3[3], gmask, gp3[3] = {0.f, 0.f, 0.f};
+            const long long plane = (long long)A.H * A.W, po = (long long)n * 3 * plane + (long long)yi * A.W + xi;
+            if (A.grad_rec) { gp3[0] = A.grad_rec[po]; gp3[1] = A.grad_rec[po + plane]; gp3[2] = A.grad_rec[po + 2 * plane]; }
+            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask, A.grad_rec ? gp3 : nullptr);      // loss_math.h
+            if (A.rec_out) { A.rec_out[po] = rec3[0]; A.rec_out[po + plane] = rec3[1]; A.rec_out[po + 2 * plane] = rec3[2]; }
             float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
             const long long cs = i4.cstride;
 #if DBW_NT_STORES
@@ -505,7 +508,7 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
 
 }  // namespace
 
-struct MseArgs { const float *env_img, *target; float scale; float *loss_part, *g_fg, *g_env; };
+struct MseArgs { const float *env_img, *target; float scale; float *loss_part, *g_fg, *g_env; float *rec_out = nullptr; const float *grad_rec = nullptr; };
 
 static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, const int32_t *num_faces,
                                     const int32_t *neighbor, const int32_t *c2o, const int32_t *clip_code,
@@ -536,6 +539,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
         DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
         DBW_REQUIRE(stage == 1 || ((mse->env_img || fold) && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
         A.env_img = mse->env_img; A.target = mse->target; A.mse_scale = mse->scale; A.loss_part = mse->loss_part; A.g_fg = mse->g_fg; A.g_env = mse->g_env;
+        A.rec_out = mse->rec_out; A.grad_rec = mse->grad_rec;
     }
     if (K > DBW_MAX_FACES_PER_PIXEL) {
         dbw_set_error("dbw_render_fwd_fused: faces_per_pixel=%d > %d", K, DBW_MAX_FACES_PER_PIXEL);
@@ -603,7 +607,7 @@ extern "C" int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t
                                         float *dists, void *workspace, size_t workspace_bytes, const float *env_image,
                                         const float *target, float mse_scale, float *loss_partial, float *grad_fg,
                                         float *grad_env, int stage, int image_layout, dbw_stream_t stream) {
-    const MseArgs mse{env_image, target, mse_scale, loss_partial, grad_fg, grad_env};
+    const MseArgs mse{env_image, target, mse_scale, loss_partial, grad_fg, grad_env, nullptr, nullptr};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
                            bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, stage, image_layout, stream);
@@ -617,8 +621,8 @@ int dbw::render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *fir
                                    int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                                    const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                                    const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                                   hipStream_t stream) {
-    const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env};
+                                   float *rec_out, const float *grad_rec, hipStream_t stream) {
+    const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env, rec_out, grad_rec};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
                            bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold);

@@ -1087,6 +1087,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.gscale = nullptr; A.geom_begin = 0; A.env_img = nullptr; A.target = nullptr; A.mse_scale = 0.f; A.loss_part = nullptr; A.g_fg = nullptr; A.g_env = nullptr;
     A.img_tiled = 0;
     A.lean_grads = 0;
+    A.rec_out = nullptr; A.grad_rec = nullptr;
     return DBW_OK;
 }
 

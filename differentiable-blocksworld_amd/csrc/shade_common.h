@@ -49,6 +49,11 @@ struct ShadeArgs {
     // g_env (identically zero; the hard backward reads the colour planes), no g_fg for a tile without a single fragment (the soft backward
     // only loads the gradient of pixels that hold fragments): 90 of the 376 MB the epilogue wrote per step at config 2
     int lean_grads;
+    // the perceptual term of the training step (dbw.py:369-371), which a network outside this path evaluates on the composite: a first run of
+    // the pass stores `rec` (N, 3, H, W planes, what the network takes), a second run adds d perceptual / d rec (same layout) to the MSE's
+    // gradient in front of the chain rule through the composite.  NULL: off
+    float *rec_out;
+    const float *grad_rec;
 };
 
 // The map descriptors of a pass in LDS.  A fragment's footprint starts with its map's six descriptor ints; read from memory that is

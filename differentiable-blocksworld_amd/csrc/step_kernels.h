@@ -116,6 +116,6 @@ int render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *first_id
                               int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                               const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                               const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                              hipStream_t stream);
+                              float *rec_out, const float *grad_rec, hipStream_t stream);
 
 }  // namespace dbw

@@ -240,6 +240,7 @@ struct dbw_step_plan {
     bool arena_clean;
     float *host_losses;                 // pinned
     bool losses_pending;
+    bool phase1_done;                   // a phase-1 run is waiting for its phase 2
     bool profile, profiled;             // dbw_train_step_profile: timing events around the four big kernels of a run
     hipEvent_t ev_t[8];
 };
@@ -275,6 +276,7 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
     }
     for (int i = 0; i < 8; ++i) p->host_losses[i] = 0.f;
     p->profile = p->profiled = false;
+    p->phase1_done = false;
     for (hipEvent_t &e : p->ev_t)
         if (hipEventCreate(&e) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
     p->rng_step = 0; p->bin_turn = 0; p->bin_ready = 0; p->uniform_ready = 0; p->arena_clean = false; p->losses_pending = false;
@@ -342,6 +344,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
     DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
     DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
+    const int phase = in->phase;          // 0: the whole iteration; 1: up to the fg pass, which stores rec; 2: the fg pass again with grad_rec, then the rest
+    DBW_REQUIRE(phase >= 0 && phase <= 2 && (phase != 1 || in->rec_out) && (phase != 2 || in->grad_rec), "phase 1 stores rec_out, phase 2 reads grad_rec");
+    DBW_REQUIRE(phase == 0 || ((p->d.fuse & 18) == 18), "the two-phase iteration (perceptual term) needs the env layer folded into the fg pass (fuse bits 1 and 4)");
+    DBW_REQUIRE(phase != 2 || p->phase1_done, "phase 2 without a phase 1 in front of it");
+    const bool head = phase != 2, rest = phase != 1;
     // M: the critical chain.  E: the env backward chain, Rg: the regularisers -- the caller's side stream, or (NULL) streams of the plan
     // at the lowest priority, so that whatever shares the GPU with the fg chain yields to it.  stream_side == stream_main: one stream.
     hipStream_t M = (hipStream_t)stream_main;
@@ -365,7 +372,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // the zero arena: cleared by the plan's own Adam launch at the end of a run; before the first run (and after a run whose caller ran
     // Adam itself without clearing it) by a fill
-    if (!p->arena_clean && !(in->arena_is_clean && p->rng_step > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
+    if (head && !p->arena_clean && !(in->arena_is_clean && p->rng_step > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
     p->arena_clean = false;
 
     // ---- texture sets: sky, blocks, ground (dbw.py:273-293,306,331-334) ----
@@ -394,14 +401,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         const long long total = (long long)B * L.tiles * 192;
         long long g = (total + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(tile_target_kernel, dim3((unsigned)g), dim3(256), 0, M, in->imgs, B, 3, H, W, FP(L.target));
-        RC(dbw_check_launch("tile_target_kernel"));
+        if (head) {
+            hipLaunchKernelGGL(tile_target_kernel, dim3((unsigned)g), dim3(256), 0, M, in->imgs, B, 3, H, W, FP(L.target));
+            RC(dbw_check_launch("tile_target_kernel"));
+        }
         target = FP(L.target);
     }
 
     // ---- M: prologue ----
     const float thresh = d.mask_threshold;
-    if (d.fuse & 1) {
+    if (!head) {
+    } else if (d.fuse & 1) {
         PrologueArgs P;
         memset(&P, 0, sizeof(P));
         for (int i = 0; i < 3; ++i) P.tex.s[i] = sets[i];
@@ -432,7 +442,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // (measured: a chain of dependent kernels enqueued from here on ONE stream runs without gaps; an event costs the stream that records or
     // waits for it ~7 us before its next kernel, and a kernel behind an event of ANOTHER stream starts 12-26 us after that event.  So the
     // critical chain -- set-up, passes, fg backward, its tail, Adam -- stays on M and only what is off it forks)
-    if (two) {
+    if (two && head) {
         HIP_OK(hipEventRecord(p->ev_prologue, M));
         HIP_OK(hipStreamWaitEvent(Rg, p->ev_prologue, 0));
     }
@@ -445,18 +455,19 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
         const double total_records = (double)d.n_bins * (double)L.bin_cap;
         cursor = IP(L.cursor[p->bin_turn]);
-        HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, Rg));
+        if (head) HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, Rg));
         if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
-            RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), Rg));
+            if (head) RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), Rg));
             blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
         } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
-            RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
+            if (head) RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
             blayout = (const uint32_t *)(ws + L.layout_uniform);
         }
-        if (two) HIP_OK(hipEventRecord(p->ev_layout, Rg));
+        if (two && head) HIP_OK(hipEventRecord(p->ev_layout, Rg));
     }
     float *vals = FP(L.vals);
-    if (d.fuse & 4) {
+    if (!head) {
+    } else if (d.fuse & 4) {
         RegulariserArgs A;
         memset(&A, 0, sizeof(A));
         A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
@@ -481,7 +492,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             sets[i].grad_sig_out = FP(L.g_sig[i]);
             sets[i].grad_sig = FP(L.g_sig[i]);
         }
-        RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
+        if (head) RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
     }
 
     // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
@@ -494,7 +505,9 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     const float margin_f = (float)sqrt((double)d.blur_radius);
     // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
     const bool setup_aside = two && fused_setup && !fold && B > d.serial_setup_max_views;
-    if (fused_setup) {
+    DBW_REQUIRE(phase == 0 || fold, "the two-phase iteration needs per-tile lists for both scenes (a binned workspace)");
+    if (!head) {
+    } else if (fused_setup) {
         SceneSetupArgs A;
         memset(&A, 0, sizeof(A));
         A.R = in->R; A.T = in->T; A.Kmat = d.Kmat; A.B = B;
@@ -576,7 +589,9 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(render_fwd_fused_mse_fold(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                      d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                      d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, target, mse_scale,
-                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, M));
+                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, phase == 1 ? in->rec_out : nullptr, phase == 2 ? in->grad_rec : nullptr, M));
+        if (phase == 1) { p->phase1_done = true; return DBW_OK; }      // the caller's term on rec_out, then phase 2
+        p->phase1_done = false;
     } else
     RC(dbw_render_fwd_fused_mse(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                 d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,

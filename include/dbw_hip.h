@@ -437,6 +437,14 @@ typedef struct dbw_step_inputs {
     int with_adam;                              /* 0: stop in front of Adam (data parallel: the caller all-reduces flat_grad first) */
     int adam_step; float lr[2], beta1, beta2, adam_eps;
     int read_losses;                            /* != 0: copy the loss values to host memory (dbw_train_step_losses) */
+    /* The perceptual term (src/model/dbw.py:369-371, loss.py:32-40: LPIPS on the composite, weight 0.1 in every shipped config) is a
+     * third-party network outside this library; the step makes room for it: phase 1 runs everything up to and including the fg pass and
+     * stores the composite `rec_out` (B,3,H,W); the caller evaluates its term on it and differentiates it; phase 2 runs the fg pass again
+     * with `grad_rec` = d term / d rec (B,3,H,W) added to the MSE's gradient in front of the chain rule through the composite, then the
+     * rest of the iteration.  phase 0 (default): the whole iteration in one call, no perceptual term.  Needs fuse bit 4. */
+    int phase;
+    float *rec_out;
+    const float *grad_rec;
     int arena_is_clean;                         /* != 0: the caller cleared the zero arena (dbw_train_step_offset 4 / 5) since the last run --
                                                  * it does when it runs Adam itself through dbw_adam_step_groups(zero_buf = the arena);
                                                  * otherwise a run that does not follow a run with_adam clears the arena with a fill of its own */
