@@ -35,22 +35,29 @@ def side_stream(dev, priority=True):
 class StepLosses(dict):
     """Loss values of a C step: five floats the step left on the device (and, with read_losses, copied to host memory by the step itself:
     ONE device -> host copy and one wait instead of six `.item()`, src/trainer.py:143).  Reads like the dict of 0-dim tensors the model
-    returns; `host()` gives plain floats."""
+    returns; `host()` gives plain floats.  perceptual: the value of the caller's network term (a device scalar), added to the total."""
     NAMES = ('rgb', 'parsimony', 'tv', 'overlap', 'total')
 
-    def __init__(self, step, dev_vals, names, pending_host):
+    def __init__(self, step, dev_vals, names, pending_host, perceptual=None):
         super().__init__()
-        self._step, self._pending = step, pending_host
-        for i, k in enumerate(self.NAMES):
-            if k in names or k == 'total':
-                dict.__setitem__(self, k, dev_vals[i])
+        self._step, self._pending, self._perceptual = step, pending_host, perceptual
+        for k in names:                     # (the model's order: rgb, perceptual, parsimony, tv, overlap, total)
+            if k == 'perceptual':
+                dict.__setitem__(self, k, perceptual)
+            elif k in self.NAMES:
+                dict.__setitem__(self, k, dev_vals[self.NAMES.index(k)])
+        dict.__setitem__(self, 'total', dev_vals[4] if perceptual is None else dev_vals[4] + perceptual)
 
     def host(self):
         """-> {name: float}; waits for the step's own copy when it made one, else reads the device values."""
         if self._pending:
             out = (ctypes.c_float * 5)()
             _lib.call('dbw_train_step_losses', self._step._plan_handle(), ctypes.cast(out, ctypes.c_void_p))
-            return {k: float(out[i]) for i, k in enumerate(self.NAMES) if k in self}
+            res = {k: float(out[self.NAMES.index(k)]) for k in self if k in self.NAMES}
+            if self._perceptual is not None:
+                res['perceptual'] = float(self._perceptual)
+                res['total'] += res['perceptual']
+            return {k: res[k] for k in self}
         v = torch.stack([dict.__getitem__(self, k) for k in self]).tolist()
         return dict(zip(self.keys(), v))
 
@@ -79,7 +86,9 @@ class CStep:
     def supported(self):
         m, w = self.m, self.m.loss_weights
         r = m.renderer
-        ok = (m.decouple_rendering and m.sync_free and 'rgb' in w and 'perceptual' not in w and r.detach_bary and r.faces_per_pixel > 1
+        # (the perceptual term: a network of the caller's evaluated between two phases of the step -- needs the env layer inside the fg pass)
+        perceptual_ok = 'perceptual' not in w or (m.perceptual_fn is not None and (self.fuse & 18) == 18)
+        ok = (m.decouple_rendering and m.sync_free and 'rgb' in w and perceptual_ok and r.detach_bary and r.faces_per_pixel > 1
               and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11) and m.n_blocks <= 64
               and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS and ops.HARD_UV_FRAGMENTS
               and ops.COARSE_BINS and ops.TEXTURE_BINS)
@@ -266,11 +275,26 @@ class CStep:
         cur = torch.cuda.current_stream(dev)
         # the env chain and the regularisers: streams of the plan (NULL), a torch stream of this process, or the caller's own stream
         side = cur.cuda_stream if not self.use_side_stream else (side_stream(dev, self.side_priority).cuda_stream if self.own_side_stream else 0)
+        w = m.loss_weights
+        perceptual = None
+        a.phase, a.rec_out, a.grad_rec = 0, 0, 0
         with torch.cuda.device(dev):
+            if 'perceptual' in w:
+                # dbw.py:369-371: weight * (1 | 0.1 after the coarse phase) * LPIPS(imgs, rec); under view-sharded data parallelism times this
+                # rank's share of the global batch (the gradients of the ranks are summed).  Phase 1 leaves the composite, the caller's
+                # network runs on it (torch autograd, MIOpen convolutions), phase 2 takes d term / d rec
+                rec = torch.empty(B, 3, m.img_size[0], m.img_size[1], device=dev)
+                a.phase, a.rec_out = 1, rec.data_ptr()
+                _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
+                with torch.enable_grad():
+                    leaf = rec.requires_grad_(True)
+                    perceptual = m._perceptual_term(inp['imgs'], leaf, m.is_live('coarse_learning'))
+                    g_rec, = torch.autograd.grad(perceptual, leaf)
+                perceptual, g_rec = perceptual.detach(), g_rec.contiguous()
+                a.phase, a.rec_out, a.grad_rec = 2, 0, g_rec.data_ptr()
+                self._keep_rec = (rec, g_rec)
             _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
         self._keep = (imgs, R, T, nz, u)            # inputs stay referenced until the next call has been enqueued behind this one
-        w = m.loss_weights
-        names = [k for k in w if k in StepLosses.NAMES]
         nb = m.n_blocks
         m._alpha, m._alpha_full = self.view('alpha', numel=nb), self.view('alpha_full', numel=nb)
-        return StepLosses(self, self.view('losses', numel=5), names, bool(self.read_losses))
+        return StepLosses(self, self.view('losses', numel=5), list(w), bool(self.read_losses), perceptual)

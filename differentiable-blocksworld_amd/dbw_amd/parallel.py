@@ -122,8 +122,7 @@ class ShardedTrainStep:
         view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
         self.model._global_count = self._global_count(inp['imgs'], global_count)
         dirty = None
-        if (self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported()
-                and self.native.supported()):
+        if self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported():
             return self._c_iteration(inp)
         if self.use_graph and self.n_steps >= self.graph_warmup and self._native_graph_ok(inp):
             losses = self._native_graph_iteration(inp)

@@ -235,3 +235,44 @@ def test_env_layer_folded_into_the_fg_pass_leaves_the_fragments_of_the_env_pass(
     for k in la:
         assert abs(la[k] - lb[k]) <= 2e-6 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
     assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
+
+
+@pytest.mark.parametrize('epoch', [0, 1600])
+def test_c_step_with_the_perceptual_term_equals_the_autograd_iteration(epoch):
+    """configs/dtu/default.yml:23 trains with perceptual_weight 0.1 (src/model/dbw.py:369-371, loss.py:32-40): LPIPS on the composite.  The
+    network stays outside the library; the step runs in two phases around it -- composite out, d term / d rec in -- and must give the
+    losses, the flat gradient and the parameters of the autograd iteration `model(inp); total.backward(); Adam` with the same network
+    (seeded LPIPS-VGG16 weights: none exist offline; the architecture is what tests/test_lpips.py pins)."""
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    H, W = 48, 64
+    inp = _inputs(3, H, W)
+    noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    torch.manual_seed(5)
+    net = LPIPSVGG(allow_random_init=True).to(DEV)
+    res = []
+    for c in (True, False):
+        torch.manual_seed(227391)
+        cfg = _cfg(4, 32, 6)
+        cfg['model']['loss']['perceptual_weight'] = 0.1
+        model = dbw_amd.create_model(cfg, (H, W)).to(DEV).train()
+        with torch.no_grad():
+            model.T.mul_(0.5)
+            model.alpha_logit.add_(torch.tensor([1.0, -6.0, 0.3, 2.0], device=DEV))
+        model.set_cur_epoch(epoch)
+        model.sync_free = True
+        model.set_perceptual(net)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, use_c_step=c, use_native=c)
+        assert (step.cstep is not None and step.cstep.supported()) == c
+        out = step(inp)
+        torch.cuda.synchronize()
+        vals = {k: float(v) for k, v in out.items()}
+        assert set(vals) == {'rgb', 'perceptual', 'parsimony', 'tv', 'overlap', 'total'} and vals['perceptual'] > 0
+        if c:
+            assert step.cstep._cur is not None and out.host() == pytest.approx(vals, rel=1e-6)
+        grad1 = step.params.grad.clone()
+        step(inp)
+        torch.cuda.synchronize()
+        res.append((step, vals, grad1, step.params.flat.clone()))
+    _compare(res[0], res[1], res[0][0].params.names)
