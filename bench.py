@@ -136,6 +136,53 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
     return res
 
 
+def measure_perceptual(dev, views=4, steps=30, warmup=5):
+    """The iteration with the loss every shipped config uses (configs/dtu/default.yml:23: perceptual_weight 0.1; src/model/dbw.py:369-371):
+    LPIPS-VGG16 on the composite, here with seeded weights (none exist offline: the architecture and its cost are real, the values are
+    not), at the reference's batch size.  The network is torch / MIOpen outside the library; the step runs in two phases around it
+    (c_step.py).  -> ms per step, and the network's forward + backward alone on the same images."""
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    from dbw_amd.parallel import ShardedTrainStep
+
+    class A:
+        pass
+    a = A()
+    a.views, a.H, a.W, a.blocks, a.fpp, a.txt = views, 300, 400, 10, 10, 256
+    model, inp = build_workload(a, dev)
+    model.loss_weights = dict(model.loss_weights)
+    model.loss_weights = {k: model.loss_weights[k] for k in model.loss_weights}
+    lw = {'rgb': model.loss_weights['rgb'], 'perceptual': 0.1}
+    lw.update({k: v for k, v in model.loss_weights.items() if k != 'rgb'})
+    model.loss_weights = lw
+    torch.manual_seed(5)
+    net = LPIPSVGG(allow_random_init=True).to(dev)
+    model.set_perceptual(net)
+    model.sync_free = True
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=227391)
+    assert step.cstep is not None and step.cstep.supported()
+    step.cstep.read_losses = True
+    for _ in range(warmup):
+        step(inp).host()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vals = step(inp).host()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    rec = torch.rand_like(inp['imgs']).requires_grad_(True)
+    for _ in range(3):
+        torch.autograd.grad(net(inp['imgs'], rec), rec)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        torch.autograd.grad(net(inp['imgs'], rec), rec)
+    torch.cuda.synchronize()
+    net_ms = (time.perf_counter() - t0) / 10 * 1e3
+    return {'what': f'batch_size {views} with perceptual_weight 0.1: LPIPS-VGG16 (seeded weights, torch / MIOpen, outside the library) between the two '
+                    'phases of the C step; loss values read every step', 'ms_per_step': ms, 'lpips_fwd_bwd_alone_ms': net_ms,
+            'render_path_ms': ms - net_ms, 'losses': {k: round(v, 6) for k, v in vals.items()}}
+
+
 def kernel_breakdown(model, inp, reps=5):
     """HIP-event timing (events recorded on the stream the kernels are launched on = torch's current stream) of the four
     kernels that dominate an iteration -- the fused forward and fused backward of the fg (soft, K faces per pixel) and env
@@ -543,6 +590,7 @@ def main():
                 out['batch7']['what'] = 'the largest per-rank batch of BASELINE config 3 (49 views over 8 ranks: 7,6,...,6), loss values read every step'
                 # the round-3 form of the same step for comparison: ~33 launches issued one by one from Python, six scalar reads
                 out['batch4_launch_by_launch'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True, c_step=False)
+                out['perceptual'] = measure_perceptual(dev)
                 # >= 2 s of steps from the initial scene with frozen parameters (learning rates 0: Adam runs, the workload does not drift)
                 out['sustained'] = measure_other(49, 300, 400, 10, 10, 256, dev, steps=200, warmup=10, lr_scale=0.0, min_seconds=2.0)
                 out['sustained']['what'] = '>= 2 s of steps of the headline workload with both learning rates 0 (the scene does not drift)'
