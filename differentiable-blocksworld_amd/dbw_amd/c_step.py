@@ -119,7 +119,9 @@ class CStep:
         Kt = renderer.cameras.K
         seq = self.backward_order
         if seq is None:
-            seq = 1 if (m.world_size > 1 or decim_blocks == 1) else 0
+            # data parallel: the fg kernel first and alone (its texture gradient is then final early: the all-reduce of that slice runs next to
+            # the env chain); one GPU: both backward kernels at once.  (Texture bins: the library adds the order of its own, see binned_concurrent)
+            seq = 1 if m.world_size > 1 else 0
         both = self.binned_concurrent
         if both is None:
             both = m.world_size == 1
