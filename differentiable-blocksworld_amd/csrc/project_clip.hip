@@ -203,8 +203,13 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
 // of its three vertices alone (clip_emit_count) -- then works on its own 256 faces exactly like project_clip_fwd_kernel does on its
 // current iteration, and goes straight on to what face_setup_kernel (raster.hip) and shade_setup_kernel (render_fused.hip) compute from
 // the values it holds in registers.  Same device functions, same bits.
+// CACHED: the scene's vertices are projected ONCE per workgroup into LDS (V * 12 bytes) and the faces gather from there: a face used to
+// start with two dependent global loads per vertex (index, then vertex), and so did every face in front of the chunk for the count --
+// chains of memory round trips that were most of this kernel's time (it is launched for few, short workgroups: latency is what it costs).
+template <bool CACHED>
 __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A) {
     __shared__ int s_wcnt[NT / DBW_WAVE];
+    extern __shared__ float s_ndc[];            // CACHED: (V, 3) projected vertices of this view
     const SceneGeom &G = A.sc[A.scene0 + blockIdx.z];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int F = G.F, nchunks = (F + NT - 1) / NT;
@@ -214,11 +219,24 @@ __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A)
     Cam cam;
     load_cam(A.R, A.T, A.Kmat, b, cam);
     const long long base_out = (long long)b * 2 * F;
-    // triangles emitted by the faces in front of this chunk
+    // this chunk's face indices and those of the faces in front of it are requested before anything waits
+    const int f = chunk * NT + tid;
+    int vi[3] = {0, 0, 0};
+    if (f < F) { vi[0] = G.faces[f * 3]; vi[1] = G.faces[f * 3 + 1]; vi[2] = G.faces[f * 3 + 2]; }
+    if (CACHED) {
+        for (int v = tid; v < G.V; v += NT) {
+            const f3 q = project(G.verts + (long long)v * 3, cam, G.cam_eps).ndc;
+            s_ndc[v * 3] = q.x; s_ndc[v * 3 + 1] = q.y; s_ndc[v * 3 + 2] = q.z;
+        }
+        __syncthreads();
+    }
+    // triangles emitted by the faces in front of this chunk: a face's count follows from its vertices' view depths alone
     int before = 0;
-    for (int f = tid; f < chunk * NT; f += NT) {
-        const float z0 = view_z(G.verts + (long long)G.faces[f * 3] * 3, cam), z1 = view_z(G.verts + (long long)G.faces[f * 3 + 1] * 3, cam),
-                    z2 = view_z(G.verts + (long long)G.faces[f * 3 + 2] * 3, cam);
+    for (int g = tid; g < chunk * NT; g += NT) {
+        const int i0 = G.faces[g * 3], i1 = G.faces[g * 3 + 1], i2 = G.faces[g * 3 + 2];
+        float z0, z1, z2;
+        if (CACHED) { z0 = s_ndc[i0 * 3 + 2]; z1 = s_ndc[i1 * 3 + 2]; z2 = s_ndc[i2 * 3 + 2]; }
+        else { z0 = view_z(G.verts + (long long)i0 * 3, cam); z1 = view_z(G.verts + (long long)i1 * 3, cam); z2 = view_z(G.verts + (long long)i2 * 3, cam); }
         before += clip_emit_count(z0, z1, z2, G.zc_on, G.zc);
     }
 #pragma unroll
@@ -229,13 +247,15 @@ __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A)
 #pragma unroll
     for (int w = 0; w < NT / DBW_WAVE; ++w) running += s_wcnt[w];
     __syncthreads();
-    const int f = chunk * NT + tid;
     ClippedFace cf;
     cf.emit = 0;
     if (f < F) {
         f3 p[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) p[i] = project(G.verts + (long long)G.faces[f * 3 + i] * 3, cam, G.cam_eps).ndc;
+        for (int i = 0; i < 3; ++i) {
+            if (CACHED) p[i] = f3{s_ndc[vi[i] * 3], s_ndc[vi[i] * 3 + 1], s_ndc[vi[i] * 3 + 2]};
+            else p[i] = project(G.verts + (long long)vi[i] * 3, cam, G.cam_eps).ndc;
+        }
         clip_face(p, G.zc_on, G.zc, G.persp, cf);
     }
     const int emit = cf.emit;
@@ -304,7 +324,12 @@ int dbw::launch_scene_setup(const SceneSetupArgs &A, hipStream_t s) {
         DBW_REQUIRE(!G.srec || (G.face_uvs && G.face_map && G.map_desc), "null pointer");
         chunks = max(chunks, (G.F + NT - 1) / NT);
     }
-    hipLaunchKernelGGL(scene_setup_kernel, dim3((unsigned)chunks, (unsigned)A.B, (unsigned)A.nscenes), dim3(NT), 0, s, A);
+    int vmax = 0;
+    for (int i = A.scene0; i < A.scene0 + A.nscenes; ++i) vmax = max(vmax, A.sc[i].V);
+    if ((size_t)vmax * 12 <= 40 * 1024)
+        hipLaunchKernelGGL(scene_setup_kernel<true>, dim3((unsigned)chunks, (unsigned)A.B, (unsigned)A.nscenes), dim3(NT), (size_t)vmax * 12, s, A);
+    else
+        hipLaunchKernelGGL(scene_setup_kernel<false>, dim3((unsigned)chunks, (unsigned)A.B, (unsigned)A.nscenes), dim3(NT), 0, s, A);
     return dbw_check_launch("scene_setup_kernel");
 }
 

@@ -23,14 +23,16 @@ constexpr int CELL_ENTRY_CAP = 1024, CELL_CHUNKS = CELL_ENTRY_CAP / 64;
 constexpr int CELL_HDR_INTS = 1 + 8 * 16;      // cell-list header: pool cursor, 8 x 16 class cursors
 
 // LDS of one binning workgroup (256 threads)
+// (12.7 KB: twelve workgroups per CU -- the per-(chunk, cell) offsets of the fill used to sit here too, 4 KB more, nine per CU; they are a
+// popcount prefix over `col`, recomputed where they are used)
 struct BinShared {
-    int wcnt[4];
+    int wcnt[2][4];
     float cmin[2][8], cmax[2][8];              // NDC extents of the pixel centres of cell column / row c (empty beyond the image)
     unsigned mask[2];
     int base;
     int ent[CELL_ENTRY_CAP];                   // the first CELL_ENTRY_CAP entries of the bin's list
     unsigned long long col[CELL_CHUNKS][64];
-    int pre[CELL_CHUNKS][64];
+    int celloff[64];                           // first pool entry of every cell's list
 };
 
 // all 256 threads; followed by a barrier of the caller
@@ -62,60 +64,74 @@ __device__ __forceinline__ int coarse_bin_block(const float4 *__restrict__ bbox,
     int *out = list + (long long)f_begin * nb + (long long)bin * nf;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int cnt = 0;
-    // (the boxes of four rounds are requested together: a round used to start with a load every thread then waited for, and the rounds
-    // of a bin are a chain -- the workgroup's latency, not its work, is what the step pays for at small batches)
+    // The rounds of a bin are a chain -- the workgroup's latency, not its work, is what the step pays for at small batches --, so: the
+    // boxes of 1024 faces are requested together (a round used to start with a load every thread then waited for), and a round covers
+    // 512 faces, two per thread, behind ONE pair of barriers (face order: first half waves 0..3, then second half waves 0..3).
     for (int base0 = 0; base0 < nf; base0 += 1024) {
-    float4 bbs[4];
+        float4 bbs[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = base0 + r * 256 + threadIdx.x;
-        bbs[r] = j < nf ? bbox[f_begin + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+        for (int r = 0; r < 4; ++r) {
+            const int j = base0 + r * 256 + threadIdx.x;
+            bbs[r] = j < nf ? bbox[f_begin + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int base = base0 + r * 256;
-        if (base >= nf) break;
-        const int j = base + threadIdx.x;
-        bool hit = false;
-        int entry = 0;
-        if (j < nf) {
-            const float4 bb = bbs[r];
-            if (!(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w)) {
-                int cx0 = 8, cx1 = -1, cy0 = 8, cy1 = -1;
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int base = base0 + r2 * 512;
+            if (base >= nf) break;
+            bool hit[2] = {false, false};
+            int entry[2] = {0, 0};
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (!(S.cmax[0][c] < bb.x || S.cmin[0][c] > bb.y)) { cx0 = min(cx0, c); cx1 = c; }
-                    if (!(S.cmax[1][c] < bb.z || S.cmin[1][c] > bb.w)) { cy0 = min(cy0, c); cy1 = c; }
-                }
-                hit = cx1 >= 0 && cy1 >= 0;        // a box that slips between the pixel centres of two cells touches no pixel at all
-                if (hit) {
-                    entry = j | (cx0 << 20) | (cx1 << 23) | (cy0 << 26) | (cy1 << 29);
-                    const unsigned row = ((1u << (cx1 - cx0 + 1)) - 1u) << cx0;
-                    unsigned lo = 0u, hi = 0u;
+            for (int h = 0; h < 2; ++h) {
+                const int j = base + h * 256 + threadIdx.x;
+                if (j < nf) {
+                    const float4 bb = bbs[r2 * 2 + h];
+                    if (!(bxmax < bb.x || bxmin > bb.y || bymax < bb.z || bymin > bb.w)) {
+                        int cx0 = 8, cx1 = -1, cy0 = 8, cy1 = -1;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (q >= cy0 && q <= cy1) lo |= row << (8 * q);
-                        if (q + 4 >= cy0 && q + 4 <= cy1) hi |= row << (8 * q);
+                        for (int c = 0; c < 8; ++c) {
+                            if (!(S.cmax[0][c] < bb.x || S.cmin[0][c] > bb.y)) { cx0 = min(cx0, c); cx1 = c; }
+                            if (!(S.cmax[1][c] < bb.z || S.cmin[1][c] > bb.w)) { cy0 = min(cy0, c); cy1 = c; }
+                        }
+                        hit[h] = cx1 >= 0 && cy1 >= 0;        // a box that slips between the pixel centres of two cells touches no pixel at all
+                        if (hit[h]) {
+                            entry[h] = j | (cx0 << 20) | (cx1 << 23) | (cy0 << 26) | (cy1 << 29);
+                            const unsigned row = ((1u << (cx1 - cx0 + 1)) - 1u) << cx0;
+                            unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (q >= cy0 && q <= cy1) lo |= row << (8 * q);
+                                if (q + 4 >= cy0 && q + 4 <= cy1) hi |= row << (8 * q);
+                            }
+                            if (lo) atomicOr(&S.mask[0], lo);
+                            if (hi) atomicOr(&S.mask[1], hi);
+                        }
                     }
-                    if (lo) atomicOr(&S.mask[0], lo);
-                    if (hi) atomicOr(&S.mask[1], hi);
                 }
             }
-        }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) S.wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
+            const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]);
+            if (lane == 0) { S.wcnt[0][wv] = __popcll(m0); S.wcnt[1][wv] = __popcll(m1); }
+            __syncthreads();
+            int off0 = 0, tot0 = 0, off1 = 0, tot1 = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = S.wcnt[w]; if (w < wv) woff += c; tot += c; }
-        if (hit) {
-            const int pos = cnt + woff + __popcll(m & ((1ull << lane) - 1ull));
-            out[pos] = entry;
-            if (pos < CELL_ENTRY_CAP) S.ent[pos] = entry;
+            for (int w = 0; w < 4; ++w) {
+                const int c0 = S.wcnt[0][w], c1 = S.wcnt[1][w];
+                if (w < wv) { off0 += c0; off1 += c1; }
+                tot0 += c0; tot1 += c1;
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (hit[0]) {
+                const int pos = cnt + off0 + __popcll(m0 & below);
+                out[pos] = entry[0];
+                if (pos < CELL_ENTRY_CAP) S.ent[pos] = entry[0];
+            }
+            if (hit[1]) {
+                const int pos = cnt + tot0 + off1 + __popcll(m1 & below);
+                out[pos] = entry[1];
+                if (pos < CELL_ENTRY_CAP) S.ent[pos] = entry[1];
+            }
+            cnt += tot0 + tot1;
+            __syncthreads();
         }
-        cnt += tot;
-        __syncthreads();
-    }
     }
     if (threadIdx.x == 0) count[n * nb + bin] = cnt;
     if (threadIdx.x < 2) mask[(n * nb + bin) * 2 + threadIdx.x] = S.mask[threadIdx.x];
@@ -183,7 +199,7 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
     const int tile = (py >> 3) * tiles_x + (px >> 3);
     if (wv == 0) {
         int all = 0;
-        for (int ch = 0; ch < chunks; ++ch) { S.pre[ch][lane] = all; all += __popcll(S.col[ch][lane]); }
+        for (int ch = 0; ch < chunks; ++ch) all += __popcll(S.col[ch][lane]);
         int incl = all;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -224,7 +240,7 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
             ranks(key, r, leader, gcount);
         }
         const int off = base_off + (incl - all);
-        for (int ch = 0; ch < chunks; ++ch) S.pre[ch][lane] += off;
+        S.celloff[lane] = off;
         if (lane == 0) S.base = (overflow || total == 0) ? -1 : 0;
         const int count = overflow ? -1 : all;
         if (in_img) cell[L] = make_int2(overflow ? 0 : off, count);
@@ -236,7 +252,8 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
     if (S.base < 0) return;
     for (int ch = wv; ch < chunks; ch += 4) {
         unsigned long long bits = S.col[ch][lane];
-        int o = S.pre[ch][lane];
+        int o = S.celloff[lane];
+        for (int c = 0; c < ch; ++c) o += __popcll(S.col[c][lane]);
         while (bits) {
             const int i = __ffsll((long long)bits) - 1;
             pool[o++] = S.ent[ch * 64 + i] & 0xfffff;
