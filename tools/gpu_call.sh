@@ -14,6 +14,7 @@ while [ $# -gt 0 ]; do
       python tools/step_sequence.py $csv > $O/step_sequence_B${v}_epoch$e.txt 2>&1
       python tools/rocprof_csv_summary.py $csv $O/kernel_stats_B${v}_epoch$e.txt "14 training steps, $v views of 400x300, 10 blocks, faces_per_pixel 10, 256^2 textures, epoch $e (tools/diag/trace_cfg.py; rocprofv3 --kernel-trace)" > /dev/null
       rm -rf $O/t; cat $O/step_sequence_B${v}_epoch$e.txt;;
+    ablate) timeout 900 python tools/ablate.py $2 > $O/ablate.log 2>&1; cat $O/ablate.log; shift;;
     bench) timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; cut -c1-1500 $O/bench.json;;
   esac
   shift
