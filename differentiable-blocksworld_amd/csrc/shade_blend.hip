@@ -900,11 +900,11 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
         if (__ballot(gd != 0.f) != 0ull && !(A.dbg & 16)) {
             f2 v0, v1, v2;
             if (PIPE) { v0 = f2{curq.v0.x, curq.v0.y}; v1 = f2{curq.v1.x, curq.v1.y}; v2 = f2{curq.v2.x, curq.v2.y}; }
-            else if (A.dbg & (1 << 20)) {       // (ablation, tools/ablate.py: no vertex load -- what that round trip per layer costs; results are wrong)
-                v0 = f2{pndc.x - 0.01f, pndc.y}; v1 = f2{pndc.x + 0.02f, pndc.y - 0.01f}; v2 = f2{pndc.x, pndc.y + 0.03f};
-            } else {
-                // (requesting these in front of the texel path -- so that its table updates run while they travel -- was measured, round 4:
-                // 13 more registers, 8 -> 6 waves per SIMD, 0.361 -> 0.361 ms; capped at 64 registers it spills: 0.40 ms)
+            else {
+                // (round 4, by ablation: this round trip per layer is 44 of the kernel's 361 us, the texel table 124, the face table 85.
+                // Requesting the vertices in front of the texel path -- so that its table updates run while they travel -- takes 13 more
+                // registers, 8 -> 6 waves per SIMD: 0.361 -> 0.361 ms; capped at 64 registers it spills: 0.40 ms.  Even the ablation switch
+                // that measured it cost 5 registers and a wave per SIMD, and is gone again)
                 const float *q = fv + (long long)(valid ? cur.fc : 0) * 9;
                 v0 = f2{q[0], q[1]}; v1 = f2{q[3], q[4]}; v2 = f2{q[6], q[7]};
             }
