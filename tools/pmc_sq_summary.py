@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(out, 'g*', '**', '*counter_collection.csv'), rec
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
         n = n.split('(')[0].strip()
-        if not any(k in n for k in ('render_fwd', 'render_bwd', 'shade_blend_bwd', 'composite', 'texbin', 'coarse_bin', 'cell_bin', 'work_scatter', 'face_setup', 'shade_setup', 'project_clip', 'env')):
+        if not any(k in n for k in ('render_fwd', 'render_bwd', 'shade_blend_bwd', 'composite', 'texbin', 'coarse_bin', 'cell_bin', 'work_scatter', 'face_setup', 'shade_setup', 'project_clip', 'env', 'scene_', 'step_', 'blocks_tail', 'regularisers')):
             continue
         vals.setdefault(n, {}).setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
         vals[n][r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
