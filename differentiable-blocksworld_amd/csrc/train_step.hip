@@ -352,7 +352,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // M: the critical chain.  E: the env backward chain, Rg: the regularisers -- the caller's side stream, or (NULL) streams of the plan
     // at the lowest priority, so that whatever shares the GPU with the fg chain yields to it.  stream_side == stream_main: one stream.
     hipStream_t M = (hipStream_t)stream_main;
-    const bool two = !(stream_side && stream_side == stream_main);
+    const bool two = !in->single_stream;
     hipStream_t E = !two ? M : (stream_side ? (hipStream_t)stream_side : p->stream_env), Rg = two ? p->stream_r : M;
     char *ws = p->ws;
 #define FP(off) ((float *)(ws + (off)))

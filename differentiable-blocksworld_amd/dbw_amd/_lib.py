@@ -58,7 +58,7 @@ class StepInputs(ctypes.Structure):
     """dbw_step_inputs of include/dbw_hip.h."""
     _fields_ = [('imgs', c_p), ('imgs_tiled', c_i), ('R', c_p), ('T', c_p), ('B', c_i), ('global_count', c_d), ('noise_override', c_p),
                 ('overlap_u_override', c_p), ('with_adam', c_i), ('adam_step', c_i), ('lr', c_f * 2), ('beta1', c_f), ('beta2', c_f), ('adam_eps', c_f),
-                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('arena_is_clean', c_i)]
+                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('single_stream', c_i), ('arena_is_clean', c_i)]
 
 
 def texture_sets(sets):

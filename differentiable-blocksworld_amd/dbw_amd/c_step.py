@@ -276,7 +276,8 @@ class CStep:
         self._arena_cleaned_by_caller = False
         cur = torch.cuda.current_stream(dev)
         # the env chain and the regularisers: streams of the plan (NULL), a torch stream of this process, or the caller's own stream
-        side = cur.cuda_stream if not self.use_side_stream else (side_stream(dev, self.side_priority).cuda_stream if self.own_side_stream else 0)
+        side = side_stream(dev, self.side_priority).cuda_stream if (self.use_side_stream and self.own_side_stream) else 0
+        a.single_stream = int(not self.use_side_stream)
         w = m.loss_weights
         perceptual = None
         a.phase, a.rec_out, a.grad_rec = 0, 0, 0

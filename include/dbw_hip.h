@@ -445,6 +445,8 @@ typedef struct dbw_step_inputs {
     int phase;
     float *rec_out;
     const float *grad_rec;
+    int single_stream;                          /* != 0: everything in order on stream_main, no side streams (every kernel then runs alone on the GPU:
+                                                 * what a per-kernel profile wants) */
     int arena_is_clean;                         /* != 0: the caller cleared the zero arena (dbw_train_step_offset 4 / 5) since the last run --
                                                  * it does when it runs Adam itself through dbw_adam_step_groups(zero_buf = the arena);
                                                  * otherwise a run that does not follow a run with_adam clears the arena with a fill of its own */
@@ -458,7 +460,7 @@ void dbw_train_step_destroy(dbw_step_plan *plan);
 /* Enqueues one iteration.  stream_main carries the critical chain -- set-up, the two passes, the fg backward and its tail, Adam (or,
  * with_adam == 0, everything the caller's all-reduce has to wait for) -- and is the only stream the caller has to order against.  The env
  * backward chain and the regularisers run next to it: on stream_side if the caller brings one, else (NULL) on the library's own
- * lowest-priority streams; stream_side == stream_main: everything in order on one stream.  On return nothing has been waited for. */
+ * lowest-priority streams; dbw_step_inputs.single_stream: everything in order on stream_main.  On return nothing has been waited for. */
 int dbw_train_step_run(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side);
 /* Blocks until the loss values of the last run with read_losses != 0 are in host memory: out5 = rgb, parsimony, tv, overlap, total */
 int dbw_train_step_losses(dbw_step_plan *plan, float *out5);

@@ -276,3 +276,42 @@ def test_c_step_with_the_perceptual_term_equals_the_autograd_iteration(epoch):
         torch.cuda.synchronize()
         res.append((step, vals, grad1, step.params.flat.clone()))
     _compare(res[0], res[1], res[0][0].params.names)
+
+
+def test_c_step_at_a_config_4_like_geometry_equals_the_native_step():
+    """BASELINE config 4's shape at a small size: 20 blocks, faces_per_pixel 16 (the K = 16 instantiation of the fused forward with the env
+    layer inside it, 1600 block faces: seven chunks of faces per view in the set-up kernel), non-square image whose sides are not
+    multiples of 16, full-resolution textures (texture bins, two consecutive steps: the second one's record sub-ranges follow the
+    first one's demand)."""
+    H, W, nb = 72, 100, 20
+    inp = _inputs(3, H, W)
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for epoch in (0, 800):
+        mk = lambda: _model(epoch, nb=nb, ts=64, fpp=16, H=H, W=W, kill=False)
+        ref = _run(mk(), inp, 3, noise, u, use_c_step=False)
+        got = _run(mk(), inp, 3, noise, u, use_c_step=True)
+        assert got[0].cstep is not None and got[0].cstep.fuse == 31
+        _compare(got, ref, ref[0].params.names)
+
+
+def test_c_step_one_stream_equals_side_streams_and_every_launch_is_there():
+    """dbw_step_inputs.single_stream: everything in order on the caller's stream (what a per-kernel profile wants) gives the same step as
+    the three-stream schedule."""
+    inp = _inputs(3, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for side in (True, False):
+        model = _model(0)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        step.cstep.use_side_stream = side
+        out = step(inp)
+        torch.cuda.synchronize()
+        vals = {k: float(v) for k, v in out.items()}
+        grad1 = step.params.grad.clone()
+        step(inp)
+        torch.cuda.synchronize()
+        res.append((step, vals, grad1, step.params.flat.clone()))
+    _compare(res[0], res[1], res[0][0].params.names)
