@@ -181,27 +181,6 @@ def test_c_step_on_fresh_minibatches_of_the_reference_batch_size():
         assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
 
 
-def test_c_step_single_stream_equals_two_streams():
-    """stream_side == stream_main: everything in order on one stream (no events) gives the same step."""
-    inp = _inputs(3, 48, 64)
-    noise = torch.zeros(4, device=DEV)
-    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
-    res = []
-    for side in (True, False):
-        model = _model(800)
-        model._noise_override, model._overlap_u_override = noise, u
-        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
-        step.cstep.use_side_stream = side
-        out = step(inp)
-        torch.cuda.synchronize()
-        vals = {k: float(v) for k, v in out.items()}
-        grad1 = step.params.grad.clone()
-        step(inp)
-        torch.cuda.synchronize()
-        res.append((step, vals, grad1, step.params.flat.clone()))
-    _compare(res[0], res[1], res[0][0].params.names)
-
-
 @pytest.mark.parametrize('epoch', [0, 800])
 def test_env_layer_folded_into_the_fg_pass_leaves_the_fragments_of_the_env_pass(epoch):
     """fuse bit 4: every 8x8 tile of the fg pass rasterises and shades its pixel of the env scene itself (per-tile lists of the env faces,
