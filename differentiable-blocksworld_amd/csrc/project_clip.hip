@@ -210,6 +210,8 @@ template <bool CACHED>
 __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A) {
     __shared__ int s_wcnt[NT / DBW_WAVE];
     extern __shared__ float s_ndc[];            // CACHED: (V, 3) projected vertices of this view
+    if (A.sync_flag && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(A.sync_flag, A.sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const SceneGeom &G = A.sc[A.scene0 + blockIdx.z];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int F = G.F, nchunks = (F + NT - 1) / NT;

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
     const int x = (int)(L / per);
     const long long seg0 = (long long)x * per;
     const int len = (int)min(per, total - seg0);
-    const int k = work_class(cell[L].y);
-    int r = rank[L], O = 0;
+    const int kr = rank[L], k = kr >> WORK_RANK_BITS;          // (the class the rank was taken in, cell_bin_block)
+    int r = kr & ((1 << WORK_RANK_BITS) - 1), O = 0;
 #pragma unroll
     for (int c = 0; c < WORK_CLASSES - 1; ++c) { const int h = hdr[1 + x * 16 + c]; if (c < k) r += h; O += h; }
     const int E = len - O;
@@ -270,7 +270,7 @@ int dbw_raster_workspace_layout(void *workspace, size_t workspace_bytes, long lo
     L.shade_recs = dbw_workspace_shade_recs(workspace, F_total);
     // (a coarse-bin entry packs the view-local face index into 20 bits: views of a million faces and more scan without bins)
     L.binned = workspace_bytes >= dbw_rasterize_workspace_bytes_binned(F_total, N, H, W) && !(g_raster_dbg & 128) && max_faces_per_view <= (1 << 20);
-    L.cells = L.binned && want_cells && !(g_raster_dbg & 4096) && DBW_CELL_LISTS;
+    L.cells = L.binned && want_cells && !(g_raster_dbg & 4096) && DBW_CELL_LISTS && (long long)N * (long long)cell_tiles(H, W) < (1LL << WORK_RANK_BITS);
     char *p = (char *)workspace + dbw_rasterize_workspace_bytes(F_total);
     L.hdr = (int *)(p + coarse_bytes(F_total, N, H, W));
     if (L.binned) {

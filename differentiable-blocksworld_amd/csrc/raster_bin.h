@@ -14,7 +14,7 @@ namespace dbw {
 // occupied ones, so that the streaming work hides behind the arithmetic instead of piling up at the end.
 //   cell_bin_block: class + rank inside (segment, class) of every tile (returning atomics on hdr[1 + segment * 16 + class])
 //   work_scatter_kernel (raster.hip): thread = tile: work[position] = view * tiles + tile
-constexpr int WORK_CLASSES = 10;
+constexpr int WORK_CLASSES = 10, WORK_RANK_BITS = 27;      // (rank < tiles of the pass < 2^27: checked where the workspace is laid out)
 __device__ __forceinline__ int work_class(int c) {
     return c < 0 ? 0 : c == 0 ? 9 : c >= 64 ? 0 : c >= 48 ? 1 : c >= 32 ? 2 : c >= 24 ? 3 : c >= 16 ? 4 : c >= 12 ? 5 : c >= 8 ? 6 : c >= 4 ? 7 : 8;
 }
@@ -206,9 +206,10 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
         const int total = __shfl(incl, 63, 64);
         // The bin's returning atomics -- its share of the pool, and one per distinct (XCD segment, face-count class) of its tiles for their
         // ranks -- are ISSUED TOGETHER and read afterwards: one round trip instead of up to eleven in a row (they were a third of the
-        // workgroup's latency).  The class of a tile needs its count, which needs to know whether the pool overflowed, which needs the pool
-        // atomic's answer: so the rank atomics are issued for the no-overflow classes, and a bin that does overflow (never, at the pool
-        // sizes in use) hands its ranks back and takes new ones for class 0.
+        // workgroup's latency).  Whether the pool overflowed is only known with the pool atomic's answer, so the tiles of a bin that does
+        // overflow (and then walk the coarse list) keep the class of their face count: the class only decides WHERE in the launch order a
+        // tile goes, any assignment of ranks that is a permutation is a correct one.  (Handing the ranks back to take new ones for class 0
+        // is not: another bin may have taken ranks above them in between -- two tiles on one position, a position without a tile.)
         int base_off = 0;
         if (lane == 0 && total > 0) base_off = atomicAdd(&hdr[0], total);
         const long long per = ((long long)N * tiles + 7) / 8;
@@ -229,24 +230,19 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
             r_out = __shfl(b0, leader, 64) + grank;
             leader_out = leader; gcount_out = gcount;
         };
-        int key = in_img ? seg16 + work_class(too_long ? -1 : all) : -1;
+        const int key = in_img ? seg16 + work_class(too_long ? -1 : all) : -1;
         int r = 0, leader = lane, gcount = 0;
         ranks(key, r, leader, gcount);
         base_off = __shfl(base_off, 0, 64);
         const bool overflow = too_long || (total > 0 && (long long)base_off + total > (long long)pool_cap);
-        if (overflow && !too_long) {          // (wave-uniform) the pool was full: the tiles walk the coarse list -> class 0
-            if (key >= 0 && lane == leader) atomicAdd(&hdr[1 + key], -gcount);
-            key = in_img ? seg16 + work_class(-1) : -1;
-            ranks(key, r, leader, gcount);
-        }
         const int off = base_off + (incl - all);
         S.celloff[lane] = off;
         if (lane == 0) S.base = (overflow || total == 0) ? -1 : 0;
         const int count = overflow ? -1 : all;
         if (in_img) cell[L] = make_int2(overflow ? 0 : off, count);
-        // (rank of the tile inside its (XCD segment, face-count class): work_scatter_kernel turns class + rank into the tile's place in the
-        // launch order)
-        if (in_img) rank[L] = r;
+        // (class, and rank of the tile inside its (XCD segment, class): work_scatter_kernel turns them into the tile's place in the launch
+        // order.  The class travels with the rank -- for a bin that overflowed the pool it is not the class of the stored count, -1)
+        if (in_img) rank[L] = r | ((key - seg16) << WORK_RANK_BITS);
     }
     __syncthreads();
     if (S.base < 0) return;

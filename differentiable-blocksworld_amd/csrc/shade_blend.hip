@@ -15,6 +15,7 @@
 // wave share one bilinear footprint), per-face opacity gradients, d/d dists, and optionally d/d barycentrics.
 #include "shade_common.h"
 #include "../../include/dbw_hip.h"
+#include "step_kernels.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     (void)SINGLE;
     TexAgg tex_agg;
     FaceAlphaAgg fa_agg;
+    if (A.sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.sync_flag, A.sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
     const bool in_img = xi < A.W && yi < A.H;
@@ -1092,6 +1094,7 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.img_tiled = 0;
     A.lean_grads = 0;
     A.rec_out = nullptr; A.grad_rec = nullptr;
+    A.sync_flag = nullptr; A.sync_val = 0;
     return DBW_OK;
 }
 
@@ -1258,6 +1261,8 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     PROF_ADD(7, t_begin, t_end);
 }
 
+__global__ void flag_store_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *grad_image, float *grad_maps,
                       float *grad_faces_alpha, float *grad_dists, float *grad_bary, int lds_aggregate, const float *fv,
                       float *gfv, int want_bary, int persp, hipStream_t s) {
@@ -1287,7 +1292,12 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     }
     // the training path's soft pass: uv-fragments, detached barycentrics; texel gradients through the LDS table (decimated maps) or
     // through texture-space bins (full-resolution maps) -> the specialised kernel
-    if (fused && K > 1 && A.tiled == 2 && !want_bary && ((A.agg & 1) || A.bin_records) && !(g_dbg_flags & (1 << 16))) {
+    const bool uv_kernel = fused && K > 1 && A.tiled == 2 && !want_bary && ((A.agg & 1) || A.bin_records) && !(g_dbg_flags & (1 << 16));
+    if (A.sync_flag && !uv_kernel) {       // (only the specialised kernel carries the step's signal: a launch of its own in front of any other)
+        hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(1), 0, s, A.sync_flag, A.sync_val);
+        A.sync_flag = nullptr;
+    }
+    if (uv_kernel) {
         static bool raised_uv = false;
         if (!raised_uv) {
             if (hipFuncSetAttribute((const void *)render_bwd_uv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
@@ -1342,7 +1352,8 @@ extern "C" int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary
                       nullptr, 0, 1, (hipStream_t)stream);
 }
 
-extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists,
+// (dbw_render_bwd_fused + the training step's cross-stream signal, see ShadeArgs::sync_flag)
+int dbw::render_bwd_fused_signal(const int32_t *pix_to_face, const float *bary, const float *dists,
                                     const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
                                     const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
                                     const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
@@ -1351,7 +1362,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                     float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
                                     int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
                                     void *bin_records, int bin_cap, const uint32_t *bin_layout, int const_geometry_faces,
-                                    const float *grad_scale, int image_layout, dbw_stream_t stream) {
+                                    const float *grad_scale, int image_layout, dbw_stream_t stream, unsigned *sync_flag, unsigned sync_val) {
     ShadeArgs A;
     int rc = fill_args(A, pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc,
                        maps, faces_alpha, alpha_len, N, H, W, K, F, sigma, background3);
@@ -1368,6 +1379,7 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     A.img_tiled = image_layout;
     A.gscale = grad_scale;
     A.geom_begin = const_geometry_faces;
+    A.sync_flag = sync_flag; A.sync_val = sync_val;
     DBW_REQUIRE((bin_base && bin_cursor && bin_records && bin_cap >= DBW_BIN_SUBCURSORS) || (!bin_base && !bin_cursor && !bin_records), "texture bins: all or none (bin_cap >= DBW_BIN_SUBCURSORS)");
     if (bin_records && !lds_aggregate) {
         A.bin_base = bin_base; A.bin_cursor = bin_cursor; A.bin_records = (int4 *)bin_records; A.bin_cap = bin_cap; A.bin_layout = bin_layout;
@@ -1375,6 +1387,22 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
     DBW_REQUIRE(!bin_records || bin_layout, "texture bins need their layout table (bin_layout: dbw_bin_layout; equal shares: all counts 0)");
     return launch_bwd(A, N, H, W, K, grad_image, grad_maps, grad_faces_alpha, nullptr, nullptr, lds_aggregate, face_verts_c,
                       grad_face_verts_c, detach_bary ? 0 : 1, perspective_correct, (hipStream_t)stream);
+}
+
+extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bary, const float *dists,
+                                    const int32_t *c2o, const int32_t *clip_code, const float *clip_w, int Fc_stride,
+                                    const float *face_uvs, const int32_t *face_map, const int32_t *map_desc,
+                                    const float *maps, const float *faces_alpha, int alpha_len, int N, int H, int W,
+                                    int K, int F, float sigma, const float *background3, const float *grad_image,
+                                    const float *face_verts_c, int perspective_correct, int detach_bary,
+                                    float *grad_maps, float *grad_faces_alpha, float *grad_face_verts_c,
+                                    int lds_aggregate, int frag_layout, const int32_t *bin_base, int32_t *bin_cursor,
+                                    void *bin_records, int bin_cap, const uint32_t *bin_layout, int const_geometry_faces,
+                                    const float *grad_scale, int image_layout, dbw_stream_t stream) {
+    return dbw::render_bwd_fused_signal(pix_to_face, bary, dists, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps, faces_alpha, alpha_len,
+                                        N, H, W, K, F, sigma, background3, grad_image, face_verts_c, perspective_correct, detach_bary, grad_maps, grad_faces_alpha,
+                                        grad_face_verts_c, lds_aggregate, frag_layout, bin_base, bin_cursor, bin_records, bin_cap, bin_layout, const_geometry_faces,
+                                        grad_scale, image_layout, stream, nullptr, 0);
 }
 
 extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,

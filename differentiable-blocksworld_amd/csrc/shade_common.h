@@ -54,6 +54,10 @@ struct ShadeArgs {
     // gradient in front of the chain rule through the composite.  NULL: off
     float *rec_out;
     const float *grad_rec;
+    // training step: the first workgroup of the backward stores sync_val to *sync_flag when it starts -- a kernel that has started says that
+    // everything in front of it on its stream is complete, so the step's other streams poll this word instead of waiting for an event
+    // recorded between two kernels of the critical chain (train_step.hip).  NULL: off
+    unsigned *sync_flag; unsigned sync_val;
 };
 
 // The map descriptors of a pass in LDS.  A fragment's footprint starts with its map's six descriptor ints; read from memory that is

@@ -63,7 +63,8 @@ struct SceneGeom {
     // shading records of the soft pass (NULL: none)
     void *srec; const float *face_uvs; const int *face_map, *map_desc; const float *map_alpha;    // one opacity per map, or NULL
 };
-struct SceneSetupArgs { SceneGeom sc[2]; const float *R, *T, *Kmat; int B; int scene0, nscenes; };     // scenes [scene0, scene0 + nscenes) of sc
+struct SceneSetupArgs { SceneGeom sc[2]; const float *R, *T, *Kmat; int B; int scene0, nscenes;       // scenes [scene0, scene0 + nscenes) of sc
+                        unsigned *sync_flag; unsigned sync_val; };     // (the first workgroup stores sync_val when it starts: ShadeArgs::sync_flag)
 int launch_scene_setup(const SceneSetupArgs &A, hipStream_t s);
 
 struct SceneBinsArgs {
@@ -117,5 +118,15 @@ int render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *first_id
                               const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                               const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
                               float *rec_out, const float *grad_rec, hipStream_t stream);
+
+// dbw_render_bwd_fused (shade_blend.hip) whose first workgroup also stores sync_val to *sync_flag when it starts (ShadeArgs::sync_flag; a
+// kernel other than the specialised uv backward gets a one-thread launch in front of it instead).  sync_flag == NULL: exactly dbw_render_bwd_fused
+int render_bwd_fused_signal(const int32_t *pix_to_face, const float *bary, const float *dists, const int32_t *c2o, const int32_t *clip_code,
+                            const float *clip_w, int Fc_stride, const float *face_uvs, const int32_t *face_map, const int32_t *map_desc, const float *maps,
+                            const float *faces_alpha, int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3,
+                            const float *grad_image, const float *face_verts_c, int perspective_correct, int detach_bary, float *grad_maps,
+                            float *grad_faces_alpha, float *grad_face_verts_c, int lds_aggregate, int frag_layout, const int32_t *bin_base,
+                            int32_t *bin_cursor, void *bin_records, int bin_cap, const uint32_t *bin_layout, int const_geometry_faces,
+                            const float *grad_scale, int image_layout, dbw_stream_t stream, unsigned *sync_flag, unsigned sync_val);
 
 }  // namespace dbw

@@ -226,6 +226,20 @@ int step_streams(hipStream_t &r, hipStream_t &e) {
     return DBW_OK;
 }
 
+// Cross-stream ordering through memory (dbw_step_desc.sync_events == 0): the producer's stream stores a counter behind its work, the
+// consumer's stream polls it in front of its own.  Kernel boundaries do the rest: the producer's kernels have released their writes before
+// the store kernel starts, and the kernel behind the poll acquires at its start like any kernel behind an event wait.
+constexpr int SYNC_FLAGS = 12, SYNC_TIMEOUT_SLOT = 15, SYNC_WORDS = 16;
+enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS_READY, F_ENV_DONE };
+__global__ void sync_set_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts) {
+    const unsigned long long t0 = wall_clock64();            // 100 MHz
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 20000000ull) { atomicAdd(timeouts, 1u); break; }
+    }
+}
+
 }  // namespace
 
 struct dbw_step_plan {
@@ -243,6 +257,8 @@ struct dbw_step_plan {
     bool phase1_done;                   // a phase-1 run is waiting for its phase 2
     bool profile, profiled;             // dbw_train_step_profile: timing events around the four big kernels of a run
     hipEvent_t ev_t[8];
+    unsigned *sync_words;               // device: SYNC_FLAGS counters + the number of polls that gave up
+    unsigned sync_val[SYNC_FLAGS];      // last value stored behind each counter (host side)
 };
 
 extern "C" size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc) {
@@ -275,6 +291,13 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
         return nullptr;
     }
     for (int i = 0; i < 8; ++i) p->host_losses[i] = 0.f;
+    p->sync_words = nullptr;
+    if (hipMalloc((void **)&p->sync_words, SYNC_WORDS * sizeof(unsigned)) != hipSuccess || hipMemset(p->sync_words, 0, SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
+        dbw_set_error("dbw_train_step_create: hipMalloc failed");
+        dbw_train_step_destroy(p);
+        return nullptr;
+    }
+    for (unsigned &v : p->sync_val) v = 0;
     p->profile = p->profiled = false;
     p->phase1_done = false;
     for (hipEvent_t &e : p->ev_t)
@@ -289,6 +312,7 @@ extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_t) (void)hipEventDestroy(e);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
+    if (p->sync_words) (void)hipFree(p->sync_words);
     delete p;
 }
 
@@ -354,6 +378,19 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     hipStream_t M = (hipStream_t)stream_main;
     const bool two = !in->single_stream;
     hipStream_t E = !two ? M : (stream_side ? (hipStream_t)stream_side : p->stream_env), Rg = two ? p->stream_r : M;
+    // one stream waiting for another: memory flags (default) or events, see dbw_step_desc.sync_events.  Every wait is enqueued AFTER the
+    // signal it waits for -- the order of the statements below -- which is what makes the polling form safe
+    const bool flags = d.sync_events == 0;
+    auto signal = [&](hipStream_t st, int idx, hipEvent_t ev) -> int {
+        if (!flags) { HIP_OK(hipEventRecord(ev, st)); return DBW_OK; }
+        hipLaunchKernelGGL(sync_set_kernel, dim3(1), dim3(1), 0, st, p->sync_words + idx, ++p->sync_val[idx]);
+        return dbw_check_launch("sync_set_kernel");
+    };
+    auto await = [&](hipStream_t st, int idx, hipEvent_t ev) -> int {
+        if (!flags) { HIP_OK(hipStreamWaitEvent(st, ev, 0)); return DBW_OK; }
+        hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx], p->sync_words + SYNC_TIMEOUT_SLOT);
+        return dbw_check_launch("sync_wait_kernel");
+    };
     char *ws = p->ws;
 #define FP(off) ((float *)(ws + (off)))
 #define IP(off) ((int *)(ws + (off)))
@@ -442,59 +479,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // (measured: a chain of dependent kernels enqueued from here on ONE stream runs without gaps; an event costs the stream that records or
     // waits for it ~7 us before its next kernel, and a kernel behind an event of ANOTHER stream starts 12-26 us after that event.  So the
     // critical chain -- set-up, passes, fg backward, its tail, Adam -- stays on M and only what is off it forks)
-    if (two && head) {
-        HIP_OK(hipEventRecord(p->ev_prologue, M));
-        HIP_OK(hipStreamWaitEvent(Rg, p->ev_prologue, 0));
-    }
-
-    // ---- Rg: texture bins: this step's cursors and record sub-ranges; the regularisers, value + gradient in one pass, weights folded into
-    // the kernels' scales (dbw.py:373-405) ----
-    int *cursor = nullptr;
-    const uint32_t *blayout = nullptr;
-    if (bins) {
-        const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
-        const double total_records = (double)d.n_bins * (double)L.bin_cap;
-        cursor = IP(L.cursor[p->bin_turn]);
-        if (head) HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, Rg));
-        if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
-            if (head) RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), Rg));
-            blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
-        } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
-            if (head) RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
-            blayout = (const uint32_t *)(ws + L.layout_uniform);
-        }
-        if (two && head) HIP_OK(hipEventRecord(p->ev_layout, Rg));
-    }
-    float *vals = FP(L.vals);
-    if (!head) {
-    } else if (d.fuse & 4) {
-        RegulariserArgs A;
-        memset(&A, 0, sizeof(A));
-        A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
-        A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
-        A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
-        A.overlap_scale = d.w_overlap;
-        A.pars_eps = 1e-6f; A.pars_scale = d.w_parsimony;
-        A.loss_parsimony = vals + 1; A.loss_overlap = vals + 3;
-        A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T; A.g_alpha_full = FP(L.g_alpha_full);
-        A.ws = FP(L.ovl_ws); A.ticket = (unsigned *)(ws + L.tickets);
-        RC(launch_regularisers(A, Rg));
-    } else {
-        if (pars_on) RC(dbw_sqrt_mean(FP(L.alpha_full), nb, 1e-6f, d.w_parsimony, vals + 1, FP(L.g_alpha_full), Rg));
-        if (overlap_on)
-            RC(dbw_overlap_loss(in->overlap_u_override, d.overlap_points, d.sq_eps, d.S, d.R6, d.T, FP(L.alpha_full), nb, d.ratio_block_scene, d.scale_min,
-                                d.overlap_temperature, d.overlap_n_blocks, d.w_overlap, vals + 3, d.g_sq_eps, d.g_S, d.g_R6, d.g_T, FP(L.g_alpha_full),
-                                FP(L.ovl_ws), Rg));
-    }
-    if (tv) {
-        for (int i = 0; i < 3; ++i) {
-            sets[i].sig = FP(L.sig[i]);
-            sets[i].grad_sig_out = FP(L.g_sig[i]);
-            sets[i].grad_sig = FP(L.g_sig[i]);
-        }
-        if (head) RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
-    }
-
     // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
     RasterWorkspace we, wf;
     // (fuse bit 4: the env layer is evaluated inside the fg pass, from per-tile lists of its own; else the hard pass walks its coarse bins)
@@ -506,6 +490,65 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
     const bool setup_aside = two && fused_setup && !fold && B > d.serial_setup_max_views;
     DBW_REQUIRE(phase == 0 || fold, "the two-phase iteration needs per-tile lists for both scenes (a binned workspace)");
+    // The prologue's signal to Rg: carried by the first workgroup of the kernel behind the prologue on M (a kernel that has started says
+    // that everything in front of it on its stream is complete) -- then Rg's work is enqueued BEHIND that kernel, because a poll must never
+    // be enqueued in front of its producer -- or, where M's next kernel is not the fused set-up, by a launch of its own
+    const bool prologue_signal_folded = flags && two && head && fused_setup && !setup_aside;
+    if (two && head && !prologue_signal_folded) RC(signal(M, F_PROLOGUE, p->ev_prologue));
+    int *cursor = nullptr;
+    const uint32_t *blayout = nullptr;
+    float *vals = FP(L.vals);
+    auto side_head = [&]() -> int {
+        if (two && head) RC(await(Rg, F_PROLOGUE, p->ev_prologue));
+
+        // ---- Rg: texture bins: this step's cursors and record sub-ranges; the regularisers, value + gradient in one pass, weights folded into
+        // the kernels' scales (dbw.py:373-405) ----
+        if (bins) {
+            const int64_t nsub = (int64_t)d.n_bins * DBW_BIN_SUBCURSORS;
+            const double total_records = (double)d.n_bins * (double)L.bin_cap;
+            cursor = IP(L.cursor[p->bin_turn]);
+            if (head) HIP_OK(hipMemsetAsync(cursor, 0, (size_t)nsub * 4, Rg));
+            if (p->bin_ready) {            // sub-ranges by the demand of the previous run (its cursors), ops.BinDemand
+                if (head) RC(dbw_bin_layout(IP(L.cursor[1 - p->bin_turn]), nsub, total_records, 64, (uint32_t *)(ws + L.layout[p->bin_turn]), Rg));
+                blayout = (const uint32_t *)(ws + L.layout[p->bin_turn]);
+            } else {                       // first run: equal shares = the layout of an all-zero demand (this run's fresh cursors)
+                if (head) RC(dbw_bin_layout(cursor, nsub, total_records, 1, (uint32_t *)(ws + L.layout_uniform), Rg));
+                blayout = (const uint32_t *)(ws + L.layout_uniform);
+            }
+            if (two && head) RC(signal(Rg, F_LAYOUT, p->ev_layout));
+        }
+        if (!head) {
+        } else if (d.fuse & 4) {
+            RegulariserArgs A;
+            memset(&A, 0, sizeof(A));
+            A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
+            A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
+            A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
+            A.overlap_scale = d.w_overlap;
+            A.pars_eps = 1e-6f; A.pars_scale = d.w_parsimony;
+            A.loss_parsimony = vals + 1; A.loss_overlap = vals + 3;
+            A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T; A.g_alpha_full = FP(L.g_alpha_full);
+            A.ws = FP(L.ovl_ws); A.ticket = (unsigned *)(ws + L.tickets);
+            RC(launch_regularisers(A, Rg));
+        } else {
+            if (pars_on) RC(dbw_sqrt_mean(FP(L.alpha_full), nb, 1e-6f, d.w_parsimony, vals + 1, FP(L.g_alpha_full), Rg));
+            if (overlap_on)
+                RC(dbw_overlap_loss(in->overlap_u_override, d.overlap_points, d.sq_eps, d.S, d.R6, d.T, FP(L.alpha_full), nb, d.ratio_block_scene, d.scale_min,
+                                    d.overlap_temperature, d.overlap_n_blocks, d.w_overlap, vals + 3, d.g_sq_eps, d.g_S, d.g_R6, d.g_T, FP(L.g_alpha_full),
+                                    FP(L.ovl_ws), Rg));
+        }
+        if (tv) {
+            for (int i = 0; i < 3; ++i) {
+                sets[i].sig = FP(L.sig[i]);
+                sets[i].grad_sig_out = FP(L.g_sig[i]);
+                sets[i].grad_sig = FP(L.g_sig[i]);
+            }
+            if (head) RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
+        }
+        return DBW_OK;
+    };
+    if (!prologue_signal_folded) RC(side_head());
+
     if (!head) {
     } else if (fused_setup) {
         SceneSetupArgs A;
@@ -541,7 +584,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             Bn.sc[0].cells = 1; Bn.sc[0].cell = we.cell; Bn.sc[0].pool = we.pool; Bn.sc[0].pool_cap = we.pool_cap; Bn.sc[0].hdr = we.hdr; Bn.sc[0].rank = we.rank;
         }
         if (setup_aside) {
-            HIP_OK(hipStreamWaitEvent(E, p->ev_prologue, 0));
+            RC(await(E, F_PROLOGUE, p->ev_prologue));
             A.scene0 = 0; A.nscenes = 1; Bn.scene0 = 0; Bn.nscenes = 1;
             RC(launch_scene_setup(A, M));
             RC(launch_scene_bins(Bn, M));
@@ -549,9 +592,10 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             RC(launch_scene_setup(A, E));
             RC(launch_scene_bins(Bn, E));
             RC(dbw_launch_work_scatter(wf, B, H, W, E));
-            HIP_OK(hipEventRecord(p->ev_scatter, E));
+            RC(signal(E, F_SCATTER, p->ev_scatter));
         } else {
             A.scene0 = 0; A.nscenes = 2; Bn.scene0 = 0; Bn.nscenes = 2;
+            if (prologue_signal_folded) { A.sync_flag = p->sync_words + F_PROLOGUE; A.sync_val = ++p->sync_val[F_PROLOGUE]; }
             RC(launch_scene_setup(A, M));
             RC(launch_scene_bins(Bn, M));
             RC(dbw_launch_work_scatter(wf, B, H, W, M));
@@ -570,6 +614,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                     nullptr, nullptr, nullptr, 1, 1, M));
     }
 
+    if (prologue_signal_folded) RC(side_head());
+
     // ---- M: the env pass (hard, one face per pixel), then the fg pass ending in the composite + MSE ----
 #define PROF(i, st) do { if (p->profile) HIP_OK(hipEventRecord(p->ev_t[i], st)); } while (0)
     PROF(0, M);
@@ -578,7 +624,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                 d.env_face_map, d.env_map_desc, FP(L.env_maps), nullptr, 0, B, Fte, H, W, 1, Fe, 0.f, 0.f, d.perspective_correct, d.bg_env,
                                 IP(L.p2f_e), FP(L.bary_e), FP(L.dists_e), FP(L.img_e), ws + L.e.rws, L.e.rws_bytes, 3, 2, 1, M));
     PROF(1, M);
-    if (setup_aside) HIP_OK(hipStreamWaitEvent(M, p->ev_scatter, 0));
+    if (setup_aside) RC(await(M, F_SCATTER, p->ev_scatter));
     PROF(2, M);
     if (fold) {
         // the fg pass with the env layer inside it: no env pass, no env image; the env scene's hard uv-fragments leave from here
@@ -599,13 +645,18 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                 FP(L.part), FP(L.g_fg), FP(L.g_env), 2, 1, M));
     PROF(3, M);
     const bool seq = d.backward_order != 0 || (bins && !d.binned_concurrent);     // the env chain waits for the fg backward KERNEL
-    if (two) HIP_OK(hipEventRecord(p->ev_fg_fwd, M));
+    // the fg pass's signal to Rg (loss values) and E (env backward): carried by the first workgroup of the fg backward, M's next kernel -- the two
+    // streams' work is then enqueued behind that launch (a poll never in front of its producer); with events: recorded here, as ever
+    const bool fwd_signal_folded = flags && two;
+    if (two && !fwd_signal_folded) RC(signal(M, F_FG_FWD, p->ev_fg_fwd));
 
     // ---- Rg: the loss values (nothing is differentiated through them) ----
-    if (two) HIP_OK(hipStreamWaitEvent(Rg, p->ev_fg_fwd, 0));
     auto loss_values = [&](hipStream_t st) -> int {
         hipLaunchKernelGGL(loss_finish_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
         RC(dbw_check_launch("loss_finish_kernel"));
+        // everything of Rg that the other streams wait for is done here: the copy to the host (of values outside the zero arena) is nobody's
+        // business but the host's -- behind the signal, so that neither the env chain nor Adam ever waits for a transfer
+        if (two) RC(signal(st, F_REG, p->ev_reg));
         if (in->read_losses) {
             HIP_OK(hipMemcpyAsync(p->host_losses, FP(L.losses), 5 * sizeof(float), hipMemcpyDeviceToHost, st));
             HIP_OK(hipEventRecord(p->ev_losses, st));
@@ -613,7 +664,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         }
         return DBW_OK;
     };
-    if (two) { RC(loss_values(Rg)); HIP_OK(hipEventRecord(p->ev_reg, Rg)); }
 
     // ---- E: backward of the env pass and its tail ----
     auto env_backward = [&](hipStream_t st) -> int {
@@ -627,31 +677,42 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
                               d.g_R6_ground, d.g_T_ground, st));
         // (Rg: the TV gradients of the sky / ground maps -- and, for M behind this chain: d / d alpha_full, the pose gradients of the overlap term)
-        if (two) HIP_OK(hipStreamWaitEvent(st, p->ev_reg, 0));
+        if (two) RC(await(st, F_REG, p->ev_reg));
         dbw_texture_set env_sets[2] = {sets[0], sets[2]};
         if (!tv) { env_sets[0].grad_sig = nullptr; env_sets[1].grad_sig = nullptr; }
         RC(dbw_texture_prep_bwd_sets(env_sets, 2, st));
         return DBW_OK;
     };
-    if (two && !seq) {
-        HIP_OK(hipStreamWaitEvent(E, p->ev_fg_fwd, 0));
-        RC(env_backward(E));
-        HIP_OK(hipEventRecord(p->ev_env_done, E));
-    }
+    auto side_after_fwd = [&]() -> int {
+        if (two) {
+            RC(await(Rg, F_FG_FWD, p->ev_fg_fwd));
+            RC(loss_values(Rg));
+        }
+        if (two && !seq) {
+            RC(await(E, F_FG_FWD, p->ev_fg_fwd));
+            RC(env_backward(E));
+            RC(signal(E, F_ENV_DONE, p->ev_env_done));
+        }
+        return DBW_OK;
+    };
+    if (!fwd_signal_folded) RC(side_after_fwd());
 
     // ---- M: backward of the fg pass and its tail ----
-    if (bins && two) HIP_OK(hipStreamWaitEvent(M, p->ev_layout, 0));      // (this step's cursors and sub-ranges come from Rg)
+    if (bins && two) RC(await(M, F_LAYOUT, p->ev_layout));      // (this step's cursors and sub-ranges come from Rg)
     PROF(4, M);
-    RC(dbw_render_bwd_fused(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
-                            d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
-                            FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
-                            bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, M));
+    unsigned *bwd_flag = nullptr, bwd_val = 0;
+    if (fwd_signal_folded) { bwd_flag = p->sync_words + F_FG_FWD; bwd_val = ++p->sync_val[F_FG_FWD]; }
+    RC(render_bwd_fused_signal(IP(L.p2f), FP(L.bary), FP(L.dists), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs, d.block_face_map,
+                               d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, H, W, K, Ff, d.sigma, d.bg_fg, FP(L.g_fg), FP(L.f.fvc), d.perspective_correct, 1,
+                               FP(L.g_blk_maps), coarse ? FP(L.g_fa) : nullptr, FP(L.g_fvc_f), d.decim_blocks > 1 ? 1 : 0, 2, bins ? d.block_bin_base : nullptr, cursor,
+                               bins ? (void *)(ws + L.records) : nullptr, bins ? L.bin_cap : 0, blayout, 0, nullptr, 1, M, bwd_flag, bwd_val));
     PROF(5, M);
+    if (fwd_signal_folded) RC(side_after_fwd());
     if (two && seq) {
-        HIP_OK(hipEventRecord(p->ev_kernel_done, M));
-        HIP_OK(hipStreamWaitEvent(E, p->ev_kernel_done, 0));
+        RC(signal(M, F_KERNEL_DONE, p->ev_kernel_done));
+        RC(await(E, F_KERNEL_DONE, p->ev_kernel_done));
         RC(env_backward(E));
-        HIP_OK(hipEventRecord(p->ev_env_done, E));
+        RC(signal(E, F_ENV_DONE, p->ev_env_done));
     }
     if (bins) RC(dbw_texbin_reduce(d.block_bin_info, cursor, ws + L.records, L.bin_cap, blayout, d.n_bins, FP(L.g_blk_maps), M));
     // the backward of the blocks' texture preparation, first in the tail: a data-parallel caller reduces the blocks' texture gradient -- 83 %
@@ -663,17 +724,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         dbw_texture_set blk = sets[1];
         if (!tv) blk.grad_sig = nullptr;
         RC(dbw_texture_prep_bwd_sets(&blk, 1, M));
-        if (early_textures) HIP_OK(hipEventRecord(p->ev_blocks_ready, M));      // (an event costs M ~7 us: only where somebody waits for it)
+        if (early_textures) RC(signal(M, F_BLOCKS_READY, p->ev_blocks_ready));      // (an event costs M ~7 us: only where somebody waits for it)
         return DBW_OK;
     };
     if (early_textures) {
-        HIP_OK(hipStreamWaitEvent(M, p->ev_reg, 0));
+        RC(await(M, F_REG, p->ev_reg));
         RC(blocks_textures());
     }
     RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
                             IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
     if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
-    if (two) HIP_OK(hipStreamWaitEvent(M, p->ev_env_done, 0));           // the env chain, and through it the regularisers (E waited for Rg)
+    if (two) RC(await(M, F_ENV_DONE, p->ev_env_done));           // the env chain, and through it the regularisers (E waited for Rg)
     if (!early_textures) RC(blocks_textures());
     if ((d.fuse & 8) && (d.fuse & 1)) {
         BlocksTailArgs A;
@@ -706,8 +767,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
 extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t stream) {
     DBW_REQUIRE(p, "null pointer");
-    HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0));
-    return DBW_OK;
+    if (p->d.sync_events) { HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0)); return DBW_OK; }
+    hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned *)(p->sync_words + F_BLOCKS_READY), p->sync_val[F_BLOCKS_READY],
+                       p->sync_words + SYNC_TIMEOUT_SLOT);
+    return dbw_check_launch("sync_wait_kernel");
+}
+
+extern "C" int dbw_train_step_sync_timeouts(dbw_step_plan *p) {
+    if (!p) return -1;
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, p->sync_words + SYNC_TIMEOUT_SLOT, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
 }
 
 extern "C" int dbw_train_step_profile(dbw_step_plan *p, int on) {

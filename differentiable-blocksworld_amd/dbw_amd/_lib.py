@@ -51,7 +51,7 @@ class StepDesc(ctypes.Structure):
                                       'g_sq_eps', 'g_S', 'g_R6', 'g_T', 'g_alpha_logit', 'g_R6_ground', 'g_T_ground', 'g_texture_bkg', 'g_texture_ground',
                                       'g_textures', 'flat_param', 'flat_grad', 'exp_avg', 'exp_avg_sq')]
                 + [('group_end', c_i64 * 2), ('small_grads', c_p), ('n_small_grads', c_i), ('fuse', c_i), ('backward_order', c_i),
-                   ('binned_concurrent', c_i), ('serial_setup_max_views', c_i), ('seed', ctypes.c_uint64)])
+                   ('binned_concurrent', c_i), ('serial_setup_max_views', c_i), ('seed', ctypes.c_uint64), ('sync_events', c_i)])
 
 
 class StepInputs(ctypes.Structure):
@@ -110,6 +110,7 @@ SIGNATURES = {
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
+    'dbw_train_step_sync_timeouts': [c_p],
     'dbw_train_step_profile': [c_p, c_i],
     'dbw_train_step_kernel_times': [c_p, c_p],
 }

@@ -9,6 +9,7 @@ Same mathematics as NativeStep (which is checked against the autograd iteration,
 tests/test_gpu_model.py::test_c_step_equals_native_step holds them to each other for every fuse mask.  Scope = NativeStep's: the decoupled
 training render with MSE + parsimony + TV + overlap on a sync-free model; anything else -> `supported()` is False."""
 import ctypes
+import os
 import weakref
 
 import torch
@@ -74,8 +75,11 @@ class CStep:
         self.use_side_stream = True         # False: everything in order on the caller's stream
         self.own_side_stream = False        # True: the env chain on a (high-priority) torch stream of the caller instead of the plan's own
         self.serial_setup_max_views = 12    # include/dbw_hip.h: up to that many views the blocks' set-up stays on the main stream
+        # how the step's streams wait for each other: polled words in device memory (include/dbw_hip.h: sync_events), or HIP events
+        self.sync_events = os.environ.get('DBW_STEP_EVENTS', '0') not in ('', '0')
         self.read_losses = False            # copy the five loss values to host memory in every step (StepLosses.host())
         self._plans = {}                    # key -> (handle, workspace tensor, keep-alive list)
+        self._pid = os.getpid()
         self._cur = None
         self._target, self._target_key = None, None
         self._env_key = None
@@ -99,8 +103,11 @@ class CStep:
         return self._cur[0]
 
     def close(self):
-        for handle, _, _ in self._plans.values():
-            _lib.load().dbw_train_step_destroy(handle)
+        # (a fork()ed child -- multiprocessing's manager / resource-sharer processes -- inherits these objects without the GPU context they
+        # belong to: only the process that made the plans destroys them)
+        if os.getpid() == self._pid:
+            for handle, _, _ in self._plans.values():
+                _lib.load().dbw_train_step_destroy(handle)
         self._plans, self._cur = {}, None
 
     def __del__(self):
@@ -129,7 +136,7 @@ class CStep:
         key = (coarse, decim, decim_blocks, max_views, m.world_size, self.fuse, int(seq), int(bool(both)), Kt.data_ptr(), m.R_world.data_ptr(),
                m.R_world._version, m.T_world._version, float(m.S_world),
                self.params.flat.data_ptr(), tuple(sorted(m.loss_weights.items())), float(m.opacity_noise or 0.0), bool(m.kill_blocks),
-               int(self.serial_setup_max_views))
+               int(self.serial_setup_max_views), bool(self.sync_events))
         if key in self._plans:
             self._cur = self._plans[key]
             return self._cur
@@ -190,6 +197,7 @@ class CStep:
         d.fuse, d.backward_order, d.binned_concurrent = self.fuse, int(seq), int(bool(both))
         d.serial_setup_max_views = int(self.serial_setup_max_views)
         d.seed = int(getattr(m, '_rng_seed', 227391)) & 0xffffffffffffffff
+        d.sync_events = int(bool(self.sync_events))
         lib = _lib.load()
         nbytes = lib.dbw_train_step_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
@@ -232,6 +240,10 @@ class CStep:
         finally:
             _lib.call('dbw_train_step_profile', self._cur[0], 0)
         return dict(zip(('env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'), [a / reps for a in acc]))
+
+    def sync_timeouts(self):
+        """Cross-stream waits of the current plan that gave up (never, in a healthy process); synchronises the device."""
+        return _lib.load().dbw_train_step_sync_timeouts(self._cur[0])
 
     def wait_blocks_ready(self, stream):
         """`stream` (a torch stream) waits until the blocks' texture gradient of the last step is final (data parallel: the early slice of

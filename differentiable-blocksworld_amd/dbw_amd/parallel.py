@@ -56,8 +56,12 @@ class ShardedTrainStep:
                  use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures', use_c_step=True,
                  fuse=None):
         self.model, self.pg = model, process_group
-        self.use_graph, self.graph_warmup, self._graph, self._static_inp, self._static_losses = use_graph, graph_warmup, None, None, None
-        self._graph_key = None
+        self.use_graph, self.graph_warmup = use_graph, graph_warmup
+        # captured iterations: {(kind, phase flags, shapes, global count): [graph, static inputs, static losses]} -- the native step and the
+        # autograd iteration never share an entry, a ragged last batch or the next training phase gets its own (GRAPHS_KEPT most recent);
+        # the FIRST iteration of a key always runs eagerly (it sizes the texture bins by demand and creates the cached tables outside
+        # the capture), the second is captured
+        self._graphs, self._graph_seen = {}, set()
         if use_graph and not getattr(model, 'sync_free', False):
             raise ValueError('use_graph=True needs model.sync_free = True (no device->host sync inside the iteration)')
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -124,10 +128,17 @@ class ShardedTrainStep:
         dirty = None
         if self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported():
             return self._c_iteration(inp)
-        if self.use_graph and self.n_steps >= self.graph_warmup and self._native_graph_ok(inp):
-            losses = self._native_graph_iteration(inp)
-        elif self.use_graph and self.n_steps >= self.graph_warmup:
-            losses = self._graph_iteration(inp)
+        kind = key = None
+        if self.use_graph and self.n_steps >= self.graph_warmup:
+            kind = 'native' if self._native_graph_ok(inp) else 'autograd'
+            key = self._graph_key(kind, inp)
+            if key not in self._graph_seen:
+                self._graph_seen.add(key)
+                kind = None
+        if kind == 'native':
+            losses = self._native_graph_iteration(inp, key)
+        elif kind == 'autograd':
+            losses = self._graph_iteration(inp, key)
         else:
             # gradients accumulate into the preallocated flat buffer, so nothing carved out of the zero arena outlives the
             # iteration: all zero-initialised scratch of the step comes from one buffer cleared by one launch
@@ -239,37 +250,61 @@ class ShardedTrainStep:
         return (self.native is not None and self.world_size == 1 and not self.overlap_allreduce and self.model.training
                 and inp['imgs'].shape[0] > 0 and self.native.supported() and self._fused_adam())
 
-    def _native_graph_iteration(self, inp):
+    GRAPHS_KEPT = 4
+
+    def _graph_key(self, kind, inp):
+        m = self.model
+        live = tuple(bool(m.is_live(k)) for k in ('coarse_learning', 'decimate_txt')) if hasattr(m, 'is_live') else ()
+        return (kind, bool(m.training), live, float(m._global_count), tuple((k, tuple(v.shape)) for k, v in sorted(inp.items())),
+                getattr(m, '_noise_override', None) is None, getattr(m, '_overlap_u_override', None) is None)
+
+    def _graph_entry(self, key):
+        e = self._graphs.pop(key, None)
+        if e is not None:
+            self._graphs[key] = e                    # (most recently used last)
+        return e
+
+    def _graph_store(self, key, entry):
+        self._graphs[key] = entry
+        while len(self._graphs) > self.GRAPHS_KEPT:
+            self._graphs.pop(next(iter(self._graphs)))
+
+    @staticmethod
+    def _graph_feed(static_inp, inp):
+        for k, v in inp.items():
+            if v.data_ptr() != static_inp[k].data_ptr():
+                static_inp[k].copy_(v)
+
+    def _native_graph_iteration(self, inp, key):
         from .native_step import LazyLosses
         m = self.model
         dev = self.params.flat.device
-        key = (m.is_live('coarse_learning'), m.is_live('decimate_txt'), float(m._global_count), tuple(inp['imgs'].shape),
-               m._noise_override is None, m._overlap_u_override is None)
-        if self._graph is None or self._graph_key != key:
-            self._static_inp = {k: v.clone() for k, v in inp.items()}
+        e = self._graph_entry(key)
+        if e is None:
+            static_inp = {k: v.clone() for k, v in inp.items()}
             torch.cuda.synchronize()
-            self._graph, self._graph_key = torch.cuda.CUDAGraph(), key
+            graph = torch.cuda.CUDAGraph()
             ops.ARENA.enabled = True
             try:
-                with torch.no_grad(), torch.cuda.graph(self._graph):
+                with torch.no_grad(), torch.cuda.graph(graph):
                     ops.ARENA.clean.pop(dev, None)              # the graph clears the arena itself, every replay
                     ops.ARENA.begin_step(dev)
-                    ll = self.native(self._static_inp, m._global_count, zero_grad=self.params.zero_grad)
+                    ll = self.native(static_inp, m._global_count, zero_grad=self.params.zero_grad)
                 ops.ARENA.end_step(dev)
                 ops.ARENA.clean.pop(dev, None)
             finally:
                 ops.ARENA.enabled = False
-            self._static_losses = (ll._vals, ll._part, ll._scale, ll._names)
+            e = [graph, static_inp, (ll._vals, ll._part, ll._scale, ll._names)]
             del ll
-        for k, v in inp.items():
-            if v.data_ptr() != self._static_inp[k].data_ptr():
-                self._static_inp[k].copy_(v)
-        self._graph.replay()
-        return LazyLosses(*self._static_losses)
+            self._graph_store(key, e)
+        self._graph_feed(e[1], inp)
+        e[0].replay()
+        return LazyLosses(*e[2])
 
-    def _graph_iteration(self, inp):
-        if self._graph is None:
-            self._static_inp = {k: v.clone() for k, v in inp.items()}
+    def _graph_iteration(self, inp, key):
+        e = self._graph_entry(key)
+        if e is None:
+            static_inp = {k: v.clone() for k, v in inp.items()}
             # torch's capture recipe: warm up on a side stream so that the AccumulateGrad nodes live on the capture stream
             if hasattr(self.model, 'release_graph'):
                 self.model.release_graph()
@@ -278,18 +313,18 @@ class ShardedTrainStep:
             with torch.cuda.stream(side):
                 for _ in range(2):
                     self.params.zero_grad()
-                    self.model(self._static_inp, None)['total'].backward()
+                    self.model(static_inp, None)['total'].backward()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 self.params.zero_grad()
-                losses = self.model(self._static_inp, None)
+                losses = self.model(static_inp, None)
                 losses['total'].backward()
-                self._static_losses = {k: v.detach() for k, v in losses.items()}
+                static_losses = {k: v.detach() for k, v in losses.items()}
             del losses
-        for k, v in inp.items():
-            if v.data_ptr() != self._static_inp[k].data_ptr():
-                self._static_inp[k].copy_(v)
-        self._graph.replay()
-        return self._static_losses
+            e = [graph, static_inp, static_losses]
+            self._graph_store(key, e)
+        self._graph_feed(e[1], inp)
+        e[0].replay()
+        return e[2]

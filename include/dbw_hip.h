@@ -425,6 +425,13 @@ typedef struct dbw_step_desc {
     int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);
                                                  * larger ones run it next to the env pass on the env stream */
     uint64_t seed;                              /* of the step's random numbers: the same on every data-parallel rank */
+    int sync_events;                            /* how the plan's streams wait for each other.  0 (default): through words in device memory -- the
+                                                 * producing stream runs a one-thread kernel that stores a counter, the waiting stream a one-thread
+                                                 * kernel that polls it (every wait is enqueued after its producer, so no ordering of the hardware
+                                                 * queues can deadlock it; a poll gives up after 0.2 s, dbw_train_step_sync_timeouts).  Measured: an
+                                                 * event costs the stream that records or waits for it 7-11 us before its next kernel and the
+                                                 * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.
+                                                 * != 0: HIP events (hipEventRecord / hipStreamWaitEvent) */
 } dbw_step_desc;
 
 typedef struct dbw_step_inputs {
@@ -473,6 +480,8 @@ int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 /* Makes `stream` wait until the blocks' texture gradient of the last run is final.  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
  * own while the rest of the step still runs. */
 int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
+/* Number of cross-stream waits of this plan that gave up (sync_events == 0; never in a healthy process) -- synchronises the device; < 0 on error */
+int dbw_train_step_sync_timeouts(dbw_step_plan *plan);
 
 /* Measurement aid (bench.py): on != 0 makes every following run record HIP timing events around its four big kernels, on the streams they
  * run on and with everything that shares the GPU with them in a real step running next to them (the events themselves cost each

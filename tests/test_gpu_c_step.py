@@ -294,3 +294,29 @@ def test_c_step_one_stream_equals_side_streams_and_every_launch_is_there():
         torch.cuda.synchronize()
         res.append((step, vals, grad1, step.params.flat.clone()))
     _compare(res[0], res[1], res[0][0].params.names)
+
+
+@pytest.mark.parametrize('epoch', [0, 800])
+def test_c_step_streams_wait_through_memory_words_as_through_events(epoch):
+    """dbw_step_desc.sync_events: the plan's streams wait for each other through polled words in device memory (default: a one-thread store
+    kernel behind the producer, a one-thread poll kernel in front of the consumer) or through HIP events -- the same step either way, over
+    several iterations (a wait that does not hold shows up as a race), and no poll ever gives up."""
+    inp = _inputs(3, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for events in (False, True):
+        model = _model(epoch)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        step.cstep.sync_events = events
+        out = step(inp)
+        torch.cuda.synchronize()
+        vals = {k: float(v) for k, v in out.items()}
+        grad1 = step.params.grad.clone()
+        for _ in range(6):
+            step(inp)
+        torch.cuda.synchronize()
+        assert step.cstep.sync_timeouts() == 0
+        res.append((step, vals, grad1, step.params.flat.clone()))
+    _compare(res[0], res[1], res[0][0].params.names)

@@ -394,6 +394,46 @@ def test_sync_free_block_culling_equals_host_packed_path_and_graph_replay_matche
     assert rel_err(finals[1][1], finals[0][1]) < 5e-3
 
 
+def test_graph_replay_keeps_a_graph_per_batch_shape_and_never_mixes_the_native_and_the_autograd_one():
+    """A ragged last batch gets a graph of its own (no recapture every epoch), the first iteration of every shape runs eagerly, and a
+    step that leaves the native path (model.eval()) does not replay the native graph."""
+    from dbw_amd.parallel import ShardedTrainStep
+    H, W = 48, 64
+    R, T, Km = O.synthetic_cameras(3, R_world=O.world_rotation(115, 0, 0))
+    full = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(3, 3, H, W, generator=torch.Generator().manual_seed(2)), R=R, T=T, K=Km).items()}
+    ragged = {k: v[:1].contiguous() for k, v in full.items()}
+    finals = []
+    for use_graph in (False, True):
+        torch.manual_seed(7)
+        model = dbw_amd.create_model(_dtu_like_cfg(5, 32, 6), (H, W)).to(DEV).train()
+        model.sync_free = True
+        model._noise_override = torch.zeros(5, device=DEV)
+        model._overlap_u_override = torch.rand(5, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+        step = ShardedTrainStep(model, use_graph=use_graph, graph_warmup=0, use_c_step=False)
+        seen = []
+        for it in range(8):
+            losses = step(full if it % 2 == 0 else ragged)
+            seen.append(losses['total'].item())
+            if use_graph:
+                assert len(step._graphs) == (0 if it < 2 else 1 if it == 2 else 2), (it, len(step._graphs))
+        if use_graph:
+            assert all(k[0] == 'native' for k in step._graphs)
+            from dbw_amd import ops
+            ops.UV_FRAGMENTS = False                  # leaves the native path: the autograd iteration has its own key, eager first, then its own graph
+            try:
+                n = len(step._graphs)
+                out = step(full)
+                assert isinstance(out, dict) and 'total' in out and len(step._graphs) == n
+                out = step(full)
+                assert isinstance(out['total'], torch.Tensor) and len(step._graphs) == n + 1 and any(k[0] == 'autograd' for k in step._graphs)
+            finally:
+                ops.UV_FRAGMENTS = True
+        torch.cuda.synchronize()
+        finals.append(seen)
+    for a, b in zip(*finals):
+        assert abs(a - b) < 1e-4 * abs(a), finals
+
+
 def test_predict_returns_reference_shaped_image_and_state_dict_roundtrip():
     model = dbw_amd.create_model(_dtu_like_cfg(), (48, 64)).to(DEV)
     model.eval()

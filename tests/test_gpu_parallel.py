@@ -59,8 +59,16 @@ def _run_nccl_single(rank, port, out):
     out[0] = float((res[0] - res[1]).abs().max())
 
 
+
+def _manager():
+    """The manager's server process is SPAWNED, not forked: a fork of this process would inherit the GPU objects earlier tests left to the
+    garbage collector (plans, graphs, streams) without the context they live in, and abort when it collects them."""
+    import gc
+    gc.collect()
+    return mp.get_context('spawn').Manager()
+
 def test_overlapped_allreduce_on_a_one_rank_rccl_group_leaves_the_step_unchanged():
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_run_nccl_single, args=(29541, out), nprocs=1, join=True)
     assert out[0] < 1e-4, out[0]          # (atomics order: not bit-identical from run to run)
@@ -100,7 +108,7 @@ def _run(rank, world, port, out, n_views=V, n_steps=3):
 
 
 def test_two_ranks_sharing_one_gpu_reproduce_the_full_batch_step():
-    mgr = mp.Manager()
+    mgr = _manager()
     ref, out = mgr.dict(), mgr.dict()
     mp.spawn(_run, args=(1, 0, ref), nprocs=1, join=True)                     # single process, all 5 views (its own CUDA context)
     mp.spawn(_run, args=(2, 29517, out), nprocs=2, join=True)                 # shards of 3 and 2 views
@@ -120,7 +128,7 @@ def test_config3_split_49_views_over_8_ranks_reproduces_the_full_batch_step():
     sharing cuda:0 over gloo: replicas bit-identical, gradient == the single-process gradient of all 49 views."""
     from dbw_amd.parallel import shard_views
     assert [shard_views(49, 8, r)[1] - shard_views(49, 8, r)[0] for r in range(8)] == [7, 6, 6, 6, 6, 6, 6, 6]
-    mgr = mp.Manager()
+    mgr = _manager()
     ref, out = mgr.dict(), mgr.dict()
     mp.spawn(_run, args=(1, 0, ref, 49, 2), nprocs=1, join=True)
     mp.spawn(_run, args=(8, 29561, out, 49, 2), nprocs=8, join=True)

@@ -11,6 +11,11 @@ model, inp = bench.build_workload(args, dev)
 model.sync_free = True
 model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
 step = ShardedTrainStep(model, seed=1)
+reads = os.environ.get("DBW_READS", "0") != "0"          # the host reads the loss values of every step (src/trainer.py:143)
+if step.cstep is not None:
+    step.cstep.read_losses = reads
 for _ in range(int(sys.argv[7]) if len(sys.argv) > 7 else 4):
-    step(inp)
+    out = step(inp)
+    if reads:
+        out.host() if hasattr(out, 'host') else [float(v) for v in out.values()]
 torch.cuda.synchronize()
