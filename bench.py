@@ -551,7 +551,8 @@ def main():
                        'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else
                                   'one C-ABI call per iteration (dbw_train_step_run: ~18 launches enqueued from C)' if step.cstep is not None else
                                   'launch by launch from Python, no host sync in the iteration') +
-                                 ('' if args.no_overlap else ', env backward chain and regularisers on side streams') +
+                                 ('' if args.no_overlap else ', env backward chain and regularisers on side streams' +
+                                  ((' that wait through HIP events' if step.cstep.sync_events else ' that wait through polled words in device memory') if step.cstep is not None else '')) +
                                  ('' if step.native is None else ', native step (no autograd)'),
                        'parallelism': f'view-sharded dp{world}, {step.params.flat.numel() * 4 / 1e6:.1f} MB of gradients all-reduced per step over RCCL'
                                       + (' (blocks\' textures overlapped with the env backward, the rest after it)' if step.overlap_allreduce else ''),

@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict
 // coarse level and, where the scene's pass reads per-tile lists, goes straight on to the fine level with the bin's list still in LDS.
 __global__ __launch_bounds__(256) void scene_bins_kernel(const SceneBinsArgs A) {
     __shared__ BinShared S;
-    const SceneBinsArgs::One &G = A.sc[A.scene0 + blockIdx.z];
+    // (workgroups start in grid order and the launch is more than one round of them at 49 views: the last scene -- the blocks, whose bins
+    // hold the long lists -- goes first, the env scene's short workgroups fill the tail)
+    const SceneBinsArgs::One &G = A.sc[A.scene0 + (A.nscenes - 1 - (int)blockIdx.z)];
     const int bin = blockIdx.x, n = blockIdx.y;
     bin_cell_extents(S, A.H, A.W, (bin % A.nx) * COARSE, (bin / A.nx) * COARSE);
     __syncthreads();

@@ -2,6 +2,8 @@
 # SQ counter passes of the bench workload (tools/pmc_target.py), summarised per kernel.  Usage (GPU box): tools/pmc_sq.sh OUTDIR [EPOCH]
 # Counters are collected on their own (--kernel-trace only), one rocprofv3 run per group.
 OUT=${1:-gpurun_out/pmc_sq}; export DBW_EPOCH=${2:-0}
+# (counter collection runs one kernel at a time: the step's streams then wait for each other through events, not through polled words)
+export DBW_STEP_EVENTS=1
 mkdir -p $OUT; export TMPDIR=/tmp
 A="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
 B="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU"
