@@ -90,18 +90,41 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 
 // One chunk of up to 64 staged faces (lane i of `jl` = view-local index of the i-th one) evaluated for the pixels of this wave:
 // records arrive in SGPRs (two s_load_dwordx16 per face), lanes are pixels.  Shared by the cell-list path and the legacy staging path.
+//
+// DBW_REC_PIPELINE (round 4, off): the record of face i + 1 requested while face i is evaluated.  The idea came from the time line of the
+// pass at the reference's batch size (tools/fwd_timeline.py, 4 views: every tile resident after 10 us, then the kernel drains for 70 -- a
+// heavy tile alone on its SIMD takes ~1.6 us per face): a scalar round trip per face that nothing hides.  Measured: 0.2410 -> 0.2462 ms per
+// step at 4 views, 0.2727 -> 0.2776 at 7, 0.9648 -> 0.9793 at 49.  The round trip is not what a lone wave waits for: its ~500 dependent
+// scalar + vector instructions per face issue at a fraction of the SIMD's rate whatever arrives when; every LDS access of the insert
+// waits for the early request anyway (lgkmcnt counts both, and scalar loads return out of order: the compiler can only wait for zero);
+// and the second record costs 16 s_mov per face and 90 more spilled SGPRs.
+#ifndef DBW_REC_PIPELINE
+#define DBW_REC_PIPELINE 0
+#endif
+__device__ __forceinline__ FaceRec load_rec_nowait(const FaceRec *__restrict__ rp) {
+    const v16f *vp = (const v16f *)rp;
+    union { v16f v[2]; FaceRec r; } u;
+    u.v[0] = vp[0];
+    u.v[1] = vp[1];
+    return u.r;
+}
+// (both halves have arrived behind this: the one wait of the iteration)
+__device__ __forceinline__ void rec_arrived(FaceRec &r) {
+    union U { v16f v[2]; FaceRec r; };
+    U &u = reinterpret_cast<U &>(r);
+    float p0 = u.v[0][0], p1 = u.v[1][0];
+    asm volatile("" : "+s"(p0), "+s"(p1));
+    u.v[0][0] = p0; u.v[1][0] = p1;
+}
+
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
                                                   int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false,
                                                   unsigned long long mask = ~0ull) {
     // (mask: the lanes of `jl` that hold faces of the chunk, in order)
-#pragma unroll 1
-    for (int i = 0; i < mcnt; ++i) {
-        if (!((mask >> i) & 1ull)) continue;
-        const int j = __builtin_amdgcn_readlane(jl, i);
-        const FaceRec r = load_rec_uniform(recs + f_begin + j);
+    auto face = [&](const FaceRec &r, int j) {
         const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
-        if (__ballot(inbox) == 0ull || no_eval) continue;           // (no_eval: ablation switch of tools/diag)
+        if (__ballot(inbox) == 0ull || no_eval) return;           // (no_eval: ablation switch of tools/diag)
         FPROF_ADD(5, 1);
         FPROF_CNT(6, inbox);
         float pz = 0.f, sd = 0.f;
@@ -119,7 +142,7 @@ __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ re
             keep = false;
             if (inbox) keep = eval_pair<false>(r, p, blur, persp, clipb, pz, sd, bc, unused, sign_only);
         }
-        if (__ballot(keep) == 0ull || no_insert) continue;        // (no_insert: ablation switch of tools/diag, dbw_debug_set_flags 32768)
+        if (__ballot(keep) == 0ull || no_insert) return;        // (no_insert: ablation switch of tools/diag, dbw_debug_set_flags 32768)
         FPROF_CNT(7, keep);
         const pay4 v{sd, bc.x, bc.y, bc.z};
         bool done = false;
@@ -129,7 +152,37 @@ __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ re
 #else
         q.insert(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
 #endif
+    };
+#if DBW_REC_PIPELINE
+    unsigned long long todo = mcnt >= 64 ? mask : (mask & ((1ull << mcnt) - 1ull));
+    if (todo == 0ull) return;
+    int j = __builtin_amdgcn_readlane(jl, __ffsll((long long)todo) - 1);
+    todo &= todo - 1ull;
+    FaceRec nxt = load_rec_nowait(recs + f_begin + j);
+#pragma unroll 1
+    for (;;) {
+        FaceRec r = nxt;
+        rec_arrived(r);
+        const int jc = j;
+        const bool more = todo != 0ull;
+        if (more) {
+            j = __builtin_amdgcn_readlane(jl, __ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            nxt = load_rec_nowait(recs + f_begin + j);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (the request for the next record stays in front of this face's arithmetic)
+        face(r, jc);
+        if (!more) break;
     }
+#else
+#pragma unroll 1
+    for (int i = 0; i < mcnt; ++i) {
+        if (!((mask >> i) & 1ull)) continue;
+        const int j = __builtin_amdgcn_readlane(jl, i);
+        const FaceRec r = load_rec_uniform(recs + f_begin + j);
+        face(r, j);
+    }
+#endif
 }
 
 // Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n

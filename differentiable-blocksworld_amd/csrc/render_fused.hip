@@ -452,7 +452,12 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     FPROF_ADD(13, wall_clock64());            // (100 MHz, common to the XCDs: the wave's place on the kernel's time line)
     bool empty = false;
     float env_rgb[3] = {0.f, 0.f, 0.f};
+#ifdef DBW_PROFILE_FWD
+    constexpr bool fold = false;        // (the cycle-accounting build measures the pass without the folded env layer: with the counters'
+    (void)E;                            // extra control flow around the record loads the backend fails on the second evaluation site)
+#else
     const bool fold = UV && E.recs != nullptr;
+#endif
     auto env_layer = [&](int n_, int xi_, int yi_, bool in_img_) {
         if constexpr (UV) { if (fold) env_fold_pixel(E, A.H, A.W, n_, xi_, yi_, in_img_, env_rgb); }
     };

@@ -9,7 +9,7 @@ import torch, bench
 from dbw_amd import _lib
 
 class A: pass
-args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 300, 400, 10, 10, 256
+args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = int(os.environ.get('DBW_VIEWS', '49')), 300, 400, 10, 10, 256
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.set_cur_epoch(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
