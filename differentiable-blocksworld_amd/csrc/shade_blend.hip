@@ -883,12 +883,29 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
                 STAT_ADD(1, tap_lanes); STAT_ADD(3, taps); STAT_ADD(7, tap_replays);
             }
 #endif
+            // Tap 0, then the lane's first other tap that carries weight, as wave-wide passes (merge + table); what is left after those, by
+            // the lanes that have it.  On a decimated map a footprint has a second texel only where it crosses a cell border (one pixel in
+            // four at decimation 8) and four only where it crosses one in x AND in y (1.6 %) -- but some lane of the 64 does, nearly always,
+            // so four wave-wide passes per layer used to run for 60 updates of which 45 belong to tap 0: a third of this kernel's
+            // instructions, and four table round trips in a row where two (and half a third) do.
+            const int f = wt[1] != 0.f ? 1 : (wt[2] != 0.f ? 2 : 3);
+            const int a2[2] = {ad[0], f == 1 ? ad[1] : (f == 2 ? ad[2] : ad[3])};
+            const float w2[2] = {wt[0], f == 1 ? wt[1] : (f == 2 ? wt[2] : wt[3])};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                bool on = tex && wt[q] != 0.f && !(A.dbg & 1);
-                if (TEX_MERGE > 0 && __ballot(on) != 0ull) lane_merge<3, TEX_MERGE>((int)((unsigned)ad[q] / 3u), on, v3);
-                if (on) tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
+            for (int q = 0; q < 2; ++q) {
+                float v3[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
+                bool on = tex && w2[q] != 0.f && !(A.dbg & 1);
+                if (TEX_MERGE > 0 && __ballot(on) != 0ull) lane_merge<3, TEX_MERGE>((int)((unsigned)a2[q] / 3u), on, v3);
+                if (on) tex_agg.add(gmaps, (int)((unsigned)a2[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
+            }
+            const bool rest = tex && !(A.dbg & 1) && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
+            if (__ballot(rest) != 0ull) {
+#pragma unroll
+                for (int q = 2; q < 4; ++q)
+                    if (rest && q > f && wt[q] != 0.f) {
+                        const float v3[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                        tex_agg.add(gmaps, (int)((unsigned)ad[q] / 3u), v3);
+                    }
             }
         }
         PROF_T(t_b);
@@ -1197,13 +1214,34 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
         const float wt[4] = {w00, w01, w10, w11};
         // neighbouring pixels that hit the same texel (magnified maps: most of them) are merged in registers first (lane_merge, up to 16
         // lanes into one; full-resolution env maps 0.27 -> 0.24 ms, decimated ones unchanged)
+        // (tap 0 and the lane's first other tap with weight as wave-wide passes; the rest -- footprints that cross a cell border in x AND y:
+        // few lanes on magnified / decimated maps, every lane on full-resolution ones -- lane by lane or wave-wide accordingly.  See the uv
+        // backward)
+        const int f = wt[1] != 0.f ? 1 : (wt[2] != 0.f ? 2 : 3);
+        const int a2[2] = {ad[0], f == 1 ? ad[1] : (f == 2 ? ad[2] : ad[3])};
+        const float w2[2] = {wt[0], f == 1 ? wt[1] : (f == 2 ? wt[2] : wt[3])};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float val[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-            bool on = tex && wt[q] != 0.f;
-            const int key = (int)((unsigned)ad[q] / 3u);
+        for (int q = 0; q < 2; ++q) {
+            float val[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
+            bool on = tex && w2[q] != 0.f;
+            const int key = (int)((unsigned)a2[q] / 3u);
             if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
             tex_agg.add_wave(gmaps, key, val, on);
+        }
+        const bool rest = tex && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
+        const unsigned long long rm = __ballot(rest);
+        if (rm != 0ull) {
+            const bool wide = __popcll(rm) > 16;
+#pragma unroll
+            for (int q = 2; q < 4; ++q) {
+                float val[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
+                bool on = rest && q > f && wt[q] != 0.f;
+                const int key = (int)((unsigned)ad[q] / 3u);
+                if (wide) {
+                    if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
+                    tex_agg.add_wave(gmaps, key, val, on);
+                } else if (on) tex_agg.add(gmaps, key, val);
+            }
         }
     }
     PROF_T(t_b);
