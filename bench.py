@@ -464,20 +464,28 @@ def main():
         mean_ms = sum(p['ms_per_step'] * p['epochs'] for p in phases.values()) / sum(p['epochs'] for p in phases.values())
         phases['schedule_weighted'] = {'ms_per_step': mean_ms, 'views_per_s': views_total / mean_ms * 1e3,
                                        'what': 'mean over the 1800-epoch schedule (750 / 750 / 300 epochs)'}
-    allreduce_ms = None
+    allreduce_ms, allreduce_bytes = None, None
+    deferred = step.cstep is not None and step.defer_textures       # the ranks sum the prepared maps' gradient + the small gradients (parallel.py)
     if world > 1:
         sync()
+        bufs = [step.cstep.map_grads(), step.params.grad[:step.params.bounds[0][1]]] if deferred else None
+        allreduce_bytes = sum(t.numel() * 4 for t in bufs) if deferred else step.params.flat.numel() * 4
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            step.allreduce_gradients()
+            if deferred:
+                step._allreduce_all(bufs)
+            else:
+                step.allreduce_gradients()
         e1.record()
         torch.cuda.synchronize()
         allreduce_ms = e0.elapsed_time(e1) / 5
         step.params.zero_grad()
+        if deferred:
+            step.cstep.arena().zero_()
 
     # ---- N > 1: the other scaling form in the same run, and what the early slice of the all-reduce buys ----
-    other_scaling, overlap_off_ms = None, None
+    other_scaling, overlap_off_ms, flat_ms = None, None, None
     if world > 1 and not args.graph:
         restore()
         model.set_cur_epoch(args.epoch)
@@ -492,6 +500,15 @@ def main():
         d, _ = timed(k, o_inp, o_count)
         other_scaling = {'scaling': o_name, 'value': o_views * k / d, 'unit': 'views/s', 'ms_per_step': d / k * 1e3, 'views_per_step': o_views,
                          'views_on_rank0': int(o_inp['R'].shape[0])}
+        # the other data-parallel flow: the whole flat gradient buffer all-reduced, with and without its early slice overlapped
+        was = step.defer_textures
+        step.defer_textures = False
+        if deferred:
+            restore()
+            for _ in range(max(args.warmup, 3)):
+                step(inp, global_count=global_count)
+            d, _ = timed(k)
+            flat_ms = d / k * 1e3
         if step.overlap_allreduce:
             restore()
             step.overlap_allreduce = False
@@ -500,6 +517,7 @@ def main():
             d, _ = timed(k)
             overlap_off_ms = d / k * 1e3
             step.overlap_allreduce = True
+        step.defer_textures = was
         restore()
         step(inp, global_count=global_count)
 
@@ -554,8 +572,12 @@ def main():
                                  ('' if args.no_overlap else ', env backward chain and regularisers on side streams' +
                                   ((' that wait through HIP events' if step.cstep.sync_events else ' that wait through polled words in device memory') if step.cstep is not None else '')) +
                                  ('' if step.native is None else ', native step (no autograd)'),
-                       'parallelism': f'view-sharded dp{world}, {step.params.flat.numel() * 4 / 1e6:.1f} MB of gradients all-reduced per step over RCCL'
-                                      + (' (blocks\' textures overlapped with the env backward, the rest after it)' if step.overlap_allreduce else ''),
+                       'parallelism': f'view-sharded dp{world}, ' + (
+                           f'{(allreduce_bytes or 0) / 1e6:.2f} MB all-reduced per step over RCCL: the gradient of the prepared texture maps (sigmoid + '
+                           f'decimation are linear behind it) + the small gradients, instead of the {step.params.flat.numel() * 4 / 1e6:.1f} MB gradient buffer'
+                           if deferred else
+                           f'{step.params.flat.numel() * 4 / 1e6:.1f} MB of gradients all-reduced per step over RCCL'
+                           + (' (blocks\' textures overlapped with the env backward, the rest after it)' if step.overlap_allreduce else '')),
                        'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -573,7 +595,7 @@ def main():
                          'limiter': 'instruction issue and latency, not HBM: see `counters` (share of the SIMD time the VALU is busy, lane '
                                     f'utilisation, HBM traffic per launch; profiles/{PMC_FILE}) and DESIGN.md section 4; frac is the '
                                     'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
-            'phases': phases, 'allreduce_ms': allreduce_ms, 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms,
+            'phases': phases, 'allreduce_ms': allreduce_ms, 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms, 'ms_per_step_flat_allreduce': flat_ms, 'allreduce_bytes': allreduce_bytes,
             'final_loss': total_loss,
         }
         if world == 1 and not args.no_extras and not args.graph:

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void tile_target_kernel(const float *__restric
 // + the per-tile sums of squared differences of the fg pass -> out5 = rgb, parsimony, tv, overlap, total (what compute_losses returns,
 // dbw.py:361-408); the workgroup that finishes last writes them
 constexpr int LOSS_BLOCKS = 32;
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restrict__ part, long long nparts, float scale, float *vals, float *__restrict__ out5) {
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restrict__ part, long long nparts, float scale, float tv_value_scale, float *vals,
+                                                          float *__restrict__ out5) {
     __shared__ float s_red[4];
     __shared__ int s_last;
     float acc = 0.f;
@@ -69,8 +70,9 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restric
     if (s_last && threadIdx.x == 0) {
         __threadfence();
         const float rgb = atomicAdd(vals, 0.f) * scale;          // (through the L2: the other workgroups' adds)
-        out5[0] = rgb; out5[1] = vals[1]; out5[2] = vals[2]; out5[3] = vals[3];
-        out5[4] = ((rgb + vals[1]) + vals[2]) + vals[3];
+        const float tvv = vals[2] * tv_value_scale;
+        out5[0] = rgb; out5[1] = vals[1]; out5[2] = tvv; out5[3] = vals[3];
+        out5[4] = ((rgb + vals[1]) + tvv) + vals[3];
     }
 }
 
@@ -84,7 +86,7 @@ struct Layout {
     size_t env_maps, blk_maps, sig[3], g_sig[3];
     size_t alpha, alpha_full, keep, blk_verts, sq_local, losses, target;
     size_t records, cursor[2], layout[2], layout_uniform;
-    size_t arena_begin, g_alpha_full, ovl_ws, vals, tickets, g_blk_maps, g_fa, g_fvc_f, g_blk_verts, g_env_maps, g_fvc_e, g_env_verts, arena_end;
+    size_t arena_begin, g_alpha_full, ovl_ws, vals, tickets, g_blk_maps, g_env_maps, g_maps_end, g_fa, g_fvc_f, g_blk_verts, g_fvc_e, g_env_verts, arena_end;
     size_t total;
     // derived sizes
     int Fe, Ff, Ve, Vf, tiles, bin_cap;
@@ -169,15 +171,48 @@ void make_layout(const dbw_step_desc &d, Layout &L) {
     L.ovl_ws = o; o += al((size_t)d.n_blocks * 18 * 4);
     L.vals = o; o += al(8 * 4);
     L.tickets = o; o += al(4 * 4);
-    L.g_blk_maps = o; o += al(L.n_blk_maps * 4);
+    L.g_blk_maps = o; o += al(L.n_blk_maps * 4);          // (the gradients of the prepared maps: ONE range, what data-parallel ranks sum)
+    L.g_env_maps = o; o += al(L.n_env_maps * 4);
+    L.g_maps_end = o;
     L.g_fa = o; o += al((size_t)d.n_blocks * 64 * 4);
     L.g_fvc_f = o; o += al((size_t)B * 2 * L.Ff * 9 * 4);
     L.g_blk_verts = o; o += al((size_t)L.Vf * 12);
-    L.g_env_maps = o; o += al(L.n_env_maps * 4);
     L.g_fvc_e = o; o += al((size_t)B * 2 * L.Fe * 9 * 4);
     L.g_env_verts = o; o += al((size_t)L.Ve * 12);
     L.arena_end = o;
     L.total = o;
+}
+
+
+// the three texture tensors of the scene as the `_sets` kernels take them: sky, blocks, ground (dbw.py:273-293,306,331-334)
+void fill_texture_sets(const dbw_step_desc &d, const Layout &L, char *ws, dbw_texture_set (&sets)[3]) {
+#define FPW(off) ((float *)(ws + (off)))
+    memset(sets, 0, sizeof(sets));
+    const float *tex[3] = {d.texture_bkg, d.textures, d.texture_ground};
+    float *gtex[3] = {d.g_texture_bkg, d.g_textures, d.g_texture_ground};
+    const int tn[3] = {1, d.n_blocks, 1}, th[3] = {d.env_txt_size, d.txt_size, d.env_txt_size}, td[3] = {d.decim_env, d.decim_blocks, d.decim_env};
+    float *maps_out[3] = {FPW(L.env_maps), FPW(L.blk_maps), FPW(L.env_maps) + L.ce};
+    float *gmaps[3] = {FPW(L.g_env_maps), FPW(L.g_blk_maps), FPW(L.g_env_maps) + L.ce};
+    const float tvw[3] = {d.w_tv_bkg, d.w_tv_blocks, d.w_tv_ground};
+    for (int i = 0; i < 3; ++i) {
+        dbw_texture_set &t = sets[i];
+        t.texture = tex[i]; t.n = tn[i]; t.h = th[i]; t.w = th[i]; t.decim = td[i];
+        t.maps = maps_out[i];
+        t.sig = td[i] > 1 ? FPW(L.sig[i]) : nullptr;
+        t.wrap_x = i == 1 ? 1 : 0;
+        t.tv_scale = tvw[i];
+        t.grad_texture = gtex[i];
+        t.grad_maps = gmaps[i];
+    }
+}
+// ... with the total-variation term on: where its gradient (to the sigmoid of the texture) goes, and comes from in the backward of the preparation
+void add_tv_fields(const Layout &L, char *ws, dbw_texture_set (&sets)[3]) {
+    for (int i = 0; i < 3; ++i) {
+        sets[i].sig = FPW(L.sig[i]);
+        sets[i].grad_sig_out = FPW(L.g_sig[i]);
+        sets[i].grad_sig = FPW(L.g_sig[i]);
+    }
+#undef FPW
 }
 
 int check_desc(const dbw_step_desc *d) {
@@ -333,6 +368,8 @@ extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
         case 10: return (int64_t)L.part;
         case 11: return (int64_t)L.p2f_e;
         case 12: return (int64_t)L.bary_e;
+        case 13: return (int64_t)L.g_blk_maps;
+        case 14: return (int64_t)L.g_maps_end;
         default: return -1;
     }
 }
@@ -368,6 +405,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
     DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
     DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
+    const bool defer = in->defer_textures != 0;       // stop in front of the texture preparation's backward (dbw_train_step_finish runs it)
+    DBW_REQUIRE(!defer || !in->with_adam, "defer_textures: Adam runs in dbw_train_step_finish");
     const int phase = in->phase;          // 0: the whole iteration; 1: up to the fg pass, which stores rec; 2: the fg pass again with grad_rec, then the rest
     DBW_REQUIRE(phase >= 0 && phase <= 2 && (phase != 1 || in->rec_out) && (phase != 2 || in->grad_rec), "phase 1 stores rec_out, phase 2 reads grad_rec");
     DBW_REQUIRE(phase == 0 || ((p->d.fuse & 18) == 18), "the two-phase iteration (perceptual term) needs the env layer folded into the fg pass (fuse bits 1 and 4)");
@@ -414,23 +453,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // ---- texture sets: sky, blocks, ground (dbw.py:273-293,306,331-334) ----
     dbw_texture_set sets[3];
-    memset(sets, 0, sizeof(sets));
-    const float *tex[3] = {d.texture_bkg, d.textures, d.texture_ground};
-    float *gtex[3] = {d.g_texture_bkg, d.g_textures, d.g_texture_ground};
-    const int tn[3] = {1, nb, 1}, th[3] = {d.env_txt_size, d.txt_size, d.env_txt_size}, td[3] = {d.decim_env, d.decim_blocks, d.decim_env};
-    float *maps_out[3] = {FP(L.env_maps), FP(L.blk_maps), FP(L.env_maps) + L.ce};
-    float *gmaps[3] = {FP(L.g_env_maps), FP(L.g_blk_maps), FP(L.g_env_maps) + L.ce};
-    const float tvw[3] = {d.w_tv_bkg, d.w_tv_blocks, d.w_tv_ground};
-    for (int i = 0; i < 3; ++i) {
-        dbw_texture_set &t = sets[i];
-        t.texture = tex[i]; t.n = tn[i]; t.h = th[i]; t.w = th[i]; t.decim = td[i];
-        t.maps = maps_out[i];
-        t.sig = td[i] > 1 ? FP(L.sig[i]) : nullptr;
-        t.wrap_x = i == 1 ? 1 : 0;
-        t.tv_scale = tvw[i];
-        t.grad_texture = gtex[i];
-        t.grad_maps = gmaps[i];
-    }
+    fill_texture_sets(d, L, ws, sets);
 
     // ---- M: targets in the tile-planar layout (a fresh mini-batch; resident views come tiled) ----
     const float *target = in->imgs;
@@ -538,11 +561,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                     FP(L.ovl_ws), Rg));
         }
         if (tv) {
-            for (int i = 0; i < 3; ++i) {
-                sets[i].sig = FP(L.sig[i]);
-                sets[i].grad_sig_out = FP(L.g_sig[i]);
-                sets[i].grad_sig = FP(L.g_sig[i]);
-            }
+            add_tv_fields(L, ws, sets);
             if (head) RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
         }
         return DBW_OK;
@@ -652,7 +671,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // ---- Rg: the loss values (nothing is differentiated through them) ----
     auto loss_values = [&](hipStream_t st) -> int {
-        hipLaunchKernelGGL(loss_finish_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale, vals, FP(L.losses));
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, FP(L.part), (long long)B * L.tiles, mse_scale,
+                           d.tv_value_scale != 0.f ? d.tv_value_scale : 1.f, vals, FP(L.losses));
         RC(dbw_check_launch("loss_finish_kernel"));
         // everything of Rg that the other streams wait for is done here: the copy to the host (of values outside the zero arena) is nobody's
         // business but the host's -- behind the signal, so that neither the env chain nor Adam ever waits for a transfer
@@ -676,6 +696,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                                 IP(L.e.c2o), IP(L.e.code), FP(L.e.cw), FP(L.g_fvc_e), FP(L.g_env_verts), st));
         RC(dbw_posed_mesh_bwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, FP(L.g_env_verts) + (size_t)d.n_sky_verts * 3,
                               d.g_R6_ground, d.g_T_ground, st));
+        if (defer) return DBW_OK;
         // (Rg: the TV gradients of the sky / ground maps -- and, for M behind this chain: d / d alpha_full, the pose gradients of the overlap term)
         if (two) RC(await(st, F_REG, p->ev_reg));
         dbw_texture_set env_sets[2] = {sets[0], sets[2]};
@@ -719,8 +740,9 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // of the gradient bytes -- as soon as ev_blocks_ready says so, next to everything below.  It needs the TV gradient of the blocks' maps
     // (Rg): data parallel M waits for it here; on one GPU the launch moves behind the join with the env chain (which has waited for Rg), so
     // that M pays for one wait instead of two
-    const bool early_textures = two && !in->with_adam;
+    const bool early_textures = two && !in->with_adam && !defer;
     auto blocks_textures = [&]() -> int {
+        if (defer) return DBW_OK;
         dbw_texture_set blk = sets[1];
         if (!tv) blk.grad_sig = nullptr;
         RC(dbw_texture_prep_bwd_sets(&blk, 1, M));
@@ -735,6 +757,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                             IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
     if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
     if (two) RC(await(M, F_ENV_DONE, p->ev_env_done));           // the env chain, and through it the regularisers (E waited for Rg)
+    if (two && defer) RC(await(M, F_REG, p->ev_reg));            // (... which it did not when the texture tail is deferred)
     if (!early_textures) RC(blocks_textures());
     if ((d.fuse & 8) && (d.fuse & 1)) {
         BlocksTailArgs A;
@@ -763,6 +786,24 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 #undef PROF
 #undef FP
 #undef IP
+}
+
+extern "C" int dbw_train_step_finish(dbw_step_plan *p, const dbw_step_inputs *in, dbw_stream_t stream) {
+    DBW_REQUIRE(p && in, "null pointer");
+    DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
+    const dbw_step_desc &d = p->d;
+    const Layout &L = p->L;
+    hipStream_t M = (hipStream_t)stream;
+    dbw_texture_set sets[3];
+    fill_texture_sets(d, L, p->ws, sets);
+    if (tv_on(d)) add_tv_fields(L, p->ws, sets);
+    RC(dbw_texture_prep_bwd_sets(sets, 3, M));
+    if (in->with_adam) {
+        RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
+                                p->ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+        p->arena_clean = true;
+    }
+    return DBW_OK;
 }
 
 extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t stream) {

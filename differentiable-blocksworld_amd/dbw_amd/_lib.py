@@ -51,14 +51,14 @@ class StepDesc(ctypes.Structure):
                                       'g_sq_eps', 'g_S', 'g_R6', 'g_T', 'g_alpha_logit', 'g_R6_ground', 'g_T_ground', 'g_texture_bkg', 'g_texture_ground',
                                       'g_textures', 'flat_param', 'flat_grad', 'exp_avg', 'exp_avg_sq')]
                 + [('group_end', c_i64 * 2), ('small_grads', c_p), ('n_small_grads', c_i), ('fuse', c_i), ('backward_order', c_i),
-                   ('binned_concurrent', c_i), ('serial_setup_max_views', c_i), ('seed', ctypes.c_uint64), ('sync_events', c_i)])
+                   ('binned_concurrent', c_i), ('serial_setup_max_views', c_i), ('seed', ctypes.c_uint64), ('sync_events', c_i), ('tv_value_scale', ctypes.c_float)])
 
 
 class StepInputs(ctypes.Structure):
     """dbw_step_inputs of include/dbw_hip.h."""
     _fields_ = [('imgs', c_p), ('imgs_tiled', c_i), ('R', c_p), ('T', c_p), ('B', c_i), ('global_count', c_d), ('noise_override', c_p),
                 ('overlap_u_override', c_p), ('with_adam', c_i), ('adam_step', c_i), ('lr', c_f * 2), ('beta1', c_f), ('beta2', c_f), ('adam_eps', c_f),
-                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('single_stream', c_i), ('arena_is_clean', c_i)]
+                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('single_stream', c_i), ('arena_is_clean', c_i), ('defer_textures', c_i)]
 
 
 def texture_sets(sets):
@@ -108,6 +108,7 @@ SIGNATURES = {
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
+    'dbw_train_step_finish': [c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
     'dbw_train_step_sync_timeouts': [c_p],

@@ -116,7 +116,7 @@ class CStep:
         except Exception:
             pass
 
-    def _plan_for(self, inp, B):
+    def _plan_for(self, inp, B, defer=False):
         m = self.m
         coarse = m.is_live('coarse_learning')
         decim = int(m.decim_factor) if m.is_live('decimate_txt') else 1
@@ -128,7 +128,7 @@ class CStep:
         if seq is None:
             # data parallel: the fg kernel first and alone (its texture gradient is then final early: the all-reduce of that slice runs next to
             # the env chain); one GPU: both backward kernels at once.  (Texture bins: the library adds the order of its own, see binned_concurrent)
-            seq = 1 if m.world_size > 1 else 0
+            seq = 1 if (m.world_size > 1 and not defer) else 0
         both = self.binned_concurrent
         if both is None:
             both = m.world_size == 1
@@ -136,7 +136,7 @@ class CStep:
         key = (coarse, decim, decim_blocks, max_views, m.world_size, self.fuse, int(seq), int(bool(both)), Kt.data_ptr(), m.R_world.data_ptr(),
                m.R_world._version, m.T_world._version, float(m.S_world),
                self.params.flat.data_ptr(), tuple(sorted(m.loss_weights.items())), float(m.opacity_noise or 0.0), bool(m.kill_blocks),
-               int(self.serial_setup_max_views), bool(self.sync_events))
+               int(self.serial_setup_max_views), bool(self.sync_events), bool(defer))
         if key in self._plans:
             self._cur = self._plans[key]
             return self._cur
@@ -163,7 +163,10 @@ class CStep:
         masked = fine or m.kill_blocks
         d.mask_threshold = (0.5 if fine else 0.01) if masked else -1.0
         tv_f = 1.0 if coarse else 0.1
-        tv = float(w['tv']) * tv_f * rs if 'tv' in w else 0.0
+        # (deferred texture gradients: the TV gradient is added on every rank BEHIND the all-reduce -- full weight in the kernels, the reported
+        # value scaled instead, include/dbw_hip.h: tv_value_scale)
+        tv = float(w['tv']) * tv_f * (1.0 if defer else rs) if 'tv' in w else 0.0
+        d.tv_value_scale = rs if defer else 1.0
         d.w_rgb = float(w['rgb'])
         d.w_parsimony = float(w['parsimony']) * rs if ('parsimony' in w and coarse) else 0.0
         d.w_tv_bkg, d.w_tv_blocks, d.w_tv_ground = tv, tv, tv * tv_f
@@ -241,6 +244,28 @@ class CStep:
             _lib.call('dbw_train_step_profile', self._cur[0], 0)
         return dict(zip(('env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'), [a / reps for a in acc]))
 
+    def map_grads(self):
+        """The gradient of the prepared texture maps (blocks, sky, ground) of the current plan: one range of its zero arena.  With
+        `defer_textures` this -- not the texture gradient: 1 / 64 of its bytes while the maps are decimated 8 x 8 -- is what data-parallel
+        ranks sum, next to the small gradients at the head of the flat buffer."""
+        lib = _lib.load()
+        a, b = lib.dbw_train_step_offset(self._cur[0], 13), lib.dbw_train_step_offset(self._cur[0], 14)
+        return self._cur[1][a:b].view(torch.float32)
+
+    def finish(self, adam=None):
+        """Behind a step with `defer_textures` and the caller's all-reduce: the backward of the texture preparation (+ the TV gradient), then
+        Adam (`adam` as in __call__), which clears the zero arena."""
+        a = self._inp
+        if adam is not None:
+            step, lrs, betas, eps = adam
+            a.with_adam, a.adam_step = 1, int(step)
+            a.lr[0], a.lr[1], a.beta1, a.beta2, a.adam_eps = float(lrs[0]), float(lrs[1]), float(betas[0]), float(betas[1]), float(eps)
+        else:
+            a.with_adam = 0
+        dev = self.params.flat.device
+        with torch.cuda.device(dev):
+            _lib.call('dbw_train_step_finish', self._cur[0], ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+
     def sync_timeouts(self):
         """Cross-stream waits of the current plan that gave up (never, in a healthy process); synchronises the device."""
         return _lib.load().dbw_train_step_sync_timeouts(self._cur[0])
@@ -251,7 +276,7 @@ class CStep:
         _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------
-    def __call__(self, inp, global_count=None, adam=None, tiled_target=True):
+    def __call__(self, inp, global_count=None, adam=None, tiled_target=True, defer_textures=False):
         """Enqueue forward + backward (+ Adam when `adam` = (step, (lr, lr_texture), (beta1, beta2), eps)) of one iteration on this rank's
         views.  -> StepLosses.  tiled_target: keep the targets in the tile-planar layout across steps while the SAME tensor comes back
         (resident training views); a fresh mini-batch is tiled by the step itself."""
@@ -260,7 +285,7 @@ class CStep:
         dev = imgs.device
         m._ensure_cameras(inp)
         B = imgs.shape[0]
-        handle, wsb, _ = self._plan_for(inp, B)
+        handle, wsb, _ = self._plan_for(inp, B, defer_textures)
         R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
         imgs = ops._chk(imgs, torch.float32, 'imgs')
         a = self._inp
@@ -283,6 +308,7 @@ class CStep:
             a.lr[0], a.lr[1], a.beta1, a.beta2, a.adam_eps = float(lrs[0]), float(lrs[1]), float(betas[0]), float(betas[1]), float(eps)
         else:
             a.with_adam = 0
+        a.defer_textures = int(bool(defer_textures))
         a.read_losses = int(self.read_losses)
         a.arena_is_clean = int(self._arena_cleaned_by_caller)
         self._arena_cleaned_by_caller = False

@@ -96,6 +96,7 @@ class ShardedTrainStep:
             overlap_allreduce = dist.is_initialized() and dist.get_backend(process_group) == 'nccl' and self.world_size > 1
         self.overlap_allreduce = bool(overlap_allreduce) and dist.is_initialized() and self._early_range is not None
         self._early_work, self._early_done = None, False
+        self.defer_textures = True        # data parallel through the C step: sum the prepared maps' gradient, not the textures' (_c_iteration)
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
             s = torch.tensor([seed if seed is not None else 0], dtype=torch.int64)
@@ -173,16 +174,25 @@ class ShardedTrainStep:
         return losses
 
     def _c_iteration(self, inp):
-        """The iteration through the C step.  One GPU: everything, Adam included, in the one call.  Data parallel: the call stops in front
-        of Adam; the blocks' texture gradient is reduced as soon as the step has it (it records an event behind the backward of the
-        blocks' texture preparation, the first kernel of the fg tail), the rest behind the step; then the fused Adam, which also clears
-        the step's zero arena."""
+        """The iteration through the C step.  One GPU: everything, Adam included, in the one call.  Data parallel: the call stops in front of
+        the backward of the texture preparation; the ranks sum the gradient of the PREPARED maps (sigmoid and decimation are linear behind it:
+        with 8x-decimated maps 1 / 64 of the texture gradient's bytes, 0.15 instead of 9.4 MB at config 2) and the 159 small gradients; a
+        second call runs that backward -- adding the TV gradient, which every rank holds in full -- and Adam, which clears the step's zero
+        arena.  A mini-batch with fewer views than ranks (some rank's shard is empty and takes the launch-by-launch path) is reduced the old
+        way on every rank -- the whole flat buffer, the blocks' texture slice early -- so that all ranks issue the same collectives."""
         cs = self.cstep
         distributed = self.world_size > 1 or self.overlap_allreduce
         with torch.no_grad():
             if not distributed:
                 losses = cs(inp, self.model._global_count, adam=(self.n_steps + 1, self.lrs, self.betas, self.eps))
                 self.n_steps += 1
+                return losses
+            if self._defer_textures(inp):
+                losses = cs(inp, self.model._global_count, adam=None, defer_textures=True)
+                small = self.params.grad[:self.params.bounds[0][1]]
+                self._allreduce_all([cs.map_grads(), small])
+                self.n_steps += 1
+                cs.finish(adam=(self.n_steps, self.lrs, self.betas, self.eps))
                 return losses
             losses = cs(inp, self.model._global_count, adam=None)
             if self.overlap_allreduce:
@@ -204,6 +214,25 @@ class ShardedTrainStep:
                                   self.lrs, self.n_steps, self.betas, self.eps, zero=cs.arena())
             cs._arena_cleaned_by_caller = True
         return losses
+
+    def _defer_textures(self, inp):
+        """Whether this step sums the map gradients instead of the texture gradients: every rank must decide the same, from what every rank
+        knows -- the size of the GLOBAL batch (a batch with fewer views than ranks leaves some rank without views, and that rank's step is
+        not the C step)."""
+        if not self.defer_textures:
+            return False
+        per_view = float(inp['imgs'][0].numel()) if inp['imgs'].shape[0] > 0 else 0.0
+        return per_view > 0 and self.model._global_count / per_view >= self.world_size
+
+    def _allreduce_all(self, tensors):
+        """Sum all-reduce of several small buffers: one coalesced collective where the backend has it (RCCL: one launch), else one each."""
+        if dist.get_backend(self.pg) == 'nccl' and all(t.is_cuda for t in tensors) and hasattr(dist, '_coalescing_manager'):
+            with dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False):
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        for t in tensors:
+            self._allreduce(t)
 
     def _fused_adam(self):
         return self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda

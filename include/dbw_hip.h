@@ -432,6 +432,10 @@ typedef struct dbw_step_desc {
                                                  * event costs the stream that records or waits for it 7-11 us before its next kernel and the
                                                  * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.
                                                  * != 0: HIP events (hipEventRecord / hipStreamWaitEvent) */
+    float tv_value_scale;                       /* 0 (= 1): factor on the REPORTED total-variation value only.  Data parallel with deferred texture
+                                                 * gradients (dbw_step_inputs.defer_textures): the TV gradient is added on every rank AFTER the
+                                                 * all-reduce, so the kernels take the full weight (w_tv_*) and the value a rank reports is scaled by
+                                                 * 1 / world_size here, as the other view-independent terms are through their weights */
 } dbw_step_desc;
 
 typedef struct dbw_step_inputs {
@@ -457,6 +461,12 @@ typedef struct dbw_step_inputs {
     int arena_is_clean;                         /* != 0: the caller cleared the zero arena (dbw_train_step_offset 4 / 5) since the last run --
                                                  * it does when it runs Adam itself through dbw_adam_step_groups(zero_buf = the arena);
                                                  * otherwise a run that does not follow a run with_adam clears the arena with a fill of its own */
+    int defer_textures;                         /* != 0 (needs with_adam == 0): stop in front of the backward of the texture preparation too.  The
+                                                 * gradient of the PREPARED maps (dbw_train_step_offset 13 .. 14: sigmoid + decimation are linear
+                                                 * behind it) is then what a data-parallel caller sums over the ranks -- with 8x-decimated maps
+                                                 * 1 / 64 of the texture gradient's bytes (0.15 instead of 9.4 MB at config 2) -- next to the 159
+                                                 * small gradients in flat_grad; dbw_train_step_finish then runs that backward (adding the TV
+                                                 * gradient, which every rank holds in full) and Adam */
 } dbw_step_inputs;
 
 typedef struct dbw_step_plan dbw_step_plan;
@@ -469,13 +479,18 @@ void dbw_train_step_destroy(dbw_step_plan *plan);
  * backward chain and the regularisers run next to it: on stream_side if the caller brings one, else (NULL) on the library's own
  * lowest-priority streams; dbw_step_inputs.single_stream: everything in order on stream_main.  On return nothing has been waited for. */
 int dbw_train_step_run(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream_main, dbw_stream_t stream_side);
+/* Behind a run with defer_textures (and the caller's all-reduce of the map gradients and the small gradients, ordered on `stream`): the
+ * backward of the texture preparation of all three tensors, then -- in->with_adam -- Adam, which clears the zero arena.  Reads of `in`:
+ * with_adam, adam_step, lr, beta1, beta2, adam_eps */
+int dbw_train_step_finish(dbw_step_plan *plan, const dbw_step_inputs *in, dbw_stream_t stream);
 /* Blocks until the loss values of the last run with read_losses != 0 are in host memory: out5 = rgb, parsimony, tv, overlap, total */
 int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
 /* Byte offset inside the workspace of one of the plan's buffers (tests, diagnostics, host-side views of per-step state):
  * which = 0 alpha (n_blocks), 1 alpha_full, 2 keep (int32), 3 loss values on the device (5 floats, valid after a run), 4 / 5 begin / end of
  * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
  * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials, 11 / 12 the env scene's hard uv-fragments (face ids;
- * u, v, face | map); -1 for an unknown name */
+ * u, v, face | map), 13 / 14 begin / end of the gradient of the prepared maps (blocks, sky, ground: one range inside the zero arena; what
+ * a data-parallel caller all-reduces with defer_textures); -1 for an unknown name */
 int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 /* Makes `stream` wait until the blocks' texture gradient of the last run is final.  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
  * own while the rest of the step still runs. */

@@ -40,6 +40,8 @@ def test_bench_two_ranks_through_torchrun(scaling):
     assert o['scaling'] == ('strong' if scaling == 'weak' else 'weak') and o['value'] > 0 and o['ms_per_step'] > 0
     assert o['views_per_step'] == (6 if scaling == 'weak' else 12) and o['views_on_rank0'] == (3 if scaling == 'weak' else 6)
     assert d['ms_per_step_overlap_allreduce_off'] is None or d['ms_per_step_overlap_allreduce_off'] > 0
+    # the ranks sum the gradient of the prepared maps + the small gradients; the step with the whole flat buffer reduced is timed next to it
+    assert 0 < d['allreduce_bytes'] < 2.0e6 and d['ms_per_step_flat_allreduce'] > 0 and 'prepared texture maps' in d['config']['parallelism']
     assert 'C-ABI call per iteration' in d['config']['launch']
 
 

@@ -320,3 +320,36 @@ def test_c_step_streams_wait_through_memory_words_as_through_events(epoch):
         assert step.cstep.sync_timeouts() == 0
         res.append((step, vals, grad1, step.params.flat.clone()))
     _compare(res[0], res[1], res[0][0].params.names)
+
+
+@pytest.mark.parametrize('epoch', [0, 800, 1600])
+def test_c_step_with_the_texture_tail_deferred_equals_the_step_in_one_call(epoch):
+    """dbw_step_inputs.defer_textures + dbw_train_step_finish: what a data-parallel rank runs around its all-reduce of the prepared maps'
+    gradient (here: no other rank, nothing to add) is the step in one call -- loss values, gradient buffer, parameters after Adam; the
+    range it would reduce holds the maps' gradient and nothing else of the arena."""
+    inp = _inputs(3, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for defer in (False, True):
+        model = _model(epoch)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        cs = step.cstep
+        grads = None
+        for it in range(3):
+            adam = (it + 1, step.lrs, step.betas, step.eps)
+            if defer:
+                out = cs(inp, None, adam=None, defer_textures=True)
+                if it == 0:
+                    mg = cs.map_grads()
+                    decim = 8 if epoch < 750 else 1
+                    assert mg.numel() >= (4 * 32 * 32 * 3 + 2 * 32 * 32 * 3) // decim ** 2 and float(mg.abs().max()) > 0
+                cs.finish(adam=adam)
+            else:
+                out = cs(inp, None, adam=adam)
+            torch.cuda.synchronize()
+            if it == 0:
+                vals, grads = {k: float(v) for k, v in out.items()}, step.params.grad.clone()
+        res.append((step, vals, grads, step.params.flat.clone()))
+    _compare(res[0], res[1], res[0][0].params.names)

@@ -42,13 +42,15 @@ def _run_nccl_single(rank, port, out):
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     res = []
-    for overlap in (False, True):
-        if overlap:
+    for overlap, defer in ((False, True), (True, False), (True, True)):
+        # (no group; the whole gradient buffer reduced with its early slice overlapped; the prepared maps' gradient reduced instead)
+        if overlap and not dist.is_initialized():
             dist.init_process_group('nccl', rank=0, world_size=1)
         torch.manual_seed(227391)
         model = dbw_amd.create_model(_cfg(), (H, W)).to(dev).train()
         model.sync_free = True
         step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, overlap_allreduce=overlap)
+        step.defer_textures = defer
         assert step.overlap_allreduce == overlap
         views = {k: v.to(dev) for k, v in _views().items()}
         for _ in range(3):
@@ -56,7 +58,7 @@ def _run_nccl_single(rank, port, out):
         torch.cuda.synchronize()
         res.append(step.params.flat.detach().cpu().clone())
     dist.destroy_process_group()
-    out[0] = float((res[0] - res[1]).abs().max())
+    out[0] = max(float((res[0] - res[1]).abs().max()), float((res[0] - res[2]).abs().max()))
 
 
 
@@ -74,7 +76,7 @@ def test_overlapped_allreduce_on_a_one_rank_rccl_group_leaves_the_step_unchanged
     assert out[0] < 1e-4, out[0]          # (atomics order: not bit-identical from run to run)
 
 
-def _run(rank, world, port, out, n_views=V, n_steps=3):
+def _run(rank, world, port, out, n_views=V, n_steps=3, defer=True):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, 'differentiable-blocksworld_amd'), os.path.join(root, 'oracle')):
@@ -91,6 +93,7 @@ def _run(rank, world, port, out, n_views=V, n_steps=3):
     model.sync_free = True
     # overlapped all-reduce: the native step announces the blocks' texture gradient from its side stream, the rest follows the step
     step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99, overlap_allreduce=world > 1)
+    step.defer_textures = defer          # True: the ranks sum the gradient of the prepared maps; False: the whole flat buffer, its early slice overlapped
     assert step.overlap_allreduce == (world > 1) and step.native is not None and step.native.on_block_grads_ready is not None
     views = {k: v.to(dev) for k, v in _views(n_views).items()}
     a, b = shard_views(n_views, world, rank)
@@ -107,11 +110,14 @@ def _run(rank, world, port, out, n_views=V, n_steps=3):
         dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_one_gpu_reproduce_the_full_batch_step():
+@pytest.mark.parametrize('defer', [True, False])
+def test_two_ranks_sharing_one_gpu_reproduce_the_full_batch_step(defer):
+    """Two ranks with shards of 3 and 2 views against one process with all 5: whether the ranks sum the gradient of the prepared maps
+    (defer: the C step's data-parallel flow) or the whole flat gradient buffer with the blocks' texture slice overlapped."""
     mgr = _manager()
     ref, out = mgr.dict(), mgr.dict()
     mp.spawn(_run, args=(1, 0, ref), nprocs=1, join=True)                     # single process, all 5 views (its own CUDA context)
-    mp.spawn(_run, args=(2, 29517, out), nprocs=2, join=True)                 # shards of 3 and 2 views
+    mp.spawn(_run, args=(2, 29517 + int(defer), out, V, 3, defer), nprocs=2, join=True)                 # shards of 3 and 2 views
     g_ref, p_ref, names = ref[0]
     for s in range(3):
         assert torch.equal(out[0][1][s], out[1][1][s]), f'replicas diverged at step {s}'           # (i) bit-identical replicas
