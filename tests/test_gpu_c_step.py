@@ -353,3 +353,27 @@ def test_c_step_with_the_texture_tail_deferred_equals_the_step_in_one_call(epoch
                 vals, grads = {k: float(v) for k, v in out.items()}, step.params.grad.clone()
         res.append((step, vals, grads, step.params.flat.clone()))
     _compare(res[0], res[1], res[0][0].params.names)
+
+
+def test_c_step_through_the_three_training_phases_and_back_no_wait_ever_gives_up():
+    """A few hundred iterations across the phase changes of the schedule (a plan per phase, the library's side streams shared by all of
+    them, the host running ahead of the GPU and reading the loss values now and then): finite, decreasing, and none of the polls through
+    which the streams wait for each other gave up."""
+    inp = _inputs(4, 48, 64)
+    model = _model(0, kill=False)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=5)
+    step.cstep.read_losses = True
+    first = {}
+    for epoch in (0, 800, 1600, 0, 1600):
+        model.set_cur_epoch(epoch)
+        for it in range(60):
+            out = step(inp)
+            if it % 7 == 0:
+                vals = out.host()
+                assert all(v == v and abs(v) < 1e3 for v in vals.values()), (epoch, it, vals)
+                first.setdefault(epoch, vals['rgb'])
+                last = vals['rgb']
+        assert last < first[epoch] * 1.05, (epoch, first[epoch], last)
+        torch.cuda.synchronize()
+        assert step.cstep.sync_timeouts() == 0
+    assert len(step.cstep._plans) == 3
