@@ -297,7 +297,11 @@ struct LdsAgg {
         unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2_SLOTS);
 #pragma unroll 1
         for (int p = 0; p < 8; ++p) {
+#ifdef DBW_ABL_NOCAS        // (tools/diag ablation: what the claim's round trip costs -- the slot is taken unseen, the sums are wrong)
+            const int old = key; keys[h] = key;
+#else
             const int old = atomicCAS(&keys[h], -1, key);
+#endif
             if (old == -1 || old == key) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)

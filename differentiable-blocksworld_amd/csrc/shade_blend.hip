@@ -548,7 +548,11 @@ struct FaceAlphaAgg {      // key = clipped face id -> 6 vertex xy-gradients + 1
         unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2);
 #pragma unroll 1
         for (int p = 0; p < 8; ++p) {
+#ifdef DBW_ABL_NOCAS
+            const int old = key; keys[h] = key;
+#else
             const int old = atomicCAS(&keys[h], -1, key);
+#endif
             if (old == -1 || old == key) {
                 aux[h] = aidx;                      // every lane of a face writes the same opacity index
 #pragma unroll
