@@ -567,6 +567,27 @@ struct FaceAlphaAgg {      // key = clipped face id -> 6 vertex xy-gradients + 1
             if (v[c] != 0.f) unsafeAtomicAdd(gfv + (long long)key * 9 + (c >> 1) * 3 + (c & 1), v[c]);
         if (v[6] != 0.f && galpha) unsafeAtomicAdd(galpha + aidx, v[6]);
     }
+    // (the claim split from the add, as LdsAgg::claim / add_claimed)
+    __device__ __forceinline__ unsigned home(int key) const { return ((unsigned)key * 2654435761u) >> (32 - LOG2); }
+    __device__ __forceinline__ int claim(unsigned h, int key) { return atomicCAS(&keys[h], -1, key); }
+    __device__ __forceinline__ void add_claimed(float *__restrict__ gfv, float *__restrict__ galpha, int key, int aidx, unsigned h, int old, const float (&v)[NV]) {
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            if (p > 0) old = atomicCAS(&keys[h], -1, key);
+            if (old == -1 || old == key) {
+                aux[h] = aidx;
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
+                return;
+            }
+            h = (h + 1) & (NSLOT - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (v[c] != 0.f) unsafeAtomicAdd(gfv + (long long)key * 9 + (c >> 1) * 3 + (c & 1), v[c]);
+        if (v[6] != 0.f && galpha) unsafeAtomicAdd(galpha + aidx, v[6]);
+    }
     __device__ __forceinline__ void flush(float *__restrict__ gfv, float *__restrict__ galpha, int tid, int nthreads) {
         for (int i = tid; i < NSLOT; i += nthreads) {
             const int k = keys[i];
@@ -624,6 +645,10 @@ constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_S
 #define DBW_FACE_MERGE_BINNED 1
 #endif
 constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
+// (round 4, off: the table claims of a layer issued together / ahead of the work in front of their use -- measured slower, see the layer loop)
+#ifndef DBW_CLAIM_AHEAD
+#define DBW_CLAIM_AHEAD 0
+#endif
 #ifndef DBW_UVB_WAVES
 #define DBW_UVB_WAVES 4      // (the binned instantiation keeps two layers of fragments + one of vertices in flight: 4 waves of 128 VGPRs, no spills --
                              // a spill reload in the layer loop is a vmcnt(0); 4 / 5 / 6 waves per SIMD measured alike before)
@@ -825,6 +850,22 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
         const float gd = (valid && A.sigma != 0.f && cur.d >= 0.f) ? ga * ak * -A.inv_sigma : 0.f;
         const float gc[3] = {wgt * gr, wgt * gg, wgt * gbl};
         const bool tex = valid && (gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f) && !(BINNED && (A.dbg & (1 << 19)));
+        float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
+        if (alpha_direct) {
+            if (g7[6] != 0.f) atomicAdd(&alpha_dir[map * ALPHA_DIRECT_SPREAD + (lane & (ALPHA_DIRECT_SPREAD - 1))], (double)g7[6]);
+            g7[6] = 0.f;
+        }
+        // DBW_CLAIM_AHEAD (off): the face table's slot claimed HERE, its answer taken behind the texel part and the distance backward, and the
+        // two texel taps' claims issued together -- one LDS round trip per layer where three follow each other (43 of the kernel's 302 us by
+        // ablation, profiles/r04_experiments.md).  Measured: alone 0.291 -> 0.318 ms, the step 0.974 -> 1.002 ms (49 views), epoch 800
+        // 1.370 -> 1.392.  Returning LDS atomics that go out back to back queue behind each other's same-address replays (round 3 saw the
+        // same with five in a row); spaced by the work between them they cost less than their latency says.
+        const bool f_pre = valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2);
+#if DBW_CLAIM_AHEAD
+        const unsigned hf = fa_agg.home(cur.fc);
+        int cf = 0;
+        if (f_pre) cf = fa_agg.claim(hf, cur.fc);
+#endif
         PROF_T(t_a);
         PROF_ADD(2, t_it, t_a);
         if (BINNED) {
@@ -895,6 +936,27 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             const int f = wt[1] != 0.f ? 1 : (wt[2] != 0.f ? 2 : 3);
             const int a2[2] = {ad[0], f == 1 ? ad[1] : (f == 2 ? ad[2] : ad[3])};
             const float w2[2] = {wt[0], f == 1 ? wt[1] : (f == 2 ? wt[2] : wt[3])};
+#if DBW_CLAIM_AHEAD
+            // (both claims issued before either answer is looked at: one LDS round trip for the two passes)
+            float v3[2][3];
+            bool on2[2];
+            int key2[2], c2[2] = {0, 0};
+            unsigned h2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v3[q][0] = gc[0] * w2[q]; v3[q][1] = gc[1] * w2[q]; v3[q][2] = gc[2] * w2[q];
+                on2[q] = tex && w2[q] != 0.f && !(A.dbg & 1);
+                key2[q] = (int)((unsigned)a2[q] / 3u);
+                if (TEX_MERGE > 0 && __ballot(on2[q]) != 0ull) lane_merge<3, TEX_MERGE>(key2[q], on2[q], v3[q]);
+                h2[q] = tex_agg.home(key2[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (on2[q]) c2[q] = tex_agg.claim(h2[q], key2[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (on2[q]) tex_agg.add_claimed(gmaps, key2[q], h2[q], c2[q], v3[q]);
+#else
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float v3[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
@@ -902,6 +964,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
                 if (TEX_MERGE > 0 && __ballot(on) != 0ull) lane_merge<3, TEX_MERGE>((int)((unsigned)a2[q] / 3u), on, v3);
                 if (on) tex_agg.add(gmaps, (int)((unsigned)a2[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
             }
+#endif
             const bool rest = tex && !(A.dbg & 1) && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
             if (__ballot(rest) != 0ull) {
 #pragma unroll
@@ -915,11 +978,6 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
         PROF_T(t_b);
         PROF_ADD(4, t_a, t_b);
         // distance -> the two vertices of the closest edge; opacity; one table update per fragment
-        float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (galpha && valid) ? ga * e : 0.f};
-        if (alpha_direct) {
-            if (g7[6] != 0.f) atomicAdd(&alpha_dir[map * ALPHA_DIRECT_SPREAD + (lane & (ALPHA_DIRECT_SPREAD - 1))], (double)g7[6]);
-            g7[6] = 0.f;
-        }
         if (__ballot(gd != 0.f) != 0ull && !(A.dbg & 16)) {
             f2 v0, v1, v2;
             if (PIPE) { v0 = f2{curq.v0.x, curq.v0.y}; v1 = f2{curq.v1.x, curq.v1.y}; v2 = f2{curq.v2.x, curq.v2.y}; }
@@ -955,12 +1013,16 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             STAT_ADD(0, 1); STAT_ADD(4, __popcll(__ballot(f_on))); STAT_ADD(5, dk); STAT_ADD(6, rp);
         }
 #endif
-        bool f_on = valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2);
+        bool f_on = f_pre;
         constexpr int FM = BINNED ? DBW_FACE_MERGE_BINNED : FACE_MERGE;
         if (FM > 0 && __ballot(f_on) != 0ull) lane_merge<7, FM>(cur.fc, f_on, g7);
         if (f_on) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
+#if DBW_CLAIM_AHEAD
+            fa_agg.add_claimed(gfv, galpha, cur.fc, aidx, hf, cf, g7);
+#else
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
+#endif
         }
         PROF_T(t_d);
         PROF_ADD(6, t_c, t_d);
