@@ -572,7 +572,7 @@ def main():
                                  ('' if args.no_overlap else ', env backward chain and regularisers on side streams' +
                                   ((' that wait through HIP events' if step.cstep.sync_events else ' that wait through polled words in device memory') if step.cstep is not None else '')) +
                                  ('' if step.native is None else ', native step (no autograd)'),
-                       'parallelism': f'view-sharded dp{world}, ' + (
+                       'parallelism': 'one GPU: all views on it, no collective' if world == 1 else f'view-sharded dp{world}, ' + (
                            f'{(allreduce_bytes or 0) / 1e6:.2f} MB all-reduced per step over RCCL: the gradient of the prepared texture maps (sigmoid + '
                            f'decimation are linear behind it) + the small gradients, instead of the {step.params.flat.numel() * 4 / 1e6:.1f} MB gradient buffer'
                            if deferred else
