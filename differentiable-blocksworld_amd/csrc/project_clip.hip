@@ -12,6 +12,7 @@
 #include "shade_common.h"
 #include "raster_bin.h"
 #include "step_kernels.h"
+#include "texture_body.h"
 #include "../../include/dbw_hip.h"
 
 using namespace dbw;
@@ -197,6 +198,18 @@ __global__ __launch_bounds__(NT) void project_clip_bwd_kernel(
     project_clip_bwd_body<LDS_TABLE>(verts, faces, R, T, Kmat, B, V, F, eps, zc, persp, num_faces, c2o, code, cw, gfvc, gverts, s_acc, blockIdx.x);
 }
 
+// ---- training step: the blocks' projection backward next to the backward of their texture preparation (step_kernels.h) -----------------
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(NT) void clip_bwd_tex_kernel(const ClipBwdArgs C, const dbw_texture_set t, int nclip) {
+    extern __shared__ float s_acc[];   // LDS_TABLE: V * 3
+    if ((int)blockIdx.x < nclip)
+        project_clip_bwd_body<LDS_TABLE>(C.verts, C.faces, C.R, C.T, C.Kmat, C.B, C.V, C.F, C.eps, C.zc, C.persp, C.num_faces, C.c2o, C.code, C.cw, C.gfvc,
+                                         C.gverts, s_acc, blockIdx.x);
+    else
+        texture_prep_bwd_body(t.texture, t.n, t.h, t.w, t.decim, t.grad_maps, t.grad_sig, t.grad_texture, (long long)blockIdx.x - nclip,
+                              (long long)gridDim.x - nclip);
+}
+
 // ---- training step: camera transform + near-plane clipping + per-face raster records (+ shading records) of both scenes -----------------
 // One workgroup per (chunk of 256 faces, view, scene).  The slots of a view's clipped faces are assigned in face order (a face emits 0,
 // 1 or 2 triangles): a workgroup first COUNTS what the faces in front of its chunk emit -- a face's count follows from the view depths
@@ -314,6 +327,22 @@ __global__ __launch_bounds__(NT) void scene_setup_kernel(const SceneSetupArgs A)
 }
 
 }  // namespace
+
+int dbw::launch_clip_bwd_tex(const ClipBwdArgs &C, const dbw_texture_set &t, hipStream_t s) {
+    DBW_REQUIRE(C.verts && C.faces && C.R && C.T && C.Kmat && C.num_faces && C.c2o && C.code && C.cw && C.gfvc && C.gverts, "null pointer");
+    DBW_REQUIRE(C.B > 0 && C.V > 0 && C.F > 0, "bad size");
+    DBW_REQUIRE(t.texture && t.grad_maps && t.grad_texture && t.n > 0 && t.h > 0 && t.w > 0 && t.decim >= 1, "bad texture set");
+    const long long work = (long long)t.n * t.h * t.w * 3;
+    long long ntex = (work + NT - 1) / NT;
+    if (ntex > 4096) ntex = 4096;
+    const bool table = (size_t)C.V * 3 * sizeof(float) <= 48 * 1024;
+    const int nclip = table ? (2 * C.F + BWD_SLOTS - 1) / BWD_SLOTS : (2 * C.F + NT / DBW_WAVE - 1) / (NT / DBW_WAVE);
+    if (table)
+        hipLaunchKernelGGL(clip_bwd_tex_kernel<true>, dim3((unsigned)(nclip + ntex)), dim3(NT), (size_t)C.V * 3 * sizeof(float), s, C, t, nclip);
+    else
+        hipLaunchKernelGGL(clip_bwd_tex_kernel<false>, dim3((unsigned)(nclip + ntex)), dim3(NT), 0, s, C, t, nclip);
+    return dbw_check_launch("clip_bwd_tex_kernel");
+}
 
 int dbw::launch_scene_setup(const SceneSetupArgs &A, hipStream_t s) {
     DBW_REQUIRE(A.R && A.T && A.Kmat && A.B > 0, "bad argument");

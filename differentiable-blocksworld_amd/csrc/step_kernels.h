@@ -105,6 +105,14 @@ struct BlocksTailArgs {
 };
 int launch_blocks_tail(const BlocksTailArgs &A, hipStream_t s);
 
+// Tail of the fg chain: the backward of the projection + clipping of the blocks and the backward of their texture preparation do not
+// depend on each other -- one launch, the grid split between them (project_clip.hip), instead of two dependent ones
+struct ClipBwdArgs {
+    const float *verts; const int *faces; const float *R, *T, *Kmat; int B, V, F; float eps, zc; int persp;
+    const int *num_faces, *c2o, *code; const float *cw, *gfvc; float *gverts;
+};
+int launch_clip_bwd_tex(const ClipBwdArgs &C, const dbw_texture_set &tex, hipStream_t s);
+
 // the env layer folded into the fg pass (render_fused.hip): the env scene's workspace (per-tile lists and shading records filled by the
 // set-up kernels), its maps and background, and where its hard uv-fragments go (frag_layout 3: what the env backward reads)
 struct EnvFoldHost {

@@ -43,37 +43,15 @@ __global__ __launch_bounds__(256) void texture_prep_fwd_sets_kernel(const Textur
     texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig);
 }
 
-// elementwise: gtex = (gcell[cell of the texel] / d^2 + gsig) * s(1-s)
-__device__ __forceinline__ void texture_prep_bwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
-                                                      const float *__restrict__ gmaps, const float *__restrict__ gsig,
-                                                      float *__restrict__ gtex) {
-    const long long total = (long long)n * h * w * 3;
-    const float inv = 1.f / (float)(d * d);
-    const int ch_ = h / d, cw_ = w / d;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const float s = sigmoidf(tex[i]);
-        float g;
-        if (d <= 1) g = gmaps[i];
-        else {
-            const int k = (int)(i % 3);
-            const long long t = i / 3;
-            const int x = (int)(t % w), y = (int)((t / w) % h), m = (int)(t / ((long long)w * h));
-            g = gmaps[(((long long)m * ch_ + y / d) * cw_ + x / d) * 3 + k] * inv;
-        }
-        if (gsig) g += gsig[i];
-        gtex[i] = g * s * (1.f - s);
-    }
-}
-
 __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
                                         const float *__restrict__ gmaps, const float *__restrict__ gsig,
                                         float *__restrict__ gtex) {
-    texture_prep_bwd_body(tex, n, h, w, d, gmaps, gsig, gtex);
+    texture_prep_bwd_body(tex, n, h, w, d, gmaps, gsig, gtex, blockIdx.x, gridDim.x);
 }
 
 __global__ void texture_prep_bwd_sets_kernel(const TextureSets S) {
     const dbw_texture_set &t = S.s[blockIdx.y];
-    texture_prep_bwd_body(t.texture, t.n, t.h, t.w, t.decim, t.grad_maps, t.grad_sig, t.grad_texture);
+    texture_prep_bwd_body(t.texture, t.n, t.h, t.w, t.decim, t.grad_maps, t.grad_sig, t.grad_texture, blockIdx.x, gridDim.x);
 }
 
 // one thread per texel (its three channels); blockIdx.y = row (map * h + y): no integer division anywhere

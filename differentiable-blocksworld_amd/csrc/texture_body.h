@@ -46,5 +46,27 @@ __device__ __forceinline__ void texture_prep_fwd_body(const float *__restrict__ 
     }
 }
 
+// Backward of the preparation, elementwise: gtex = (gcell[cell of the texel] / d^2 + gsig) * s (1 - s).  A grid-stride loop over blocks
+// bid of nblk (a kernel that runs it next to something else gives it a slice of its own grid)
+__device__ __forceinline__ void texture_prep_bwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
+                                                      const float *__restrict__ gmaps, const float *__restrict__ gsig,
+                                                      float *__restrict__ gtex, long long bid, long long nblk) {
+    const long long total = (long long)n * h * w * 3;
+    const float inv = 1.f / (float)(d * d);
+    const int ch_ = h / d, cw_ = w / d;
+    for (long long i = bid * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
+        const float s = tex_sigmoid(tex[i]);
+        float g;
+        if (d <= 1) g = gmaps[i];
+        else {
+            const int k = (int)(i % 3);
+            const long long t = i / 3;
+            const int x = (int)(t % w), y = (int)((t / w) % h), m = (int)(t / ((long long)w * h));
+            g = gmaps[(((long long)m * ch_ + y / d) * cw_ + x / d) * 3 + k] * inv;
+        }
+        if (gsig) g += gsig[i];
+        gtex[i] = g * s * (1.f - s);
+    }
+}
 
 }  // namespace dbw

@@ -753,12 +753,24 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(await(M, F_REG, p->ev_reg));
         RC(blocks_textures());
     }
-    RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
-                            IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
+    // fuse bit 5: the blocks' projection backward and the backward of their texture preparation -- independent of each other -- in ONE launch
+    // behind the join, instead of one in front of it and one behind (a dependent launch less on the critical chain)
+    const bool tail_merged = (d.fuse & 32) && !early_textures && !defer;
+    if (!tail_merged)
+        RC(dbw_project_clip_bwd(FP(L.blk_verts), d.block_faces, in->R, in->T, d.Kmat, B, Vf, Ff, d.cam_eps, d.z_clip, d.perspective_correct, IP(L.f.num),
+                                IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), FP(L.g_fvc_f), FP(L.g_blk_verts), M));
     if (!two) { RC(env_backward(M)); RC(loss_values(M)); }
     if (two) RC(await(M, F_ENV_DONE, p->ev_env_done));           // the env chain, and through it the regularisers (E waited for Rg)
     if (two && defer) RC(await(M, F_REG, p->ev_reg));            // (... which it did not when the texture tail is deferred)
-    if (!early_textures) RC(blocks_textures());
+    if (tail_merged) {
+        ClipBwdArgs C;
+        C.verts = FP(L.blk_verts); C.faces = d.block_faces; C.R = in->R; C.T = in->T; C.Kmat = d.Kmat; C.B = B; C.V = Vf; C.F = Ff;
+        C.eps = d.cam_eps; C.zc = d.z_clip; C.persp = d.perspective_correct;
+        C.num_faces = IP(L.f.num); C.c2o = IP(L.f.c2o); C.code = IP(L.f.code); C.cw = FP(L.f.cw); C.gfvc = FP(L.g_fvc_f); C.gverts = FP(L.g_blk_verts);
+        dbw_texture_set blk = sets[1];
+        if (!tv) blk.grad_sig = nullptr;
+        RC(launch_clip_bwd_tex(C, blk, M));
+    } else if (!early_textures) RC(blocks_textures());
     if ((d.fuse & 8) && (d.fuse & 1)) {
         BlocksTailArgs A;
         memset(&A, 0, sizeof(A));

@@ -419,7 +419,8 @@ typedef struct dbw_step_desc {
     float *small_grads; int n_small_grads;      /* the accumulated (not fully written) gradients: cleared at the head of every run */
     /* ---- options ---- */
     int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail, 4: the env layer inside the
-                                                 * fg pass (no env pass, no env image; needs bit 1); 0 = the operator-level kernels */
+                                                 * fg pass (no env pass, no env image; needs bit 1), 5: the blocks' projection backward and the backward of
+                                                 * their texture preparation in one launch; 0 = the operator-level kernels */
     int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel) */
     int binned_concurrent;                      /* texture bins (which otherwise imply order 1): the env chain starts next to the fg kernel */
     int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);
