@@ -290,7 +290,7 @@ __global__ void sqrt_mean_kernel(const float *x, int n, float eps, float scale, 
 __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P) {
     if ((int)blockIdx.y < P.nsets) {
         const dbw_texture_set &t = P.tex.s[blockIdx.y];
-        texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig);
+        texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig, blockIdx.x, gridDim.x);
         return;
     }
     const int k = blockIdx.x, tid = threadIdx.x;

@@ -19,6 +19,7 @@
 #include "raster_common.h"
 #include "raster_bin.h"
 #include "step_kernels.h"
+#include "texture_body.h"
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
 }
 
 __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restrict__ cell, const int *__restrict__ rank, const int *__restrict__ hdr,
-                                                           long long total, int *__restrict__ work) {
+                                                           long long total, int *__restrict__ work, unsigned *sync_flag, unsigned sync_val) {
+    if (sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sync_flag, sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
     const long long per = (total + 7) / 8;
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict
 // coarse level and, where the scene's pass reads per-tile lists, goes straight on to the fine level with the bin's list still in LDS.
 __global__ __launch_bounds__(256) void scene_bins_kernel(const SceneBinsArgs A) {
     __shared__ BinShared S;
+    if ((int)blockIdx.z >= A.nscenes) {        // the step's texture preparation, in the shadow of the bins (SceneBinsArgs::tex)
+        const int zi = (int)blockIdx.z - A.nscenes, set = zi / A.tex_z, slice = zi - set * A.tex_z;
+        const long long per = (long long)gridDim.x * gridDim.y;
+        const dbw_texture_set &t = A.tex.s[set];
+        texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig, (long long)slice * per + (long long)blockIdx.y * gridDim.x + blockIdx.x,
+                              per * A.tex_z);
+        return;
+    }
     // (workgroups start in grid order and the launch is more than one round of them at 49 views: the last scene -- the blocks, whose bins
     // hold the long lists -- goes first, the env scene's short workgroups fill the tail)
     const SceneBinsArgs::One &G = A.sc[A.scene0 + (A.nscenes - 1 - (int)blockIdx.z)];
@@ -325,7 +335,8 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
                 rc = dbw_check_launch("cell_bin_kernel");
                 if (rc) return rc;
                 const long long total = (long long)N * (long long)cell_tiles(H, W);
-                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work);
+                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work,
+                                   (unsigned *)nullptr, 0u);
                 rc = dbw_check_launch("work_scatter_kernel");
                 if (rc) return rc;
             }
@@ -343,14 +354,20 @@ int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
         DBW_REQUIRE(G.bbox && G.recs && G.first_idx && G.num_faces && G.list && G.count && G.mask, "null pointer");
         DBW_REQUIRE(!G.cells || (G.cell && G.pool && G.hdr && G.rank && G.pool_cap > 0), "null pointer (cell lists)");
     }
-    hipLaunchKernelGGL(scene_bins_kernel, dim3((unsigned)(A.nx * A.ny), (unsigned)A.B, (unsigned)A.nscenes), dim3(256), 0, s, A);
+    DBW_REQUIRE(A.tex_sets >= 0 && A.tex_sets <= STEP_MAX_SETS && (A.tex_sets == 0 || A.tex_z >= 1), "bad texture slices");
+    for (int i = 0; i < A.tex_sets; ++i) {
+        const dbw_texture_set &t = A.tex.s[i];
+        DBW_REQUIRE(t.texture && t.maps && t.n > 0 && t.h > 1 && t.w > 1 && t.decim >= 1 && (t.decim == 1 || (t.sig && t.h % t.decim == 0 && t.w % t.decim == 0)),
+                    "bad texture set");
+    }
+    hipLaunchKernelGGL(scene_bins_kernel, dim3((unsigned)(A.nx * A.ny), (unsigned)A.B, (unsigned)(A.nscenes + A.tex_sets * A.tex_z)), dim3(256), 0, s, A);
     return dbw_check_launch("scene_bins_kernel");
 }
 
 // the launch-order kernel alone (the training step's fused set-up fills cell / rank / hdr itself)
-int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s) {
+int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val) {
     const long long total = (long long)N * (long long)cell_tiles(H, W);
-    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work);
+    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work, sync_flag, sync_val);
     return dbw_check_launch("work_scatter_kernel");
 }
 

@@ -75,9 +75,13 @@ struct SceneBinsArgs {
     } sc[2];
     int B, H, W, nx, ny;
     int scene0, nscenes;
+    // the texture preparation of the step (sigmoid + decimation of tex_sets tensors) in the shadow of the bins: tex_z more slices of the
+    // grid per tensor run it -- the prologue then only computes what the set-up waits for.  tex_sets == 0: off
+    StepTextureSets tex; int tex_sets, tex_z;
 };
 int launch_scene_bins(const SceneBinsArgs &A, hipStream_t s);
-int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s);
+// (sync_flag: the first workgroup stores sync_val when it starts -- "everything in front of this launch is complete", ShadeArgs::sync_flag)
+int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag = nullptr, unsigned sync_val = 0);
 
 struct RegulariserArgs {
     // overlap (dbw.py:389-405): scale = 0 -> off

@@ -30,7 +30,7 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {  // NT threa
 
 __global__ __launch_bounds__(256) void texture_prep_fwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,
                                                                float *__restrict__ maps, float *__restrict__ sig) {
-    texture_prep_fwd_body(tex, n, h, w, d, maps, sig);
+    texture_prep_fwd_body(tex, n, h, w, d, maps, sig, blockIdx.x, gridDim.x);
 }
 
 // several texture sets in ONE launch (blockIdx.y = set): the three maps of a scene (blocks, sky, ground) differ in shape, and one
@@ -40,7 +40,7 @@ struct TextureSets { dbw_texture_set s[MAX_SETS]; };
 
 __global__ __launch_bounds__(256) void texture_prep_fwd_sets_kernel(const TextureSets S) {
     const dbw_texture_set &t = S.s[blockIdx.y];
-    texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig);
+    texture_prep_fwd_body(t.texture, t.n, t.h, t.w, t.decim, t.maps, t.sig, blockIdx.x, gridDim.x);
 }
 
 __global__ void texture_prep_bwd_kernel(const float *__restrict__ tex, int n, int h, int w, int d,

@@ -9,11 +9,12 @@ __device__ __forceinline__ float tex_sigmoid(float x) { return 1.f / (1.f + expf
 
 // d == 1: elementwise.  d > 1: one WAVE per (d x d) cell (lane <-> texel, wave-sum for the cell mean); `maps` is written
 // at CELL resolution (n, h/d, w/d, 3).
+// (blocks bid of nblk: a kernel that runs the preparation next to something else gives it a slice of its own grid)
 __device__ __forceinline__ void texture_prep_fwd_body(const float *__restrict__ tex, int n, int h, int w, int d,
-                                                      float *__restrict__ maps, float *__restrict__ sig) {
+                                                      float *__restrict__ maps, float *__restrict__ sig, long long bid, long long nblk) {
     if (d <= 1) {
         const long long total = (long long)n * h * w * 3;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = bid * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
             const float s = tex_sigmoid(tex[i]);
             maps[i] = s;
             if (sig) sig[i] = s;
@@ -22,7 +23,7 @@ __device__ __forceinline__ void texture_prep_fwd_body(const float *__restrict__ 
     }
     const int ch_ = h / d, cw_ = w / d, lane = threadIdx.x & 63;
     const long long cells = (long long)n * ch_ * cw_;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long wave = (bid * blockDim.x + threadIdx.x) >> 6, nwaves = (nblk * blockDim.x) >> 6;
     for (long long c = wave; c < cells; c += nwaves) {
         const int m = (int)(c / (ch_ * cw_));
         const int r = (int)(c % (ch_ * cw_));

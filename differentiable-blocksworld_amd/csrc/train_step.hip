@@ -265,7 +265,7 @@ int step_streams(hipStream_t &r, hipStream_t &e) {
 // consumer's stream polls it in front of its own.  Kernel boundaries do the rest: the producer's kernels have released their writes before
 // the store kernel starts, and the kernel behind the poll acquires at its start like any kernel behind an event wait.
 constexpr int SYNC_FLAGS = 12, SYNC_TIMEOUT_SLOT = 15, SYNC_WORDS = 16;
-enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS_READY, F_ENV_DONE };
+enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS_READY, F_ENV_DONE, F_TEX };
 __global__ void sync_set_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts) {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
@@ -468,6 +468,21 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         target = FP(L.target);
     }
 
+    // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
+    RasterWorkspace we, wf;
+    // (fuse bit 4: the env layer is evaluated inside the fg pass, from per-tile lists of its own; else the hard pass walks its coarse bins)
+    RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, (d.fuse & 16) != 0, we));
+    RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
+    const bool fused_setup = (d.fuse & 2) && we.binned && wf.binned && wf.cells;
+    const bool fold = fused_setup && (d.fuse & 16) && we.cells;
+    const float margin_f = (float)sqrt((double)d.blur_radius);
+    // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
+    const bool setup_aside = two && fused_setup && !fold && B > d.serial_setup_max_views;
+    DBW_REQUIRE(phase == 0 || fold, "the two-phase iteration needs per-tile lists for both scenes (a binned workspace)");
+    // the step's texture preparation in the shadow of the bins (fuse bit 6): the prologue then only computes what the set-up waits for.  Its
+    // consumers -- the fg pass (behind the bins on M) and the TV term on Rg, which polls a word the launch behind the bins stores (memory
+    // words only: an event recorded there would cost M what this saves)
+    const bool tex_in_bins = (d.fuse & 64) && (d.fuse & 1) && flags && two && fused_setup && !setup_aside;
     // ---- M: prologue ----
     const float thresh = d.mask_threshold;
     if (!head) {
@@ -476,7 +491,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         memset(&P, 0, sizeof(P));
         for (int i = 0; i < 3; ++i) P.tex.s[i] = sets[i];
         P.tex.s[3] = sets[0];
-        P.nsets = 3;
+        P.nsets = tex_in_bins ? 0 : 3;
         P.alpha_logit = d.alpha_logit; P.noise = noise_on ? in->noise_override : nullptr;
         P.noise_scale = noise_on ? d.opacity_noise : 0.f; P.thresh = thresh; P.nb = nb;
         P.alpha = FP(L.alpha); P.alpha_full = FP(L.alpha_full); P.keep = IP(L.keep);
@@ -502,17 +517,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // (measured: a chain of dependent kernels enqueued from here on ONE stream runs without gaps; an event costs the stream that records or
     // waits for it ~7 us before its next kernel, and a kernel behind an event of ANOTHER stream starts 12-26 us after that event.  So the
     // critical chain -- set-up, passes, fg backward, its tail, Adam -- stays on M and only what is off it forks)
-    // ---- M: camera transform, clipping, per-face records, bins of both scenes, launch order of the fg pass's tiles ----
-    RasterWorkspace we, wf;
-    // (fuse bit 4: the env layer is evaluated inside the fg pass, from per-tile lists of its own; else the hard pass walks its coarse bins)
-    RC(dbw_raster_workspace_layout(ws + L.e.rws, L.e.rws_bytes, Fte, 2 * Fe, B, H, W, (d.fuse & 16) != 0, we));
-    RC(dbw_raster_workspace_layout(ws + L.f.rws, L.f.rws_bytes, Ftf, 2 * Ff, B, H, W, true, wf));
-    const bool fused_setup = (d.fuse & 2) && we.binned && wf.binned && wf.cells;
-    const bool fold = fused_setup && (d.fuse & 16) && we.cells;
-    const float margin_f = (float)sqrt((double)d.blur_radius);
-    // large batches: the blocks' set-up runs on E next to the env pass (which is long enough to hide the hop); small ones: on M
-    const bool setup_aside = two && fused_setup && !fold && B > d.serial_setup_max_views;
-    DBW_REQUIRE(phase == 0 || fold, "the two-phase iteration needs per-tile lists for both scenes (a binned workspace)");
     // The prologue's signal to Rg: carried by the first workgroup of the kernel behind the prologue on M (a kernel that has started says
     // that everything in front of it on its stream is complete) -- then Rg's work is enqueued BEHIND that kernel, because a poll must never
     // be enqueued in front of its producer -- or, where M's next kernel is not the fused set-up, by a launch of its own
@@ -562,6 +566,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         }
         if (tv) {
             add_tv_fields(L, ws, sets);
+            if (head && tex_in_bins) RC(await(Rg, F_TEX, p->ev_prologue));     // (the sigmoid of the textures: written next to the bins)
             if (head) RC(dbw_tv_l2sq_sets(sets, 3, vals + 2, Rg));
         }
         return DBW_OK;
@@ -616,8 +621,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             A.scene0 = 0; A.nscenes = 2; Bn.scene0 = 0; Bn.nscenes = 2;
             if (prologue_signal_folded) { A.sync_flag = p->sync_words + F_PROLOGUE; A.sync_val = ++p->sync_val[F_PROLOGUE]; }
             RC(launch_scene_setup(A, M));
+            unsigned *tex_flag = nullptr, tex_val = 0;
+            if (tex_in_bins) {
+                for (int i = 0; i < 3; ++i) Bn.tex.s[i] = sets[i];
+                Bn.tex.s[3] = sets[0];
+                Bn.tex_sets = 3;
+                const long long per = (long long)Bn.nx * Bn.ny * B;
+                Bn.tex_z = (int)((2048 + per - 1) / per);
+                tex_flag = p->sync_words + F_TEX; tex_val = ++p->sync_val[F_TEX];
+            }
             RC(launch_scene_bins(Bn, M));
-            RC(dbw_launch_work_scatter(wf, B, H, W, M));
+            RC(dbw_launch_work_scatter(wf, B, H, W, M, tex_flag, tex_val));
         }
     } else {
         RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),

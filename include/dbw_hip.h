@@ -420,7 +420,8 @@ typedef struct dbw_step_desc {
     /* ---- options ---- */
     int fuse;                                   /* bit 0: prologue, 1: scene set-up + bins, 2: regularisers, 3: blocks' tail, 4: the env layer inside the
                                                  * fg pass (no env pass, no env image; needs bit 1), 5: the blocks' projection backward and the backward of
-                                                 * their texture preparation in one launch; 0 = the operator-level kernels */
+                                                 * their texture preparation in one launch, 6: the texture preparation (forward) in the shadow of the
+                                                 * bins' launch instead of the prologue's (needs bits 0, 1 and sync_events == 0); 0 = the operator-level kernels */
     int backward_order;                         /* 0: both backward kernels at once, 1: the fg kernel first and alone (data parallel) */
     int binned_concurrent;                      /* texture bins (which otherwise imply order 1): the env chain starts next to the fg kernel */
     int serial_setup_max_views;                 /* runs of up to this many views keep the blocks' set-up on stream_main (no cross-stream hop);

@@ -75,7 +75,7 @@ def _compare(a, b, names):
 
 
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
-@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 15, 31, 63])
+@pytest.mark.parametrize('fuse', [0, 1, 2, 4, 9, 15, 31, 63, 127])
 def test_c_step_equals_native_step(epoch, fuse):
     inp = _inputs(3, 48, 64)
     noise = torch.randn(4, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -98,7 +98,7 @@ def test_c_step_at_the_benchmark_geometry_fused_equals_operator_level_kernels(ep
     u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
     mk = lambda: _model(epoch, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
     ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
-    for fuse in (0, 15, 31, 63):
+    for fuse in (0, 15, 31, 127):
         got = _run(mk(), inp, 2, noise, u, use_c_step=True, fuse=fuse)
         _compare(got, ref, ref[0].params.names)
 
@@ -270,7 +270,7 @@ def test_c_step_at_a_config_4_like_geometry_equals_the_native_step():
         mk = lambda: _model(epoch, nb=nb, ts=64, fpp=16, H=H, W=W, kill=False)
         ref = _run(mk(), inp, 3, noise, u, use_c_step=False)
         got = _run(mk(), inp, 3, noise, u, use_c_step=True)
-        assert got[0].cstep is not None and got[0].cstep.fuse == 63
+        assert got[0].cstep is not None and got[0].cstep.fuse == 127
         _compare(got, ref, ref[0].params.names)
 
 

@@ -11,7 +11,7 @@ from dbw_amd.parallel import ShardedTrainStep
 dev = torch.device('cuda', 0)
 epoch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 batches = [int(x) for x in sys.argv[2:] if x.isdigit()] or [4, 7, 49]
-VARIANTS = [x for x in sys.argv[2:] if not x.isdigit()] or ['py', 'c31', 'c63']
+VARIANTS = [x for x in sys.argv[2:] if not x.isdigit()] or ['py', 'c63', 'c127']
 
 
 class A:
@@ -24,7 +24,7 @@ def measure(B, variant, reads, steps):
     model, inp = bench.build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c31': dict(fuse=31), 'c31ev': dict(fuse=31), 'c63': dict(fuse=63)}[variant]
+    kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c31': dict(fuse=31), 'c31ev': dict(fuse=31), 'c63': dict(fuse=63), 'c127': dict(fuse=127)}[variant]
     if variant == 'c0':          # the operator-level kernels need the caller's draws
         model._noise_override = torch.randn(10, device=dev)
         model._overlap_u_override = torch.rand(10, 1000, 3, device=dev)
