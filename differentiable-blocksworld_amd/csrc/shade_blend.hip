@@ -1064,6 +1064,9 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 // (profiles/r01_lds_atomic_ubench.txt).  Records arrive in runs of up to 64 written by one wave of the backward (an 8x8 pixel
 // patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
 // transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
+#ifndef DBW_REDUCE_PREFETCH
+#define DBW_REDUCE_PREFETCH 0        // (round 4: measured slower, see the kernel)
+#endif
 #ifndef DBW_BIN_STAGE
 #define DBW_BIN_STAGE 512       // (round 3: 1024 -> 512 records per batch and 4 -> 2 sub-ranges per workgroup: 43 instead of 60 KB of LDS, three
 #endif                          // workgroups per CU instead of two, eight per bin: 0.268 -> 0.236 ms at config 2; 256 records: 0.234)
@@ -1086,23 +1089,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
     if (total == 0) return;
     for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0.0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
-    const int n = n_sub[g];
-    const int4 *rec = records + (long long)first[g] * 2;
-    for (int sb = 0; sb < n; sb += BIN_STAGE) {
-        const int m = min(n - sb, BIN_STAGE);
-        __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
-#pragma unroll
-        for (int it = 0; it < BIN_PER_THREAD; ++it) {
-            const int r = it * 256 + threadIdx.x;
-            if (r < m) {
-                const int4 a = rec[(sb + r) * 2], b = rec[(sb + r) * 2 + 1];
-                stage[r * 2 + r / BIN_LANE_STRIDE] = a;
-                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = b;
-            }
-        }
-        __syncthreads();
+    auto accumulate = [&](int m) {
 #pragma unroll 2
         for (int j = 0; j < BIN_PER_THREAD; ++j) {
             const int r = lane * BIN_LANE_STRIDE + wv * BIN_PER_THREAD + j;
@@ -1122,8 +1109,66 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                 atomicAdd(&tile[idx[q] + 2], (double)(g2 * w[q]));
             }
         }
+    };
+#if DBW_REDUCE_PREFETCH
+    // (off) The records of the NEXT batch travel (to registers) while this one is accumulated.  The LDS atomic unit is busy a quarter of this
+    // kernel's time (SQ counters; tools/ubench/lds_atomic3: random texels 21.6 clk per wave instruction, bank-sorted ones 9.0 -- the kernel
+    // pays ~70) and a batch waits for its own loads between two barriers -- but three workgroups per CU already fill each other's waits:
+    // with the prefetch epoch 800 went 1.370 -> 1.406 ms per step, the fine phase 0.835 -> 0.859.
+    int g = 0, sb = 0, m = 0;
+    int4 ra[BIN_PER_THREAD], rb[BIN_PER_THREAD];
+    auto fetch = [&]() {
+        while (g < BIN_SUB_PER_WG && sb >= n_sub[g]) { ++g; sb = 0; }
+        m = 0;
+        if (g >= BIN_SUB_PER_WG) return;
+        m = min(n_sub[g] - sb, BIN_STAGE);
+        const int4 *rec = records + (long long)first[g] * 2 + (long long)sb * 2;
+#pragma unroll
+        for (int it = 0; it < BIN_PER_THREAD; ++it) {
+            const int r = it * 256 + threadIdx.x;
+            if (r < m) { ra[it] = rec[r * 2]; rb[it] = rec[r * 2 + 1]; }
+        }
+        sb += BIN_STAGE;
+    };
+    fetch();
+#pragma unroll 1
+    while (m > 0) {
+        const int mc = m;
+        __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
+#pragma unroll
+        for (int it = 0; it < BIN_PER_THREAD; ++it) {
+            const int r = it * 256 + threadIdx.x;
+            if (r < mc) {
+                stage[r * 2 + r / BIN_LANE_STRIDE] = ra[it];
+                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = rb[it];
+            }
+        }
+        __syncthreads();
+        fetch();
+        accumulate(mc);
+    }
+#else
+#pragma unroll 1
+    for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
+    const int n = n_sub[g];
+    const int4 *rec = records + (long long)first[g] * 2;
+    for (int sb = 0; sb < n; sb += BIN_STAGE) {
+        const int m = min(n - sb, BIN_STAGE);
+        __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
+#pragma unroll
+        for (int it = 0; it < BIN_PER_THREAD; ++it) {
+            const int r = it * 256 + threadIdx.x;
+            if (r < m) {
+                const int4 a = rec[(sb + r) * 2], b = rec[(sb + r) * 2 + 1];
+                stage[r * 2 + r / BIN_LANE_STRIDE] = a;
+                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = b;
+            }
+        }
+        __syncthreads();
+        accumulate(m);
     }
     }
+#endif
     __syncthreads();
     const long long off = bin_info[bin * 4];
     const int ws = bin_info[bin * 4 + 1], hs = bin_info[bin * 4 + 2];
