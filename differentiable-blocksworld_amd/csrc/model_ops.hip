@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P
             float loc[3], de1[3], de2[3];
             parametric_sq_point(P.trig[o], P.trig[plane + o], P.trig[2 * plane + o], P.trig[3 * plane + o], p.e1, p.e2, P.ratio, loc, de1, de2);
             pose_fwd(p, loc, P.S_world, P.Rw, P.Tw, P.blk_verts + o * 3);
-            if (P.sq_local) {          // the backward of this block (scene_tail_kernel) re-reads what it would otherwise recompute with 8 powf / logf per vertex
+            if (P.sq_local) {          // the backward of this block (blocks_tail_kernel) re-reads what it would otherwise recompute with 8 powf / logf per vertex
                 float *q = P.sq_local + o * 9;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { q[i] = loc[i]; q[3 + i] = de1[i]; q[6 + i] = de2[i]; }

@@ -1,18 +1,22 @@
-// Fused small kernels of the training step (train_step.hip enqueues them): each replaces a chain of dependent 5-20 us launches of the
-// operator-level path -- a dependent launch costs a gap of 5-9 us on the GPU whatever it computes, and at the reference's batch size
-// (4 views, configs/dtu/default.yml:28) those gaps were the step.  The kernels live next to the kernels they fuse (same device
+// Fused small kernels of the training step (train_step.hip enqueues them).  Each replaces a chain of dependent 5-20 us launches of the
+// operator-level path, or runs two independent ones in one launch: at the reference's batch size (4 views, configs/dtu/default.yml:28) the
+// step is as long as its chain of dependent launches, whatever they compute.  The kernels live next to the kernels they fuse (same device
 // functions, same arithmetic, bit-identical results); this header is their host-side interface.  Internal: not part of the C ABI.
 //
-//   step_prologue     (model_ops.hip)     sigmoid / decimation of the three texture tensors, block opacities (+ their noise), blocks'
-//                                         vertices, ground vertices, clearing of the small gradients      [was 7 launches]
+//   step_prologue     (model_ops.hip)     block opacities (+ their noise), blocks' vertices, ground vertices, clearing of the small
+//                                         gradients [+ sigmoid / decimation of the three texture tensors when the bins do not take it]
+//                                                                                                         [was 7 launches]
 //   scene_setup       (project_clip.hip)  camera transform + near-plane clipping + per-face raster records + shading records of BOTH
 //                                         scenes (env: sky + ground, fg: blocks)                          [was 5]
-//   scene_bins        (raster.hip)        coarse bins of both scenes + per-tile face lists of the fg pass [was 3]
+//   scene_bins        (raster.hip)        coarse bins of both scenes + per-tile face lists + (in extra slices of its grid, in the shadow
+//                                         of the bins' latency) the texture preparation                   [was 3 + 1]
 //   regularisers      (model_ops.hip)     parsimony + overlap (samples drawn in registers) + its finish   [was 4]
+//   clip_bwd_tex      (project_clip.hip)  the blocks' projection backward next to the backward of their texture preparation [was 2]
 //   blocks_tail       (model_ops.hip)     backward of the blocks' pose / shape (from the points the prologue kept) + of their opacities [was 2]
-// (What is NOT fused, on purpose: a chain of dependent kernels on ONE stream enqueued from C runs without gaps -- measured -- so fusing it
-// buys nothing, and a "last workgroup finishes the job" epilogue serialises what separate kernels run in parallel: the tails built that
-// way were slower than the launches they replaced.)
+//   + the env layer inside the fg pass (render_fused.hip) and the cross-stream signals inside scene_setup / work_scatter / the uv backward
+// (What is NOT fused, on purpose: a chain of dependent kernels on ONE stream enqueued from C runs without gaps -- measured -- so fusing
+// dependent kernels buys nothing unless the fusion is parallel over the same index space, and a "last workgroup finishes the job" epilogue
+// serialises what separate kernels run in parallel: the tails built that way were slower than the launches they replaced.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

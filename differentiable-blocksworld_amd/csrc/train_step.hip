@@ -2,19 +2,26 @@
 //
 // Replaces one pass of src/trainer.py:137-147 (zero_grad -> model(images) -> total.backward() -> optimizer.step()) for the decoupled
 // training render (src/model/dbw.py:198-223, 361-408; src/model/renderer.py:84-98) with MSE + parsimony + TV + overlap.  This file is
-// host-side orchestration: which kernel goes on which of the two streams, in which order, with which event between them -- plus two
-// small kernels of its own (tiling of the target images, reduction of the loss values).  The arithmetic lives in the kernels it
-// launches, each of which is the kernel the operator-level path uses or a fusion of several of them out of the same device functions
-// (step_kernels.h), so a step computes what dbw_amd/native_step.py computes through ~33 launches -- tests/test_gpu_model.py holds the
-// two (and every fuse mask in between) to each other.
+// host-side orchestration: which kernel goes on which of three streams, in which order, and how the streams wait for each other -- plus
+// a few small kernels of its own (tiling of the target images, reduction of the loss values, the one-thread store / poll through which the
+// streams wait).  The arithmetic lives in the kernels it launches, each of which is the kernel the operator-level path uses or a fusion of
+// several of them out of the same device functions (step_kernels.h), so a step computes what dbw_amd/native_step.py computes through ~33
+// launches -- tests/test_gpu_c_step.py holds the two (and every fuse mask in between) to each other.
 //
-// Schedule (M = stream_main, S = stream_side; `|` = an event):
-//   M: prologue -> scene set-up -> bins | env pass ............ | fg pass + MSE | env backward -> ground tail -> env textures ...... | Adam
-//   S: tile targets, bin layout ...... | launch order | regularisers, TV ...... | fg backward [-> bin reduction] -> blocks' textures
-//                                                                                  -> blocks' tail -> loss values ................. |
-// (backward_order 1: the env backward waits for the fg backward KERNEL -- two kernels that each fill the GPU gain nothing from sharing
-// it, and the blocks' texture gradient, 83 % of the gradient bytes, is then final early enough for a data-parallel caller to reduce it
-// next to the env chain.)
+// Schedule with every fuse bit set (M = the caller's stream: the critical chain; E, Rg = the library's two lowest-priority streams of the
+// device; `*` = the launch whose first workgroup stores the word the other streams poll -- see dbw_step_desc.sync_events):
+//   M:  [tile targets] -> prologue (opacities, vertices) -> scene set-up* -> bins (+ texture preparation) -> launch order* -> fg pass (+ env
+//       layer + composite + MSE) -> [poll: bin layout] fg backward* [-> bin reduction] -> poll (E) -> blocks' projection backward +
+//       texture preparation backward -> blocks' tail -> Adam (clears the zero arena)
+//   E:  poll (fg pass) -> env backward -> projection backward -> ground pose backward -> poll (Rg) -> env texture preparation backward -> store
+//   Rg: poll (prologue) -> [bin cursors, layout -> store] -> regularisers -> poll (textures) -> TV -> poll (fg pass) -> loss values -> store
+//       -> copy to the host
+// Every poll is enqueued BEHIND the launch that carries its store (the order of the statements of dbw_train_step_run): that is what makes
+// polling safe under any mapping of streams to hardware queues.  The legacy arrangements -- operator-level kernels, the env pass as a pass
+// of its own, events instead of words, one stream -- are the same function with fuse bits / options cleared, and are what the tests
+// compare the default with.
+// (backward_order 1: the env backward waits for the fg backward KERNEL; data parallel with the whole gradient buffer reduced, the blocks'
+// texture gradient -- 83 % of its bytes -- is then final early enough to be reduced next to the env chain.)
 #include "dbw_common.h"
 #include "raster_bin.h"
 #include "step_kernels.h"
