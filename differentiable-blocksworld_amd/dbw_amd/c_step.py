@@ -268,12 +268,14 @@ class CStep:
 
     def sync_timeouts(self):
         """Cross-stream waits of the current plan that gave up (never, in a healthy process); synchronises the device."""
-        return _lib.load().dbw_train_step_sync_timeouts(self._cur[0])
+        with torch.cuda.device(self.params.flat.device):
+            return _lib.load().dbw_train_step_sync_timeouts(self._cur[0])
 
     def wait_blocks_ready(self, stream):
         """`stream` (a torch stream) waits until the blocks' texture gradient of the last step is final (data parallel: the early slice of
         the all-reduce)."""
-        _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
+        with torch.cuda.device(self.params.flat.device):
+            _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------
     def __call__(self, inp, global_count=None, adam=None, tiled_target=True, defer_textures=False):
