@@ -377,3 +377,18 @@ def test_c_step_through_the_three_training_phases_and_back_no_wait_ever_gives_up
         torch.cuda.synchronize()
         assert step.cstep.sync_timeouts() == 0
     assert len(step.cstep._plans) == 3
+
+
+def test_c_step_at_the_full_benchmark_batch_equals_the_native_step():
+    """BASELINE config 2 at full size -- 49 views of 300x400, 10 blocks, faces_per_pixel 10, 256^2 textures, the first training phase: the
+    one-call step with every fusion on against the launch-by-launch native step (itself held to the autograd iteration and the oracle at
+    sizes the oracle finishes)."""
+    inp = _inputs(49, 300, 400)
+    nb = 10
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    mk = lambda: _model(0, nb=nb, ts=256, fpp=10, H=300, W=400, kill=False)
+    ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
+    got = _run(mk(), inp, 2, noise, u, use_c_step=True)
+    assert got[0].cstep is not None and got[0].cstep._cur is not None and got[0].cstep.sync_timeouts() == 0
+    _compare(got, ref, ref[0].params.names)
