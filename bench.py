@@ -597,6 +597,8 @@ def main():
                                     'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
             'phases': phases, 'allreduce_ms': allreduce_ms, 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms, 'ms_per_step_flat_allreduce': flat_ms, 'allreduce_bytes': allreduce_bytes,
             'final_loss': total_loss,
+            # polls between the step's streams that gave up (dbw_train_step_sync_timeouts): anything but 0 voids the run
+            'sync_timeouts': step.cstep.sync_timeouts() if step.cstep is not None and step.cstep._cur is not None else None,
         }
         if world == 1 and not args.no_extras and not args.graph:
             default = (args.views, args.H, args.W, args.blocks, args.fpp, args.txt, args.epoch) == (49, 300, 400, 10, 10, 256, 0)

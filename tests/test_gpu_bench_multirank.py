@@ -42,7 +42,7 @@ def test_bench_two_ranks_through_torchrun(scaling):
     assert d['ms_per_step_overlap_allreduce_off'] is None or d['ms_per_step_overlap_allreduce_off'] > 0
     # the ranks sum the gradient of the prepared maps + the small gradients; the step with the whole flat buffer reduced is timed next to it
     assert 0 < d['allreduce_bytes'] < 2.0e6 and d['ms_per_step_flat_allreduce'] > 0 and 'prepared texture maps' in d['config']['parallelism']
-    assert 'C-ABI call per iteration' in d['config']['launch']
+    assert 'C-ABI call per iteration' in d['config']['launch'] and d['sync_timeouts'] == 0
 
 
 def test_bench_defaults_to_config_3_as_written_when_it_gets_more_than_one_gpu():
