@@ -274,11 +274,17 @@ int step_streams(hipStream_t &r, hipStream_t &e) {
 constexpr int SYNC_FLAGS = 12, SYNC_TIMEOUT_SLOT = 15, SYNC_WORDS = 16;
 enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS_READY, F_ENV_DONE, F_TEX };
 __global__ void sync_set_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts) {
+// (timeouts: a counter in device memory; host_timeouts: the same in mapped host memory -- the next dbw_train_step_run sees it without a
+// transfer and fails loudly: a poll that gave up let its stream run ahead of what it was waiting for)
+__global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts, unsigned *host_timeouts) {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > 20000000ull) { atomicAdd(timeouts, 1u); break; }
+        if (wall_clock64() - t0 > 20000000ull) {
+            atomicAdd(timeouts, 1u);
+            __hip_atomic_fetch_add(host_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
 }
 
@@ -300,6 +306,7 @@ struct dbw_step_plan {
     bool profile, profiled;             // dbw_train_step_profile: timing events around the four big kernels of a run
     hipEvent_t ev_t[8];
     unsigned *sync_words;               // device: SYNC_FLAGS counters + the number of polls that gave up
+    unsigned *host_timeouts, *host_timeouts_dev;      // ... and the same number in mapped host memory (host pointer, device pointer)
     unsigned sync_val[SYNC_FLAGS];      // last value stored behind each counter (host side)
 };
 
@@ -340,6 +347,14 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
         return nullptr;
     }
     for (unsigned &v : p->sync_val) v = 0;
+    p->host_timeouts = nullptr; p->host_timeouts_dev = nullptr;
+    if (hipHostMalloc((void **)&p->host_timeouts, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&p->host_timeouts_dev, p->host_timeouts, 0) != hipSuccess) {
+        dbw_set_error("dbw_train_step_create: hipHostMalloc (mapped) failed");
+        dbw_train_step_destroy(p);
+        return nullptr;
+    }
+    *p->host_timeouts = 0u;
     p->profile = p->profiled = false;
     p->phase1_done = false;
     for (hipEvent_t &e : p->ev_t)
@@ -355,6 +370,7 @@ extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     for (hipEvent_t e : p->ev_t) (void)hipEventDestroy(e);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
     if (p->sync_words) (void)hipFree(p->sync_words);
+    if (p->host_timeouts) (void)hipHostFree(p->host_timeouts);
     delete p;
 }
 
@@ -409,6 +425,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     const dbw_step_desc &d = p->d;
     const Layout &L = p->L;
     DBW_REQUIRE(in->imgs && in->R && in->T, "null input");
+    if (*(volatile unsigned *)p->host_timeouts != 0u) {
+        dbw_set_error("dbw_train_step_run: %u cross-stream wait(s) of an earlier run gave up after 0.2 s -- the streams of this plan ran ahead of each "
+                      "other and its results are void; create the plan with sync_events = 1", *(volatile unsigned *)p->host_timeouts);
+        return DBW_ERR_LAUNCH;
+    }
     DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
     DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
     DBW_REQUIRE(!in->with_adam || in->adam_step >= 1, "adam_step >= 1");
@@ -434,7 +455,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     };
     auto await = [&](hipStream_t st, int idx, hipEvent_t ev) -> int {
         if (!flags) { HIP_OK(hipStreamWaitEvent(st, ev, 0)); return DBW_OK; }
-        hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx], p->sync_words + SYNC_TIMEOUT_SLOT);
+        hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx], p->sync_words + SYNC_TIMEOUT_SLOT,
+                           p->host_timeouts_dev);
         return dbw_check_launch("sync_wait_kernel");
     };
     char *ws = p->ws;
@@ -843,8 +865,15 @@ extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t s
     DBW_REQUIRE(p, "null pointer");
     if (p->d.sync_events) { HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0)); return DBW_OK; }
     hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned *)(p->sync_words + F_BLOCKS_READY), p->sync_val[F_BLOCKS_READY],
-                       p->sync_words + SYNC_TIMEOUT_SLOT);
+                       p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev);
     return dbw_check_launch("sync_wait_kernel");
+}
+
+// (tests: what a poll that gave up leaves behind, without having to make one give up)
+extern "C" int dbw_debug_train_step_sync_timeout(dbw_step_plan *p) {
+    if (!p) return DBW_ERR_INVALID;
+    *(volatile unsigned *)p->host_timeouts += 1u;
+    return DBW_OK;
 }
 
 extern "C" int dbw_train_step_sync_timeouts(dbw_step_plan *p) {

@@ -112,6 +112,7 @@ SIGNATURES = {
     'dbw_train_step_losses': [c_p, c_p],
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
     'dbw_train_step_sync_timeouts': [c_p],
+    'dbw_debug_train_step_sync_timeout': [c_p],
     'dbw_train_step_profile': [c_p, c_i],
     'dbw_train_step_kernel_times': [c_p, c_p],
 }

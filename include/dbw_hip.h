@@ -430,7 +430,8 @@ typedef struct dbw_step_desc {
     int sync_events;                            /* how the plan's streams wait for each other.  0 (default): through words in device memory -- the
                                                  * producing stream runs a one-thread kernel that stores a counter, the waiting stream a one-thread
                                                  * kernel that polls it (every wait is enqueued after its producer, so no ordering of the hardware
-                                                 * queues can deadlock it; a poll gives up after 0.2 s, dbw_train_step_sync_timeouts).  Measured: an
+                                                 * queues can deadlock it; a poll gives up after 0.2 s and says so in mapped host memory: the plan's next
+                                                 * run fails with that message; dbw_train_step_sync_timeouts counts them).  Measured: an
                                                  * event costs the stream that records or waits for it 7-11 us before its next kernel and the
                                                  * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.
                                                  * != 0: HIP events (hipEventRecord / hipStreamWaitEvent) */
@@ -499,6 +500,8 @@ int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
 /* Number of cross-stream waits of this plan that gave up (sync_events == 0; never in a healthy process) -- synchronises the device; < 0 on error */
 int dbw_train_step_sync_timeouts(dbw_step_plan *plan);
+/* tests: marks the plan as if one of its polls had given up (the next dbw_train_step_run must refuse to go on) */
+int dbw_debug_train_step_sync_timeout(dbw_step_plan *plan);
 
 /* Measurement aid (bench.py): on != 0 makes every following run record HIP timing events around its four big kernels, on the streams they
  * run on and with everything that shares the GPU with them in a real step running next to them (the events themselves cost each

@@ -392,3 +392,17 @@ def test_c_step_at_the_full_benchmark_batch_equals_the_native_step():
     got = _run(mk(), inp, 2, noise, u, use_c_step=True)
     assert got[0].cstep is not None and got[0].cstep._cur is not None and got[0].cstep.sync_timeouts() == 0
     _compare(got, ref, ref[0].params.names)
+
+
+def test_c_step_refuses_to_go_on_after_a_wait_that_gave_up():
+    """A poll between the step's streams that gives up (0.2 s) lets its stream run ahead of what it waited for: the results of that run are
+    void, and the plan says so -- in mapped host memory, so the next run fails loudly instead of training on."""
+    inp = _inputs(2, 48, 64)
+    model = _model(0)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+    step(inp)
+    torch.cuda.synchronize()
+    assert step.cstep.sync_timeouts() == 0
+    _lib.call('dbw_debug_train_step_sync_timeout', step.cstep._cur[0])
+    with pytest.raises(RuntimeError, match='gave up'):
+        step(inp)
