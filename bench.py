@@ -81,8 +81,7 @@ def build_workload(args, dev):
 BIN_STATS = {}
 
 
-def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0, use_graph=False,
-                  c_step=True):
+def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses=False, lr_scale=1.0, min_seconds=0.0, epoch=0, c_step=True):
     """One more workload measured like the headline (same step, same launch path, inputs resident), outside its timed region:
     -> ms per step, views / s and the share of the HBM roofline the WHOLE-PATH algorithmic bytes (64 P K + 140 P per view)
     reach.  read_losses: every loss value is read on the host after every step, as the reference's trainer does
@@ -96,8 +95,7 @@ def measure_other(views, H, W, blocks, fpp, txt, dev, steps, warmup, read_losses
     model, inp = build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391, use_graph=use_graph, graph_warmup=2,
-                            use_c_step=c_step)
+    step = ShardedTrainStep(model, lr=5e-3 * lr_scale, lr_texture=5e-2 * lr_scale, seed=227391, use_c_step=c_step)
     if step.cstep is not None:
         step.cstep.read_losses = bool(read_losses)        # the step copies its five loss values to host memory itself
 
@@ -348,9 +346,6 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the measurements reported next to the headline at N = 1: the reference\'s own '
                     'operating point (batch 4, loss values read every step), BASELINE configs 4 and 5 (per-GPU share) and the sustained run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay zero_grad+forward+backward from a captured hipGraph (measured slower than '
-                    'eager launches on this workload: ~2 us of inter-node dependency cost x ~130 nodes, see profiles/)')
-    ap.add_argument('--no-graph', action='store_true', help='(default) eager launches')
     ap.add_argument('--backward-order', choices=['auto', 'sequential', 'concurrent'], default='auto', help='debug: the two backward kernels')
     ap.add_argument('--no-side-priority', action='store_true', help='debug: the side stream of the native step at normal priority')
     ap.add_argument('--no-overlap', action='store_true', help='everything in order on ONE stream: every kernel alone on the GPU (per-kernel averages of a '
@@ -397,7 +392,7 @@ def main():
     else:
         global_count = inp['imgs'].numel() * world
         views_total = args.views * world
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=args.graph, graph_warmup=1, seed=227391, use_c_step=not args.launch_by_launch)
+    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=227391, use_c_step=not args.launch_by_launch)
     # every phase below is measured from the SAME state (freshly initialised parameters + its own warm-up), not from whatever the
     # previously measured phase left behind (opacities drift, blocks get filtered: the workload would change)
     if step.native is not None and args.backward_order != 'auto':
@@ -436,7 +431,7 @@ def main():
             dt = t.item()
         return dt, out
 
-    for _ in range(max(args.warmup, 2 if args.graph else 0)):     # graph capture happens in the second iteration
+    for _ in range(args.warmup):
         step(inp, global_count=global_count)
     dt, losses = timed(args.steps)
     total_loss = losses['total'].item()
@@ -446,7 +441,7 @@ def main():
     PHASES = (('epoch0', 0, 'coarse, decimated textures', 750), ('epoch800', 800, 'coarse, full-resolution textures', 750),
               ('epoch1600', 1600, 'fine', 300))          # default.yml:15-16,39: decimation until 750, coarse until 1500, 1800 epochs
     phases = None
-    if not args.no_phases and not args.graph:
+    if not args.no_phases:
         phases = {}
         for name, epoch, what, n_ep in PHASES:
             if epoch == args.epoch:
@@ -486,7 +481,7 @@ def main():
 
     # ---- N > 1: the other scaling form in the same run, and what the early slice of the all-reduce buys ----
     other_scaling, overlap_off_ms, flat_ms = None, None, None
-    if world > 1 and not args.graph:
+    if world > 1:
         restore()
         model.set_cur_epoch(args.epoch)
         if args.scaling == 'strong':
@@ -528,32 +523,54 @@ def main():
         views_per_s = views_total * args.steps / dt
         P = args.H * args.W
         bytes_per_view = 64 * P * args.fpp + 140 * P                      # whole-path algorithmic bytes
-        kb = kernel_breakdown(model, inp)
-        dom = max(kb, key=lambda k: kb[k][0])
+        # the kernels of an iteration in exactly the form the step launches them (the fg forward WITH the env layer folded into it, the
+        # composite + MSE epilogue, tiled images): the step's own HIP events around its four big kernels, once with everything in order on ONE
+        # stream (every kernel alone on the GPU: `frac`), once as the step really runs (side streams next to them: `frac_in_step`)
+        K_ = args.fpp
+        B_ = inp['R'].shape[0]
+        fg_bytes, env_bytes = (20 * P * K_ + 16 * P) * B_, (20 * P + 16 * P) * B_
+        if step.cstep is not None and world == 1:
+            restore()
+            alone = step.cstep.kernel_times(inp, global_count, alone=True)
+            folded = alone['env_fwd'] < 1e-3 and (step.cstep.fuse & 18) == 18          # no env pass of its own was launched
+            name_of = {'env_fwd': 'render_fwd_fused K=1 (env pass)',
+                       'fg_fwd': f'render_fwd_fused K={K_} (fg pass' + (' + folded env layer)' if folded else ')'),
+                       'fg_bwd': f'render_bwd_fused K={K_} (fg pass)', 'env_bwd': 'render_bwd_fused K=1 (env pass)'}
+            # algorithmic bytes per launch (zbuf not materialised): a pass writes 20 P K of fragments + 16 P of image and its
+            # backward reads them back; the folded forward does the env pass's writes (K = 1) too
+            nbytes_of = {'env_fwd': env_bytes, 'fg_fwd': fg_bytes + (env_bytes if folded else 0), 'fg_bwd': fg_bytes, 'env_bwd': env_bytes}
+            kb = {name_of[k]: (v, nbytes_of[k]) for k, v in alone.items() if not (k == 'env_fwd' and folded)}
+            restore()
+            kt = step.cstep.kernel_times(inp, global_count)
+            in_step = {name_of[k]: round(v, 4) for k, v in kt.items() if not (k == 'env_fwd' and folded)}
+            restore()
+        else:
+            kb, in_step = kernel_breakdown(model, inp), None
+        order = sorted(kb, key=lambda k: -kb[k][0])
+        dom = order[0]
         ms, nbytes = kb[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9
+
+        def kernel_line(k):
+            t, nb_ = kb[k]
+            return {'kernel': k, 'avg_ms_per_launch': t, 'algorithmic_bytes_per_launch': nb_, 'achieved': nb_ / (t * 1e-3) / 1e9,
+                    'frac': nb_ / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'avg_ms_in_step': None if not in_step else in_step.get(k),
+                    'frac_in_step': None if not in_step or not in_step.get(k) else nb_ / (in_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # counter evidence for the dominant kernel from the rocprofv3 PMC passes of this same workload (profiles/, see its _how):
         # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE with the gfx950 correction) and the SQ issue counters
         traffic, counters, counters_note = None, None, None
         sha = csrc_sha16()
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
-            if inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0) and dom in pmc:
+            pmc_key = next((k for k in pmc if not k.startswith('_') and k.split(' (')[0] == dom.split(' (')[0] and ('fg' in k) == ('fg' in dom)), None)
+            if inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0) and pmc_key:
                 if pmc.get('_csrc_sha16') == sha:
-                    traffic, counters = pmc[dom].get('hbm_bytes'), {k: v for k, v in pmc[dom].items() if k != 'hbm_bytes'}
+                    traffic, counters = pmc[pmc_key].get('hbm_bytes'), {k: v for k, v in pmc[pmc_key].items() if k != 'hbm_bytes'}
                 else:       # counters of another build of the kernels say nothing about this one
                     counters_note = f'profiles/{PMC_FILE} was collected on csrc {pmc.get("_csrc_sha16")}, this library is built from {sha}: not reported'
         except (OSError, ValueError, KeyError):
             pass
-        # the same kernels INSIDE a step: HIP events recorded by the step on the streams they run on, everything that shares the GPU with
-        # them running next to them (dbw_train_step_profile)
-        in_step = None
-        if step.cstep is not None and world == 1:
-            restore()
-            kt = step.cstep.kernel_times(inp, global_count)
-            name_of = {'env_fwd': 'render_fwd_fused K=1 (env pass)', 'fg_fwd': f'render_fwd_fused K={args.fpp} (fg pass)',
-                       'fg_bwd': f'render_bwd_fused K={args.fpp} (fg pass)', 'env_bwd': 'render_bwd_fused K=1 (env pass)'}
-            in_step = {name_of[k]: round(v, 4) for k, v in kt.items()}
         local_views = inp['R'].shape[0]
         out = {
             'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
@@ -566,8 +583,7 @@ def main():
                                    f'MSE+parsimony+TV+overlap, Adam; LPIPS excluded',
                        'views_per_gpu': local_views, 'views_per_step': views_total, 'image_hw': [args.H, args.W], 'n_blocks': args.blocks,
                        'faces_per_pixel': args.fpp, 'txt_size': args.txt,
-                       'launch': ('hipGraph replay of zero_grad+forward+backward' if args.graph else
-                                  'one C-ABI call per iteration (dbw_train_step_run: ~18 launches enqueued from C)' if step.cstep is not None else
+                       'launch': ('one C-ABI call per iteration (dbw_train_step_run: ~18 launches enqueued from C)' if step.cstep is not None else
                                   'launch by launch from Python, no host sync in the iteration') +
                                  ('' if args.no_overlap else ', env backward chain and regularisers on side streams' +
                                   ((' that wait through HIP events' if step.cstep.sync_events else ' that wait through polled words in device memory') if step.cstep is not None else '')) +
@@ -582,9 +598,13 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
-                         # frac: the kernel launched alone (HIP events around back-to-back launches); frac_in_step: the same kernel where it
-                         # runs, sharing the GPU with the env backward chain and the regularisers (events recorded by the step itself)
-                         'frac_in_step': None if not in_step or dom not in in_step else nbytes / (in_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # frac: the kernel alone on the GPU, launched by the step itself in order on one stream (HIP events recorded by the
+                         # step); frac_in_step: the same launch where it really runs, sharing the GPU with the env backward chain and the
+                         # regularisers on their side streams
+                         'frac_in_step': None if not in_step or not in_step.get(dom) else nbytes / (in_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'top_kernels': [kernel_line(k) for k in order[:2]],
+                         'measured_as': 'dbw_train_step_profile: the kernels the training step launches, in the form it launches them' if in_step is not None
+                                        else 'operator-level launches from Python (tools form: fg forward without the folded env layer)',
                          'all_kernels_ms_in_step': in_step,
                          'all_kernels_ms': {k: round(v[0], 4) for k, v in kb.items()}, 'texbins': BIN_STATS or None,
                          'whole_path_frac': views_per_s / world * bytes_per_view / 1e9 / HBM_PEAK_GBS,
@@ -600,7 +620,7 @@ def main():
             # polls between the step's streams that gave up (dbw_train_step_sync_timeouts): anything but 0 voids the run
             'sync_timeouts': step.cstep.sync_timeouts() if step.cstep is not None and step.cstep._cur is not None else None,
         }
-        if world == 1 and not args.no_extras and not args.graph:
+        if world == 1 and not args.no_extras:
             default = (args.views, args.H, args.W, args.blocks, args.fpp, args.txt, args.epoch) == (49, 300, 400, 10, 10, 256, 0)
             if default:
                 del step, model, inp
@@ -609,16 +629,17 @@ def main():
                 # loss value on the host each iteration
                 def best_of(n, *a, **k):
                     # (the small-batch numbers are 0.3 ms windows on a shared box: a run that catches another tenant's burst or a clock ramp
-                    # reads 2x; the lower of two runs, both kept)
+                    # reads 2x; the lowest of n runs, all kept, the median next to it)
                     runs = [measure_other(*a, **k) for _ in range(n)]
                     best = min(runs, key=lambda r: r['ms_per_step'])
                     best['runs_ms_per_step'] = [round(r['ms_per_step'], 4) for r in runs]
+                    best['median_ms_per_step'] = sorted(best['runs_ms_per_step'])[len(runs) // 2]
                     return best
-                out['batch4'] = best_of(2, 4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
+                out['batch4'] = best_of(3, 4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
                 out['batch4']['what'] = ('batch_size 4 (configs/dtu/default.yml:28), the loss values on the host after every step '
                                          '(src/trainer.py:143): one C-ABI call per iteration, the step copies its loss values itself')
-                out['batch4_no_reads'] = best_of(2, 4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=False)
-                out['batch7'] = best_of(2, 7, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
+                out['batch4_no_reads'] = best_of(3, 4, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=False)
+                out['batch7'] = best_of(3, 7, 300, 400, 10, 10, 256, dev, steps=200, warmup=20, read_losses=True)
                 out['batch7']['what'] = 'the largest per-rank batch of BASELINE config 3 (49 views over 8 ranks: 7,6,...,6), loss values read every step'
                 # the round-3 form of the same step for comparison: ~33 launches issued one by one from Python, six scalar reads
                 out['batch4_launch_by_launch'] = measure_other(4, 300, 400, 10, 10, 256, dev, steps=100, warmup=10, read_losses=True, c_step=False)

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P
         load_pose(nullptr, nullptr, P.R6g, P.Tg, 0, 0.f, p);
         for (int v = tid; v < P.ngv; v += blockDim.x) pose_fwd(p, P.ground_base + (long long)v * 3, P.S_world, P.Rw, P.Tw, P.ground_verts + (long long)v * 3);
         for (int i = tid; i < P.nzero0; i += blockDim.x) P.zero0[i] = 0.f;
+        if (tid == 0 && P.void_flag) *P.void_flag = 0.f;
     }
 }
 

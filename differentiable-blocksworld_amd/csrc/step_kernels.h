@@ -51,6 +51,7 @@ struct PrologueArgs {
     float *ground_verts;
     // floats cleared by the launch (the accumulated pose / shape / opacity gradients)
     float *zero0; int nzero0;
+    float *void_flag;                               // the step's void flag (train_step.hip: sync_wait_kernel), cleared with them
 };
 int launch_step_prologue(const PrologueArgs &P, hipStream_t s);
 

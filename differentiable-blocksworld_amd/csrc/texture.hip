@@ -145,7 +145,10 @@ struct AdamGroups { long long end[MAX_SETS]; float step_size[MAX_SETS]; };
 // next step does not open with a fill launch in front of its first kernel
 __global__ void adam_groups_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                                    long long n, const AdamGroups G, float beta1, float beta2, float eps, float bc2_sqrt,
-                                   uint4 *__restrict__ zero_buf, long long zero_vec) {
+                                   uint4 *__restrict__ zero_buf, long long zero_vec, const float *__restrict__ skip_flag) {
+    // (skip_flag: a training step whose cross-stream wait gave up -- its gradients may be incomplete -- moves nothing; the flag lies
+    // outside zero_buf and nobody writes it while this launch runs)
+    if (skip_flag && *skip_flag != 0.f) n = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float step_size = G.step_size[0];
 #pragma unroll
@@ -262,7 +265,7 @@ extern "C" int dbw_tv_l2sq_sets(const dbw_texture_set *sets, int nsets, float *l
 
 extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
                                     const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
-                                    int64_t zero_bytes, dbw_stream_t stream) {
+                                    int64_t zero_bytes, const float *skip_flag, dbw_stream_t stream) {
     DBW_REQUIRE(param && grad && exp_avg && exp_avg_sq && group_end && lr, "null pointer");
     DBW_REQUIRE(zero_bytes >= 0 && (zero_bytes == 0 || (zero_buf && zero_bytes % 16 == 0 && ((uintptr_t)zero_buf & 15) == 0)),
                 "zero_buf: 16-byte aligned, a multiple of 16 bytes");
@@ -277,7 +280,7 @@ extern "C" int dbw_adam_step_groups(float *param, const float *grad, float *exp_
         G.step_size[k] = (float)(lr[k < ngroups ? k : ngroups - 1] / bc1);
     }
     hipLaunchKernelGGL(adam_groups_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, G,
-                       beta1, beta2, eps, (float)sqrt(bc2), (uint4 *)zero_buf, (long long)(zero_bytes / 16));
+                       beta1, beta2, eps, (float)sqrt(bc2), (uint4 *)zero_buf, (long long)(zero_bytes / 16), skip_flag);
     return dbw_check_launch("adam_groups_kernel");
 }
 

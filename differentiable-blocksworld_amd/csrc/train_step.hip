@@ -28,6 +28,7 @@
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
+#include <mutex>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -252,7 +253,9 @@ int check_desc(const dbw_step_desc *d) {
 // critical chain on the caller's stream yields to it.
 constexpr int MAX_DEVICES = 64;
 hipStream_t g_stream_r[MAX_DEVICES], g_stream_env[MAX_DEVICES];
+std::mutex g_stream_lock;
 int step_streams(hipStream_t &r, hipStream_t &e) {
+    std::lock_guard<std::mutex> hold(g_stream_lock);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { dbw_set_error("dbw_train_step_create: no current device"); return DBW_ERR_LAUNCH; }
     if (!g_stream_r[dev]) {
@@ -276,17 +279,24 @@ enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS
 __global__ void sync_set_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 // (timeouts: a counter in device memory; host_timeouts: the same in mapped host memory -- the next dbw_train_step_run sees it without a
 // transfer and fails loudly: a poll that gave up let its stream run ahead of what it was waiting for)
-__global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts, unsigned *host_timeouts) {
+// A poll that gives up (`limit` ticks of the 100 MHz wall clock: 1 s; the order of the enqueues rules a deadlock out, so this only ever
+// fires when the process's queues were descheduled that long) VOIDS the step instead of letting it update anything: it raises `void_flag`
+// (device float, what the step's Adam launch -- and, summed over the ranks, every rank's -- reads: != 0 -> the update is skipped, the arena
+// still cleared), counts itself in device memory, and leaves a nonzero word in mapped host memory (a plain system-scope store: no PCIe
+// atomics needed) that the next dbw_train_step_run sees without a transfer: from then on the plan orders its streams through events.
+__global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts, unsigned *host_timeouts, float *void_flag, unsigned long long limit) {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > 20000000ull) {
+        if (wall_clock64() - t0 > limit) {
             atomicAdd(timeouts, 1u);
-            __hip_atomic_fetch_add(host_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(void_flag, 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
 }
+constexpr unsigned long long SYNC_LIMIT_TICKS = 100000000ull;      // 1 s
 
 }  // namespace
 
@@ -297,7 +307,7 @@ struct dbw_step_plan {
     RasterWorkspace rw_e, rw_f;         // for max_views (the pointers of a run follow from the run's own B)
     hipEvent_t ev_prologue, ev_scatter, ev_fg_fwd, ev_reg, ev_layout, ev_kernel_done, ev_blocks_ready, ev_env_done, ev_losses;
     hipStream_t stream_r, stream_env;   // the library's two side streams of this device (step_streams): the regularisers; the env backward chain
-    unsigned long long rng_step;
+    unsigned long long runs;            // completed calls of dbw_train_step_run
     int bin_turn, bin_ready, uniform_ready;
     bool arena_clean;
     float *host_losses;                 // pinned
@@ -308,6 +318,8 @@ struct dbw_step_plan {
     unsigned *sync_words;               // device: SYNC_FLAGS counters + the number of polls that gave up
     unsigned *host_timeouts, *host_timeouts_dev;      // ... and the same number in mapped host memory (host pointer, device pointer)
     unsigned sync_val[SYNC_FLAGS];      // last value stored behind each counter (host side)
+    int voided_runs;                    // runs whose cross-stream wait gave up (seen at the next run): the plan then runs on events
+    int force_timeout;                  // debug (dbw_debug_train_step_force_timeout): the next run's join polls for a value that never comes
 };
 
 extern "C" size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc) {
@@ -320,23 +332,23 @@ extern "C" size_t dbw_train_step_workspace_bytes(const dbw_step_desc *desc) {
 extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void *workspace, size_t workspace_bytes) {
     if (check_desc(desc)) return nullptr;
     if (!workspace || ((uintptr_t)workspace & 255)) { dbw_set_error("dbw_train_step_create: the workspace must be 256-byte aligned"); return nullptr; }
-    dbw_step_plan *p = new (std::nothrow) dbw_step_plan();
-    if (!p) { dbw_set_error("dbw_train_step_create: out of host memory"); return nullptr; }
+    dbw_step_plan *p = new (std::nothrow) dbw_step_plan();        // (value-initialised: every handle below starts out null, and
+    if (!p) { dbw_set_error("dbw_train_step_create: out of host memory"); return nullptr; }      // dbw_train_step_destroy skips what is null)
     p->d = *desc;
     make_layout(p->d, p->L);
     if (workspace_bytes < p->L.total) {
         dbw_set_error("dbw_train_step_create: workspace of %zu bytes, %zu needed", workspace_bytes, p->L.total);
-        delete p;
+        dbw_train_step_destroy(p);
         return nullptr;
     }
     p->ws = (char *)workspace;
     hipEvent_t *evs[] = {&p->ev_prologue, &p->ev_scatter, &p->ev_fg_fwd, &p->ev_reg, &p->ev_layout, &p->ev_kernel_done, &p->ev_blocks_ready, &p->ev_env_done, &p->ev_losses};
     for (hipEvent_t *e : evs)
-        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
-    if (step_streams(p->stream_r, p->stream_env)) { delete p; return nullptr; }
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); dbw_train_step_destroy(p); return nullptr; }
+    if (step_streams(p->stream_r, p->stream_env)) { dbw_train_step_destroy(p); return nullptr; }
     if (hipHostMalloc((void **)&p->host_losses, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         dbw_set_error("dbw_train_step_create: hipHostMalloc failed");
-        delete p;
+        dbw_train_step_destroy(p);
         return nullptr;
     }
     for (int i = 0; i < 8; ++i) p->host_losses[i] = 0.f;
@@ -358,16 +370,16 @@ extern "C" dbw_step_plan *dbw_train_step_create(const dbw_step_desc *desc, void 
     p->profile = p->profiled = false;
     p->phase1_done = false;
     for (hipEvent_t &e : p->ev_t)
-        if (hipEventCreate(&e) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); delete p; return nullptr; }
-    p->rng_step = 0; p->bin_turn = 0; p->bin_ready = 0; p->uniform_ready = 0; p->arena_clean = false; p->losses_pending = false;
+        if (hipEventCreate(&e) != hipSuccess) { dbw_set_error("dbw_train_step_create: hipEventCreate failed"); dbw_train_step_destroy(p); return nullptr; }
+    p->runs = 0; p->voided_runs = 0; p->force_timeout = 0; p->bin_turn = 0; p->bin_ready = 0; p->uniform_ready = 0; p->arena_clean = false; p->losses_pending = false;
     return p;
 }
 
 extern "C" void dbw_train_step_destroy(dbw_step_plan *p) {
     if (!p) return;
     hipEvent_t evs[] = {p->ev_prologue, p->ev_scatter, p->ev_fg_fwd, p->ev_reg, p->ev_layout, p->ev_kernel_done, p->ev_blocks_ready, p->ev_env_done, p->ev_losses};
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-    for (hipEvent_t e : p->ev_t) (void)hipEventDestroy(e);
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_t) if (e) (void)hipEventDestroy(e);
     if (p->host_losses) (void)hipHostFree(p->host_losses);
     if (p->sync_words) (void)hipFree(p->sync_words);
     if (p->host_timeouts) (void)hipHostFree(p->host_timeouts);
@@ -426,9 +438,14 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     const Layout &L = p->L;
     DBW_REQUIRE(in->imgs && in->R && in->T, "null input");
     if (*(volatile unsigned *)p->host_timeouts != 0u) {
-        dbw_set_error("dbw_train_step_run: %u cross-stream wait(s) of an earlier run gave up after 0.2 s -- the streams of this plan ran ahead of each "
-                      "other and its results are void; create the plan with sync_events = 1", *(volatile unsigned *)p->host_timeouts);
-        return DBW_ERR_LAUNCH;
+        // A cross-stream poll of the previous run gave up: that run voided itself on the device (void_flag: no parameter moved, its arena was
+        // cleared; data-parallel ranks saw the flag through their gradient sum and skipped the update too).  From here on this plan orders
+        // its streams through events -- the form that cannot give up -- and the caller simply goes on: one optimisation step was lost.
+        HIP_OK(hipDeviceSynchronize());
+        *(volatile unsigned *)p->host_timeouts = 0u;
+        p->d.sync_events = 1;
+        p->voided_runs += 1;
+        p->arena_clean = false;          // (whatever the voided run left in the arena: this run opens with a fill)
     }
     DBW_REQUIRE(in->B >= 1 && in->B <= d.max_views, "B must lie in [1, max_views]");
     DBW_REQUIRE(in->global_count > 0.0, "global_count must be positive");
@@ -453,13 +470,17 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         hipLaunchKernelGGL(sync_set_kernel, dim3(1), dim3(1), 0, st, p->sync_words + idx, ++p->sync_val[idx]);
         return dbw_check_launch("sync_set_kernel");
     };
+    char *ws = p->ws;
+    float *void_flag = (float *)(ws + L.losses) + 7;          // raised by a poll that gave up; cleared by the head of every run; read by Adam
+    const int force_timeout = p->force_timeout;
+    p->force_timeout = 0;
     auto await = [&](hipStream_t st, int idx, hipEvent_t ev) -> int {
         if (!flags) { HIP_OK(hipStreamWaitEvent(st, ev, 0)); return DBW_OK; }
-        hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx], p->sync_words + SYNC_TIMEOUT_SLOT,
-                           p->host_timeouts_dev);
+        const bool forced = force_timeout && idx == F_ENV_DONE;       // (tests: a value that never comes, a 0.05 s limit)
+        hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx] + (forced ? 0x10000000u : 0u),
+                           p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, void_flag, forced ? 5000000ull : SYNC_LIMIT_TICKS);
         return dbw_check_launch("sync_wait_kernel");
     };
-    char *ws = p->ws;
 #define FP(off) ((float *)(ws + (off)))
 #define IP(off) ((int *)(ws + (off)))
     const int B = in->B, H = d.H, W = d.W, K = d.faces_per_pixel, nb = d.n_blocks, nv = d.block_nv;
@@ -477,8 +498,9 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
 
     // the zero arena: cleared by the plan's own Adam launch at the end of a run; before the first run (and after a run whose caller ran
     // Adam itself without clearing it) by a fill
-    if (head && !p->arena_clean && !(in->arena_is_clean && p->rng_step > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
+    if (head && !p->arena_clean && !(in->arena_is_clean && p->runs > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
     p->arena_clean = false;
+    if (head && !(d.fuse & 1)) HIP_OK(hipMemsetAsync(void_flag, 0, sizeof(float), M));       // (the fused prologue clears it itself)
 
     // ---- texture sets: sky, blocks, ground (dbw.py:273-293,306,331-334) ----
     dbw_texture_set sets[3];
@@ -524,7 +546,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         P.alpha_logit = d.alpha_logit; P.noise = noise_on ? in->noise_override : nullptr;
         P.noise_scale = noise_on ? d.opacity_noise : 0.f; P.thresh = thresh; P.nb = nb;
         P.alpha = FP(L.alpha); P.alpha_full = FP(L.alpha_full); P.keep = IP(L.keep);
-        P.seed = d.seed; P.rng_step = p->rng_step;
+        P.seed = d.seed; P.rng_step = in->rng_step;
+        P.void_flag = void_flag;
         P.sq_eps = d.sq_eps; P.S = d.S; P.R6 = d.R6; P.T = d.T; P.trig = d.trig; P.nv = nv;
         P.ratio = d.ratio_block_scene; P.scale_min = d.scale_min; P.S_world = d.S_world; P.Rw = d.R_world; P.Tw = d.T_world;
         P.blk_verts = FP(L.blk_verts);
@@ -577,7 +600,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         } else if (d.fuse & 4) {
             RegulariserArgs A;
             memset(&A, 0, sizeof(A));
-            A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = p->rng_step;
+            A.u = overlap_on ? in->overlap_u_override : nullptr; A.npts = d.overlap_points; A.seed = d.seed; A.rng_step = in->rng_step;
             A.sq_eps = d.sq_eps; A.S = d.S; A.R6 = d.R6; A.T = d.T; A.alpha_full = FP(L.alpha_full); A.nb = nb;
             A.ratio = d.ratio_block_scene; A.scale_min = d.scale_min; A.inv_temp = overlap_on ? 1.f / d.overlap_temperature : 1.f; A.thresh = d.overlap_n_blocks;
             A.overlap_scale = d.w_overlap;
@@ -831,11 +854,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----
     if (in->with_adam) {
         RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
-                                ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+                                ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), void_flag, M));
         p->arena_clean = true;
     }
     if (bins) { p->bin_turn = 1 - p->bin_turn; p->bin_ready = 1; }
-    p->rng_step += 1;
+    p->runs += 1;
     p->profiled = p->profile;
     return DBW_OK;
 #undef PROF
@@ -855,7 +878,7 @@ extern "C" int dbw_train_step_finish(dbw_step_plan *p, const dbw_step_inputs *in
     RC(dbw_texture_prep_bwd_sets(sets, 3, M));
     if (in->with_adam) {
         RC(dbw_adam_step_groups(d.flat_param, d.flat_grad, d.exp_avg, d.exp_avg_sq, d.group_end, in->lr, 2, in->beta1, in->beta2, in->adam_eps, in->adam_step,
-                                p->ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), M));
+                                p->ws + L.arena_begin, (int64_t)(L.arena_end - L.arena_begin), (const float *)(p->ws + L.losses) + 7, M));
         p->arena_clean = true;
     }
     return DBW_OK;
@@ -865,16 +888,20 @@ extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t s
     DBW_REQUIRE(p, "null pointer");
     if (p->d.sync_events) { HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0)); return DBW_OK; }
     hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned *)(p->sync_words + F_BLOCKS_READY), p->sync_val[F_BLOCKS_READY],
-                       p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev);
+                       p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, (float *)(p->ws + p->L.losses) + 7, SYNC_LIMIT_TICKS);
     return dbw_check_launch("sync_wait_kernel");
 }
 
-// (tests: what a poll that gave up leaves behind, without having to make one give up)
-extern "C" int dbw_debug_train_step_sync_timeout(dbw_step_plan *p) {
+// (tests: the join of the NEXT run polls for a value that never comes and gives up after 0.05 s -- the real thing, end to end)
+extern "C" int dbw_debug_train_step_force_timeout(dbw_step_plan *p) {
     if (!p) return DBW_ERR_INVALID;
-    *(volatile unsigned *)p->host_timeouts += 1u;
+    p->force_timeout = 1;
     return DBW_OK;
 }
+
+extern "C" int dbw_train_step_voided_runs(const dbw_step_plan *p) { return p ? p->voided_runs + (*(volatile unsigned *)p->host_timeouts != 0u ? 1 : 0) : -1; }
+
+extern "C" int64_t dbw_train_step_void_flag_offset(const dbw_step_plan *p) { return p ? (int64_t)p->L.losses + 7 * (int64_t)sizeof(float) : -1; }
 
 extern "C" int dbw_train_step_sync_timeouts(dbw_step_plan *p) {
     if (!p) return -1;

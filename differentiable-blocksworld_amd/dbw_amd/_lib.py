@@ -58,7 +58,8 @@ class StepInputs(ctypes.Structure):
     """dbw_step_inputs of include/dbw_hip.h."""
     _fields_ = [('imgs', c_p), ('imgs_tiled', c_i), ('R', c_p), ('T', c_p), ('B', c_i), ('global_count', c_d), ('noise_override', c_p),
                 ('overlap_u_override', c_p), ('with_adam', c_i), ('adam_step', c_i), ('lr', c_f * 2), ('beta1', c_f), ('beta2', c_f), ('adam_eps', c_f),
-                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('single_stream', c_i), ('arena_is_clean', c_i), ('defer_textures', c_i)]
+                ('read_losses', c_i), ('phase', c_i), ('rec_out', c_p), ('grad_rec', c_p), ('single_stream', c_i), ('arena_is_clean', c_i), ('rng_step', ctypes.c_uint64),
+                ('defer_textures', c_i)]
 
 
 def texture_sets(sets):
@@ -106,13 +107,13 @@ SIGNATURES = {
     'dbw_texture_prep_fwd_sets': [c_p, c_i, c_p],
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
-    'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p],
+    'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_finish': [c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
     'dbw_train_step_sync_timeouts': [c_p],
-    'dbw_debug_train_step_sync_timeout': [c_p],
+    'dbw_debug_train_step_force_timeout': [c_p],
     'dbw_train_step_profile': [c_p, c_i],
     'dbw_train_step_kernel_times': [c_p, c_p],
 }
@@ -122,6 +123,8 @@ OTHER_SIGNATURES = {
     'dbw_train_step_create': (c_p, [c_p, c_p, c_sz]),
     'dbw_train_step_destroy': (None, [c_p]),
     'dbw_train_step_offset': (c_i64, [c_p, c_i]),
+    'dbw_train_step_void_flag_offset': (c_i64, [c_p]),
+    'dbw_train_step_voided_runs': (c_i, [c_p]),
 }
 
 

@@ -10,6 +10,7 @@ tests/test_gpu_model.py::test_c_step_equals_native_step holds them to each other
 training render with MSE + parsimony + TV + overlap on a sync-free model; anything else -> `supported()` is False."""
 import ctypes
 import os
+import warnings
 import weakref
 
 import torch
@@ -84,7 +85,9 @@ class CStep:
         self._target, self._target_key = None, None
         self._env_key = None
         self._inp = _lib.StepInputs()
-        self._arena_cleaned_by_caller = False     # set by a caller that ran Adam itself with zero = self.arena() (parallel.py)
+        self._clean_plan = None             # handle of the plan whose arena a caller cleared itself (arena_cleaned_by_caller)
+        self._calls = 0                     # default counter of the step's random numbers (callers with a step count of their own pass it)
+        self._voided_seen = {}              # plan handle -> voided runs already reported
 
     # ---- what the plan covers -----------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -106,7 +109,7 @@ class CStep:
         # (a fork()ed child -- multiprocessing's manager / resource-sharer processes -- inherits these objects without the GPU context they
         # belong to: only the process that made the plans destroys them)
         if os.getpid() == self._pid:
-            for handle, _, _ in self._plans.values():
+            for handle, *_ in self._plans.values():
                 _lib.load().dbw_train_step_destroy(handle)
         self._plans, self._cur = {}, None
 
@@ -132,14 +135,25 @@ class CStep:
         both = self.binned_concurrent
         if both is None:
             both = m.world_size == 1
-        max_views = max(int(self.max_views or 0), B)
-        key = (coarse, decim, decim_blocks, max_views, m.world_size, self.fuse, int(seq), int(bool(both)), Kt.data_ptr(), m.R_world.data_ptr(),
+        # ONE plan (and one workspace) per phase / configuration, whatever the batch size: a plan runs any B up to its max_views, so a
+        # ragged last mini-batch or a smaller shard reuses the plan of the full batch; only a LARGER batch replaces it
+        key = (coarse, decim, decim_blocks, m.world_size, self.fuse, int(seq), int(bool(both)), Kt.data_ptr(), m.R_world.data_ptr(),
                m.R_world._version, m.T_world._version, float(m.S_world),
                self.params.flat.data_ptr(), tuple(sorted(m.loss_weights.items())), float(m.opacity_noise or 0.0), bool(m.kill_blocks),
                int(self.serial_setup_max_views), bool(self.sync_events), bool(defer))
-        if key in self._plans:
-            self._cur = self._plans[key]
+        have = self._plans.get(key)
+        if have is not None and have[3] >= B:
+            self._cur = have
             return self._cur
+        max_views = max(int(self.max_views or 0), B)
+        if have is not None:
+            if os.getpid() == self._pid:
+                with torch.cuda.device(dev):
+                    torch.cuda.synchronize(dev)
+                    _lib.load().dbw_train_step_destroy(have[0])
+            if self._clean_plan == have[0]:
+                self._clean_plan = None
+            del self._plans[key]
         w = m.loss_weights
         rs = 1.0 / m.world_size
         fine = not coarse
@@ -212,36 +226,67 @@ class CStep:
             handle = lib.dbw_train_step_create(ctypes.byref(d), wsb.data_ptr(), nbytes)
         if not handle:
             raise RuntimeError(f'dbw_train_step_create: {lib.dbw_last_error().decode()}')
-        self._plans[key] = self._cur = (handle, wsb, keep + [d])
+        self._plans[key] = self._cur = (handle, wsb, keep + [d], max_views)
         return self._cur
 
     def view(self, name, dtype=torch.float32, numel=None):
         """A buffer of the current plan's workspace as a tensor (tests, diagnostics, the opacities a logging tick reads)."""
-        handle, wsb, _ = self._cur
+        handle, wsb = self._cur[:2]
         off = _lib.load().dbw_train_step_offset(handle, _OFF[name])
         t = wsb[off:].view(dtype)
         return t if numel is None else t[:numel]
 
     def arena(self):
-        handle, wsb, _ = self._cur
+        handle, wsb = self._cur[:2]
         lib = _lib.load()
         return wsb[lib.dbw_train_step_offset(handle, 4):lib.dbw_train_step_offset(handle, 5)]
 
-    def kernel_times(self, inp, global_count=None, reps=5):
+    def arena_cleaned_by_caller(self):
+        """The caller has just enqueued a clear of the CURRENT plan's zero arena (it ran Adam itself with zero = self.arena()): the next run
+        of THAT plan skips its own fill.  Tracked per plan -- another plan's arena is none the cleaner for it."""
+        self._clean_plan = self._cur[0]
+
+    def void_flag(self):
+        """One float of the current plan's workspace: != 0 behind a run whose cross-stream wait gave up (include/dbw_hip.h:
+        dbw_train_step_void_flag_offset).  The plan's own Adam launches read it; a data-parallel caller sums it over the ranks with the
+        gradients and hands it to ops.adam_step_groups_(skip=...), so that every rank skips the update of a step one of them voided."""
+        handle, wsb = self._cur[:2]
+        off = _lib.load().dbw_train_step_void_flag_offset(handle)
+        return wsb[off:off + 4].view(torch.float32)
+
+    def voided_runs(self):
+        """Runs of the current plan that voided themselves (host-side counter, no synchronisation); > 0: the plan now runs on events."""
+        return int(_lib.load().dbw_train_step_voided_runs(self._cur[0]))
+
+    def _report_voided(self):
+        h = self._cur[0]
+        n = self.voided_runs()
+        if n > self._voided_seen.get(h, 0):
+            self._voided_seen[h] = n
+            warnings.warn(f'dbw C step: a cross-stream wait gave up ({n} run(s) so far): the step voided itself -- no parameter was updated -- '
+                          'and the plan orders its streams through HIP events from now on', RuntimeWarning)
+
+    def kernel_times(self, inp, global_count=None, reps=5, alone=False):
         """ms of the four big kernels INSIDE a step (env pass, fg pass, fg backward, env backward), everything that shares the GPU with them
         in a real step running next to them: HIP events recorded by the step itself on the streams the kernels run on; averaged over
-        `reps` steps without Adam (the parameters do not move).  -> {'env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'}"""
-        self(inp, global_count)
-        _lib.call('dbw_train_step_profile', self._cur[0], 1)
+        `reps` steps without Adam (the parameters do not move).  alone: the same launches in order on ONE stream -- every kernel by
+        itself on the GPU, in exactly the form the step launches it.  -> {'env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'} (env_fwd is 0 when
+        the env layer is folded into the fg pass)"""
+        was = self.use_side_stream
+        if alone:
+            self.use_side_stream = False
         acc = [0.0] * 4
         out = (ctypes.c_float * 4)()
         try:
+            self(inp, global_count)
+            _lib.call('dbw_train_step_profile', self._cur[0], 1)
             for _ in range(reps):
                 self(inp, global_count)
                 _lib.call('dbw_train_step_kernel_times', self._cur[0], ctypes.cast(out, ctypes.c_void_p))
                 acc = [a + float(o) for a, o in zip(acc, out)]
         finally:
             _lib.call('dbw_train_step_profile', self._cur[0], 0)
+            self.use_side_stream = was
         return dict(zip(('env_fwd', 'fg_fwd', 'fg_bwd', 'env_bwd'), [a / reps for a in acc]))
 
     def map_grads(self):
@@ -278,16 +323,18 @@ class CStep:
             _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------
-    def __call__(self, inp, global_count=None, adam=None, tiled_target=True, defer_textures=False):
+    def __call__(self, inp, global_count=None, adam=None, tiled_target=True, defer_textures=False, rng_step=None):
         """Enqueue forward + backward (+ Adam when `adam` = (step, (lr, lr_texture), (beta1, beta2), eps)) of one iteration on this rank's
         views.  -> StepLosses.  tiled_target: keep the targets in the tile-planar layout across steps while the SAME tensor comes back
-        (resident training views); a fresh mini-batch is tiled by the step itself."""
+        (resident training views); a fresh mini-batch is tiled by the step itself.  rng_step: the counter the step's random numbers are
+        keyed on -- the optimisation-step count of the caller (ShardedTrainStep.n_steps: identical on every rank, checkpointed); default:
+        the number of calls made through this object."""
         m = self.m
         imgs = inp['imgs']
         dev = imgs.device
         m._ensure_cameras(inp)
         B = imgs.shape[0]
-        handle, wsb, _ = self._plan_for(inp, B, defer_textures)
+        handle, wsb = self._plan_for(inp, B, defer_textures)[:2]
         R, T = inp['R'].float().contiguous(), inp['T'].float().contiguous()
         imgs = ops._chk(imgs, torch.float32, 'imgs')
         a = self._inp
@@ -312,8 +359,11 @@ class CStep:
             a.with_adam = 0
         a.defer_textures = int(bool(defer_textures))
         a.read_losses = int(self.read_losses)
-        a.arena_is_clean = int(self._arena_cleaned_by_caller)
-        self._arena_cleaned_by_caller = False
+        a.arena_is_clean = int(self._clean_plan is not None and self._clean_plan == handle)
+        if a.arena_is_clean:
+            self._clean_plan = None
+        a.rng_step = int(self._calls if rng_step is None else rng_step) & 0xffffffffffffffff
+        self._calls += 1
         cur = torch.cuda.current_stream(dev)
         # the env chain and the regularisers: streams of the plan (NULL), a torch stream of this process, or the caller's own stream
         side = side_stream(dev, self.side_priority).cuda_stream if (self.use_side_stream and self.own_side_stream) else 0
@@ -326,7 +376,7 @@ class CStep:
                 # dbw.py:369-371: weight * (1 | 0.1 after the coarse phase) * LPIPS(imgs, rec); under view-sharded data parallelism times this
                 # rank's share of the global batch (the gradients of the ranks are summed).  Phase 1 leaves the composite, the caller's
                 # network runs on it (torch autograd, MIOpen convolutions), phase 2 takes d term / d rec
-                rec = torch.empty(B, 3, m.img_size[0], m.img_size[1], device=dev)
+                rec = torch.empty(B, 3, m.img_size[0], m.img_size[1], device=dev)       # (a fresh leaf every step: autograd owns it)
                 a.phase, a.rec_out = 1, rec.data_ptr()
                 _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
                 with torch.enable_grad():
@@ -338,6 +388,7 @@ class CStep:
                 self._keep_rec = (rec, g_rec)
             _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
         self._keep = (imgs, R, T, nz, u)            # inputs stay referenced until the next call has been enqueued behind this one
+        self._report_voided()
         nb = m.n_blocks
         m._alpha, m._alpha_full = self.view('alpha', numel=nb), self.view('alpha_full', numel=nb)
         return StepLosses(self, self.view('losses', numel=5), list(w), bool(self.read_losses), perceptual)

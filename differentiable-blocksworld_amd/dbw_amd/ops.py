@@ -947,16 +947,17 @@ def fused_losses(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, 
     return _FusedLosses.apply(fg, env, imgs, alpha_full, bkg_maps, blocks_maps, ground_maps, sq_eps, S, R6, T, u, cfg)
 
 
-def adam_step_groups_(param, grad, exp_avg, exp_avg_sq, group_end, lrs, step, betas=(0.9, 0.999), eps=1e-8, zero=None):
+def adam_step_groups_(param, grad, exp_avg, exp_avg_sq, group_end, lrs, step, betas=(0.9, 0.999), eps=1e-8, zero=None, skip=None):
     """One launch for parameter groups that lie back to back in one flat buffer and differ in learning rate (optimizer.py:10-17).
-    zero: a uint8 device tensor the same launch clears (the zero arena of the next iteration, ZeroArena.end_step)."""
+    zero: a uint8 device tensor the same launch clears (the zero arena of the next iteration, ZeroArena.end_step).
+    skip: a one-float device tensor; != 0 at launch time -> nothing is updated, only `zero` is cleared (a voided C step, c_step.py)."""
     import ctypes
     n = len(lrs)
     ends = (ctypes.c_int64 * n)(*[int(e) for e in group_end])
     lr = (ctypes.c_float * n)(*[float(x) for x in lrs])
     zb = 0 if zero is None else (zero.numel() + 15) // 16 * 16
     _lib.call('dbw_adam_step_groups', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ends, lr, n, float(betas[0]),
-              float(betas[1]), float(eps), int(step), _ptr(zero), zb, _stream(param))
+              float(betas[1]), float(eps), int(step), _ptr(zero), zb, _ptr(skip), _stream(param))
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):

@@ -47,23 +47,14 @@ class FlatParams:
 
 
 class ShardedTrainStep:
-    """use_graph=True captures zero_grad + forward + backward of one iteration into a hipGraph after `graph_warmup` eager
-    iterations of the AUTOGRAD path (its ~66 kernel launches then replay from one host call; measured slower than eager launches, and
-    the native step does not use it); requires model.sync_free and inputs of constant shape.  The gradient all-reduce and the Adam
-    launch stay outside the graph."""
+    """One optimisation step per call: the C step (c_step.py: one call into the library per iteration) where it covers the model's
+    configuration, else the launch-by-launch native step, else the autograd iteration; the gradient sum over the ranks; fused Adam.
+    (Replaying an iteration from a hipGraph was built in rounds 2-3 and measured slower than the C step's plain enqueues -- a graph node
+    costs what a launch costs once the host is out of the way, profiles/r03_experiments.md -- and is gone.)"""
 
     def __init__(self, model, lr=5e-3, lr_texture=5e-2, betas=(0.9, 0.999), eps=1e-8, process_group=None, adam_fn=None,
-                 use_graph=False, graph_warmup=3, seed=None, use_native=True, overlap_allreduce=None, early_param='textures', use_c_step=True,
-                 fuse=None):
+                 seed=None, use_native=True, overlap_allreduce=None, early_param='textures', use_c_step=True, fuse=None):
         self.model, self.pg = model, process_group
-        self.use_graph, self.graph_warmup = use_graph, graph_warmup
-        # captured iterations: {(kind, phase flags, shapes, global count): [graph, static inputs, static losses]} -- the native step and the
-        # autograd iteration never share an entry, a ragged last batch or the next training phase gets its own (GRAPHS_KEPT most recent);
-        # the FIRST iteration of a key always runs eagerly (it sizes the texture bins by demand and creates the cached tables outside
-        # the capture), the second is captured
-        self._graphs, self._graph_seen = {}, set()
-        if use_graph and not getattr(model, 'sync_free', False):
-            raise ValueError('use_graph=True needs model.sync_free = True (no device->host sync inside the iteration)')
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         model.world_size, model.rank = self.world_size, self.rank
@@ -84,7 +75,7 @@ class ShardedTrainStep:
         # kernels, the random numbers drawn inside them, Adam inside the call on one GPU) where the library has it; the launch-by-launch
         # native step stays as the form the C step is tested against
         self.cstep = None
-        if use_c_step and self.native is not None and self.params.flat.is_cuda and not use_graph:
+        if use_c_step and self.native is not None and self.params.flat.is_cuda:
             from .c_step import CStep, FUSE_ALL
             self.cstep = CStep(model, self.params, (self.exp_avg, self.exp_avg_sq), fuse=FUSE_ALL if fuse is None else fuse)
         # Overlapped all-reduce: the blocks' texture gradient (`early_param`: 83 % of the buffer at config 2) is final long before the
@@ -96,6 +87,7 @@ class ShardedTrainStep:
             overlap_allreduce = dist.is_initialized() and dist.get_backend(process_group) == 'nccl' and self.world_size > 1
         self.overlap_allreduce = bool(overlap_allreduce) and dist.is_initialized() and self._early_range is not None
         self._early_work, self._early_done = None, False
+        self._coalesce = True
         self.defer_textures = True        # data parallel through the C step: sum the prepared maps' gradient, not the textures' (_c_iteration)
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
@@ -107,6 +99,9 @@ class ShardedTrainStep:
                 dist.broadcast(s, src=0, group=process_group)
             torch.manual_seed(int(s.item()))
             model._rng_seed = int(s.item())           # the C step's counter-based generator: the same key on every rank
+        else:
+            # one process, no seed given: the key follows torch's own seed (the trainer's torch.manual_seed(cfg seed)), not a constant
+            model._rng_seed = int(torch.initial_seed()) & 0xffffffffffffffff
 
     def _global_count(self, imgs, global_count):
         """Number of image elements in the GLOBAL batch (MSE is a mean over all views of all ranks, dbw.py:367).  Callers that
@@ -129,36 +124,24 @@ class ShardedTrainStep:
         dirty = None
         if self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported():
             return self._c_iteration(inp)
-        kind = key = None
-        if self.use_graph and self.n_steps >= self.graph_warmup:
-            kind = 'native' if self._native_graph_ok(inp) else 'autograd'
-            key = self._graph_key(kind, inp)
-            if key not in self._graph_seen:
-                self._graph_seen.add(key)
-                kind = None
-        if kind == 'native':
-            losses = self._native_graph_iteration(inp, key)
-        elif kind == 'autograd':
-            losses = self._graph_iteration(inp, key)
-        else:
-            # gradients accumulate into the preallocated flat buffer, so nothing carved out of the zero arena outlives the
-            # iteration: all zero-initialised scratch of the step comes from one buffer cleared by one launch
-            ops.ARENA.enabled = True
-            try:
-                ops.ARENA.begin_step(self.params.flat.device)
-                native = self.native is not None and self.model.training and inp['imgs'].shape[0] > 0 and self.native.supported()
-                if native:
-                    with torch.no_grad():         # (zeroes the gradient buffer itself: on its side stream, off the critical path)
-                        losses = self.native(inp, self.model._global_count, zero_grad=self.params.zero_grad)
-                else:
-                    self.params.zero_grad()
-                    losses = self.model(inp, labels)
-                    losses['total'].backward()
-                dirty = ops.ARENA.end_step(self.params.flat.device) if (native and self._fused_adam()) else None
-            finally:
-                ops.ARENA.enabled = False
-            if not native:
-                losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
+        # gradients accumulate into the preallocated flat buffer, so nothing carved out of the zero arena outlives the
+        # iteration: all zero-initialised scratch of the step comes from one buffer cleared by one launch
+        ops.ARENA.enabled = True
+        try:
+            ops.ARENA.begin_step(self.params.flat.device)
+            native = self.native is not None and self.model.training and inp['imgs'].shape[0] > 0 and self.native.supported()
+            if native:
+                with torch.no_grad():         # (zeroes the gradient buffer itself: on its side stream, off the critical path)
+                    losses = self.native(inp, self.model._global_count, zero_grad=self.params.zero_grad)
+            else:
+                self.params.zero_grad()
+                losses = self.model(inp, labels)
+                losses['total'].backward()
+            dirty = ops.ARENA.end_step(self.params.flat.device) if (native and self._fused_adam()) else None
+        finally:
+            ops.ARENA.enabled = False
+        if not native:
+            losses = {k: v.detach() for k, v in losses.items()}    # logging values only: do not keep the autograd graph alive
         if self.world_size > 1 or self.overlap_allreduce:     # (a one-rank group with the overlap forced on: the API smoke test)
             self.allreduce_gradients()
         self.n_steps += 1
@@ -182,19 +165,24 @@ class ShardedTrainStep:
         way on every rank -- the whole flat buffer, the blocks' texture slice early -- so that all ranks issue the same collectives."""
         cs = self.cstep
         distributed = self.world_size > 1 or self.overlap_allreduce
+        # the step's random numbers are keyed on the optimisation-step count: identical on every rank whatever plan / batch size / phase a
+        # rank's run uses, never replayed by a ragged batch or a new phase, restored with a checkpoint (n_steps is part of it)
+        rng = self.n_steps
         with torch.no_grad():
             if not distributed:
-                losses = cs(inp, self.model._global_count, adam=(self.n_steps + 1, self.lrs, self.betas, self.eps))
+                losses = cs(inp, self.model._global_count, adam=(self.n_steps + 1, self.lrs, self.betas, self.eps), rng_step=rng)
                 self.n_steps += 1
                 return losses
+            # (cs.void_flag(): != 0 where a rank's cross-stream wait gave up -- summed with the gradients, so that EVERY rank skips the
+            # update of a step one of them voided and the replicas stay identical)
             if self._defer_textures(inp):
-                losses = cs(inp, self.model._global_count, adam=None, defer_textures=True)
+                losses = cs(inp, self.model._global_count, adam=None, defer_textures=True, rng_step=rng)
                 small = self.params.grad[:self.params.bounds[0][1]]
-                self._allreduce_all([cs.map_grads(), small])
+                self._allreduce_all([cs.map_grads(), small, cs.void_flag()])
                 self.n_steps += 1
                 cs.finish(adam=(self.n_steps, self.lrs, self.betas, self.eps))
                 return losses
-            losses = cs(inp, self.model._global_count, adam=None)
+            losses = cs(inp, self.model._global_count, adam=None, rng_step=rng)
             if self.overlap_allreduce:
                 # the blocks' texture gradient is final long before the step ends (the step says when): its slice is reduced from a
                 # stream of its own next to the rest of the fg tail and the env chain
@@ -209,10 +197,13 @@ class ShardedTrainStep:
                     self.start_early_allreduce()
                 torch.cuda.current_stream(dev).wait_stream(side)      # (a synchronous backend -- gloo through a host copy -- wrote on `side`)
             self.allreduce_gradients()
+            void = cs.void_flag()
+            if self.world_size > 1:
+                self._allreduce(void)
             self.n_steps += 1
             ops.adam_step_groups_(self.params.flat, self.params.grad, self.exp_avg, self.exp_avg_sq, [b for _, b in self.params.bounds],
-                                  self.lrs, self.n_steps, self.betas, self.eps, zero=cs.arena())
-            cs._arena_cleaned_by_caller = True
+                                  self.lrs, self.n_steps, self.betas, self.eps, zero=cs.arena(), skip=void)
+            cs.arena_cleaned_by_caller()
         return losses
 
     def _defer_textures(self, inp):
@@ -226,11 +217,18 @@ class ShardedTrainStep:
 
     def _allreduce_all(self, tensors):
         """Sum all-reduce of several small buffers: one coalesced collective where the backend has it (RCCL: one launch), else one each."""
-        if dist.get_backend(self.pg) == 'nccl' and all(t.is_cuda for t in tensors) and hasattr(dist, '_coalescing_manager'):
-            with dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False):
-                for t in tensors:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-            return
+        if self._coalesce and dist.get_backend(self.pg) == 'nccl' and all(t.is_cuda for t in tensors) and hasattr(dist, '_coalescing_manager'):
+            # (torch's coalescing context is not public API: if this build of torch refuses it, one collective per tensor from then on --
+            # decided before any collective of the call is issued, so every rank decides the same)
+            try:
+                cm = dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False)
+            except (TypeError, RuntimeError):
+                self._coalesce = False
+            else:
+                with cm:
+                    for t in tensors:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+                return
         for t in tensors:
             self._allreduce(t)
 
@@ -269,91 +267,3 @@ class ShardedTrainStep:
         if self._early_work is not None:
             self._early_work.wait()                  # (the current stream waits, not the host)
         self._early_work, self._early_done = None, False
-
-    # ---- the native step as ONE hipGraph -----------------------------------------------------------------------------------------
-    # At the reference's own operating point (batch_size 4, configs/dtu/default.yml:28) a step is ~0.1 ms of kernels behind ~0.45 ms
-    # of Python: 33 launches through ctypes, events, small torch allocations.  Captured once per training phase, the same launches
-    # (both streams, their fork / join events, the zero fills) replay from one host call; the fused Adam stays outside (its step
-    # count and learning rates change every iteration).  Single process only: the early all-reduce hook is a host-side callback.
-    def _native_graph_ok(self, inp):
-        return (self.native is not None and self.world_size == 1 and not self.overlap_allreduce and self.model.training
-                and inp['imgs'].shape[0] > 0 and self.native.supported() and self._fused_adam())
-
-    GRAPHS_KEPT = 4
-
-    def _graph_key(self, kind, inp):
-        m = self.model
-        live = tuple(bool(m.is_live(k)) for k in ('coarse_learning', 'decimate_txt')) if hasattr(m, 'is_live') else ()
-        return (kind, bool(m.training), live, float(m._global_count), tuple((k, tuple(v.shape)) for k, v in sorted(inp.items())),
-                getattr(m, '_noise_override', None) is None, getattr(m, '_overlap_u_override', None) is None)
-
-    def _graph_entry(self, key):
-        e = self._graphs.pop(key, None)
-        if e is not None:
-            self._graphs[key] = e                    # (most recently used last)
-        return e
-
-    def _graph_store(self, key, entry):
-        self._graphs[key] = entry
-        while len(self._graphs) > self.GRAPHS_KEPT:
-            self._graphs.pop(next(iter(self._graphs)))
-
-    @staticmethod
-    def _graph_feed(static_inp, inp):
-        for k, v in inp.items():
-            if v.data_ptr() != static_inp[k].data_ptr():
-                static_inp[k].copy_(v)
-
-    def _native_graph_iteration(self, inp, key):
-        from .native_step import LazyLosses
-        m = self.model
-        dev = self.params.flat.device
-        e = self._graph_entry(key)
-        if e is None:
-            static_inp = {k: v.clone() for k, v in inp.items()}
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            ops.ARENA.enabled = True
-            try:
-                with torch.no_grad(), torch.cuda.graph(graph):
-                    ops.ARENA.clean.pop(dev, None)              # the graph clears the arena itself, every replay
-                    ops.ARENA.begin_step(dev)
-                    ll = self.native(static_inp, m._global_count, zero_grad=self.params.zero_grad)
-                ops.ARENA.end_step(dev)
-                ops.ARENA.clean.pop(dev, None)
-            finally:
-                ops.ARENA.enabled = False
-            e = [graph, static_inp, (ll._vals, ll._part, ll._scale, ll._names)]
-            del ll
-            self._graph_store(key, e)
-        self._graph_feed(e[1], inp)
-        e[0].replay()
-        return LazyLosses(*e[2])
-
-    def _graph_iteration(self, inp, key):
-        e = self._graph_entry(key)
-        if e is None:
-            static_inp = {k: v.clone() for k, v in inp.items()}
-            # torch's capture recipe: warm up on a side stream so that the AccumulateGrad nodes live on the capture stream
-            if hasattr(self.model, 'release_graph'):
-                self.model.release_graph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.params.zero_grad()
-                    self.model(static_inp, None)['total'].backward()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self.params.zero_grad()
-                losses = self.model(static_inp, None)
-                losses['total'].backward()
-                static_losses = {k: v.detach() for k, v in losses.items()}
-            del losses
-            e = [graph, static_inp, static_losses]
-            self._graph_store(key, e)
-        self._graph_feed(e[1], inp)
-        e[0].replay()
-        return e[2]

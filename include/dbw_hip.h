@@ -26,8 +26,10 @@
 #endif
 
 /* ABI revision of this header (dbw_abi_version() returns the value the library was built with).  2: image_layout argument of the fused
- * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry) */
-#define DBW_ABI_VERSION 4
+ * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry); 5: dbw_step_inputs.rng_step
+ * (the random-number counter is the caller's step count, not the plan's), skip_flag of dbw_adam_step_groups, a cross-stream wait that
+ * gives up voids its step and moves the plan to events instead of failing the next run (dbw_train_step_voided_runs) */
+#define DBW_ABI_VERSION 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -355,10 +357,13 @@ int dbw_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 /* The same over parameter groups that are contiguous in ONE flat buffer and differ only in learning rate (optimizer.py:10-17: the
  * texture group vs the rest): group k covers [group_end[k-1], group_end[k]) (group_end[-1] = 0), 1 <= ngroups <= 4; host arrays.
  * zero_buf / zero_bytes (optional, NULL / 0): device scratch cleared by the same launch -- the zero-initialised work space of the NEXT
- * iteration, so that it does not have to open with a fill (16-byte aligned, a multiple of 16 bytes). */
+ * iteration, so that it does not have to open with a fill (16-byte aligned, a multiple of 16 bytes).
+ * skip_flag (optional, NULL): one device float; when it is != 0 at launch time NOTHING is updated (parameters and moments keep their
+ * values) and only zero_buf is cleared -- how a training step whose cross-stream wait gave up (dbw_step_desc.sync_events) is kept from
+ * applying gradients that may be incomplete (dbw_train_step_void_flag_offset). */
 int dbw_adam_step_groups(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *group_end,
                          const float *lr, int ngroups, float beta1, float beta2, float eps, int step, void *zero_buf,
-                         int64_t zero_bytes, dbw_stream_t stream);
+                         int64_t zero_bytes, const float *skip_flag, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The whole optimisation iteration of the training path behind ONE entry point (ABI 4).
@@ -430,8 +435,11 @@ typedef struct dbw_step_desc {
     int sync_events;                            /* how the plan's streams wait for each other.  0 (default): through words in device memory -- the
                                                  * producing stream runs a one-thread kernel that stores a counter, the waiting stream a one-thread
                                                  * kernel that polls it (every wait is enqueued after its producer, so no ordering of the hardware
-                                                 * queues can deadlock it; a poll gives up after 0.2 s and says so in mapped host memory: the plan's next
-                                                 * run fails with that message; dbw_train_step_sync_timeouts counts them).  Measured: an
+                                                 * queues can deadlock it; a poll that still gives up -- after 1 s: the process's queues were
+                                                 * descheduled that long -- VOIDS its step on the device: the step's Adam launch (and, through the
+                                                 * summed flag, every data-parallel rank's) skips the update, and the plan's next run -- which sees
+                                                 * a word in mapped host memory -- switches the plan to events for good and goes on:
+                                                 * dbw_train_step_voided_runs, dbw_train_step_sync_timeouts).  Measured: an
                                                  * event costs the stream that records or waits for it 7-11 us before its next kernel and the
                                                  * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.
                                                  * != 0: HIP events (hipEventRecord / hipStreamWaitEvent) */
@@ -464,6 +472,10 @@ typedef struct dbw_step_inputs {
     int arena_is_clean;                         /* != 0: the caller cleared the zero arena (dbw_train_step_offset 4 / 5) since the last run --
                                                  * it does when it runs Adam itself through dbw_adam_step_groups(zero_buf = the arena);
                                                  * otherwise a run that does not follow a run with_adam clears the arena with a fill of its own */
+    uint64_t rng_step;                          /* counter of the step's random numbers (opacity noise, overlap samples: Philox keyed on
+                                                 * (seed, rng_step, stream, index)): the caller's optimisation-step count -- the same on every
+                                                 * data-parallel rank whatever plan, batch size or phase a rank's run uses, never repeated by a
+                                                 * ragged last batch or the next phase, and part of what a checkpoint already holds */
     int defer_textures;                         /* != 0 (needs with_adam == 0): stop in front of the backward of the texture preparation too.  The
                                                  * gradient of the PREPARED maps (dbw_train_step_offset 13 .. 14: sigmoid + decimation are linear
                                                  * behind it) is then what a data-parallel caller sums over the ranks -- with 8x-decimated maps
@@ -500,8 +512,15 @@ int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
 /* Number of cross-stream waits of this plan that gave up (sync_events == 0; never in a healthy process) -- synchronises the device; < 0 on error */
 int dbw_train_step_sync_timeouts(dbw_step_plan *plan);
-/* tests: marks the plan as if one of its polls had given up (the next dbw_train_step_run must refuse to go on) */
-int dbw_debug_train_step_sync_timeout(dbw_step_plan *plan);
+/* Runs of this plan that voided themselves because one of their waits gave up (host-side, no synchronisation: a run counts once the NEXT
+ * run -- or this call -- has seen its word in mapped host memory).  > 0: the plan runs on events (as if created with sync_events = 1). */
+int dbw_train_step_voided_runs(const dbw_step_plan *plan);
+/* Byte offset inside the workspace of the step's void flag: one float, != 0 behind a run whose wait gave up, cleared by the head of the
+ * next run.  A data-parallel caller sums it over the ranks next to the gradients and hands it to dbw_adam_step_groups as skip_flag (the
+ * plan's own Adam launches -- dbw_train_step_run with_adam, dbw_train_step_finish -- read it themselves), so that all ranks skip together. */
+int64_t dbw_train_step_void_flag_offset(const dbw_step_plan *plan);
+/* tests: the join of the plan's NEXT run polls for a value that never comes and gives up after 0.05 s */
+int dbw_debug_train_step_force_timeout(dbw_step_plan *plan);
 
 /* Measurement aid (bench.py): on != 0 makes every following run record HIP timing events around its four big kernels, on the streams they
  * run on and with everything that shares the GPU with them in a real step running next to them (the events themselves cost each

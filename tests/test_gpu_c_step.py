@@ -126,8 +126,17 @@ def test_c_step_draws_its_noise_and_samples_from_the_counter_based_generator():
             want = torch.sigmoid(logit + float(model.opacity_noise) * z)
             assert float((got[-1] - want).abs().max()) < 2e-6, (t, got[-1], want)
         assert not torch.equal(got[0], got[1])
-        alphas.append(torch.stack(got))
         ov = float(out['overlap'])
+        # the counter is the optimisation step, not a per-plan count: a ragged batch and the next phase's plan (epoch 800) go on with t = 3, 4
+        for t, (e, nv) in ((3, (0, 1)), (4, (800, 2))):
+            model.set_cur_epoch(e)
+            step({k: v[:nv].contiguous() for k, v in inp.items()})
+            torch.cuda.synchronize()
+            got.append(step.cstep.view('alpha', numel=4).cpu().clone())
+            z = torch.empty(4)
+            L.host_step_noise(1234, t, 4, ctypes.c_void_p(z.data_ptr()))
+            assert float((got[-1] - torch.sigmoid(logit + float(model.opacity_noise) * z)).abs().max()) < 2e-6, t
+        alphas.append(torch.stack(got))
     assert torch.equal(alphas[0], alphas[1])
     # overlap with torch's samples (the launch-by-launch step): same scene, frozen parameters
     model = _model(0, kill=False)
@@ -394,15 +403,77 @@ def test_c_step_at_the_full_benchmark_batch_equals_the_native_step():
     _compare(got, ref, ref[0].params.names)
 
 
-def test_c_step_refuses_to_go_on_after_a_wait_that_gave_up():
-    """A poll between the step's streams that gives up (0.2 s) lets its stream run ahead of what it waited for: the results of that run are
-    void, and the plan says so -- in mapped host memory, so the next run fails loudly instead of training on."""
+def test_c_step_voids_a_step_whose_wait_gave_up_and_goes_on_through_events():
+    """A poll between the step's streams that gives up must not let the step update anything: forced here for real (the join of the run
+    polls for a value that never comes, 0.05 s) -- the step's Adam launch sees the void flag and moves no parameter and no moment, the
+    next run notices the word in mapped host memory, switches the plan to HIP events and goes on; from then on the plan equals a plan
+    created on events, run for run."""
+    import warnings
     inp = _inputs(2, 48, 64)
-    model = _model(0)
-    step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def mk(events):
+        model = _model(0)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        step.cstep.sync_events = events
+        return step
+    ref = mk(True)
+    ref(inp)
+    ref(inp)                               # reference: two applied steps on events
+    step = mk(False)
     step(inp)
     torch.cuda.synchronize()
-    assert step.cstep.sync_timeouts() == 0
-    _lib.call('dbw_debug_train_step_sync_timeout', step.cstep._cur[0])
-    with pytest.raises(RuntimeError, match='gave up'):
-        step(inp)
+    assert step.cstep.sync_timeouts() == 0 and step.cstep.voided_runs() == 0
+    before = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone())
+    _lib.call('dbw_debug_train_step_force_timeout', step.cstep._cur[0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        step(inp)                          # voided: its join gives up
+        torch.cuda.synchronize()
+        assert step.cstep.sync_timeouts() == 1 and step.cstep.voided_runs() == 1
+        for a, b in zip(before, (step.params.flat, step.exp_avg, step.exp_avg_sq)):
+            assert torch.equal(a, b)       # nothing moved
+        step.n_steps -= 1                  # (test only: line the Adam step count up with the reference's two applied steps)
+        out = step(inp)                    # goes on: through events from here
+        torch.cuda.synchronize()
+    assert any('gave up' in str(x.message) for x in w)
+    assert step.cstep.sync_timeouts() == 1 and step.cstep.voided_runs() == 1
+    assert all(torch.isfinite(v).all() for v in out.values())
+    diff = (step.params.flat - ref.params.flat).abs()
+    assert float((diff > 1e-4).float().mean()) < 1e-2 and float(diff.max()) < 0.02, (float((diff > 1e-4).float().mean()), float(diff.max()))
+
+
+def test_arena_cleaned_by_the_caller_counts_for_the_plan_it_cleaned_only():
+    """A caller that runs Adam itself (data parallel, whole-buffer flow) clears the CURRENT plan's zero arena; a run of ANOTHER plan --
+    the next phase -- must still open with its own fill: the mark is per plan."""
+    inp = _inputs(2, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    model = _model(0)
+    model._noise_override, model._overlap_u_override = noise, u
+    step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=99)
+    cs = step.cstep
+    want0 = {k: float(v) for k, v in step(inp).items()}
+    g0 = step.params.grad.clone()
+    model.set_cur_epoch(800)
+    want1 = {k: float(v) for k, v in step(inp).items()}
+    g1 = step.params.grad.clone()
+    cs(inp, adam=None)                                        # the epoch-800 plan is left dirty (no Adam, nobody cleared its arena)
+    model.set_cur_epoch(0)
+    cs(inp, adam=None)                                        # ... and so is the epoch-0 plan; the caller now cleans THIS one:
+    cs.arena().zero_()
+    cs.arena_cleaned_by_caller()
+    model.set_cur_epoch(800)
+    got1 = {k: float(v) for k, v in cs(inp, adam=None).items()}      # must not inherit the mark
+    torch.cuda.synchronize()
+    for k in want1:
+        assert abs(got1[k] - want1[k]) <= 2e-6 * max(abs(want1[k]), 1e-3), (k, got1[k], want1[k])
+    assert float((step.params.grad - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    model.set_cur_epoch(0)
+    got0 = {k: float(v) for k, v in cs(inp, adam=None).items()}      # the cleaned plan runs without a fill, on a clean arena
+    torch.cuda.synchronize()
+    for k in want0:
+        assert abs(got0[k] - want0[k]) <= 2e-6 * max(abs(want0[k]), 1e-3), (k, got0[k], want0[k])
+    assert float((step.params.grad - g0).abs().max()) <= 1e-5 * float(g0.abs().max())

@@ -57,6 +57,9 @@ def _run_nccl_single(rank, port, out):
             step(views)
         torch.cuda.synchronize()
         res.append(step.params.flat.detach().cpu().clone())
+    # (the deferred flow went through ONE coalesced RCCL call for the map gradients + the small gradients + the void flag: torch's
+    # coalescing context was accepted, not replaced by the per-tensor fallback)
+    out[1] = bool(step._coalesce) and dist.get_backend() == 'nccl'
     dist.destroy_process_group()
     out[0] = max(float((res[0] - res[1]).abs().max()), float((res[0] - res[2]).abs().max()))
 
@@ -74,6 +77,7 @@ def test_overlapped_allreduce_on_a_one_rank_rccl_group_leaves_the_step_unchanged
     out = mgr.dict()
     mp.spawn(_run_nccl_single, args=(29541, out), nprocs=1, join=True)
     assert out[0] < 1e-4, out[0]          # (atomics order: not bit-identical from run to run)
+    assert out[1] is True
 
 
 def _run(rank, world, port, out, n_views=V, n_steps=3, defer=True):

@@ -88,6 +88,26 @@ def test_rasterize_forward_bit_exact(H, W, K, nf, blur, persp, clipb, flags, ras
         assert torch.equal(a.cpu(), b), f'{name}: max abs diff {(a.cpu() - b).abs().max().item()}'
 
 
+@pytest.mark.parametrize('H,W,K,nf,blur', [(64, 48, 10, 300, math.log(1e4 - 1) * 1e-4), (40, 40, 1, 100, 0.0)])
+@pytest.mark.parametrize('flags', [0, 256, 4096])
+def test_rasterize_forward_bit_exact_with_backface_culling(H, W, K, nf, blur, flags, raster_flags):
+    """`cull_backfaces=True` of the `_C.rasterize_meshes` signature (no shipped config sets it; the boundary declares it): faces whose
+    NDC winding is negative are dropped -- by the per-face record on the device (REC box emptied: never binned, never evaluated), per pixel
+    in the oracle -- and what is left is bit-exact, soft and hard.  Random faces are about half back-facing, so the culled and the unculled
+    lists differ substantially (asserted)."""
+    raster_flags(flags)
+    fv = random_faces(nf, seed=nf + K)
+    fv = torch.cat([fv, fv * torch.tensor([0.9, -1.1, 1.0])], 0)         # (the mirrored copy flips every winding)
+    first, num = torch.tensor([0, nf]), torch.tensor([nf, nf])
+    ref = O.rasterize_fwd_raw(fv, first, num, None, (H, W), blur, K, True, True, cull_backfaces=True, n_threads=8)
+    unculled = O.rasterize_fwd_raw(fv, first, num, None, (H, W), blur, K, True, True, cull_backfaces=False, n_threads=8)
+    assert (ref[0] != unculled[0]).float().mean() > 0.05 and (ref[0] >= 0).sum() > 100
+    out = ops.rasterize_meshes(fv.to(DEV), first.to(DEV), num.to(DEV), None, (H, W), blur, K, 0, 0, True, True, True)
+    assert torch.equal(out[0].cpu(), ref[0]), f'pix_to_face mismatch on {(out[0].cpu() != ref[0]).sum().item()} slots'
+    for name, a, b in zip(['zbuf', 'bary', 'dists'], out[1:], ref[1:]):
+        assert torch.equal(a.cpu(), b), f'{name}: max abs diff {(a.cpu() - b).abs().max().item()}'
+
+
 def test_two_level_binning_is_bit_identical_to_the_full_scan(monkeypatch):
     """Coarse 64x64-pixel bins (default) vs every tile scanning every face: same candidate order, so every output bit matches,
     on an image spanning several bins with ragged borders and uneven meshes (one empty)."""

@@ -13,7 +13,7 @@ args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 30
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.set_cur_epoch(int(sys.argv[1])); model.sync_free = True; model.overlap_passes = len(sys.argv) < 3
-step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=False, seed=227391)
+step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=227391)
 lib = _lib.load()
 for flags in [0, 1, 2, 3, 0]:
     lib.dbw_debug_set_flags(flags)

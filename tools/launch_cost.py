@@ -12,7 +12,7 @@ args = A(); args.views, args.H, args.W, args.blocks, args.fpp, args.txt = 49, 30
 dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.sync_free = True; model.overlap_passes = True
-step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, use_graph=False, seed=227391)
+step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=227391)
 full = dict(model.loss_weights)
 for name, w in (('all losses', full), ('rgb only', {'rgb': full['rgb']}), ('all losses', full)):
     model.loss_weights = w
