@@ -532,7 +532,7 @@ def main():
         if step.cstep is not None and world == 1:
             restore()
             alone = step.cstep.kernel_times(inp, global_count, alone=True)
-            folded = alone['env_fwd'] < 1e-3 and (step.cstep.fuse & 18) == 18          # no env pass of its own was launched
+            folded = alone['env_fwd'] < 0.03 and (step.cstep.fuse & 18) == 18          # no env pass of its own between its two events (an empty pair reads ~5 us)
             name_of = {'env_fwd': 'render_fwd_fused K=1 (env pass)',
                        'fg_fwd': f'render_fwd_fused K={K_} (fg pass' + (' + folded env layer)' if folded else ')'),
                        'fg_bwd': f'render_bwd_fused K={K_} (fg pass)', 'env_bwd': 'render_bwd_fused K=1 (env pass)'}

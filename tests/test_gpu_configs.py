@@ -117,7 +117,11 @@ def _iteration(shape, seed, epoch, decimate, c_step=False):
     ref = orc.forward(inp, training=True, coarse=coarse, decimate=decimate, opacity_noise=noise, overlap_points=u, n_threads=16)
     ref['total'].backward()
     model._noise_override, model._overlap_u_override = noise.to(DEV), u.to(DEV)
+    flips_c = None
     if c_step:
+        # (the fragment-flip count is taken from the model as the autograd test sees it -- host-packed blocks, its own vertex count --
+        # BEFORE the parameters are re-homed into the flat buffers and the model is made sync-free for the step)
+        flips_c = _fragment_flips(model, orc, inp, coarse, decimate, noise if coarse else None)
         # the benchmarked entry point: ONE call into the library per iteration (dbw_train_step_run, every fusion on: env layer folded into
         # the fg pass, fused set-up / tails); learning rates 0, so Adam runs and nothing moves -- gradients are read from the flat buffer
         from dbw_amd.parallel import ShardedTrainStep
@@ -146,7 +150,12 @@ def _iteration(shape, seed, epoch, decimate, c_step=False):
             n_off, worst = off_entries(gh, v.grad, floor=0.1)          # of the largest entry -- each entry is a sum of ~10^4 terms of
             if n_off:                                                   # either sign, accumulated in fp32 on both sides)
                 errs['grad ' + k] = max(errs['grad ' + k], REL * worst)
-    flips = _fragment_flips(model, orc, inp, coarse, decimate, noise if coarse else None) if max(errs.values()) >= REL else 0
+    if flips_c is not None:
+        flips = flips_c if max(errs.values()) >= REL else 0
+    else:
+        flips = _fragment_flips(model, orc, inp, coarse, decimate, noise if coarse else None) if max(errs.values()) >= REL else 0
+    if max(errs.values()) >= REL:
+        print(f'seed {seed}, epoch {epoch}: {flips} fragment flips; off: ' + ', '.join(f'{k} {v:.2e}' for k, v in errs.items() if v >= REL))
     if flips == 0 and max(errs.values()) >= REL:
         # No fragment differs, yet a gradient is off by more than 1e-4 of its largest entry: then it must be an ill-conditioned sum
         # (the ground pose only receives gradient through barycentrics -> uv -> texel differences of a noise texture: tens of
