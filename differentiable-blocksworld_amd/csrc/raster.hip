@@ -84,6 +84,45 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
     work[seg0 + p] = (int)L;
 }
 
+// The launch order of the SPLIT form of the soft forward (render_fused.hip: render_fwd_split_kernel, small batches): a workgroup there is
+// four waves that either share one tile with SPLIT_MIN_FACES faces or more (classes 0..6; also a tile that walks its coarse bin) -- each
+// wave evaluates a quarter of the tile's ordered face list, the lists are merged in LDS -- or take one light / empty tile each (classes 7,
+// 8, 9).  Per XCD segment: O shared tiles, heaviest first, E' = len - O light ones in G = ceil(E' / 4) groups, spread evenly between them as
+// above; work4[(seg0 + p) * 4 + w] = tile of wave w of the workgroup at position p, entry 0 flagged WORK_SHARED for a shared tile, -1 for
+// the unused waves of the segment's last group; hdr[1 + x * 16 + 15] = O + G, the workgroups of the segment that have work at all.
+__global__ __launch_bounds__(256) void work_scatter_split_kernel(const int *__restrict__ rank, int *__restrict__ hdr, long long total, int *__restrict__ work4,
+                                                                 unsigned *sync_flag, unsigned sync_val) {
+    if (sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sync_flag, sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= total) return;
+    const long long per = (total + 7) / 8;
+    const int x = (int)(L / per);
+    const long long seg0 = (long long)x * per;
+    const int len = (int)min(per, total - seg0);
+    const int kr = rank[L], k = kr >> WORK_RANK_BITS;
+    int r = kr & ((1 << WORK_RANK_BITS) - 1), O = 0, below = 0;
+#pragma unroll
+    for (int c = 0; c < WORK_CLASSES - 1; ++c) {
+        const int h = hdr[1 + x * 16 + c];
+        if (c < k) below += h;
+        if (c < WORK_SHARED_CLASSES) O += h;
+    }
+    r += below;                                   // rank over all classes in order (the empty tiles' own count is never needed: they come last)
+    const int E = len - O, G = (E + 3) >> 2, Wseg = O + G;
+    if (L == seg0) hdr[1 + x * 16 + 15] = Wseg;
+    int *out = work4 + seg0 * 4;
+    if (k < WORK_SHARED_CLASSES) {                // the r-th of O slots spread evenly over the Wseg workgroups of the segment
+        const unsigned p = (unsigned)((((unsigned long long)(r + 1)) * (unsigned long long)Wseg + (unsigned long long)O - 1ull) / (unsigned long long)O - 1ull);
+        out[(long long)p * 4] = (int)L | WORK_SHARED;
+    } else {                                      // light tile e of E: wave e % 4 of group e / 4, the group at the (e / 4)-th position that is not a slot
+        const int e = r - O, j = e >> 2;
+        const unsigned p = (unsigned)(((unsigned long long)j * (unsigned long long)Wseg) / (unsigned long long)G);
+        out[(long long)p * 4 + (e & 3)] = (int)L;
+        if (e == E - 1)
+            for (int w = (e & 3) + 1; w < 4; ++w) out[(long long)p * 4 + w] = -1;
+    }
+}
+
 __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
                                                        const int *__restrict__ num_faces, int N, int H, int W, int nx, int ny,
                                                        const int *__restrict__ clist, const int *__restrict__ ccount, int2 *__restrict__ cell,
@@ -252,8 +291,10 @@ static size_t cell_pool_entries(int64_t F_total, int N, int H, int W) {
 }
 extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
+    // (the launch order: one int per tile, or -- split form of the soft forward -- four per workgroup position)
     return dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W) + align256(CELL_HDR_INTS * sizeof(int)) +
-           align256(n * t * sizeof(int2)) + 2 * align256(n * t * sizeof(int)) + align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
+           align256(n * t * sizeof(int2)) + align256(4 * n * t * sizeof(int)) + align256(n * t * sizeof(int)) +
+           align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
 }
 
 const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
@@ -294,7 +335,7 @@ int dbw_raster_workspace_layout(void *workspace, size_t workspace_bytes, long lo
             const size_t t = cell_tiles(H, W);
             L.cell = (int2 *)((char *)L.hdr + align256(CELL_HDR_INTS * sizeof(int)));
             L.work = (int *)((char *)L.cell + align256((size_t)N * t * sizeof(int2)));
-            L.rank = (int *)((char *)L.work + align256((size_t)N * t * sizeof(int)));
+            L.rank = (int *)((char *)L.work + align256(4 * (size_t)N * t * sizeof(int)));
             L.pool = (int *)((char *)L.rank + align256((size_t)N * t * sizeof(int)));
             L.pool_cap = (int)cell_pool_entries(F_total, N, H, W);
         }
@@ -309,7 +350,7 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
     // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass, or the fused set-up
     // kernels of the training step); only `cb` is rebuilt
     cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
-    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
+    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr; cb.hdr = nullptr;
     if (F_total <= 0) return DBW_OK;
     dbw::RasterWorkspace L;
     int rc = dbw_raster_workspace_layout(workspace, workspace_bytes, F_total, max_faces_per_view, N, H, W, want_cells, L);
@@ -340,7 +381,7 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
                 rc = dbw_check_launch("work_scatter_kernel");
                 if (rc) return rc;
             }
-            cb.cell = L.cell; cb.pool = L.pool; cb.work = L.work;
+            cb.cell = L.cell; cb.pool = L.pool; cb.work = L.work; cb.hdr = L.hdr;
         }
     }
     return DBW_OK;
@@ -365,8 +406,12 @@ int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
 }
 
 // the launch-order kernel alone (the training step's fused set-up fills cell / rank / hdr itself)
-int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val) {
+int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val, bool split) {
     const long long total = (long long)N * (long long)cell_tiles(H, W);
+    if (split) {
+        hipLaunchKernelGGL(work_scatter_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.rank, L.hdr, total, L.work, sync_flag, sync_val);
+        return dbw_check_launch("work_scatter_split_kernel");
+    }
     hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work, sync_flag, sync_val);
     return dbw_check_launch("work_scatter_kernel");
 }

@@ -63,6 +63,15 @@ extern "C" void dbw_debug_read_fwd_profile_raw(unsigned long long *out, int nblo
 }
 #endif
 int g_render_variant = 0;
+// the split form of the soft forward (render_fwd_split_kernel): -1 = by size (passes of at most g_split_max_tiles tiles), 0 = never, 1 = always,
+// 2 = always, and every shared tile takes the whole-list path of the sibling rule (tests)
+int g_split_mode = -1;
+long long g_split_max_tiles = 24000;
+extern "C" void dbw_debug_set_split(int mode, int64_t max_tiles) { g_split_mode = mode; if (max_tiles > 0) g_split_max_tiles = max_tiles; }
+bool dbw::split_forward_wanted(long long tiles, int K) {
+    if (K <= 1 || K > 16 || g_split_mode == 0) return false;       // (K > 16: the four payload homes would not fit the LDS twice)
+    return g_split_mode > 0 || tiles <= g_split_max_tiles;
+}
 int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
                             // compute their (unused) distances too (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
@@ -185,7 +194,7 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
     float pz = 0.f;
     s.fik = 0;
     s.v = pay4{0.f, 0.f, 0.f, 0.f};
-    s.valid = q.get(k, home, 64, threadIdx.x, pz, s.fik, s.v) && in_img;
+    s.valid = q.get(k, home, 64, threadIdx.x & 63, pz, s.fik, s.v) && in_img;
     if (!s.valid) s.fik = 0;
     s.sr = srec[s.fik];
     return s;
@@ -212,7 +221,7 @@ struct EnvFold {
 };
 
 __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, int n_, int xi, int yi, bool in_img, float (&rgb)[3]) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;          // (one wave per tile; the split form runs four of them in a workgroup)
     const int n = __builtin_amdgcn_readfirstlane(n_);          // (the tile's view: wave-uniform, and the record loads below need to know)
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int L = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -334,7 +343,7 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
 template <int KMAX>
 __device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image,
                                                 const float *env_rgb = nullptr) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -351,7 +360,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
                                           float *__restrict__ image, int dbg, const float *env_rgb = nullptr) {
     // dbg (tools/diag ablations, dbw_debug_set_flags): 32 = no fragment stores (flags 8192), 64 = no layer loop at all (16384)
-    const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
+    const int lane = threadIdx.x & 63;       // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -435,6 +444,145 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
 }
 
+// ---- the soft pass of the training step at SMALL batches: a tile's face list split over the four waves of a workgroup -----------------------
+// One wave per tile lasts as long as the tile's list: ~1.6 us per face for a wave that has its SIMD to itself, so at the reference's batch
+// size (4 views: 2 249 tiles with faces for 1 024 SIMDs) the pass was one round of waves that drained for 70 us behind its heaviest tiles
+// (profiles/r04_fwd_timeline_batch4.txt) -- 28 us of arithmetic spread over 94.  Here a workgroup is four waves:
+//   * a tile with >= 8 faces (or one that walks its coarse bin) gets all four: wave w evaluates a contiguous quarter of the tile's ORDERED
+//     list into a top-K list of its own (same eval_pair, same insert), wave 3 -- which gets a shorter quarter -- also rasterises the env
+//     layer; the lists meet in LDS and wave 0 merges them in slice order.  Bit-exactness is a merge, not a re-sort: the global list is the
+//     K smallest (depth, face id) keys of the union, slice w holds larger face ids than every slice before it, and a slice's entries come
+//     in key order -- exactly the precondition of TopK::insert_ordered (equal depths go behind), so the merged list is the list one wave
+//     would have built, payload for payload.  Wave 0 then shades as ever.
+//   * the one rule that is not a function of the set of candidates -- the sibling rule of clipped split quads (whichever half is closer
+//     replaces the other IN PLACE, which depends on what the list held when the second half arrived) -- is not split: a wave that meets
+//     such a face says so, and wave 0 then evaluates the tile's whole list alone (blocks in front of the camera are hardly ever clipped).
+//   * tiles with fewer faces, and the empty ones (70 % of them), share a workgroup four by four, a wave each, exactly as in the one-wave
+//     kernel.  work_scatter_split_kernel (raster.hip) packs and orders the workgroups.
+// The host picks this form when the pass has at most DBW_SPLIT_MAX_TILES tiles (one round of waves or less); beyond that the GPU is full of
+// one-wave tiles anyway and the merge would be pure overhead.
+constexpr int SPLIT = 4, SPLIT_ENV_FACES = 4;       // (the env layer counts as that many faces of wave 3's share)
+constexpr int SPLIT_DBG_WHOLE = 1 << 30;            // kernel-side test switch (dbw_debug_set_split 2): every shared tile takes the whole-list path
+
+template <int KMAX, bool PAY3>
+__device__ __forceinline__ void eval_list_range(const FaceRec *__restrict__ recs, int fb, const int *__restrict__ lst, int lo, int hi, bool walk, int cx, int cy,
+                                                bool in_img, f2 p, int K, float blur, int persp, bool fastdiv, TopK<KMAX, PAY3> &q, pay4 *home, int lane,
+                                                int *saw_sibling) {
+#pragma unroll 1
+    for (int cb0 = lo; cb0 < hi; cb0 += DBW_WAVE) {
+        const bool have = cb0 + lane < hi;
+        const int e = have ? lst[cb0 + lane] : 0;
+        const bool hit = have && (!walk || !(cx < ((e >> 20) & 7) || cx > ((e >> 23) & 7) || cy < ((e >> 26) & 7) || cy > ((e >> 29) & 7)));
+        const unsigned long long m = __ballot(hit);
+        eval_staged_chunk<KMAX, PAY3>(recs, fb, e & 0xfffff, min(DBW_WAVE, hi - cb0), in_img, p, K, blur, persp, 1, fastdiv, false, q, home, DBW_WAVE, lane, false,
+                                      false, m, saw_sibling);
+    }
+}
+
+#define DBW_SPLIT_WG(KMAX) ((KMAX) <= 10 ? 3 : (KMAX) <= 16 ? 2 : 1)
+template <int KMAX>
+__global__ __launch_bounds__(SPLIT * 64, DBW_SPLIT_WG(KMAX)) void render_fwd_split_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
+                                                                                         const int *__restrict__ num_faces, float blur, int persp, int dbg,
+                                                                                         long long total_blocks, ShadeArgs A, CoarseBins cb,
+                                                                                         const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
+                                                                                         float *__restrict__ bary, float *__restrict__ dists, const EnvFold E) {
+    __shared__ float s_home[SPLIT][KMAX * 64 * 3];                 // the payload homes of the four waves' lists (PAY3: 12 B per entry)
+    __shared__ uint32_t s_keys[SPLIT - 1][KMAX][2][64];            // the lists of waves 1..3 as wave 0 reads them: depth word, id | slot word
+    __shared__ float s_env[3][64];
+    __shared__ int s_sib[SPLIT];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long lg = xcd_remap(blockIdx.x, total_blocks);
+    if (lg < 0) return;
+    const long long per = (total_blocks + 7) / 8;
+    const int x = (int)(lg / per);
+    if ((int)(lg - (long long)x * per) >= cb.hdr[1 + x * 16 + 15]) return;          // a position beyond the segment's packed workgroups
+    const int e0 = __builtin_amdgcn_readfirstlane(cb.work[lg * 4]);
+    const bool shared = (e0 & WORK_SHARED) != 0;
+    int lt = e0 & WORK_TILE_MASK;
+    if (!shared && wv > 0) {
+        lt = __builtin_amdgcn_readfirstlane(cb.work[lg * 4 + wv]);
+        if (lt < 0) return;
+    }
+    const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3, per_view = tiles_x * tiles_y;
+    const int n = lt / per_view, t = lt - n * per_view, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int xi = tx * 8 + (lane & 7), yi = ty * 8 + (lane >> 3);
+    const bool in_img = xi < A.W && yi < A.H;
+    const bool fold = E.recs != nullptr;
+    const int2 c = cb.cell[lt];
+    // the tile's list: its own, or (count < 0: the bin's lists did not fit the pool) the coarse bin's, filtered by cell range
+    const bool walk = c.y < 0;
+    int total = c.y > 0 ? c.y : 0, cx = 0, cy = 0, fb = 0;
+    const int *__restrict__ lst = cb.pool + c.x;
+    if (c.y != 0) fb = __builtin_amdgcn_readfirstlane(first_idx[n]);
+    if (walk) {
+        const int x0 = tx * 8, y0 = ty * 8;
+        const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
+        total = __builtin_amdgcn_readfirstlane(cb.count[n * nb + bin]);
+        lst = cb.list + (long long)fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(num_faces[n]);
+        cx = (x0 & (COARSE - 1)) >> 3; cy = (y0 & (COARSE - 1)) >> 3;
+    }
+    int lo = 0, hi = total;
+    if (shared) {
+        const int t4 = total + (fold ? SPLIT_ENV_FACES : 0);
+        lo = min(total, t4 * wv / SPLIT);
+        hi = wv == SPLIT - 1 ? total : min(total, t4 * (wv + 1) / SPLIT);
+    }
+    float env_rgb[3] = {0.f, 0.f, 0.f};
+    if (fold && (!shared || wv == SPLIT - 1)) env_fold_pixel(E, A.H, A.W, n, xi, yi, in_img, env_rgb);
+    if (c.y == 0) {          // (never a shared tile)
+        shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, nullptr, fold ? env_rgb : nullptr);
+        return;
+    }
+    const NdcAxis ax = ndc_axis(A.W, A.H), ay = ndc_axis(A.H, A.W);
+    f2 p;
+    p.x = pix_to_ndc_fast(A.W - 1 - xi, ax);
+    p.y = pix_to_ndc_fast(A.H - 1 - yi, ay);
+    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1);
+    TopK<KMAX, true> q;
+    q.init();
+    pay4 *home = (pay4 *)s_home[wv];
+    int sib = 0;
+#pragma unroll 1
+    for (int pass = 0;; ++pass) {
+        eval_list_range<KMAX, true>(recs, fb, lst, lo, hi, walk, cx, cy, in_img, p, A.K, blur, persp, fastdiv, q, home, lane, &sib);
+        if (!shared || pass == 1) break;
+        if (wv > 0) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) { s_keys[wv - 1][k][0][lane] = q.khi[k]; s_keys[wv - 1][k][1][lane] = q.klo[k]; }
+        }
+        if (wv == SPLIT - 1 && fold) { s_env[0][lane] = env_rgb[0]; s_env[1][lane] = env_rgb[1]; s_env[2][lane] = env_rgb[2]; }
+        if (lane == 0) s_sib[wv] = sib;
+        __syncthreads();
+        if (wv != 0) return;
+        if (fold) { env_rgb[0] = s_env[0][lane]; env_rgb[1] = s_env[1][lane]; env_rgb[2] = s_env[2][lane]; }
+        const int any_sib = __builtin_amdgcn_readfirstlane(s_sib[0] | s_sib[1] | s_sib[2] | s_sib[3]);
+        if (any_sib || (dbg & SPLIT_DBG_WHOLE)) {          // a split quad among the tile's faces (or the test switch): the whole list in this wave
+            q.init();
+            lo = 0; hi = total;
+            continue;
+        }
+        // merge, slice by slice in list order: every entry of slice w is a candidate behind everything of slices < w
+#pragma unroll 1
+        for (int w = 1; w < SPLIT; ++w) {
+            const float *hw = s_home[w];
+#pragma unroll 1
+            for (int k = 0; k < KMAX; ++k) {
+                const uint32_t chi = s_keys[w - 1][k][0][lane], clo = s_keys[w - 1][k][1][lane];
+                uint32_t lhi, llo;
+                q.last(A.K, lhi, llo);
+                const bool on = k < A.K && chi != 0xffffffffu && chi < lhi;       // (entries come in depth order: behind the first one that no
+                if (__ballot(on) == 0ull) break;                                   // pixel admits, none is admitted)
+                const uint32_t slot = clo & 31u;
+                const float *h = hw + slot * 3 * 64 + lane;
+                const pay4 v{h[0], h[64], h[128], 0.f};
+                q.insert_ordered(A.K, on, u2f(chi), (int)((clo >> 5) & TOPK_ID_MASK), v, home, DBW_WAVE, lane);
+            }
+        }
+        break;
+    }
+    shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
+}
+
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
 #define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
 template <int KMAX, int TW, int TH, int GROUP, bool UV>
@@ -493,7 +641,16 @@ int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, cons
 template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
-           hipStream_t s) {
+           hipStream_t s, bool split) {
+    if constexpr (KMAX > 1 && KMAX <= 16) {
+        if (split) {          // (the caller has laid the launch order out for it: dbw_launch_work_scatter(split = true))
+            DBW_REQUIRE(A.tiled == 2 && A.target && cb.cell && cb.work && cb.hdr, "the split soft forward is the training step's pass on per-tile lists");
+            const long long total = (long long)A.N * ((A.W + 7) / 8) * ((A.H + 7) / 8);
+            hipLaunchKernelGGL((render_fwd_split_kernel<KMAX>), dim3(dbw_xcd_grid(total)), dim3(SPLIT * 64), 0, s, recs, first_idx, num_faces, blur, persp,
+                               g_render_dbg | (g_split_mode == 2 ? SPLIT_DBG_WHOLE : 0), total, A, cb, srec, p2f, bary, dists, E);
+            return dbw_check_launch("render_fwd_split_kernel");
+        }
+    }
 #define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, E, s)
     if constexpr (KMAX == 1) {                                 // hard K=1 pass: large faces (sky dome, ground); the single payload stays in registers
         if (g_render_variant == 1) return DBW_V(8, 8, 2, false);
@@ -523,7 +680,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
                                     int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream,
-                                    const dbw::EnvFoldHost *fold = nullptr) {
+                                    const dbw::EnvFoldHost *fold = nullptr, bool split = false) {
     DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
@@ -581,7 +738,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
         E.p2f = fold->p2f; E.uvj = fold->uvj; E.persp = perspective_correct; E.dbg = g_render_dbg;
         A.lean_grads = 1;          // (the training step: its two backward kernels are the only readers of the gradient images)
     }
-#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s)
+#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s, split)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);
@@ -626,9 +783,9 @@ int dbw::render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *fir
                                    int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                                    const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                                    const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                                   float *rec_out, const float *grad_rec, hipStream_t stream) {
+                                   float *rec_out, const float *grad_rec, hipStream_t stream, bool split) {
     const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env, rec_out, grad_rec};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold);
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold, split);
 }

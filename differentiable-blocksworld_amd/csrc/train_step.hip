@@ -405,6 +405,9 @@ extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
         case 12: return (int64_t)L.bary_e;
         case 13: return (int64_t)L.g_blk_maps;
         case 14: return (int64_t)L.g_maps_end;
+        case 15: return (int64_t)L.p2f;
+        case 16: return (int64_t)L.bary;
+        case 17: return (int64_t)L.dists;
         default: return -1;
     }
 }
@@ -534,6 +537,8 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // consumers -- the fg pass (behind the bins on M) and the TV term on Rg, which polls a word the launch behind the bins stores (memory
     // words only: an event recorded there would cost M what this saves)
     const bool tex_in_bins = (d.fuse & 64) && (d.fuse & 1) && flags && two && fused_setup && !setup_aside;
+    // small batches: the fg pass in its split form -- four waves per heavy tile (render_fused.hip: render_fwd_split_kernel)
+    const bool split_fwd = fold && split_forward_wanted((long long)B * L.tiles, K);
     // ---- M: prologue ----
     const float thresh = d.mask_threshold;
     if (!head) {
@@ -667,7 +672,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             A.scene0 = 1; Bn.scene0 = 1;
             RC(launch_scene_setup(A, E));
             RC(launch_scene_bins(Bn, E));
-            RC(dbw_launch_work_scatter(wf, B, H, W, E));
+            RC(dbw_launch_work_scatter(wf, B, H, W, E, nullptr, 0, split_fwd));
             RC(signal(E, F_SCATTER, p->ev_scatter));
         } else {
             A.scene0 = 0; A.nscenes = 2; Bn.scene0 = 0; Bn.nscenes = 2;
@@ -683,7 +688,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                 tex_flag = p->sync_words + F_TEX; tex_val = ++p->sync_val[F_TEX];
             }
             RC(launch_scene_bins(Bn, M));
-            RC(dbw_launch_work_scatter(wf, B, H, W, M, tex_flag, tex_val));
+            RC(dbw_launch_work_scatter(wf, B, H, W, M, tex_flag, tex_val, split_fwd));
         }
     } else {
         RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),
@@ -720,7 +725,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(render_fwd_fused_mse_fold(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                      d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                      d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, target, mse_scale,
-                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, phase == 1 ? in->rec_out : nullptr, phase == 2 ? in->grad_rec : nullptr, M));
+                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, phase == 1 ? in->rec_out : nullptr, phase == 2 ? in->grad_rec : nullptr, M, split_fwd));
         if (phase == 1) { p->phase1_done = true; return DBW_OK; }      // the caller's term on rec_out, then phase 2
         p->phase1_done = false;
     } else
