@@ -19,10 +19,6 @@ __device__ __forceinline__ int work_class(int c) {
     return c < 0 ? 0 : c == 0 ? 9 : c >= 64 ? 0 : c >= 48 ? 1 : c >= 32 ? 2 : c >= 24 ? 3 : c >= 16 ? 4 : c >= 12 ? 5 : c >= 8 ? 6 : c >= 4 ? 7 : 8;
 }
 
-// split form of the soft forward: tiles of the first WORK_SHARED_CLASSES classes (>= 8 faces, or walking their coarse bin) get a workgroup
-// of four waves to themselves, lighter ones share a workgroup four by four (raster.hip: work_scatter_split_kernel)
-constexpr int WORK_SHARED_CLASSES = 7, WORK_SHARED = 1 << 30, WORK_TILE_MASK = (1 << WORK_RANK_BITS) - 1;
-
 constexpr int CELL_ENTRY_CAP = 1024, CELL_CHUNKS = CELL_ENTRY_CAP / 64;
 constexpr int CELL_HDR_INTS = 1 + 8 * 16;      // cell-list header: pool cursor, 8 x 16 class cursors
 

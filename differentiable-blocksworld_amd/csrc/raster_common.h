@@ -32,8 +32,8 @@ struct CoarseBins {
     const int2 *cell;   // (N, tiles): {first entry in `pool`, count}; count < 0: the pool was full, the tile walks its coarse bin
     const int *pool;    // view-local face indices
     const int *work;    // (N * tiles): launch order of the tiles (work_order_kernel): position in the XCD-aware grid -> view * tiles + tile
-                        // (split form of the soft forward: four entries per position, raster.hip: work_scatter_split_kernel)
-    const int *hdr;     // the cell-list header (raster_bin.h): per XCD segment x, hdr[1 + x * 16 + 15] = workgroups of the split form with work
+                        // (split form of the soft forward: int4 work items and the list of cut tiles, raster.hip: work_scatter_slices_kernel)
+    const int *hdr;     // the cell-list header (raster_bin.h): per XCD segment x, hdr[1 + x * 16 + 15] / [.. + 14] = work items / cut tiles of the split form
 };
 #ifndef DBW_CELL_LISTS
 #define DBW_CELL_LISTS 1

@@ -63,8 +63,8 @@ extern "C" void dbw_debug_read_fwd_profile_raw(unsigned long long *out, int nblo
 }
 #endif
 int g_render_variant = 0;
-// the split form of the soft forward (render_fwd_split_kernel): -1 = by size (passes of at most g_split_max_tiles tiles), 0 = never, 1 = always,
-// 2 = always, and every shared tile takes the whole-list path of the sibling rule (tests)
+// the split form of the soft forward (render_fwd_slices_kernel + render_fwd_merge_kernel): -1 = by size (passes of at most g_split_max_tiles tiles), 0 = never, 1 = always,
+// 2 = always, and every cut tile takes the whole-list path of the sibling rule (tests)
 int g_split_mode = -1;
 long long g_split_max_tiles = 24000;
 extern "C" void dbw_debug_set_split(int mode, int64_t max_tiles) { g_split_mode = mode; if (max_tiles > 0) g_split_max_tiles = max_tiles; }
@@ -72,6 +72,7 @@ bool dbw::split_forward_wanted(long long tiles, int K) {
     if (K <= 1 || K > 16 || g_split_mode == 0) return false;       // (K > 16: the four payload homes would not fit the LDS twice)
     return g_split_mode > 0 || tiles <= g_split_max_tiles;
 }
+size_t dbw::slice_slot_bytes(int K) { return (size_t)(K * 5 + 3) * 64 * sizeof(float); }      // (slice_slot_floats below)
 int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
                             // compute their (unused) distances too (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
@@ -444,25 +445,30 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
 }
 
-// ---- the soft pass of the training step at SMALL batches: a tile's face list split over the four waves of a workgroup -----------------------
+// ---- the soft pass of the training step at SMALL batches: a tile's face list cut into slices, one wave each -------------------------------
 // One wave per tile lasts as long as the tile's list: ~1.6 us per face for a wave that has its SIMD to itself, so at the reference's batch
 // size (4 views: 2 249 tiles with faces for 1 024 SIMDs) the pass was one round of waves that drained for 70 us behind its heaviest tiles
-// (profiles/r04_fwd_timeline_batch4.txt) -- 28 us of arithmetic spread over 94.  Here a workgroup is four waves:
-//   * a tile with >= 8 faces (or one that walks its coarse bin) gets all four: wave w evaluates a contiguous quarter of the tile's ORDERED
-//     list into a top-K list of its own (same eval_pair, same insert), wave 3 -- which gets a shorter quarter -- also rasterises the env
-//     layer; the lists meet in LDS and wave 0 merges them in slice order.  Bit-exactness is a merge, not a re-sort: the global list is the
-//     K smallest (depth, face id) keys of the union, slice w holds larger face ids than every slice before it, and a slice's entries come
-//     in key order -- exactly the precondition of TopK::insert_ordered (equal depths go behind), so the merged list is the list one wave
-//     would have built, payload for payload.  Wave 0 then shades as ever.
-//   * the one rule that is not a function of the set of candidates -- the sibling rule of clipped split quads (whichever half is closer
-//     replaces the other IN PLACE, which depends on what the list held when the second half arrived) -- is not split: a wave that meets
-//     such a face says so, and wave 0 then evaluates the tile's whole list alone (blocks in front of the camera are hardly ever clipped).
-//   * tiles with fewer faces, and the empty ones (70 % of them), share a workgroup four by four, a wave each, exactly as in the one-wave
-//     kernel.  work_scatter_split_kernel (raster.hip) packs and orders the workgroups.
-// The host picks this form when the pass has at most DBW_SPLIT_MAX_TILES tiles (one round of waves or less); beyond that the GPU is full of
-// one-wave tiles anyway and the merge would be pure overhead.
-constexpr int SPLIT = 4, SPLIT_ENV_FACES = 4;       // (the env layer counts as that many faces of wave 3's share)
-constexpr int SPLIT_DBG_WHOLE = 1 << 30;            // kernel-side test switch (dbw_debug_set_split 2): every shared tile takes the whole-list path
+// (profiles/r04_fwd_timeline_batch4.txt) -- 28 us of arithmetic spread over 94.  The split form is two kernels on per-tile face lists:
+//   render_fwd_slices_kernel  one wave per WORK ITEM (raster.hip: work_scatter_slices_kernel): a tile with few faces is one item and is
+//       rasterised, shaded and finished exactly as in the one-wave kernel; a heavier tile is S items, each evaluating a contiguous slice of
+//       the tile's ORDERED list into a top-K list of its own (same eval_pair, same insert) that it leaves in scratch memory, entries in
+//       list order; the last slice -- cut shorter -- also rasterises the tile's env layer.
+//   render_fwd_merge_kernel   one wave per cut tile: merges the S lists in slice order and shades.  Bit-exactness is a merge, not a
+//       re-sort: the tile's list is the K smallest (depth, face id) keys of the union of the slices' lists, slice s holds larger face ids
+//       than every slice before it and its entries arrive in key order -- exactly the precondition of TopK::insert_ordered (equal depths
+//       go behind) -- so the merged list is the list one wave would have built, payload for payload.
+// The kernel boundary between the two is the hand-off (no fences, no tickets: an in-launch hand-off costs an agent-scope release per slice,
+// MI355X_MICROARCH.md).  The one rule that is not a function of the SET of candidates -- the sibling rule of clipped split quads: whichever
+// half is closer replaces the other in place, which depends on what the list held when the second half arrived -- is not cut: a slice that
+// meets such a face flags its slot and the merge wave evaluates the tile's whole list itself (blocks in front of the camera are hardly
+// ever clipped).  The host picks this form for passes of at most g_split_max_tiles tiles (about one round of waves): beyond that the GPU
+// is full of one-wave tiles anyway.
+#define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
+constexpr int SPLIT_ENV_FACES = 3;                  // (the env layer counts as that many faces of the last slice's share)
+constexpr int SPLIT_DBG_WHOLE = 1 << 30;            // kernel-side test switch (dbw_debug_set_split 2): every cut tile takes the whole-list path
+// a slot of the scratch: the K entries of a slice's list in list order, five planes of 64 lanes each (depth word, face id, signed distance,
+// b0, b1), then the env layer's colour (three planes, written by the tile's last slice)
+__host__ __device__ constexpr int slice_slot_floats(int K) { return (K * 5 + 3) * 64; }
 
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_list_range(const FaceRec *__restrict__ recs, int fb, const int *__restrict__ lst, int lo, int hi, bool walk, int cx, int cy,
@@ -479,112 +485,183 @@ __device__ __forceinline__ void eval_list_range(const FaceRec *__restrict__ recs
     }
 }
 
-#define DBW_SPLIT_WG(KMAX) ((KMAX) <= 10 ? 3 : (KMAX) <= 16 ? 2 : 1)
-template <int KMAX>
-__global__ __launch_bounds__(SPLIT * 64, DBW_SPLIT_WG(KMAX)) void render_fwd_split_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
-                                                                                         const int *__restrict__ num_faces, float blur, int persp, int dbg,
-                                                                                         long long total_blocks, ShadeArgs A, CoarseBins cb,
-                                                                                         const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
-                                                                                         float *__restrict__ bary, float *__restrict__ dists, const EnvFold E) {
-    __shared__ float s_home[SPLIT][KMAX * 64 * 3];                 // the payload homes of the four waves' lists (PAY3: 12 B per entry)
-    __shared__ uint32_t s_keys[SPLIT - 1][KMAX][2][64];            // the lists of waves 1..3 as wave 0 reads them: depth word, id | slot word
-    __shared__ float s_env[3][64];
-    __shared__ int s_sib[SPLIT];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long lg = xcd_remap(blockIdx.x, total_blocks);
-    if (lg < 0) return;
-    const long long per = (total_blocks + 7) / 8;
-    const int x = (int)(lg / per);
-    if ((int)(lg - (long long)x * per) >= cb.hdr[1 + x * 16 + 15]) return;          // a position beyond the segment's packed workgroups
-    const int e0 = __builtin_amdgcn_readfirstlane(cb.work[lg * 4]);
-    const bool shared = (e0 & WORK_SHARED) != 0;
-    int lt = e0 & WORK_TILE_MASK;
-    if (!shared && wv > 0) {
-        lt = __builtin_amdgcn_readfirstlane(cb.work[lg * 4 + wv]);
-        if (lt < 0) return;
-    }
+// the tile of a work item: its pixels, its face list (its own, or -- count < 0: the bin's lists did not fit the pool -- the coarse bin's,
+// filtered by cell range)
+struct SplitTile { int n, xi, yi; bool in_img; int count; bool walk; int total, cx, cy, fb; const int *lst; };
+__device__ __forceinline__ SplitTile split_tile(const ShadeArgs &A, const CoarseBins &cb, const int *__restrict__ first_idx, const int *__restrict__ num_faces,
+                                                int lt, int lane) {
+    SplitTile T;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3, per_view = tiles_x * tiles_y;
-    const int n = lt / per_view, t = lt - n * per_view, ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int xi = tx * 8 + (lane & 7), yi = ty * 8 + (lane >> 3);
-    const bool in_img = xi < A.W && yi < A.H;
-    const bool fold = E.recs != nullptr;
+    T.n = lt / per_view;
+    const int t = lt - T.n * per_view, ty = t / tiles_x, tx = t - ty * tiles_x;
+    T.xi = tx * 8 + (lane & 7); T.yi = ty * 8 + (lane >> 3);
+    T.in_img = T.xi < A.W && T.yi < A.H;
     const int2 c = cb.cell[lt];
-    // the tile's list: its own, or (count < 0: the bin's lists did not fit the pool) the coarse bin's, filtered by cell range
-    const bool walk = c.y < 0;
-    int total = c.y > 0 ? c.y : 0, cx = 0, cy = 0, fb = 0;
-    const int *__restrict__ lst = cb.pool + c.x;
-    if (c.y != 0) fb = __builtin_amdgcn_readfirstlane(first_idx[n]);
-    if (walk) {
+    T.count = c.y;
+    T.walk = c.y < 0;
+    T.total = c.y > 0 ? c.y : 0; T.cx = T.cy = 0; T.fb = 0;
+    T.lst = cb.pool + c.x;
+    if (c.y != 0) T.fb = __builtin_amdgcn_readfirstlane(first_idx[T.n]);
+    if (T.walk) {
         const int x0 = tx * 8, y0 = ty * 8;
         const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
-        total = __builtin_amdgcn_readfirstlane(cb.count[n * nb + bin]);
-        lst = cb.list + (long long)fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(num_faces[n]);
-        cx = (x0 & (COARSE - 1)) >> 3; cy = (y0 & (COARSE - 1)) >> 3;
+        T.total = __builtin_amdgcn_readfirstlane(cb.count[T.n * nb + bin]);
+        T.lst = cb.list + (long long)T.fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(num_faces[T.n]);
+        T.cx = (x0 & (COARSE - 1)) >> 3; T.cy = (y0 & (COARSE - 1)) >> 3;
     }
-    int lo = 0, hi = total;
-    if (shared) {
-        const int t4 = total + (fold ? SPLIT_ENV_FACES : 0);
-        lo = min(total, t4 * wv / SPLIT);
-        hi = wv == SPLIT - 1 ? total : min(total, t4 * (wv + 1) / SPLIT);
+    return T;
+}
+
+struct SliceBufs { float *lists; int *flags; };
+
+template <int KMAX>
+__global__ __launch_bounds__(64, DBW_RENDER_WAVES(KMAX, true)) void render_fwd_slices_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
+                                                                                           const int *__restrict__ num_faces, float blur, int persp, int dbg,
+                                                                                           long long total_blocks, ShadeArgs A, CoarseBins cb, const int4 *__restrict__ work,
+                                                                                           const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
+                                                                                           float *__restrict__ bary, float *__restrict__ dists, const EnvFold E,
+                                                                                           const SliceBufs SB) {
+    __shared__ pay4 s_home[(KMAX * 64 * 3 + 3) / 4];
+    const int lane = threadIdx.x;
+    const long long lg = xcd_remap(blockIdx.x, total_blocks);
+    if (lg < 0) return;
+    const long long per2 = (total_blocks + 7) / 8;              // positions per XCD segment: twice its tiles
+    const int x = (int)(lg / per2);
+    if ((int)(lg - (long long)x * per2) >= cb.hdr[1 + x * 16 + 15]) return;
+    const int4 w = work[lg];
+    const int lt = __builtin_amdgcn_readfirstlane(w.x), sl = __builtin_amdgcn_readfirstlane(w.y), S = __builtin_amdgcn_readfirstlane(w.z);
+    const long long slot = __builtin_amdgcn_readfirstlane(w.w);
+    const SplitTile T = split_tile(A, cb, first_idx, num_faces, lt, lane);
+    const bool fold = E.recs != nullptr;
+    int lo = 0, hi = T.total;
+    if (S > 1) {
+        const int t4 = T.total + (fold ? SPLIT_ENV_FACES : 0);
+        lo = min(T.total, t4 * sl / S);
+        hi = sl == S - 1 ? T.total : min(T.total, t4 * (sl + 1) / S);
     }
     float env_rgb[3] = {0.f, 0.f, 0.f};
-    if (fold && (!shared || wv == SPLIT - 1)) env_fold_pixel(E, A.H, A.W, n, xi, yi, in_img, env_rgb);
-    if (c.y == 0) {          // (never a shared tile)
-        shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, nullptr, fold ? env_rgb : nullptr);
+    if (fold && sl == S - 1) env_fold_pixel(E, A.H, A.W, T.n, T.xi, T.yi, T.in_img, env_rgb);
+    if (T.count == 0) {
+        shade_uv8_empty<KMAX>(A, T.n, T.xi, T.yi, p2f, nullptr, fold ? env_rgb : nullptr);
         return;
     }
     const NdcAxis ax = ndc_axis(A.W, A.H), ay = ndc_axis(A.H, A.W);
     f2 p;
-    p.x = pix_to_ndc_fast(A.W - 1 - xi, ax);
-    p.y = pix_to_ndc_fast(A.H - 1 - yi, ay);
-    const bool fastdiv = DBW_RASTER_FASTDIV && !(dbg & 1);
+    p.x = pix_to_ndc_fast(A.W - 1 - T.xi, ax);
+    p.y = pix_to_ndc_fast(A.H - 1 - T.yi, ay);
     TopK<KMAX, true> q;
     q.init();
-    pay4 *home = (pay4 *)s_home[wv];
     int sib = 0;
-#pragma unroll 1
-    for (int pass = 0;; ++pass) {
-        eval_list_range<KMAX, true>(recs, fb, lst, lo, hi, walk, cx, cy, in_img, p, A.K, blur, persp, fastdiv, q, home, lane, &sib);
-        if (!shared || pass == 1) break;
-        if (wv > 0) {
+    eval_list_range<KMAX, true>(recs, T.fb, T.lst, lo, hi, T.walk, T.cx, T.cy, T.in_img, p, A.K, blur, persp, DBW_RASTER_FASTDIV && !(dbg & 1), q, s_home, lane, &sib);
+    if (S == 1) {
+        shade_uv8<KMAX>(A, srec, q, s_home, T.n, T.xi, T.yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
+        return;
+    }
+    // the slice's list -> its slot, entries in list order: rows up to the deepest list of the wave, one row of sentinels behind a list that ends
+    // before the K-th row (what the merge reads as "no more entries")
+    float *__restrict__ out = SB.lists + slot * slice_slot_floats(A.K) + lane;
+    const int cnt = T.in_img ? q.cnt : 0;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) { s_keys[wv - 1][k][0][lane] = q.khi[k]; s_keys[wv - 1][k][1][lane] = q.klo[k]; }
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < A.K && __ballot(cnt + 1 > k) != 0ull) {
+            const bool valid = k < cnt;
+            float pz = 0.f;
+            int fi = 0;
+            pay4 v{0.f, 0.f, 0.f, 0.f};
+            if (valid) q.get(k, s_home, 64, lane, pz, fi, v);
+            float *o = out + k * 5 * 64;
+            o[0] = __uint_as_float(valid ? q.khi[k] : 0xffffffffu);
+            if (valid) { o[64] = __int_as_float(fi); o[128] = v.x; o[192] = v.y; o[256] = v.z; }
         }
-        if (wv == SPLIT - 1 && fold) { s_env[0][lane] = env_rgb[0]; s_env[1][lane] = env_rgb[1]; s_env[2][lane] = env_rgb[2]; }
-        if (lane == 0) s_sib[wv] = sib;
-        __syncthreads();
-        if (wv != 0) return;
-        if (fold) { env_rgb[0] = s_env[0][lane]; env_rgb[1] = s_env[1][lane]; env_rgb[2] = s_env[2][lane]; }
-        const int any_sib = __builtin_amdgcn_readfirstlane(s_sib[0] | s_sib[1] | s_sib[2] | s_sib[3]);
-        if (any_sib || (dbg & SPLIT_DBG_WHOLE)) {          // a split quad among the tile's faces (or the test switch): the whole list in this wave
-            q.init();
-            lo = 0; hi = total;
-            continue;
-        }
-        // merge, slice by slice in list order: every entry of slice w is a candidate behind everything of slices < w
+    }
+    if (fold && sl == S - 1) {
+        float *o = out + A.K * 5 * 64;
+        o[0] = env_rgb[0]; o[64] = env_rgb[1]; o[128] = env_rgb[2];
+    }
+    if (lane == 0) SB.flags[slot] = sib;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64, DBW_RENDER_WAVES(KMAX, true)) void render_fwd_merge_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
+                                                                                          const int *__restrict__ num_faces, float blur, int persp, int dbg,
+                                                                                          long long total_blocks, ShadeArgs A, CoarseBins cb, const int4 *__restrict__ cut,
+                                                                                          const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
+                                                                                          float *__restrict__ bary, float *__restrict__ dists, int fold,
+                                                                                          const SliceBufs SB) {
+    __shared__ pay4 s_home[(KMAX * 64 * 3 + 3) / 4];
+    const int lane = threadIdx.x;
+    const long long lg = xcd_remap(blockIdx.x, total_blocks);
+    if (lg < 0) return;
+    const long long per = (total_blocks + 7) / 8;
+    const int x = (int)(lg / per);
+    if ((int)(lg - (long long)x * per) >= cb.hdr[1 + x * 16 + 14]) return;          // beyond the segment's cut tiles
+    const int4 w = cut[lg];
+    const int lt = __builtin_amdgcn_readfirstlane(w.x), S = __builtin_amdgcn_readfirstlane(w.z);
+    const long long slot0 = __builtin_amdgcn_readfirstlane(w.y);
+    const SplitTile T = split_tile(A, cb, first_idx, num_faces, lt, lane);
+    const int SF = slice_slot_floats(A.K);
+    float env_rgb[3] = {0.f, 0.f, 0.f};
+    if (fold) {
+        const float *e = SB.lists + (slot0 + S - 1) * SF + A.K * 5 * 64 + lane;
+        env_rgb[0] = e[0]; env_rgb[1] = e[64]; env_rgb[2] = e[128];
+    }
+    int any_sib = (dbg & SPLIT_DBG_WHOLE) ? 1 : 0;
+    {
+        int fl[8];                                // (a tile is cut into at most 8 slices: their flag words in one round trip)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fl[s] = s < S ? SB.flags[slot0 + s] : 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) any_sib |= fl[s];
+        any_sib = __builtin_amdgcn_readfirstlane(any_sib);
+    }
+    TopK<KMAX, true> q;
+    q.init();
+    if (any_sib) {          // a split quad among the tile's faces (or the test switch): the whole list in this wave
+        const NdcAxis ax = ndc_axis(A.W, A.H), ay = ndc_axis(A.H, A.W);
+        f2 p;
+        p.x = pix_to_ndc_fast(A.W - 1 - T.xi, ax);
+        p.y = pix_to_ndc_fast(A.H - 1 - T.yi, ay);
+        eval_list_range<KMAX, true>(recs, T.fb, T.lst, 0, T.total, T.walk, T.cx, T.cy, T.in_img, p, A.K, blur, persp, DBW_RASTER_FASTDIV && !(dbg & 1), q, s_home, lane,
+                                    nullptr);
+    } else {
+        // merge, slice by slice in list order: every entry of slice s is a candidate behind everything of the slices before it.  A lone
+        // wave pays a memory round trip for every dependent load: all K rows of a slice are requested TOGETHER, five planes each, and merged
+        // out of registers.  (A slot holds rows up to the slice's deepest list + one row of sentinels; what lies behind that row is stale
+        // memory and is never looked at: `alive` ends with the first row no pixel has an entry in.)
 #pragma unroll 1
-        for (int w = 1; w < SPLIT; ++w) {
-            const float *hw = s_home[w];
-#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            const float *__restrict__ in = SB.lists + (slot0 + s) * SF + lane;
+            float r[KMAX][5];
+#pragma unroll
             for (int k = 0; k < KMAX; ++k) {
-                const uint32_t chi = s_keys[w - 1][k][0][lane], clo = s_keys[w - 1][k][1][lane];
-                uint32_t lhi, llo;
-                q.last(A.K, lhi, llo);
-                const bool on = k < A.K && chi != 0xffffffffu && chi < lhi;       // (entries come in depth order: behind the first one that no
-                if (__ballot(on) == 0ull) break;                                   // pixel admits, none is admitted)
-                const uint32_t slot = clo & 31u;
-                const float *h = hw + slot * 3 * 64 + lane;
-                const pay4 v{h[0], h[64], h[128], 0.f};
-                q.insert_ordered(A.K, on, u2f(chi), (int)((clo >> 5) & TOPK_ID_MASK), v, home, DBW_WAVE, lane);
+                if (k < A.K) {
+                    r[k][0] = in[k * 5 * 64];
+                    r[k][1] = in[k * 5 * 64 + 64]; r[k][2] = in[k * 5 * 64 + 128]; r[k][3] = in[k * 5 * 64 + 192]; r[k][4] = in[k * 5 * 64 + 256];
+                }
+            }
+            bool alive = true;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < A.K && alive) {
+                    const uint32_t chi = __float_as_uint(r[k][0]);
+                    const bool valid = T.in_img && chi != 0xffffffffu;
+                    alive = __ballot(valid) != 0ull;
+                    uint32_t lhi, llo;
+                    q.last(A.K, lhi, llo);
+                    const bool on = valid && chi < lhi;          // (entries come in depth order: behind the first one that no pixel admits, none is
+                    if (__ballot(on) == 0ull) alive = false;    // admitted)
+                    else {
+                        const pay4 v{r[k][2], r[k][3], r[k][4], 0.f};
+                        q.insert_ordered(A.K, on, u2f(chi), on ? __float_as_int(r[k][1]) : 0, v, s_home, DBW_WAVE, lane);
+                    }
+                }
             }
         }
-        break;
     }
-    shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
+    shade_uv8<KMAX>(A, srec, q, s_home, T.n, T.xi, T.yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
 }
 
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
-#define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
 template <int KMAX, int TW, int TH, int GROUP, bool UV>
 __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
@@ -641,14 +718,22 @@ int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, cons
 template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
-           hipStream_t s, bool split) {
+           hipStream_t s, const dbw::SliceScratch *split) {
     if constexpr (KMAX > 1 && KMAX <= 16) {
-        if (split) {          // (the caller has laid the launch order out for it: dbw_launch_work_scatter(split = true))
-            DBW_REQUIRE(A.tiled == 2 && A.target && cb.cell && cb.work && cb.hdr, "the split soft forward is the training step's pass on per-tile lists");
-            const long long total = (long long)A.N * ((A.W + 7) / 8) * ((A.H + 7) / 8);
-            hipLaunchKernelGGL((render_fwd_split_kernel<KMAX>), dim3(dbw_xcd_grid(total)), dim3(SPLIT * 64), 0, s, recs, first_idx, num_faces, blur, persp,
-                               g_render_dbg | (g_split_mode == 2 ? SPLIT_DBG_WHOLE : 0), total, A, cb, srec, p2f, bary, dists, E);
-            return dbw_check_launch("render_fwd_split_kernel");
+        if (split) {          // (the caller has laid the work items out for it: dbw_launch_work_scatter(split = true))
+            DBW_REQUIRE(A.tiled == 2 && A.target && cb.cell && cb.work && cb.hdr && split->lists && split->flags, "the split soft forward is the training step's pass on per-tile lists");
+            const long long tiles = (long long)A.N * ((A.W + 7) / 8) * ((A.H + 7) / 8), per = (tiles + 7) / 8;
+            DBW_REQUIRE(split->slots >= tiles, "the split soft forward needs one scratch slot per tile of the pass");
+            const int4 *work = (const int4 *)(((uintptr_t)cb.work + 15) & ~(uintptr_t)15);
+            const SliceBufs SB{split->lists, split->flags};
+            const int dbg = g_render_dbg | (g_split_mode == 2 ? SPLIT_DBG_WHOLE : 0);
+            hipLaunchKernelGGL((render_fwd_slices_kernel<KMAX>), dim3((unsigned)(16 * per)), dim3(64), 0, s, recs, first_idx, num_faces, blur, persp, dbg, 16 * per, A, cb,
+                               work, srec, p2f, bary, dists, E, SB);
+            int rc = dbw_check_launch("render_fwd_slices_kernel");
+            if (rc) return rc;
+            hipLaunchKernelGGL((render_fwd_merge_kernel<KMAX>), dim3((unsigned)(8 * per)), dim3(64), 0, s, recs, first_idx, num_faces, blur, persp, dbg, 8 * per, A, cb,
+                               work + 16 * per, srec, p2f, bary, dists, E.recs != nullptr ? 1 : 0, SB);
+            return dbw_check_launch("render_fwd_merge_kernel");
         }
     }
 #define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, E, s)
@@ -680,7 +765,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
                                     int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream,
-                                    const dbw::EnvFoldHost *fold = nullptr, bool split = false) {
+                                    const dbw::EnvFoldHost *fold = nullptr, const dbw::SliceScratch *split = nullptr) {
     DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
@@ -783,7 +868,7 @@ int dbw::render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *fir
                                    int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                                    const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                                    const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                                   float *rec_out, const float *grad_rec, hipStream_t stream, bool split) {
+                                   float *rec_out, const float *grad_rec, hipStream_t stream, const SliceScratch *split) {
     const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env, rec_out, grad_rec};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
