@@ -23,7 +23,6 @@
 #include "../../include/dbw_hip.h"
 
 #include <math.h>
-#include <stdlib.h>
 
 using namespace dbw;
 
@@ -83,58 +82,6 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
         else p = (unsigned)(((unsigned long long)e * (unsigned long long)len) / (unsigned long long)E);
     }
     work[seg0 + p] = (int)L;
-}
-
-// The launch order of the SPLIT form of the soft forward (render_fused.hip: render_fwd_slices_kernel + render_fwd_merge_kernel, small batches): a
-// tile of face-count class c is cut into S_c slices of its ordered face list, each a work item (one wave) of the first kernel; the second
-// kernel merges the slices' lists of every cut tile and shades it.  Per XCD segment x of `per` tiles (the segment has room for 2 * per work
-// items in the grid of the first kernel):
-//   O = sum_c h[c] * S_c work items of tiles with faces (if that exceeded per -- a dense scene, where nothing needs cutting -- every S_c = 1),
-//   E empty tiles, Wseg = O + E positions in use; item q of O at position ceil((q + 1) * Wseg / O) - 1, heaviest class first, the empty tiles
-//   spread evenly between them (as work_scatter_kernel does);
-//   work[x * 2 per + p] = {tile, slice, S, slot}: slot = x * per + q indexes the scratch the slices' lists go through (consecutive for the
-//   slices of a tile); merge[x * per + i] = {tile, first slot, S} for the i-th cut tile of the segment;
-//   hdr[1 + x * 16 + 15] = Wseg, hdr[1 + x * 16 + 14] = number of cut tiles.
-struct SliceTable { int S[WORK_CLASSES]; };
-__global__ __launch_bounds__(256) void work_scatter_slices_kernel(const int *__restrict__ rank, int *__restrict__ hdr, long long total, int4 *__restrict__ work,
-                                                                  int4 *__restrict__ merge, unsigned *sync_flag, unsigned sync_val, const SliceTable T) {
-    if (sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sync_flag, sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= total) return;
-    const long long per = (total + 7) / 8;
-    const int x = (int)(L / per);
-    const long long seg0 = (long long)x * per;
-    const int len = (int)min(per, total - seg0);
-    const int kr = rank[L], k = kr >> WORK_RANK_BITS, r = kr & ((1 << WORK_RANK_BITS) - 1);
-    int h[WORK_CLASSES - 1], occupied = 0;
-    long long items = 0;
-#pragma unroll
-    for (int c = 0; c < WORK_CLASSES - 1; ++c) { h[c] = hdr[1 + x * 16 + c]; occupied += h[c]; items += (long long)h[c] * T.S[c]; }
-    const bool cut = items <= per;
-    int O = 0, q0 = 0, ncut = 0, icut = 0, Sk = 1;
-#pragma unroll
-    for (int c = 0; c < WORK_CLASSES - 1; ++c) {
-        const int Sc = cut ? T.S[c] : 1;
-        if (c < k) { q0 += h[c] * Sc; if (Sc > 1) icut += h[c]; }
-        if (c == k) Sk = Sc;
-        O += h[c] * Sc;
-        if (Sc > 1) ncut += h[c];
-    }
-    const int E = len - occupied, Wseg = O + E;
-    if (L == seg0) { hdr[1 + x * 16 + 15] = Wseg; hdr[1 + x * 16 + 14] = ncut; }
-    int4 *out = work + seg0 * 2;
-    if (k < WORK_CLASSES - 1) {
-        q0 += r * Sk;
-        for (int s = 0; s < Sk; ++s) {
-            const int q = q0 + s;
-            const unsigned p = (unsigned)((((unsigned long long)(q + 1)) * (unsigned long long)Wseg + (unsigned long long)O - 1ull) / (unsigned long long)O - 1ull);
-            out[p] = make_int4((int)L, s, Sk, (int)(seg0 + q));
-        }
-        if (Sk > 1) merge[seg0 + icut + r] = make_int4((int)L, (int)(seg0 + q0), Sk, 0);
-    } else {
-        const unsigned p = (unsigned)(((unsigned long long)r * (unsigned long long)Wseg) / (unsigned long long)E);
-        out[p] = make_int4((int)L, 0, 1, -1);
-    }
 }
 
 __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
@@ -305,10 +252,8 @@ static size_t cell_pool_entries(int64_t F_total, int N, int H, int W) {
 }
 extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
-    // (the launch order: one int per tile, or -- split form of the soft forward -- an int4 for each of 2 n t work items + n t cut tiles)
     return dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W) + align256(CELL_HDR_INTS * sizeof(int)) +
-           align256(n * t * sizeof(int2)) + align256(12 * n * t * sizeof(int) + 512) + align256(n * t * sizeof(int)) +
-           align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
+           align256(n * t * sizeof(int2)) + 2 * align256(n * t * sizeof(int)) + align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
 }
 
 const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
@@ -349,7 +294,7 @@ int dbw_raster_workspace_layout(void *workspace, size_t workspace_bytes, long lo
             const size_t t = cell_tiles(H, W);
             L.cell = (int2 *)((char *)L.hdr + align256(CELL_HDR_INTS * sizeof(int)));
             L.work = (int *)((char *)L.cell + align256((size_t)N * t * sizeof(int2)));
-            L.rank = (int *)((char *)L.work + align256(12 * (size_t)N * t * sizeof(int) + 512));
+            L.rank = (int *)((char *)L.work + align256((size_t)N * t * sizeof(int)));
             L.pool = (int *)((char *)L.rank + align256((size_t)N * t * sizeof(int)));
             L.pool_cap = (int)cell_pool_entries(F_total, N, H, W);
         }
@@ -364,7 +309,7 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
     // launch == false: the workspace was filled by an earlier call with the same arguments (a staged render pass, or the fused set-up
     // kernels of the training step); only `cb` is rebuilt
     cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
-    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr; cb.hdr = nullptr;
+    cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
     if (F_total <= 0) return DBW_OK;
     dbw::RasterWorkspace L;
     int rc = dbw_raster_workspace_layout(workspace, workspace_bytes, F_total, max_faces_per_view, N, H, W, want_cells, L);
@@ -395,7 +340,7 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
                 rc = dbw_check_launch("work_scatter_kernel");
                 if (rc) return rc;
             }
-            cb.cell = L.cell; cb.pool = L.pool; cb.work = L.work; cb.hdr = L.hdr;
+            cb.cell = L.cell; cb.pool = L.pool; cb.work = L.work;
         }
     }
     return DBW_OK;
@@ -420,27 +365,8 @@ int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
 }
 
 // the launch-order kernel alone (the training step's fused set-up fills cell / rank / hdr itself)
-int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val, bool split) {
+int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val) {
     const long long total = (long long)N * (long long)cell_tiles(H, W);
-    if (split) {
-        // slices per face-count class (raster_bin.h: work_class -- >= 64 faces or walking the coarse bin, 48.., 32.., 24.., 16.., 12.., 8.., 4.., 1..):
-        // a slice of ~10 faces costs its wave about what the env layer + the shading of an uncut tile cost
-        static SliceTable T = {{8, 6, 4, 3, 2, 2, 1, 1, 1, 1}};
-        static bool read = false;
-        if (!read) {
-            read = true;
-            if (const char *e = getenv("DBW_SLICES")) {          // (tuning: "8,6,4,3,2,2,1,1,1")
-                int i = 0;
-                for (const char *c = e; *c && i < WORK_CLASSES - 1; ++i) { T.S[i] = atoi(c); while (*c && *c != ',') ++c; if (*c) ++c; }
-                for (int j = 0; j < WORK_CLASSES; ++j) T.S[j] = T.S[j] < 1 ? 1 : (T.S[j] > 8 ? 8 : T.S[j]);
-            }
-        }
-        const long long per = (total + 7) / 8;
-        int4 *work = (int4 *)(((uintptr_t)L.work + 15) & ~(uintptr_t)15);
-        hipLaunchKernelGGL(work_scatter_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.rank, L.hdr, total, work, work + 16 * per, sync_flag,
-                           sync_val, T);
-        return dbw_check_launch("work_scatter_slices_kernel");
-    }
     hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work, sync_flag, sync_val);
     return dbw_check_launch("work_scatter_kernel");
 }

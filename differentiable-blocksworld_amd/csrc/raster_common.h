@@ -32,8 +32,6 @@ struct CoarseBins {
     const int2 *cell;   // (N, tiles): {first entry in `pool`, count}; count < 0: the pool was full, the tile walks its coarse bin
     const int *pool;    // view-local face indices
     const int *work;    // (N * tiles): launch order of the tiles (work_order_kernel): position in the XCD-aware grid -> view * tiles + tile
-                        // (split form of the soft forward: int4 work items and the list of cut tiles, raster.hip: work_scatter_slices_kernel)
-    const int *hdr;     // the cell-list header (raster_bin.h): per XCD segment x, hdr[1 + x * 16 + 15] / [.. + 14] = work items / cut tiles of the split form
 };
 #ifndef DBW_CELL_LISTS
 #define DBW_CELL_LISTS 1
@@ -122,11 +120,9 @@ __device__ __forceinline__ void rec_arrived(FaceRec &r) {
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
                                                   int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false,
-                                                  unsigned long long mask = ~0ull, int *saw_sibling = nullptr) {
-    // (mask: the lanes of `jl` that hold faces of the chunk, in order; saw_sibling: set when a face of the chunk is one half of a clipped
-    // split quad -- the split forward then gives the tile's whole list to one wave, see render_fwd_split_kernel)
+                                                  unsigned long long mask = ~0ull) {
+    // (mask: the lanes of `jl` that hold faces of the chunk, in order)
     auto face = [&](const FaceRec &r, int j) {
-        if (saw_sibling && r.nb != -1) *saw_sibling = 1;
         const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
         if (__ballot(inbox) == 0ull || no_eval) return;           // (no_eval: ablation switch of tools/diag)
         FPROF_ADD(5, 1);

@@ -63,16 +63,6 @@ extern "C" void dbw_debug_read_fwd_profile_raw(unsigned long long *out, int nblo
 }
 #endif
 int g_render_variant = 0;
-// the split form of the soft forward (render_fwd_slices_kernel + render_fwd_merge_kernel): -1 = by size (passes of at most g_split_max_tiles tiles), 0 = never, 1 = always,
-// 2 = always, and every cut tile takes the whole-list path of the sibling rule (tests)
-int g_split_mode = -1;
-long long g_split_max_tiles = 24000;
-extern "C" void dbw_debug_set_split(int mode, int64_t max_tiles) { g_split_mode = mode; if (max_tiles > 0) g_split_max_tiles = max_tiles; }
-bool dbw::split_forward_wanted(long long tiles, int K) {
-    if (K <= 1 || K > 16 || g_split_mode == 0) return false;       // (K > 16: the four payload homes would not fit the LDS twice)
-    return g_split_mode > 0 || tiles <= g_split_max_tiles;
-}
-size_t dbw::slice_slot_bytes(int K) { return (size_t)(K * 5 + 3) * 64 * sizeof(float); }      // (slice_slot_floats below)
 int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
                             // compute their (unused) distances too (dbw_debug_set_flags >> 8)
 extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
@@ -195,7 +185,7 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
     float pz = 0.f;
     s.fik = 0;
     s.v = pay4{0.f, 0.f, 0.f, 0.f};
-    s.valid = q.get(k, home, 64, threadIdx.x & 63, pz, s.fik, s.v) && in_img;
+    s.valid = q.get(k, home, 64, threadIdx.x, pz, s.fik, s.v) && in_img;
     if (!s.valid) s.fik = 0;
     s.sr = srec[s.fik];
     return s;
@@ -222,7 +212,7 @@ struct EnvFold {
 };
 
 __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, int n_, int xi, int yi, bool in_img, float (&rgb)[3]) {
-    const int lane = threadIdx.x & 63;          // (one wave per tile; the split form runs four of them in a workgroup)
+    const int lane = threadIdx.x;
     const int n = __builtin_amdgcn_readfirstlane(n_);          // (the tile's view: wave-uniform, and the record loads below need to know)
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int L = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -344,7 +334,7 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
 template <int KMAX>
 __device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image,
                                                 const float *env_rgb = nullptr) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -361,7 +351,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
                                           float *__restrict__ image, int dbg, const float *env_rgb = nullptr) {
     // dbg (tools/diag ablations, dbw_debug_set_flags): 32 = no fragment stores (flags 8192), 64 = no layer loop at all (16384)
-    const int lane = threadIdx.x & 63;       // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
+    const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
@@ -445,223 +435,8 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
 }
 
-// ---- the soft pass of the training step at SMALL batches: a tile's face list cut into slices, one wave each -------------------------------
-// One wave per tile lasts as long as the tile's list: ~1.6 us per face for a wave that has its SIMD to itself, so at the reference's batch
-// size (4 views: 2 249 tiles with faces for 1 024 SIMDs) the pass was one round of waves that drained for 70 us behind its heaviest tiles
-// (profiles/r04_fwd_timeline_batch4.txt) -- 28 us of arithmetic spread over 94.  The split form is two kernels on per-tile face lists:
-//   render_fwd_slices_kernel  one wave per WORK ITEM (raster.hip: work_scatter_slices_kernel): a tile with few faces is one item and is
-//       rasterised, shaded and finished exactly as in the one-wave kernel; a heavier tile is S items, each evaluating a contiguous slice of
-//       the tile's ORDERED list into a top-K list of its own (same eval_pair, same insert) that it leaves in scratch memory, entries in
-//       list order; the last slice -- cut shorter -- also rasterises the tile's env layer.
-//   render_fwd_merge_kernel   one wave per cut tile: merges the S lists in slice order and shades.  Bit-exactness is a merge, not a
-//       re-sort: the tile's list is the K smallest (depth, face id) keys of the union of the slices' lists, slice s holds larger face ids
-//       than every slice before it and its entries arrive in key order -- exactly the precondition of TopK::insert_ordered (equal depths
-//       go behind) -- so the merged list is the list one wave would have built, payload for payload.
-// The kernel boundary between the two is the hand-off (no fences, no tickets: an in-launch hand-off costs an agent-scope release per slice,
-// MI355X_MICROARCH.md).  The one rule that is not a function of the SET of candidates -- the sibling rule of clipped split quads: whichever
-// half is closer replaces the other in place, which depends on what the list held when the second half arrived -- is not cut: a slice that
-// meets such a face flags its slot and the merge wave evaluates the tile's whole list itself (blocks in front of the camera are hardly
-// ever clipped).  The host picks this form for passes of at most g_split_max_tiles tiles (about one round of waves): beyond that the GPU
-// is full of one-wave tiles anyway.
-#define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
-constexpr int SPLIT_ENV_FACES = 3;                  // (the env layer counts as that many faces of the last slice's share)
-constexpr int SPLIT_DBG_WHOLE = 1 << 30;            // kernel-side test switch (dbw_debug_set_split 2): every cut tile takes the whole-list path
-// a slot of the scratch: the K entries of a slice's list in list order, five planes of 64 lanes each (depth word, face id, signed distance,
-// b0, b1), then the env layer's colour (three planes, written by the tile's last slice)
-__host__ __device__ constexpr int slice_slot_floats(int K) { return (K * 5 + 3) * 64; }
-
-template <int KMAX, bool PAY3>
-__device__ __forceinline__ void eval_list_range(const FaceRec *__restrict__ recs, int fb, const int *__restrict__ lst, int lo, int hi, bool walk, int cx, int cy,
-                                                bool in_img, f2 p, int K, float blur, int persp, bool fastdiv, TopK<KMAX, PAY3> &q, pay4 *home, int lane,
-                                                int *saw_sibling) {
-#pragma unroll 1
-    for (int cb0 = lo; cb0 < hi; cb0 += DBW_WAVE) {
-        const bool have = cb0 + lane < hi;
-        const int e = have ? lst[cb0 + lane] : 0;
-        const bool hit = have && (!walk || !(cx < ((e >> 20) & 7) || cx > ((e >> 23) & 7) || cy < ((e >> 26) & 7) || cy > ((e >> 29) & 7)));
-        const unsigned long long m = __ballot(hit);
-        eval_staged_chunk<KMAX, PAY3>(recs, fb, e & 0xfffff, min(DBW_WAVE, hi - cb0), in_img, p, K, blur, persp, 1, fastdiv, false, q, home, DBW_WAVE, lane, false,
-                                      false, m, saw_sibling);
-    }
-}
-
-// the tile of a work item: its pixels, its face list (its own, or -- count < 0: the bin's lists did not fit the pool -- the coarse bin's,
-// filtered by cell range)
-struct SplitTile { int n, xi, yi; bool in_img; int count; bool walk; int total, cx, cy, fb; const int *lst; };
-__device__ __forceinline__ SplitTile split_tile(const ShadeArgs &A, const CoarseBins &cb, const int *__restrict__ first_idx, const int *__restrict__ num_faces,
-                                                int lt, int lane) {
-    SplitTile T;
-    const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3, per_view = tiles_x * tiles_y;
-    T.n = lt / per_view;
-    const int t = lt - T.n * per_view, ty = t / tiles_x, tx = t - ty * tiles_x;
-    T.xi = tx * 8 + (lane & 7); T.yi = ty * 8 + (lane >> 3);
-    T.in_img = T.xi < A.W && T.yi < A.H;
-    const int2 c = cb.cell[lt];
-    T.count = c.y;
-    T.walk = c.y < 0;
-    T.total = c.y > 0 ? c.y : 0; T.cx = T.cy = 0; T.fb = 0;
-    T.lst = cb.pool + c.x;
-    if (c.y != 0) T.fb = __builtin_amdgcn_readfirstlane(first_idx[T.n]);
-    if (T.walk) {
-        const int x0 = tx * 8, y0 = ty * 8;
-        const int nb = cb.nx * cb.ny, bin = (y0 / COARSE) * cb.nx + (x0 / COARSE);
-        T.total = __builtin_amdgcn_readfirstlane(cb.count[T.n * nb + bin]);
-        T.lst = cb.list + (long long)T.fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(num_faces[T.n]);
-        T.cx = (x0 & (COARSE - 1)) >> 3; T.cy = (y0 & (COARSE - 1)) >> 3;
-    }
-    return T;
-}
-
-struct SliceBufs { float *lists; int *flags; };
-
-template <int KMAX>
-__global__ __launch_bounds__(64, DBW_RENDER_WAVES(KMAX, true)) void render_fwd_slices_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
-                                                                                           const int *__restrict__ num_faces, float blur, int persp, int dbg,
-                                                                                           long long total_blocks, ShadeArgs A, CoarseBins cb, const int4 *__restrict__ work,
-                                                                                           const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
-                                                                                           float *__restrict__ bary, float *__restrict__ dists, const EnvFold E,
-                                                                                           const SliceBufs SB) {
-    __shared__ pay4 s_home[(KMAX * 64 * 3 + 3) / 4];
-    const int lane = threadIdx.x;
-    const long long lg = xcd_remap(blockIdx.x, total_blocks);
-    if (lg < 0) return;
-    const long long per2 = (total_blocks + 7) / 8;              // positions per XCD segment: twice its tiles
-    const int x = (int)(lg / per2);
-    if ((int)(lg - (long long)x * per2) >= cb.hdr[1 + x * 16 + 15]) return;
-    const int4 w = work[lg];
-    const int lt = __builtin_amdgcn_readfirstlane(w.x), sl = __builtin_amdgcn_readfirstlane(w.y), S = __builtin_amdgcn_readfirstlane(w.z);
-    const long long slot = __builtin_amdgcn_readfirstlane(w.w);
-    const SplitTile T = split_tile(A, cb, first_idx, num_faces, lt, lane);
-    const bool fold = E.recs != nullptr;
-    int lo = 0, hi = T.total;
-    if (S > 1) {
-        const int t4 = T.total + (fold ? SPLIT_ENV_FACES : 0);
-        lo = min(T.total, t4 * sl / S);
-        hi = sl == S - 1 ? T.total : min(T.total, t4 * (sl + 1) / S);
-    }
-    float env_rgb[3] = {0.f, 0.f, 0.f};
-    if (fold && sl == S - 1) env_fold_pixel(E, A.H, A.W, T.n, T.xi, T.yi, T.in_img, env_rgb);
-    if (T.count == 0) {
-        shade_uv8_empty<KMAX>(A, T.n, T.xi, T.yi, p2f, nullptr, fold ? env_rgb : nullptr);
-        return;
-    }
-    const NdcAxis ax = ndc_axis(A.W, A.H), ay = ndc_axis(A.H, A.W);
-    f2 p;
-    p.x = pix_to_ndc_fast(A.W - 1 - T.xi, ax);
-    p.y = pix_to_ndc_fast(A.H - 1 - T.yi, ay);
-    TopK<KMAX, true> q;
-    q.init();
-    int sib = 0;
-    eval_list_range<KMAX, true>(recs, T.fb, T.lst, lo, hi, T.walk, T.cx, T.cy, T.in_img, p, A.K, blur, persp, DBW_RASTER_FASTDIV && !(dbg & 1), q, s_home, lane, &sib);
-    if (S == 1) {
-        shade_uv8<KMAX>(A, srec, q, s_home, T.n, T.xi, T.yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
-        return;
-    }
-    // the slice's list -> its slot, entries in list order: rows up to the deepest list of the wave, one row of sentinels behind a list that ends
-    // before the K-th row (what the merge reads as "no more entries")
-    float *__restrict__ out = SB.lists + slot * slice_slot_floats(A.K) + lane;
-    const int cnt = T.in_img ? q.cnt : 0;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        if (k < A.K && __ballot(cnt + 1 > k) != 0ull) {
-            const bool valid = k < cnt;
-            float pz = 0.f;
-            int fi = 0;
-            pay4 v{0.f, 0.f, 0.f, 0.f};
-            if (valid) q.get(k, s_home, 64, lane, pz, fi, v);
-            float *o = out + k * 5 * 64;
-            o[0] = __uint_as_float(valid ? q.khi[k] : 0xffffffffu);
-            if (valid) { o[64] = __int_as_float(fi); o[128] = v.x; o[192] = v.y; o[256] = v.z; }
-        }
-    }
-    if (fold && sl == S - 1) {
-        float *o = out + A.K * 5 * 64;
-        o[0] = env_rgb[0]; o[64] = env_rgb[1]; o[128] = env_rgb[2];
-    }
-    if (lane == 0) SB.flags[slot] = sib;
-}
-
-template <int KMAX>
-__global__ __launch_bounds__(64, DBW_RENDER_WAVES(KMAX, true)) void render_fwd_merge_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
-                                                                                          const int *__restrict__ num_faces, float blur, int persp, int dbg,
-                                                                                          long long total_blocks, ShadeArgs A, CoarseBins cb, const int4 *__restrict__ cut,
-                                                                                          const ShadeRec *__restrict__ srec, int *__restrict__ p2f,
-                                                                                          float *__restrict__ bary, float *__restrict__ dists, int fold,
-                                                                                          const SliceBufs SB) {
-    __shared__ pay4 s_home[(KMAX * 64 * 3 + 3) / 4];
-    const int lane = threadIdx.x;
-    const long long lg = xcd_remap(blockIdx.x, total_blocks);
-    if (lg < 0) return;
-    const long long per = (total_blocks + 7) / 8;
-    const int x = (int)(lg / per);
-    if ((int)(lg - (long long)x * per) >= cb.hdr[1 + x * 16 + 14]) return;          // beyond the segment's cut tiles
-    const int4 w = cut[lg];
-    const int lt = __builtin_amdgcn_readfirstlane(w.x), S = __builtin_amdgcn_readfirstlane(w.z);
-    const long long slot0 = __builtin_amdgcn_readfirstlane(w.y);
-    const SplitTile T = split_tile(A, cb, first_idx, num_faces, lt, lane);
-    const int SF = slice_slot_floats(A.K);
-    float env_rgb[3] = {0.f, 0.f, 0.f};
-    if (fold) {
-        const float *e = SB.lists + (slot0 + S - 1) * SF + A.K * 5 * 64 + lane;
-        env_rgb[0] = e[0]; env_rgb[1] = e[64]; env_rgb[2] = e[128];
-    }
-    int any_sib = (dbg & SPLIT_DBG_WHOLE) ? 1 : 0;
-    {
-        int fl[8];                                // (a tile is cut into at most 8 slices: their flag words in one round trip)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) fl[s] = s < S ? SB.flags[slot0 + s] : 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) any_sib |= fl[s];
-        any_sib = __builtin_amdgcn_readfirstlane(any_sib);
-    }
-    TopK<KMAX, true> q;
-    q.init();
-    if (any_sib) {          // a split quad among the tile's faces (or the test switch): the whole list in this wave
-        const NdcAxis ax = ndc_axis(A.W, A.H), ay = ndc_axis(A.H, A.W);
-        f2 p;
-        p.x = pix_to_ndc_fast(A.W - 1 - T.xi, ax);
-        p.y = pix_to_ndc_fast(A.H - 1 - T.yi, ay);
-        eval_list_range<KMAX, true>(recs, T.fb, T.lst, 0, T.total, T.walk, T.cx, T.cy, T.in_img, p, A.K, blur, persp, DBW_RASTER_FASTDIV && !(dbg & 1), q, s_home, lane,
-                                    nullptr);
-    } else {
-        // merge, slice by slice in list order: every entry of slice s is a candidate behind everything of the slices before it.  A lone
-        // wave pays a memory round trip for every dependent load: all K rows of a slice are requested TOGETHER, five planes each, and merged
-        // out of registers.  (A slot holds rows up to the slice's deepest list + one row of sentinels; what lies behind that row is stale
-        // memory and is never looked at: `alive` ends with the first row no pixel has an entry in.)
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) {
-            const float *__restrict__ in = SB.lists + (slot0 + s) * SF + lane;
-            float r[KMAX][5];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                if (k < A.K) {
-                    r[k][0] = in[k * 5 * 64];
-                    r[k][1] = in[k * 5 * 64 + 64]; r[k][2] = in[k * 5 * 64 + 128]; r[k][3] = in[k * 5 * 64 + 192]; r[k][4] = in[k * 5 * 64 + 256];
-                }
-            }
-            bool alive = true;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                if (k < A.K && alive) {
-                    const uint32_t chi = __float_as_uint(r[k][0]);
-                    const bool valid = T.in_img && chi != 0xffffffffu;
-                    alive = __ballot(valid) != 0ull;
-                    uint32_t lhi, llo;
-                    q.last(A.K, lhi, llo);
-                    const bool on = valid && chi < lhi;          // (entries come in depth order: behind the first one that no pixel admits, none is
-                    if (__ballot(on) == 0ull) alive = false;    // admitted)
-                    else {
-                        const pay4 v{r[k][2], r[k][3], r[k][4], 0.f};
-                        q.insert_ordered(A.K, on, u2f(chi), on ? __float_as_int(r[k][1]) : 0, v, s_home, DBW_WAVE, lane);
-                    }
-                }
-            }
-        }
-    }
-    shade_uv8<KMAX>(A, srec, q, s_home, T.n, T.xi, T.yi, p2f, bary, dists, nullptr, dbg, fold ? env_rgb : nullptr);
-}
-
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
+#define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
 template <int KMAX, int TW, int TH, int GROUP, bool UV>
 __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
@@ -718,24 +493,7 @@ int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, cons
 template <int KMAX>
 int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
            int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
-           hipStream_t s, const dbw::SliceScratch *split) {
-    if constexpr (KMAX > 1 && KMAX <= 16) {
-        if (split) {          // (the caller has laid the work items out for it: dbw_launch_work_scatter(split = true))
-            DBW_REQUIRE(A.tiled == 2 && A.target && cb.cell && cb.work && cb.hdr && split->lists && split->flags, "the split soft forward is the training step's pass on per-tile lists");
-            const long long tiles = (long long)A.N * ((A.W + 7) / 8) * ((A.H + 7) / 8), per = (tiles + 7) / 8;
-            DBW_REQUIRE(split->slots >= tiles, "the split soft forward needs one scratch slot per tile of the pass");
-            const int4 *work = (const int4 *)(((uintptr_t)cb.work + 15) & ~(uintptr_t)15);
-            const SliceBufs SB{split->lists, split->flags};
-            const int dbg = g_render_dbg | (g_split_mode == 2 ? SPLIT_DBG_WHOLE : 0);
-            hipLaunchKernelGGL((render_fwd_slices_kernel<KMAX>), dim3((unsigned)(16 * per)), dim3(64), 0, s, recs, first_idx, num_faces, blur, persp, dbg, 16 * per, A, cb,
-                               work, srec, p2f, bary, dists, E, SB);
-            int rc = dbw_check_launch("render_fwd_slices_kernel");
-            if (rc) return rc;
-            hipLaunchKernelGGL((render_fwd_merge_kernel<KMAX>), dim3((unsigned)(8 * per)), dim3(64), 0, s, recs, first_idx, num_faces, blur, persp, dbg, 8 * per, A, cb,
-                               work + 16 * per, srec, p2f, bary, dists, E.recs != nullptr ? 1 : 0, SB);
-            return dbw_check_launch("render_fwd_merge_kernel");
-        }
-    }
+           hipStream_t s) {
 #define DBW_V(TW, TH, G, UV) launch_v<KMAX, TW, TH, G, UV>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, E, s)
     if constexpr (KMAX == 1) {                                 // hard K=1 pass: large faces (sky dome, ground); the single payload stays in registers
         if (g_render_variant == 1) return DBW_V(8, 8, 2, false);
@@ -765,7 +523,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
                                     int perspective_correct, const float *background3, int32_t *pix_to_face, float *bary,
                                     float *dists, float *image, void *workspace, size_t workspace_bytes,
                                     int frag_layout, const MseArgs *mse, int stage, int image_layout, dbw_stream_t stream,
-                                    const dbw::EnvFoldHost *fold = nullptr, const dbw::SliceScratch *split = nullptr) {
+                                    const dbw::EnvFoldHost *fold = nullptr) {
     DBW_REQUIRE(stage >= 0 && stage <= 2, "stage must be 0 (whole pass), 1 (workspace only) or 2 (workspace already prepared)");
     DBW_REQUIRE(face_verts_c && first_idx && num_faces && pix_to_face && bary && dists && (image || mse) && workspace, "null pointer");
     DBW_REQUIRE(workspace_bytes >= dbw_rasterize_workspace_bytes(F_total), "workspace too small");
@@ -823,7 +581,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
         E.p2f = fold->p2f; E.uvj = fold->uvj; E.persp = perspective_correct; E.dbg = g_render_dbg;
         A.lean_grads = 1;          // (the training step: its two backward kernels are the only readers of the gradient images)
     }
-#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s, split)
+#define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s)
     if (K == 1) return DBW_RF(1);
     if (K <= 4) return DBW_RF(4);
     if (K <= 10) return DBW_RF(10);
@@ -868,9 +626,9 @@ int dbw::render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *fir
                                    int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                                    const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                                    const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                                   float *rec_out, const float *grad_rec, hipStream_t stream, const SliceScratch *split) {
+                                   float *rec_out, const float *grad_rec, hipStream_t stream) {
     const MseArgs mse{nullptr, target, mse_scale, loss_partial, grad_fg, grad_env, rec_out, grad_rec};
     return render_fwd_impl(face_verts_c, first_idx, num_faces, neighbor, c2o, clip_code, clip_w, Fc_stride, face_uvs, face_map, map_desc, maps,
                            faces_alpha, alpha_len, N, F_total, H, W, K, F, sigma, blur_radius, perspective_correct, background3, pix_to_face,
-                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold, split);
+                           bary, dists, nullptr, workspace, workspace_bytes, 2, &mse, 2, 1, (dbw_stream_t)stream, &fold);
 }

@@ -86,8 +86,7 @@ struct SceneBinsArgs {
 };
 int launch_scene_bins(const SceneBinsArgs &A, hipStream_t s);
 // (sync_flag: the first workgroup stores sync_val when it starts -- "everything in front of this launch is complete", ShadeArgs::sync_flag)
-int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag = nullptr, unsigned sync_val = 0,
-                            bool split = false);       // split: work items + cut tiles of the split soft forward (raster.hip: work_scatter_slices_kernel)
+int dbw_launch_work_scatter(const RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag = nullptr, unsigned sync_val = 0);
 
 struct RegulariserArgs {
     // overlap (dbw.py:389-405): scale = 0 -> off
@@ -135,13 +134,7 @@ int render_fwd_fused_mse_fold(const float *face_verts_c, const int32_t *first_id
                               int64_t F_total, int H, int W, int K, int F, float sigma, float blur_radius, int perspective_correct,
                               const float *background3, int32_t *pix_to_face, float *bary, float *dists, void *workspace, size_t workspace_bytes,
                               const float *target, float mse_scale, float *loss_partial, float *grad_fg, float *grad_env, const EnvFoldHost &fold,
-                              float *rec_out, const float *grad_rec, hipStream_t stream, const struct SliceScratch *split = nullptr);
-// The split form of the soft forward (render_fused.hip): whether a pass of `tiles` 8x8 tiles with K layers takes it (by size, or forced by
-// dbw_debug_set_split); the scratch its two kernels hand the slices' lists through -- `slots` of slice_slot_bytes(K) each (one per tile of
-// the pass is always enough) and one int per slot; and it needs the launch order of dbw_launch_work_scatter(split = true)
-struct SliceScratch { float *lists; int *flags; long long slots; };
-bool split_forward_wanted(long long tiles, int K);
-size_t slice_slot_bytes(int K);
+                              float *rec_out, const float *grad_rec, hipStream_t stream);
 
 // dbw_render_bwd_fused (shade_blend.hip) whose first workgroup also stores sync_val to *sync_flag when it starts (ShadeArgs::sync_flag; a
 // kernel other than the specialised uv backward gets a one-thread launch in front of it instead).  sync_flag == NULL: exactly dbw_render_bwd_fused

@@ -94,7 +94,6 @@ struct Layout {
     size_t env_maps, blk_maps, sig[3], g_sig[3];
     size_t alpha, alpha_full, keep, blk_verts, sq_local, losses, target;
     size_t records, cursor[2], layout[2], layout_uniform;
-    size_t fwd_slices, fwd_flags; long long slice_slots;        // scratch of the split soft forward (small batches)
     size_t arena_begin, g_alpha_full, ovl_ws, vals, tickets, g_blk_maps, g_env_maps, g_maps_end, g_fa, g_fvc_f, g_blk_verts, g_fvc_e, g_env_verts, arena_end;
     size_t total;
     // derived sizes
@@ -174,14 +173,6 @@ void make_layout(const dbw_step_desc &d, Layout &L) {
         for (int i = 0; i < 2; ++i) { L.cursor[i] = o; o += al(nsub * 4); }
         for (int i = 0; i < 2; ++i) { L.layout[i] = o; o += al(nsub * 8); }
         L.layout_uniform = o; o += al(nsub * 8);
-    }
-    // the split form of the fg pass (passes small enough to leave the GPU short of waves): one slot per tile for the slices' lists
-    L.slice_slots = 0;
-    if ((d.fuse & 18) == 18 && K > 1 && K <= 16) {
-        long long cap = 32768;                    // (a run takes the split form when its B * tiles fit: larger passes do not want it)
-        L.slice_slots = (long long)bt < cap ? (long long)bt : cap;
-        L.fwd_slices = o; o += al((size_t)L.slice_slots * slice_slot_bytes(K));
-        L.fwd_flags = o; o += al((size_t)L.slice_slots * 4);
     }
     L.arena_begin = o;
     L.g_alpha_full = o; o += al((size_t)d.n_blocks * 4);
@@ -414,9 +405,6 @@ extern "C" int64_t dbw_train_step_offset(const dbw_step_plan *p, int which) {
         case 12: return (int64_t)L.bary_e;
         case 13: return (int64_t)L.g_blk_maps;
         case 14: return (int64_t)L.g_maps_end;
-        case 15: return (int64_t)L.p2f;
-        case 16: return (int64_t)L.bary;
-        case 17: return (int64_t)L.dists;
         default: return -1;
     }
 }
@@ -546,9 +534,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // consumers -- the fg pass (behind the bins on M) and the TV term on Rg, which polls a word the launch behind the bins stores (memory
     // words only: an event recorded there would cost M what this saves)
     const bool tex_in_bins = (d.fuse & 64) && (d.fuse & 1) && flags && two && fused_setup && !setup_aside;
-    // small batches: the fg pass in its split form -- four waves per heavy tile (render_fused.hip: render_fwd_split_kernel)
-    const bool split_fwd = fold && (long long)B * L.tiles <= L.slice_slots && split_forward_wanted((long long)B * L.tiles, K);
-    const SliceScratch slices{split_fwd ? FP(L.fwd_slices) : nullptr, split_fwd ? IP(L.fwd_flags) : nullptr, L.slice_slots};
     // ---- M: prologue ----
     const float thresh = d.mask_threshold;
     if (!head) {
@@ -682,7 +667,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             A.scene0 = 1; Bn.scene0 = 1;
             RC(launch_scene_setup(A, E));
             RC(launch_scene_bins(Bn, E));
-            RC(dbw_launch_work_scatter(wf, B, H, W, E, nullptr, 0, split_fwd));
+            RC(dbw_launch_work_scatter(wf, B, H, W, E));
             RC(signal(E, F_SCATTER, p->ev_scatter));
         } else {
             A.scene0 = 0; A.nscenes = 2; Bn.scene0 = 0; Bn.nscenes = 2;
@@ -698,7 +683,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
                 tex_flag = p->sync_words + F_TEX; tex_val = ++p->sync_val[F_TEX];
             }
             RC(launch_scene_bins(Bn, M));
-            RC(dbw_launch_work_scatter(wf, B, H, W, M, tex_flag, tex_val, split_fwd));
+            RC(dbw_launch_work_scatter(wf, B, H, W, M, tex_flag, tex_val));
         }
     } else {
         RC(dbw_project_clip_fwd(d.env_verts, d.env_faces, in->R, in->T, d.Kmat, B, Ve, Fe, d.cam_eps, zc_on, d.z_clip, d.perspective_correct, FP(L.e.fvc),
@@ -735,7 +720,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         RC(render_fwd_fused_mse_fold(FP(L.f.fvc), IP(L.f.first), IP(L.f.num), IP(L.f.nbr), IP(L.f.c2o), IP(L.f.code), FP(L.f.cw), 2 * Ff, d.block_face_uvs,
                                      d.block_face_map, d.block_map_desc, FP(L.blk_maps), fa, alpha_len, B, Ftf, H, W, K, Ff, d.sigma, d.blur_radius,
                                      d.perspective_correct, d.bg_fg, IP(L.p2f), FP(L.bary), FP(L.dists), ws + L.f.rws, L.f.rws_bytes, target, mse_scale,
-                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, phase == 1 ? in->rec_out : nullptr, phase == 2 ? in->grad_rec : nullptr, M, split_fwd ? &slices : nullptr));
+                                     FP(L.part), FP(L.g_fg), FP(L.g_env), fh, phase == 1 ? in->rec_out : nullptr, phase == 2 ? in->grad_rec : nullptr, M));
         if (phase == 1) { p->phase1_done = true; return DBW_OK; }      // the caller's term on rec_out, then phase 2
         p->phase1_done = false;
     } else

@@ -125,7 +125,6 @@ OTHER_SIGNATURES = {
     'dbw_train_step_offset': (c_i64, [c_p, c_i]),
     'dbw_train_step_void_flag_offset': (c_i64, [c_p]),
     'dbw_train_step_voided_runs': (c_i, [c_p]),
-    'dbw_debug_set_split': (None, [c_i, c_i64]),
 }
 
 

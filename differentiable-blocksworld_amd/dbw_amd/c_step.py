@@ -22,7 +22,7 @@ _p = ops._ptr
 FUSE_ALL = 127          # include/dbw_hip.h: dbw_step_desc.fuse
 _SIDE_STREAMS = {}
 _OFF = {'alpha': 0, 'alpha_full': 1, 'keep': 2, 'losses': 3, 'arena_begin': 4, 'arena_end': 5, 'g_fg': 6, 'g_env': 7, 'env_img': 8, 'blk_verts': 9,
-        'loss_part': 10, 'p2f_env': 11, 'uvj_env': 12, 'p2f': 15, 'bary': 16, 'dists': 17}
+        'loss_part': 10, 'p2f_env': 11, 'uvj_env': 12}
 
 
 def side_stream(dev, priority=True):

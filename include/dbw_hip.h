@@ -52,11 +52,6 @@ const char *dbw_last_error(void);
  * face lists (every tile walks its coarse bin); bits 16 and up: wall-clock ablations of the fused kernels for tools/diag (results
  * are wrong by construction): 1 << 17 no record stores, 1 << 18 no cursor atomics, 1 << 19 no record path in the binned backward */
 void dbw_debug_set_flags(int flags);
-/* The soft forward of the training step has two forms: one wave per 8x8 tile, and -- for passes small enough to leave the GPU short of
- * waves -- the split form: four waves per heavy tile, each on a quarter of the tile's ordered face list, merged in LDS (bit-identical
- * results).  mode -1 (default): by size -- split when the pass has at most max_tiles tiles; 0: never; 1: always; 2 (tests): always, and every
- * shared tile takes the whole-list path that otherwise only tiles with clipped split quads take.  max_tiles <= 0: keep the threshold. */
-void dbw_debug_set_split(int mode, int64_t max_tiles);
 /* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
  * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */
 int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream);
@@ -510,8 +505,7 @@ int dbw_train_step_losses(dbw_step_plan *plan, float *out5);
  * the zero arena (cleared by the plan's own Adam launch; a caller that runs Adam itself clears it), 6 grad of the fg image (tiled), 7 grad
  * of the env image, 8 env image, 9 the blocks' world vertices, 10 per-tile loss partials, 11 / 12 the env scene's hard uv-fragments (face ids;
  * u, v, face | map), 13 / 14 begin / end of the gradient of the prepared maps (blocks, sky, ground: one range inside the zero arena; what
- * a data-parallel caller all-reduces with defer_textures), 15 / 16 / 17 the fg pass's uv-fragments (ids [tile][K][64], eight value planes
- * [tile][K][8][64], distances [tile][K][64]); -1 for an unknown name */
+ * a data-parallel caller all-reduces with defer_textures); -1 for an unknown name */
 int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 /* Makes `stream` wait until the blocks' texture gradient of the last run is final.  Data parallel: the caller reduces that slice -- 83 % of the gradient bytes -- on a stream of its
  * own while the rest of the step still runs. */

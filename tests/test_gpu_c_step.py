@@ -190,73 +190,6 @@ def test_c_step_on_fresh_minibatches_of_the_reference_batch_size():
         assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
 
 
-def _fg_pass_outputs(cs, B, H, W, K):
-    """What the fg pass of the last step wrote, restricted to what is defined: fragment ids / distances / the eight value planes of the
-    OCCUPIED slots of pixels inside the image (empty slots below a pixel's first layer are not written at all), the per-tile loss sums,
-    the gradient image of the env layer, the env layer's hard uv-fragments."""
-    ty, tx = (H + 7) // 8, (W + 7) // 8
-    tiles = B * ty * tx
-    p2f = cs.view('p2f', torch.int32, tiles * K * 64).view(tiles, K, 64).clone()
-    dists = cs.view('dists', torch.int32, tiles * K * 64).view(tiles, K, 64).clone()
-    planes = cs.view('bary', torch.int32, tiles * K * 512).view(tiles, K, 8, 64).clone()
-    yy = (torch.arange(ty, device=DEV)[:, None, None] * 8 + torch.arange(64, device=DEV)[None, None, :] // 8).expand(ty, tx, 64)
-    xx = (torch.arange(tx, device=DEV)[None, :, None] * 8 + torch.arange(64, device=DEV)[None, None, :] % 8).expand(ty, tx, 64)
-    inside = ((yy < H) & (xx < W)).reshape(1, ty * tx, 64).expand(B, -1, -1).reshape(tiles, 64)
-    first = p2f[:, 0, :]
-    cnt = torch.where((first < 0) | ~inside, torch.zeros_like(first), first >> 26)
-    valid = torch.arange(K, device=DEV)[None, :, None] < cnt[:, None, :]
-    env_p2f = cs.view('p2f_env', torch.int32, tiles * 64).view(tiles, 64).clone()
-    env_uvj = cs.view('uvj_env', torch.int32, tiles * 192).view(tiles, 3, 64).clone()
-    env_ok = inside & (env_p2f >= 0)
-    return {'count': cnt, 'ids': p2f[valid], 'dists': dists[valid], 'planes': planes.permute(0, 1, 3, 2)[valid],
-            'loss_part': cs.view('loss_part', torch.int32, tiles).clone(),
-            'g_env_rgb': cs.view('g_env', torch.int32, tiles * 256).view(tiles, 4, 64)[:, :3][inside[:, None, :].expand(-1, 3, -1)].clone(),
-            'env_ids': env_p2f[inside], 'env_uvj': env_uvj.permute(0, 2, 1)[env_ok]}
-
-
-@pytest.mark.parametrize('epoch,fpp', [(0, 10), (1600, 10), (0, 4), (0, 16)])
-def test_split_forward_leaves_the_fragments_of_the_one_wave_kernel(epoch, fpp):
-    """Small batches run the soft forward in its split form (render_fwd_split_kernel: four waves per heavy tile, each on a quarter of the
-    tile's ordered face list, merged in LDS; light and empty tiles four to a workgroup).  Everything the pass writes must be what the
-    one-wave kernel writes, BIT FOR BIT -- the merged list is the list one wave would have built: fragment counts, ids, distances, the
-    resolved uv / opacity / colour / transmittance planes, the per-tile loss sums, the env layer's fragments and gradient image.  A block
-    pushed through the near plane of the first cameras puts clipped split quads (the sibling rule: whole-list path) among the fg faces;
-    mode 2 sends EVERY shared tile down that path."""
-    H, W, nb, B = 96, 128, 10, 3
-    inp = _inputs(B, H, W)
-    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
-    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
-    lib = _lib.load()
-    outs = []
-    try:
-        for mode in (0, 1, 2):
-            lib.dbw_debug_set_split(mode, 0)
-            model = _model(epoch, nb=nb, ts=32, fpp=fpp, H=H, W=W, kill=False)
-            with torch.no_grad():
-                model.S[0] += 1.0                                 # a large block ...
-                model.T[0] = torch.tensor([0.0, 0.0, 0.0], device=DEV)
-            model._noise_override, model._overlap_u_override = noise, u
-            step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=99)
-            out = step(inp)
-            torch.cuda.synchronize()
-            assert step.cstep.sync_timeouts() == 0
-            res = _fg_pass_outputs(step.cstep, B, H, W, fpp)
-            res['losses'] = {k: float(v) for k, v in out.items()}
-            res['grad'] = step.params.grad.clone()
-            outs.append(res)
-    finally:
-        lib.dbw_debug_set_split(-1, 0)
-    ref = outs[0]
-    heavy = int((ref['count'].view(-1, 64).max(1).values >= 1).sum())
-    assert heavy > 20 and int(ref['count'].sum()) > 5000, (heavy, int(ref['count'].sum()))
-    for mode, got in zip((1, 2), outs[1:]):
-        for k in ('count', 'ids', 'dists', 'planes', 'loss_part', 'g_env_rgb', 'env_ids', 'env_uvj'):
-            assert got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), (mode, k, int((got[k] != ref[k]).sum()) if got[k].shape == ref[k].shape else 'shape')
-        for k, v in ref['losses'].items():
-            assert abs(got['losses'][k] - v) <= 2e-6 * max(abs(v), 1e-3), (mode, k)
-        assert float((got['grad'] - ref['grad']).abs().max()) <= 1e-5 * float(ref['grad'].abs().max())
-
-
 @pytest.mark.parametrize('epoch', [0, 800])
 def test_env_layer_folded_into_the_fg_pass_leaves_the_fragments_of_the_env_pass(epoch):
     """fuse bit 4: every 8x8 tile of the fg pass rasterises and shades its pixel of the env scene itself (per-tile lists of the env faces,

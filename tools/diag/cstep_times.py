@@ -1,8 +1,7 @@
 """GPU helper: ms per step of the launch-by-launch native step and of the C step (operator-level kernels from C, fused kernels), at
 the reference's batch size (4), at the per-rank batch of config 3 (7) and at the benchmark batch (49); with the loss values read every
 step and without; and the host time to ENQUEUE a step (no synchronisation inside the timed loop, one at its end).
-usage: cstep_times.py [epoch] [batches...] [variants: py c0 c15 c31 c31ev c127 c127s0 c127s1 ...]
-(suffix s0 / s1: the split form of the soft forward forced off / on, dbw_debug_set_split; default: by size)"""
+usage: cstep_times.py [epoch] [batches...] [variants: py c0 c15 c31 c31ev ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
@@ -25,11 +24,6 @@ def measure(B, variant, reads, steps):
     model, inp = bench.build_workload(a, dev)
     model.set_cur_epoch(epoch)
     model.sync_free = True
-    from dbw_amd import _lib
-    split = -1
-    if variant[-2:] in ('s0', 's1'):
-        split, variant = int(variant[-1]), variant[:-2]
-    _lib.load().dbw_debug_set_split(split, 0)
     kw = {'py': dict(use_c_step=False), 'c0': dict(fuse=0), 'c15': dict(fuse=15), 'c31': dict(fuse=31), 'c31ev': dict(fuse=31), 'c63': dict(fuse=63), 'c127': dict(fuse=127)}[variant]
     if variant == 'c0':          # the operator-level kernels need the caller's draws
         model._noise_override = torch.randn(10, device=dev)

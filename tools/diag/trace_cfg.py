@@ -10,9 +10,6 @@ dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.sync_free = True
 model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
-if os.environ.get("DBW_SPLIT"):                          # the split form of the soft forward forced off (0) / on (1), dbw_debug_set_split
-    from dbw_amd import _lib
-    _lib.load().dbw_debug_set_split(int(os.environ["DBW_SPLIT"]), 0)
 step = ShardedTrainStep(model, seed=1)
 reads = os.environ.get("DBW_READS", "0") != "0"          # the host reads the loss values of every step (src/trainer.py:143)
 if step.cstep is not None:
