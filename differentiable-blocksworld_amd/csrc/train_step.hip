@@ -555,6 +555,11 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         P.ground_base = d.ground_base; P.ngv = d.n_ground_verts; P.R6g = d.R6_ground; P.Tg = d.T_ground;
         P.ground_verts = d.env_verts + (size_t)d.n_sky_verts * 3;
         P.zero0 = d.small_grads; P.nzero0 = d.n_small_grads;
+        // The two-phase iteration (a network of the caller's -- LPIPS-VGG16: ~330 MIOpen / rocBLAS / torch launches, 12 ms -- runs between the
+        // phases on this stream): behind it, THESE 636 bytes of stores kept the prologue busy for 1.8 ms, step after step (2.1 of the 2.5 ms the
+        // render path cost such a step; bisected down to this loop, profiles/r05_experiments.md: not the polls, not events, not scratch, not
+        // clocks, not the host; a fill node in front of the launch writes the same bytes in 2 us).  So there the fill node does it.
+        if (phase == 1) { HIP_OK(hipMemsetAsync(d.small_grads, 0, (size_t)d.n_small_grads * 4, M)); P.nzero0 = 0; }
         RC(launch_step_prologue(P, M));
     } else {
         RC(dbw_posed_mesh_fwd(d.ground_base, d.n_ground_verts, d.R6_ground, d.T_ground, d.S_world, d.R_world, d.T_world,
