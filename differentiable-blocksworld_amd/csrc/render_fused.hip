@@ -198,6 +198,13 @@ __device__ __forceinline__ UvSlot uv_slot(const TopK<KMAX, true> &q, const pay4 
 // the env scene's per-tile face list (2-3 large faces: the same eval_pair / TopK<1> / sibling rule the env pass runs, so the same face, the
 // same barycentrics), shades it through the face's ShadeRec and keeps the colour in three registers for the composite; what the env
 // BACKWARD needs -- the hard uv-fragment (frag_layout 3: clipped face, u, v, face | map) -- is stored exactly as the env pass stores it.
+// a shading record through scalar loads (wave-uniform address): one s_load_dwordx16 instead of four vector loads per lane
+__device__ __forceinline__ ShadeRec load_srec_uniform(const ShadeRec *__restrict__ sp) {
+    union { v16f v; ShadeRec r; } u;
+    u.v = *(const v16f *)sp;
+    return u.r;
+}
+
 struct EnvFold {
     const FaceRec *recs;            // nullptr: not folded (the epilogue reads env_img)
     const int *first_idx;
@@ -224,7 +231,8 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
     q.init();
     const bool fastdiv = DBW_RASTER_FASTDIV && !(E.dbg & 1);
     const int fb = __builtin_amdgcn_readfirstlane(E.first_idx[n]);
-    const int2 c = E.cell[L];
+    const int2 c_ = E.cell[L];
+    const int2 c = make_int2(__builtin_amdgcn_readfirstlane(c_.x), __builtin_amdgcn_readfirstlane(c_.y));
     // the tile's own list; or, where the bin's lists did not fit the pool (count < 0), the bin's coarse list: its entries in order, those
     // whose cell range covers this tile.  ONE evaluation site for both (everything wave-uniform, and said so: the record loads inside
     // want scalar addresses under uniform control flow)
@@ -237,6 +245,62 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
         total = __builtin_amdgcn_readfirstlane(E.ccount[n * nb + bin]);
         lst = E.clist + (long long)fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(E.num_faces[n]);
         cx = (x0 & (COARSE - 1)) >> 3; cy = (y0 & (COARSE - 1)) >> 3;
+    }
+    // Most tiles of the env layer lie INSIDE one large face that is in front of everything else on their list -- the ground in front of
+    // the sky dome, a sky face alone.  Uniform fast path: the depth ranges of the (at most four) listed faces are compared as scalars; if
+    // one face's farthest vertex is nearer than every other face's nearest (depths are convex combinations of the vertex depths, so it
+    // wins at every pixel it covers) and it is no half of a split quad, ONLY that face is evaluated -- the same eval_pair, the same
+    // barycentrics, bit for bit -- and if every pixel of the tile passes its box and inside tests the tile is done: no list walk, no top-1
+    // list, no evaluation of the faces behind, shading record through scalar loads, no validity masks.  Anything else -- a pixel outside
+    // the face, overlapping depth ranges, an operand outside the guarded range of the shared-reciprocal divisions -- takes the general path.
+    if (!walk && total >= 1 && total <= 4 && fastdiv && !(E.dbg & 4096)) {          // (dbw_debug_set_flags 1 << 20: the general path everywhere)
+        const int mine = lane < total ? lst[lane] : 0;
+        int jb = 0;
+        float near_b = 0.f, far_b = INFINITY, near_others = INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < total) {
+                const int j = __builtin_amdgcn_readlane(mine, i);
+                const float *zp = (const float *)(E.recs + fb + j) + 6;          // FaceRec::z0, z1, z2 (scalar loads)
+                const float z0 = zp[0], z1 = zp[1], z2 = zp[2];
+                const float zn = fminf(z0, fminf(z1, z2)), zf = fmaxf(z0, fmaxf(z1, z2));
+                if (zf < far_b) { near_others = fminf(near_others, near_b > 0.f ? near_b : INFINITY); jb = j; near_b = zn; far_b = zf; }
+                else near_others = fminf(near_others, zn);
+            }
+        }
+        if (far_b * 1.00001f < near_others) {
+            const FaceRec r = load_rec_nowait(E.recs + fb + jb);          // (uniform address: scalar loads)
+            if ((r.flags & REC_FAST) && r.nb == -1) {
+                float pz1 = 0.f, sd1 = 0.f;
+                f3 bc1{0.f, 0.f, 0.f};
+                bool unsafe = false;
+                const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
+                const bool keep = inbox && eval_pair<true>(r, p, 0.f, E.persp, 1, pz1, sd1, bc1, unsafe, true);
+                if (__ballot(in_img && (!keep || unsafe)) == 0ull) {
+                    const ShadeRec sr = load_srec_uniform(E.srec + fb + jb);
+                    const float bc[3] = {bc1.x, bc1.y, bc1.z};
+                    float bo[3], u, vv;
+                    convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
+                    interp_uv(bo, sr.uv, u, vv);
+                    Sample s;
+                    footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+                    fetch(E.maps, s, rgb);
+                    if (in_img) {
+                        const long long o = ((long long)L << 6) + lane;
+                        float *bp = E.uvj + ((long long)L * 3 << 6) + lane;
+#if DBW_NT_STORES
+                        __builtin_nontemporal_store(fb + jb, E.p2f + o);
+                        __builtin_nontemporal_store(u, bp); __builtin_nontemporal_store(vv, bp + 64);
+                        __builtin_nontemporal_store(__int_as_float(sr.j | (sr.map << 20)), bp + 128);
+#else
+                        E.p2f[o] = fb + jb;
+                        bp[0] = u; bp[64] = vv; bp[128] = __int_as_float(sr.j | (sr.map << 20));
+#endif
+                    }
+                    return;
+                }
+            }
+        }
     }
 #pragma unroll 1
     for (int cb0 = 0; cb0 < total; cb0 += DBW_WAVE) {
