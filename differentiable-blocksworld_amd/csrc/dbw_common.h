@@ -297,31 +297,7 @@ struct LdsAgg {
         unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2_SLOTS);
 #pragma unroll 1
         for (int p = 0; p < 8; ++p) {
-#ifdef DBW_ABL_NOCAS        // (tools/diag ablation: what the claim's round trip costs -- the slot is taken unseen, the sums are wrong)
-            const int old = key; keys[h] = key;
-#else
             const int old = atomicCAS(&keys[h], -1, key);
-#endif
-            if (old == -1 || old == key) {
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
-                return;
-            }
-            h = (h + 1) & (NSLOT - 1);
-        }
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-            if (v[c] != 0.f) unsafeAtomicAdd(gbase + (long long)key * NV + c, v[c]);
-    }
-    // `add` in two halves, so that the claim's LDS round trip runs behind other work of the caller: claim() issues the ds_cmpst on the key's
-    // home slot, add_claimed() takes its answer (and goes on probing, blocking, where the home slot belongs to another key)
-    __device__ __forceinline__ unsigned home(int key) const { return ((unsigned)key * 2654435761u) >> (32 - LOG2_SLOTS); }
-    __device__ __forceinline__ int claim(unsigned h, int key) { return atomicCAS(&keys[h], -1, key); }
-    __device__ __forceinline__ void add_claimed(float *__restrict__ gbase, int key, unsigned h, int old, const float (&v)[NV]) {
-#pragma unroll 1
-        for (int p = 0; p < 8; ++p) {
-            if (p > 0) old = atomicCAS(&keys[h], -1, key);
             if (old == -1 || old == key) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)

@@ -90,17 +90,8 @@ __device__ unsigned long long g_fprof[FPROF_BLOCKS * 16];
 
 // One chunk of up to 64 staged faces (lane i of `jl` = view-local index of the i-th one) evaluated for the pixels of this wave:
 // records arrive in SGPRs (two s_load_dwordx16 per face), lanes are pixels.  Shared by the cell-list path and the legacy staging path.
-//
-// DBW_REC_PIPELINE (round 4, off): the record of face i + 1 requested while face i is evaluated.  The idea came from the time line of the
-// pass at the reference's batch size (tools/fwd_timeline.py, 4 views: every tile resident after 10 us, then the kernel drains for 70 -- a
-// heavy tile alone on its SIMD takes ~1.6 us per face): a scalar round trip per face that nothing hides.  Measured: 0.2410 -> 0.2462 ms per
-// step at 4 views, 0.2727 -> 0.2776 at 7, 0.9648 -> 0.9793 at 49.  The round trip is not what a lone wave waits for: its ~500 dependent
-// scalar + vector instructions per face issue at a fraction of the SIMD's rate whatever arrives when; every LDS access of the insert
-// waits for the early request anyway (lgkmcnt counts both, and scalar loads return out of order: the compiler can only wait for zero);
-// and the second record costs 16 s_mov per face and 90 more spilled SGPRs.
-#ifndef DBW_REC_PIPELINE
-#define DBW_REC_PIPELINE 0
-#endif
+// (Requesting the record of face i + 1 while face i is evaluated was measured slower at every batch size: profiles/r04_experiments.md.)
+// The same record through plain loads, for a site whose address is uniform but whose result need not be pinned to SGPRs:
 __device__ __forceinline__ FaceRec load_rec_nowait(const FaceRec *__restrict__ rp) {
     const v16f *vp = (const v16f *)rp;
     union { v16f v[2]; FaceRec r; } u;
@@ -108,15 +99,6 @@ __device__ __forceinline__ FaceRec load_rec_nowait(const FaceRec *__restrict__ r
     u.v[1] = vp[1];
     return u.r;
 }
-// (both halves have arrived behind this: the one wait of the iteration)
-__device__ __forceinline__ void rec_arrived(FaceRec &r) {
-    union U { v16f v[2]; FaceRec r; };
-    U &u = reinterpret_cast<U &>(r);
-    float p0 = u.v[0][0], p1 = u.v[1][0];
-    asm volatile("" : "+s"(p0), "+s"(p1));
-    u.v[0][0] = p0; u.v[1][0] = p1;
-}
-
 template <int KMAX, bool PAY3>
 __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ recs, int f_begin, int jl, int mcnt, bool in_img, f2 p, int K, float blur,
                                                   int persp, int clipb, bool fastdiv, bool sign_only, TopK<KMAX, PAY3> &q, pay4 *home, int NT, int tid, bool no_insert = false, bool no_eval = false,
@@ -153,28 +135,6 @@ __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ re
         q.insert(K, keep && !done, pz, f_begin + j, v, home, NT, tid);
 #endif
     };
-#if DBW_REC_PIPELINE
-    unsigned long long todo = mcnt >= 64 ? mask : (mask & ((1ull << mcnt) - 1ull));
-    if (todo == 0ull) return;
-    int j = __builtin_amdgcn_readlane(jl, __ffsll((long long)todo) - 1);
-    todo &= todo - 1ull;
-    FaceRec nxt = load_rec_nowait(recs + f_begin + j);
-#pragma unroll 1
-    for (;;) {
-        FaceRec r = nxt;
-        rec_arrived(r);
-        const int jc = j;
-        const bool more = todo != 0ull;
-        if (more) {
-            j = __builtin_amdgcn_readlane(jl, __ffsll((long long)todo) - 1);
-            todo &= todo - 1ull;
-            nxt = load_rec_nowait(recs + f_begin + j);
-        }
-        __builtin_amdgcn_sched_barrier(0);          // (the request for the next record stays in front of this face's arithmetic)
-        face(r, jc);
-        if (!more) break;
-    }
-#else
 #pragma unroll 1
     for (int i = 0; i < mcnt; ++i) {
         if (!((mask >> i) & 1ull)) continue;
@@ -182,7 +142,6 @@ __device__ __forceinline__ void eval_staged_chunk(const FaceRec *__restrict__ re
         const FaceRec r = load_rec_uniform(recs + f_begin + j);
         face(r, j);
     }
-#endif
 }
 
 // Rasterises the tile of this workgroup: on return every thread holds the sorted top-K list of its pixel (xi, yi) of view n
@@ -207,10 +166,6 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     __shared__ int s_wcnt[NW];
     __shared__ pay4 s_home[KMAX == 1 ? 1 : (PAY3 ? (KMAX * NT * 3 + 3) / 4 : KMAX * NT)];
     home = s_home;
-#ifdef DBW_LDS_PAD      // occupancy experiments (tools/variants.sh): extra LDS per workgroup
-    __shared__ int s_pad[DBW_LDS_PAD / 4];
-    if (blur < 0.f) s_pad[threadIdx.x] = 1;
-#endif
 
     FPROF_T(t_pro);
     const long long logical = xcd_remap(blockIdx.x, total_blocks);

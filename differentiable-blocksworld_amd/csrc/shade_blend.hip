@@ -548,34 +548,9 @@ struct FaceAlphaAgg {      // key = clipped face id -> 6 vertex xy-gradients + 1
         unsigned h = ((unsigned)key * 2654435761u) >> (32 - LOG2);
 #pragma unroll 1
         for (int p = 0; p < 8; ++p) {
-#ifdef DBW_ABL_NOCAS
-            const int old = key; keys[h] = key;
-#else
             const int old = atomicCAS(&keys[h], -1, key);
-#endif
             if (old == -1 || old == key) {
                 aux[h] = aidx;                      // every lane of a face writes the same opacity index
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-                    if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
-                return;
-            }
-            h = (h + 1) & (NSLOT - 1);
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-            if (v[c] != 0.f) unsafeAtomicAdd(gfv + (long long)key * 9 + (c >> 1) * 3 + (c & 1), v[c]);
-        if (v[6] != 0.f && galpha) unsafeAtomicAdd(galpha + aidx, v[6]);
-    }
-    // (the claim split from the add, as LdsAgg::claim / add_claimed)
-    __device__ __forceinline__ unsigned home(int key) const { return ((unsigned)key * 2654435761u) >> (32 - LOG2); }
-    __device__ __forceinline__ int claim(unsigned h, int key) { return atomicCAS(&keys[h], -1, key); }
-    __device__ __forceinline__ void add_claimed(float *__restrict__ gfv, float *__restrict__ galpha, int key, int aidx, unsigned h, int old, const float (&v)[NV]) {
-#pragma unroll 1
-        for (int p = 0; p < 8; ++p) {
-            if (p > 0) old = atomicCAS(&keys[h], -1, key);
-            if (old == -1 || old == key) {
-                aux[h] = aidx;
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
                     if (v[c] != 0.f) atomicAdd(&vals[h * NV + c], (double)v[c]);
@@ -646,9 +621,6 @@ constexpr size_t ALPHA_DIRECT_BYTES = (size_t)ALPHA_DIRECT_MAPS * ALPHA_DIRECT_S
 #endif
 constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
 // (round 4, off: the table claims of a layer issued together / ahead of the work in front of their use -- measured slower, see the layer loop)
-#ifndef DBW_CLAIM_AHEAD
-#define DBW_CLAIM_AHEAD 0
-#endif
 #ifndef DBW_UVB_WAVES
 #define DBW_UVB_WAVES 4      // (the binned instantiation keeps two layers of fragments + one of vertices in flight: 4 waves of 128 VGPRs, no spills --
                              // a spill reload in the layer loop is a vmcnt(0); 4 / 5 / 6 waves per SIMD measured alike before)
@@ -855,17 +827,9 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             if (g7[6] != 0.f) atomicAdd(&alpha_dir[map * ALPHA_DIRECT_SPREAD + (lane & (ALPHA_DIRECT_SPREAD - 1))], (double)g7[6]);
             g7[6] = 0.f;
         }
-        // DBW_CLAIM_AHEAD (off): the face table's slot claimed HERE, its answer taken behind the texel part and the distance backward, and the
-        // two texel taps' claims issued together -- one LDS round trip per layer where three follow each other (43 of the kernel's 302 us by
-        // ablation, profiles/r04_experiments.md).  Measured: alone 0.291 -> 0.318 ms, the step 0.974 -> 1.002 ms (49 views), epoch 800
-        // 1.370 -> 1.392.  Returning LDS atomics that go out back to back queue behind each other's same-address replays (round 3 saw the
-        // same with five in a row); spaced by the work between them they cost less than their latency says.
+        // (claiming the tables' slots ahead of their use -- one LDS round trip per layer instead of three -- was measured slower: returning LDS
+        // atomics that go out back to back queue behind each other's same-address replays, profiles/r04_experiments.md)
         const bool f_pre = valid && (gd != 0.f || g7[6] != 0.f) && !(A.dbg & 2);
-#if DBW_CLAIM_AHEAD
-        const unsigned hf = fa_agg.home(cur.fc);
-        int cf = 0;
-        if (f_pre) cf = fa_agg.claim(hf, cur.fc);
-#endif
         PROF_T(t_a);
         PROF_ADD(2, t_it, t_a);
         if (BINNED) {
@@ -936,27 +900,6 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
             const int f = wt[1] != 0.f ? 1 : (wt[2] != 0.f ? 2 : 3);
             const int a2[2] = {ad[0], f == 1 ? ad[1] : (f == 2 ? ad[2] : ad[3])};
             const float w2[2] = {wt[0], f == 1 ? wt[1] : (f == 2 ? wt[2] : wt[3])};
-#if DBW_CLAIM_AHEAD
-            // (both claims issued before either answer is looked at: one LDS round trip for the two passes)
-            float v3[2][3];
-            bool on2[2];
-            int key2[2], c2[2] = {0, 0};
-            unsigned h2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v3[q][0] = gc[0] * w2[q]; v3[q][1] = gc[1] * w2[q]; v3[q][2] = gc[2] * w2[q];
-                on2[q] = tex && w2[q] != 0.f && !(A.dbg & 1);
-                key2[q] = (int)((unsigned)a2[q] / 3u);
-                if (TEX_MERGE > 0 && __ballot(on2[q]) != 0ull) lane_merge<3, TEX_MERGE>(key2[q], on2[q], v3[q]);
-                h2[q] = tex_agg.home(key2[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (on2[q]) c2[q] = tex_agg.claim(h2[q], key2[q]);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (on2[q]) tex_agg.add_claimed(gmaps, key2[q], h2[q], c2[q], v3[q]);
-#else
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float v3[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
@@ -964,7 +907,6 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
                 if (TEX_MERGE > 0 && __ballot(on) != 0ull) lane_merge<3, TEX_MERGE>((int)((unsigned)a2[q] / 3u), on, v3);
                 if (on) tex_agg.add(gmaps, (int)((unsigned)a2[q] / 3u), v3);      // (dbg 1, 2, 16, 128: ablations, tools/diag)
             }
-#endif
             const bool rest = tex && !(A.dbg & 1) && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
             if (__ballot(rest) != 0ull) {
 #pragma unroll
@@ -1018,11 +960,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
         if (FM > 0 && __ballot(f_on) != 0ull) lane_merge<7, FM>(cur.fc, f_on, g7);
         if (f_on) {
             const int aidx = A.faces_alpha ? (int)alpha_grad_index(A, n, j, map) : 0;
-#if DBW_CLAIM_AHEAD
-            fa_agg.add_claimed(gfv, galpha, cur.fc, aidx, hf, cf, g7);
-#else
             fa_agg.add(gfv, galpha, cur.fc, aidx, g7);
-#endif
         }
         PROF_T(t_d);
         PROF_ADD(6, t_c, t_d);
@@ -1064,9 +1002,6 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 // (profiles/r01_lds_atomic_ubench.txt).  Records arrive in runs of up to 64 written by one wave of the backward (an 8x8 pixel
 // patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
 // transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
-#ifndef DBW_REDUCE_PREFETCH
-#define DBW_REDUCE_PREFETCH 0        // (round 4: measured slower, see the kernel)
-#endif
 #ifndef DBW_BIN_STAGE
 #define DBW_BIN_STAGE 512       // (round 3: 1024 -> 512 records per batch and 4 -> 2 sub-ranges per workgroup: 43 instead of 60 KB of LDS, three
 #endif                          // workgroups per CU instead of two, eight per bin: 0.268 -> 0.236 ms at config 2; 256 records: 0.234)
@@ -1110,44 +1045,6 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
             }
         }
     };
-#if DBW_REDUCE_PREFETCH
-    // (off) The records of the NEXT batch travel (to registers) while this one is accumulated.  The LDS atomic unit is busy a quarter of this
-    // kernel's time (SQ counters; tools/ubench/lds_atomic3: random texels 21.6 clk per wave instruction, bank-sorted ones 9.0 -- the kernel
-    // pays ~70) and a batch waits for its own loads between two barriers -- but three workgroups per CU already fill each other's waits:
-    // with the prefetch epoch 800 went 1.370 -> 1.406 ms per step, the fine phase 0.835 -> 0.859.
-    int g = 0, sb = 0, m = 0;
-    int4 ra[BIN_PER_THREAD], rb[BIN_PER_THREAD];
-    auto fetch = [&]() {
-        while (g < BIN_SUB_PER_WG && sb >= n_sub[g]) { ++g; sb = 0; }
-        m = 0;
-        if (g >= BIN_SUB_PER_WG) return;
-        m = min(n_sub[g] - sb, BIN_STAGE);
-        const int4 *rec = records + (long long)first[g] * 2 + (long long)sb * 2;
-#pragma unroll
-        for (int it = 0; it < BIN_PER_THREAD; ++it) {
-            const int r = it * 256 + threadIdx.x;
-            if (r < m) { ra[it] = rec[r * 2]; rb[it] = rec[r * 2 + 1]; }
-        }
-        sb += BIN_STAGE;
-    };
-    fetch();
-#pragma unroll 1
-    while (m > 0) {
-        const int mc = m;
-        __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
-#pragma unroll
-        for (int it = 0; it < BIN_PER_THREAD; ++it) {
-            const int r = it * 256 + threadIdx.x;
-            if (r < mc) {
-                stage[r * 2 + r / BIN_LANE_STRIDE] = ra[it];
-                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = rb[it];
-            }
-        }
-        __syncthreads();
-        fetch();
-        accumulate(mc);
-    }
-#else
 #pragma unroll 1
     for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
     const int n = n_sub[g];
@@ -1168,7 +1065,6 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
         accumulate(m);
     }
     }
-#endif
     __syncthreads();
     const long long off = bin_info[bin * 4];
     const int ws = bin_info[bin * 4 + 1], hs = bin_info[bin * 4 + 2];
