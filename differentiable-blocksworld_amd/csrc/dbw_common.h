@@ -23,51 +23,68 @@ __device__ __forceinline__ void edge_fn_bwd(f2 p, f2 a, f2 b, float g, f2 &gp, f
     gb.x = g * (a.y - p.y); gb.y = g * (p.x - a.x);
 }
 
+// FAST = true replaces the IEEE divisions by v_rcp_f32 (1 ulp): used by the fused backward only, whose gradients are compared at
+// 1e-4 relative tolerance -- the forward rasteriser keeps the exact arithmetic that decides the face indices.
+template <bool FAST>
+__device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+
+template <bool FAST = false>
 __device__ __forceinline__ f3 bary_fwd(f2 p, f2 v0, f2 v1, f2 v2) {
     const float area = DBW_AREA_EPS(edge_fn(v2, v0, v1));
     f3 w;
+    if (FAST) {
+        const float r = __builtin_amdgcn_rcpf(area);
+        w.x = edge_fn(p, v1, v2) * r; w.y = edge_fn(p, v2, v0) * r; w.z = edge_fn(p, v0, v1) * r;
+        return w;
+    }
     w.x = edge_fn(p, v1, v2) / area;
     w.y = edge_fn(p, v2, v0) / area;
     w.z = edge_fn(p, v0, v1) / area;
     return w;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ void bary_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g, f2 &g0, f2 &g1, f2 &g2) {
     const float area = DBW_AREA_EPS(edge_fn(v2, v0, v1));
+    const float area_inv = FAST ? __builtin_amdgcn_rcpf(area) : 1.0f / area;
+    const float area2_inv = FAST ? area_inv * area_inv : 0.f;
     const float area2 = area * area;
-    const float area_inv = 1.0f / area;
     const float e0 = edge_fn(p, v1, v2);
     const float e1 = edge_fn(p, v2, v0);
     const float e2 = edge_fn(p, v0, v1);
     f2 gp, ga, gb, hp, ha, hb;
     g0.x = g0.y = g1.x = g1.y = g2.x = g2.y = 0.f;
     edge_fn_bwd(p, v1, v2, g.x * area_inv, gp, ga, gb);
-    edge_fn_bwd(v2, v0, v1, g.x * (-e0 / area2), hp, ha, hb);
+    edge_fn_bwd(v2, v0, v1, g.x * (FAST ? -e0 * area2_inv : -e0 / area2), hp, ha, hb);
     g0.x += ha.x;        g0.y += ha.y;
     g1.x += ga.x + hb.x; g1.y += ga.y + hb.y;
     g2.x += gb.x + hp.x; g2.y += gb.y + hp.y;
     edge_fn_bwd(p, v2, v0, g.y * area_inv, gp, ga, gb);
-    edge_fn_bwd(v2, v0, v1, g.y * (-e1 / area2), hp, ha, hb);
+    edge_fn_bwd(v2, v0, v1, g.y * (FAST ? -e1 * area2_inv : -e1 / area2), hp, ha, hb);
     g0.x += gb.x + ha.x; g0.y += gb.y + ha.y;
     g1.x += hb.x;        g1.y += hb.y;
     g2.x += ga.x + hp.x; g2.y += ga.y + hp.y;
     edge_fn_bwd(p, v0, v1, g.z * area_inv, gp, ga, gb);
-    edge_fn_bwd(v2, v0, v1, g.z * (-e2 / area2), hp, ha, hb);
+    edge_fn_bwd(v2, v0, v1, g.z * (FAST ? -e2 * area2_inv : -e2 / area2), hp, ha, hb);
     g0.x += ga.x + ha.x; g0.y += ga.y + ha.y;
     g1.x += gb.x + hb.x; g1.y += gb.y + hb.y;
     g2.x += hp.x;        g2.y += hp.y;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ f3 persp_fwd(f3 b, float z0, float z1, float z2) {
     const float t0 = b.x * z1 * z2;
     const float t1 = z0 * b.y * z2;
     const float t2 = z0 * z1 * b.z;
     float denom = t0 + t1 + t2;
     if (!(denom > DBW_EPS)) denom = DBW_EPS;
-    f3 w; w.x = t0 / denom; w.y = t1 / denom; w.z = t2 / denom;
+    f3 w;
+    if (FAST) { const float r = __builtin_amdgcn_rcpf(denom); w.x = t0 * r; w.y = t1 * r; w.z = t2 * r; return w; }
+    w.x = t0 / denom; w.y = t1 / denom; w.z = t2 / denom;
     return w;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ f3 persp_bwd(f3 b, float z0, float z1, float z2, f3 g, float &gz0, float &gz1, float &gz2) {
     const float t0 = b.x * z1 * z2;
     const float t1 = z0 * b.y * z2;
@@ -75,10 +92,11 @@ __device__ __forceinline__ f3 persp_bwd(f3 b, float z0, float z1, float z2, f3 g
     float denom = t0 + t1 + t2;
     if (!(denom > DBW_EPS)) denom = DBW_EPS;
     const float g_denom_top = -t0 * g.x - t1 * g.y - t2 * g.z;
-    const float g_denom = g_denom_top / (denom * denom);
-    const float gt0 = g_denom + g.x / denom;
-    const float gt1 = g_denom + g.y / denom;
-    const float gt2 = g_denom + g.z / denom;
+    const float rd = FAST ? __builtin_amdgcn_rcpf(denom) : 0.f;
+    const float g_denom = FAST ? g_denom_top * rd * rd : g_denom_top / (denom * denom);
+    const float gt0 = g_denom + (FAST ? g.x * rd : g.x / denom);
+    const float gt1 = g_denom + (FAST ? g.y * rd : g.y / denom);
+    const float gt2 = g_denom + (FAST ? g.z * rd : g.z / denom);
     f3 gb; gb.x = gt0 * z1 * z2; gb.y = gt1 * z0 * z2; gb.z = gt2 * z0 * z1;
     gz0 = gt1 * b.y * z2 + gt2 * b.z * z1;
     gz1 = gt0 * b.x * z2 + gt2 * b.z * z0;
@@ -95,6 +113,7 @@ __device__ __forceinline__ f3 clip_fwd(f3 b) {
     return w;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ f3 clip_bwd(f3 b, f3 g) {
     f3 w;
     w.x = b.x > 0.f ? b.x : 0.f; w.y = b.y > 0.f ? b.y : 0.f; w.z = b.z > 0.f ? b.z : 0.f;
@@ -103,6 +122,13 @@ __device__ __forceinline__ f3 clip_bwd(f3 b, f3 g) {
     if (s < 1e-5f) { gsc = 0.f; s = 1e-5f; }
     const float cx = b.x < 0.f ? 0.f : 1.f, cy = b.y < 0.f ? 0.f : 1.f, cz = b.z < 0.f ? 0.f : 1.f;
     const float s2 = s * s;
+    if (FAST) {
+        const float rs = __builtin_amdgcn_rcpf(s), rs2 = rs * rs;
+        const float common = (g.x * -w.x + g.y * -w.y + g.z * -w.z) * rs2 * gsc;
+        f3 o;
+        o.x = cx * (g.x * rs + common); o.y = cy * (g.y * rs + common); o.z = cz * (g.z * rs + common);
+        return o;
+    }
     const float gsx = -w.x / s2 * gsc, gsy = -w.y / s2 * gsc, gsz = -w.z / s2 * gsc;
     const float common = g.x * gsx + g.y * gsy + g.z * gsz;
     f3 o;
@@ -121,11 +147,6 @@ __device__ __forceinline__ float point_line_dist(f2 p, f2 a, f2 b) {
     const float qx = a.x + tt * dx, qy = a.y + tt * dy;
     return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
-
-// FAST = true replaces the IEEE divisions by v_rcp_f32 (1 ulp): used by the fused backward only, whose gradients are compared at
-// 1e-4 relative tolerance -- the forward rasteriser keeps the exact arithmetic that decides the face indices.
-template <bool FAST>
-__device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 
 template <bool FAST = false>
 __device__ __forceinline__ void point_line_dist_bwd(f2 p, f2 a, f2 b, float g, f2 &ga, f2 &gb) {

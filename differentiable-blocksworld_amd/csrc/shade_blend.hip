@@ -1278,14 +1278,15 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
                 const float z0 = q[2], z1 = q[5], z2 = q[8];
-                const f3 bary0 = bary_fwd(pndc, a, b, c);
-                const f3 bp = persp ? persp_fwd(bary0, z0, z1, z2) : bary0;
+                // (gradient-only arithmetic: v_rcp_f32 instead of ~15 IEEE divisions per pixel, as in the soft backward -- held at 1e-4)
+                const f3 bary0 = bary_fwd<true>(pndc, a, b, c);
+                const f3 bp = persp ? persp_fwd<true>(bary0, z0, z1, z2) : bary0;
                 f3 gg3{gb[0], gb[1], gb[2]};
-                gg3 = clip_bwd(bp, gg3);
+                gg3 = clip_bwd<true>(bp, gg3);
                 float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
-                if (persp) gg3 = persp_bwd(bary0, z0, z1, z2, gg3, pz0, pz1, pz2);
+                if (persp) gg3 = persp_bwd<true>(bary0, z0, z1, z2, gg3, pz0, pz1, pz2);
                 f2 e0, e1, e2;
-                bary_bwd(pndc, a, b, c, gg3, e0, e1, e2);
+                bary_bwd<true>(pndc, a, b, c, gg3, e0, e1, e2);
                 g9[0] = e0.x; g9[1] = e0.y; g9[2] = pz0;
                 g9[3] = e1.x; g9[4] = e1.y; g9[5] = pz1;
                 g9[6] = e2.x; g9[7] = e2.y; g9[8] = pz2;
