@@ -35,11 +35,17 @@ for x in range(8):
     print('XCD %d: waves %6d  first start %7.1f  last start %7.1f  last end %7.1f us   staged pairs %8d   wave-cycles %.1f M   longest wave %.1f us'
           % (x, m.sum(), t0[m].min(), t0[m].max(), t1[m].max(), pairs[m].sum(), cyc[m].sum() / 1e6, (t1[m] - t0[m]).max()))
 dur = t1 - t0
+# the phases of a wave's life (cycle counters of the wave, scaled to its wall-clock life): prologue, list walk + staging, staged-face
+# loop (evaluate + insert), shading + stores + loss epilogue
+ph = buf[b][:, [12, 0, 1, 2]].astype(np.float64)
+ph = ph / np.maximum(cyc, 1)[:, None] * dur[:, None]
 for lo, hi in ((0, 1), (1, 4), (4, 16), (16, 64), (64, 10 ** 9)):
     m = (pairs >= lo) & (pairs < hi)
     if m.any():
-        print('tiles with %3d..%-4s staged faces: %6d   mean life %6.1f us   max %6.1f us   share of the wave time %.1f %%'
-              % (lo, hi - 1 if hi < 10 ** 9 else '', m.sum(), dur[m].mean(), dur[m].max(), 100 * dur[m].sum() / dur.sum()))
+        print('tiles with %3d..%-4s staged faces: %6d   mean life %6.1f us   max %6.1f us   share of the wave time %.1f %%   mean us of: prologue %.1f, list walk %.1f, '
+              'evaluate + insert %.1f (%.2f per face), shading + stores + epilogue %.1f'
+              % (lo, hi - 1 if hi < 10 ** 9 else '', m.sum(), dur[m].mean(), dur[m].max(), 100 * dur[m].sum() / dur.sum(), ph[m, 0].mean(), ph[m, 1].mean(),
+                 ph[m, 2].mean(), ph[m, 2].sum() / max(pairs[m].sum(), 1), ph[m, 3].mean()))
 # resident waves over time (whole GPU: 1024 SIMDs)
 edges = np.linspace(0, t1.max(), 41)
 for i in range(40):
