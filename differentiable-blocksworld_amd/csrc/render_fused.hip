@@ -569,7 +569,7 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
 #ifndef DBW_FWD_GROUP
 #define DBW_FWD_GROUP 2
 #endif
-        if (A.tiled == 2 && (A.target || !(g_render_dbg & 4))) return DBW_V(8, 8, DBW_FWD_GROUP, true);
+        if (A.tiled == 2 && (A.target || !(g_render_dbg & 4)) && A.sigma >= 0.f) return DBW_V(8, 8, DBW_FWD_GROUP, true);      // (sigma < 0, the sigmoid opacity: generic shading)
         return DBW_V(8, 8, DBW_FWD_GROUP, false);
     }
 #undef DBW_V
@@ -605,7 +605,7 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     A.tiled = frag_layout;
     A.img_tiled = image_layout;
     if (mse) {
-        DBW_REQUIRE(frag_layout == 2 && K > 1, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1)");
+        DBW_REQUIRE(frag_layout == 2 && K > 1 && sigma >= 0.f, "the composite + MSE epilogue belongs to the uv-fragment soft pass (frag_layout 2, K > 1, sigma >= 0)");
         DBW_REQUIRE(stage == 1 || ((mse->env_img || fold) && mse->target && mse->loss_part && mse->g_fg && mse->g_env), "null pointer");
         A.env_img = mse->env_img; A.target = mse->target; A.mse_scale = mse->scale; A.loss_part = mse->loss_part; A.g_fg = mse->g_fg; A.g_env = mse->g_env;
         A.rec_out = mse->rec_out; A.grad_rec = mse->grad_rec;

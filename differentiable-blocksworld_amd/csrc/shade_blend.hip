@@ -344,7 +344,8 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
         PROF_ADD(2, t_it, t_a);
         // geometric alpha -> dists ; learned opacity
         float gd = 0.f;
-        if (valid && A.sigma != 0.f && fr.d >= 0.f) gd = ga * fr.a * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
+        if (valid && A.sigma > 0.f && fr.d >= 0.f) gd = ga * fr.a * (FUSED ? -A.inv_sigma : -1.f / A.sigma);
+        else if (valid && A.sigma < 0.f) gd = ga * fr.a * (1.f - fr.e) * (FUSED ? -A.inv_sigma : 1.f / A.sigma);      // d sigmoid(-d / s) / dd = -e (1 - e) / s, every d
         if (!FUSED && gdists && in_img) gdists[pix * KK + k] = gd;
         if (galpha && !(A.dbg & 2)) {
             const float gfa[1] = {valid ? ga * fr.e : 0.f};
@@ -475,15 +476,16 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
                 gbary[o] = gb[0]; gbary[o + 1] = gb[1]; gbary[o + 2] = gb[2];
             } else if (valid && (gd != 0.f || gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f)) {
                 // rasteriser backward for this fragment (same math as raster_bwd_kernel, grad_zbuf = 0; divisions by v_rcp_f32).
-                // d/d dist is non-zero only outside the triangle (fr.d >= 0), so its sign is +1 and the barycentrics are only
-                // recomputed when a barycentric gradient has to be propagated.
+                // With the exponential opacity d/d dist is non-zero only outside the triangle (fr.d >= 0: sign +1); the sigmoid opacity of
+                // clip_inside = False (sigma < 0) also differentiates inside, where the stored distance is MINUS the distance to the nearest
+                // edge.  The barycentrics are only recomputed when a barycentric gradient has to be propagated.
                 fc = BINNED ? (A.tiled == 2 ? (A.p2f[fo.s] & FRAG_FACE_MASK) : A.p2f[fo.s]) : fr.fc;      // (the binned instantiation re-reads the id: one live register less, it sits at the 128-VGPR edge)
                 has_g9 = true;
                 const float *q = fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
                 if (gd != 0.f) {
                     f2 d0, d1, d2;
-                    point_tri_dist_bwd<true>(pndc, a, b, c, gd, d0, d1, d2);
+                    point_tri_dist_bwd<true>(pndc, a, b, c, fr.d < 0.f ? -gd : gd, d0, d1, d2);
                     g9[0] = d0.x; g9[1] = d0.y; g9[3] = d1.x; g9[4] = d1.y; g9[6] = d2.x; g9[7] = d2.y;
                 }
                 if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
@@ -1105,10 +1107,9 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     DBW_REQUIRE(N >= 0 && H > 0 && W > 0 && K > 0 && F > 0, "bad size");
     DBW_REQUIRE(!faces_alpha || alpha_len == F || (long long)alpha_len == (long long)N * F || alpha_len < 0,
                 "faces_alpha length must be F, N*F, or -(number of maps) for one opacity per texture map");
-    DBW_REQUIRE(sigma >= 0.f, "sigma < 0");
     A.p2f = pix_to_face; A.bary = bary; A.dists = dists; A.c2o = c2o; A.code = clip_code; A.cw = clip_w;
     A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;
-    A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma; A.inv_sigma = sigma > 0.f ? 1.f / sigma : 0.f;
+    A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma; A.inv_sigma = sigma != 0.f ? 1.f / fabsf(sigma) : 0.f;
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
     A.dbg = g_dbg_flags;
     A.agg = 0;
@@ -1338,7 +1339,8 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
     }
     // the training path's soft pass: uv-fragments, detached barycentrics; texel gradients through the LDS table (decimated maps) or
     // through texture-space bins (full-resolution maps) -> the specialised kernel
-    const bool uv_kernel = fused && K > 1 && A.tiled == 2 && !want_bary && ((A.agg & 1) || A.bin_records) && !(g_dbg_flags & (1 << 16));
+    // (sigma < 0 -- the sigmoid opacity of clip_inside = False, no shipped config -- runs on the general kernel)
+    const bool uv_kernel = fused && K > 1 && A.tiled == 2 && !want_bary && ((A.agg & 1) || A.bin_records) && !(g_dbg_flags & (1 << 16)) && A.sigma >= 0.f;
     if (A.sync_flag && !uv_kernel) {       // (only the specialised kernel carries the step's signal: a launch of its own in front of any other)
         hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(1), 0, s, A.sync_flag, A.sync_val);
         A.sync_flag = nullptr;

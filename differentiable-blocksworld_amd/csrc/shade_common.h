@@ -19,7 +19,7 @@ struct ShadeArgs {
     const int *c2o; const int *code; const float *cw; int Fc_stride;
     const float *face_uvs; const int *face_map; const int *map_desc; const float *maps;
     const float *faces_alpha; int alpha_len;
-    int N, H, W, K, F; float sigma, inv_sigma; float bg[3];
+    int N, H, W, K, F; float sigma, inv_sigma; float bg[3];     // sigma > 0: exp(-max(d, 0) / sigma); == 0: hard; < 0: sigmoid(-d / |sigma|) (clip_inside = False); inv_sigma = 1 / |sigma|
     int tiled; // fragment layout: 0 = (N,H,W,K[,3]) as PyTorch3D returns them; 1, 2 = internal 8x8-tile planar layout of the
                // fused path: [n][tile_y][tile_x][k][64 lanes] (bary: [..][k][3][64]) -> every wave access is one 256 B line pair;
                // 2 = same, with the bary planes holding (u, v, bitcast(face | map << 20)) for detach_bary passes
@@ -159,6 +159,7 @@ __device__ __forceinline__ long long alpha_grad_index(const ShadeArgs &A, int n,
 template <bool FAST = false>
 __device__ __forceinline__ void frag_alpha(const ShadeArgs &A, int n, Frag &fr) {
     if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else if (A.sigma < 0.f) fr.e = FAST ? __builtin_amdgcn_rcpf(1.f + __expf(fr.d * A.inv_sigma)) : 1.f / (1.f + expf(fr.d / -A.sigma));      // clip_inside = False
     else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
     else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
     fr.fa = 1.f;
@@ -236,6 +237,7 @@ __device__ __forceinline__ bool load_frag(const ShadeArgs &A, int n, const FragA
         fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
         fr.d = A.dists[o.s];
         if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+        else if (A.sigma < 0.f) fr.e = FAST ? __builtin_amdgcn_rcpf(1.f + __expf(fr.d * A.inv_sigma)) : 1.f / (1.f + expf(fr.d / -A.sigma));  // clip_inside = False
         else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
         else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
         fr.fa = 1.f;      // not needed: a = e * fa is stored
@@ -278,6 +280,7 @@ __device__ __forceinline__ void frag_from_raw_uv(const ShadeArgs &A, int n, cons
     fr.cd = -1; fr.w2 = fr.w3 = 0.f; fr.bo[0] = fr.bo[1] = fr.bo[2] = 0.f;
     fr.d = r.d;
     if (A.sigma == 0.f) fr.e = fr.d <= 0.f ? 1.f : 0.f;
+    else if (A.sigma < 0.f) fr.e = FAST ? __builtin_amdgcn_rcpf(1.f + __expf(fr.d * A.inv_sigma)) : 1.f / (1.f + expf(fr.d / -A.sigma));      // clip_inside = False
     else if (FAST) fr.e = __expf(-(fr.d > 0.f ? fr.d : 0.f) * A.inv_sigma);
     else fr.e = expf(-(fr.d > 0.f ? fr.d : 0.f) / A.sigma);
     fr.fa = 1.f;

@@ -122,6 +122,7 @@ DBW_HD void sample_grad_uv(const float *maps, const Sample &s, const float gc[3]
 // geometric alpha of a fragment from its signed squared distance (renderer.py:252-258): exp(-max(d, 0) / sigma), hard indicator at 0
 DBW_HD float geometric_alpha(float d, float sigma) {
     if (sigma == 0.f) return d <= 0.f ? 1.f : 0.f;
+    if (sigma < 0.f) return 1.f / (1.f + expf(d / -sigma));          // clip_inside = False (renderer.py:257-258): sigmoid(-d / |sigma|)
     return expf(-(d > 0.f ? d : 0.f) / sigma);
 }
 

@@ -278,12 +278,13 @@ def shade_blend_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa
 class RenderCfg:
     __slots__ = ('H', 'W', 'K', 'sigma', 'blur', 'z_clip', 'persp', 'detach_bary', 'eps', 'F', 'lds_aggregate', 'texbins', 'const_faces', 'bin_demand')
 
-    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None, const_faces=0):
+    def __init__(self, H, W, K, sigma, z_clip, persp, detach_bary, F_, eps=1e-8, lds_aggregate=False, texbins=None, const_faces=0, clip_inside=True):
         self.lds_aggregate = lds_aggregate
         self.const_faces = int(const_faces)   # the first that many faces have constant vertices (sky dome): no geometry gradient for them
         self.texbins = texbins          # (bin_base, bin_info, nbins): texture-space binning of texel gradients when not aggregating
         self.bin_demand = None          # optional BinDemand of the caller (one per pass, kept across steps): record sub-ranges by demand
-        self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma), z_clip, persp
+        # sigma as the library takes it: > 0 exp(-max(d, 0) / sigma), 0 hard, < 0 sigmoid(-d / |sigma|) = clip_inside False (renderer.py:257-258)
+        self.H, self.W, self.K, self.sigma, self.z_clip, self.persp = H, W, K, float(sigma) if clip_inside else -float(sigma), z_clip, persp
         self.blur = math.log(1. / 1e-4 - 1.) * float(sigma)            # renderer.py:51
         self.detach_bary, self.eps, self.F = detach_bary, eps, F_
 
@@ -382,7 +383,7 @@ class _RenderScene(torch.autograd.Function):
         cfg, cl, bg = ctx.cfg, ctx.cl, ctx.bg
         fa = fa if ctx.has_alpha else None
         need_geom = ctx.needs_input_grad[0]
-        want_dists = need_geom and cfg.sigma > 0
+        want_dists = need_geom and cfg.sigma != 0
         want_bary = need_geom and not cfg.detach_bary
         if FUSED_BACKWARD and (ctx.tiled or (need_geom and (want_dists or want_bary))):
             g_maps, g_alpha, g_fvc = _fused_bwd(p2f, bary, dists, cl, face_uvs, face_map, map_desc, maps, fa, cfg, bg, ctx.tiled, g_img.contiguous(),

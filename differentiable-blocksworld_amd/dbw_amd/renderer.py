@@ -3,7 +3,7 @@ src/model/renderer.py:24-60,84-98 (`Renderer(img_size, **cfg.model.renderer)`; `
 viz_purpose=False, faces_alpha=...) -> (B,4,H,W)` BCHW, premultiplied RGB + alpha), with everything below it
 (PyTorch3D MeshRenderer / MeshRasterizer / TexturesUV sampling / LayeredShader + layered_rgb_blend) replaced by the
 HIP path in libdbw_hip.so.  Only the configuration the hot path uses is implemented:
-perspective cameras with an explicit NDC K matrix, ambient white light, the 'raw' layered shader with clip_inside.
+perspective cameras with an explicit NDC K matrix, ambient white light, the 'raw' layered shader (clip_inside True or False).
 Anything else raises NotImplementedError instead of silently rendering something different."""
 from copy import deepcopy
 
@@ -54,8 +54,7 @@ class Renderer(nn.Module):
         kwargs.pop('debug', False)
         if not kwargs.pop('layered_shader', True):
             raise NotImplementedError('only the layered shader is on the hot path (renderer.py:39-43)')
-        if not kwargs.pop('clip_inside', True):
-            raise NotImplementedError('clip_inside=False')
+        self.clip_inside = bool(kwargs.pop('clip_inside', True))          # False: sigmoid(-d / sigma) instead of exp(-max(d, 0) / sigma), renderer.py:257-258
         if kwargs.pop('shading_type', 'raw') != 'raw':
             raise NotImplementedError("only shading_type='raw' (phong/flat/gouraud are visualisation-only)")
         self.detach_bary = kwargs.pop('detach_bary', False)
@@ -100,7 +99,7 @@ class Renderer(nn.Module):
         if viz:   # exact anti-aliased rendering for visualisation (renderer.py:56-60): 4x res, sigma 0, 1 face per pixel
             return ops.RenderCfg(H * 4, W * 4, 1, 0.0, self.z_clip, self.perspective_correct, False, n_faces, EPS)
         cfg = ops.RenderCfg(H, W, self.faces_per_pixel, self.sigma, self.z_clip, self.perspective_correct, self.detach_bary,
-                            n_faces, EPS, lds_aggregate, texbins, const_faces)
+                            n_faces, EPS, lds_aggregate, texbins, const_faces, clip_inside=self.clip_inside)
         if texbins is not None:         # the texture bins' record sub-ranges follow the demand of this renderer's previous backward (ops.BinDemand)
             if getattr(self, '_bin_demand', None) is None:
                 self._bin_demand = ops.BinDemand()

@@ -139,6 +139,9 @@ int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_face, const
  *    its faces, dbw.py:219 -- this form needs no repeated copy).  Its gradient buffer grad_faces_alpha then holds 64 partial
  *    sums per opacity (M x 64 floats, spread by face index so that a mesh's fragments do not all hit one address), to be added
  *    by the caller (dbw_block_alpha_bwd does, g_alpha_parts = 64).
+ *  sigma: the blend's opacity from the signed squared distance d (renderer.py:252-258).  sigma > 0: exp(-max(d, 0) / sigma) (clip_inside =
+ *    True, every shipped config); sigma == 0: the hard indicator [d <= 0]; sigma < 0: sigmoid(-d / |sigma|) (clip_inside = False) -- here and
+ *    in every entry point that takes `sigma` except the training step (dbw_step_desc.sigma > 0) and the composite + MSE epilogue.
  *  background3: HOST pointer to 3 floats (blend background colour, renderer.py:32), NULL = black.
  *  image (N,4,H,W): premultiplied RGB + alpha (BCHW).
  */

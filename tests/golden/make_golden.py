@@ -122,6 +122,31 @@ def main():
             out[f'{tag}/g_faces_alpha'] = _np(fa.grad)
     np.savez_compressed(os.path.join(HERE, 'blend.npz'), **out)
 
+    # ---- 1b. the same with clip_inside=False: sigmoid(-d / sigma) instead of exp(-max(d, 0) / sigma) (renderer.py:257-258; no shipped config
+    # sets it, the Renderer's constructor takes it) -- a file of its own, drawn from a generator of its own, so that blend.npz stays as it is
+    g2 = torch.Generator().manual_seed(20240905)
+    out = {}
+    for tag, sigma, use_alpha in [('sig1e-4_a', 1e-4, True), ('sig1e-4', 1e-4, False), ('sig5e-6_a', 5e-6, True)]:
+        p2f = torch.randint(-1, N * Ff, (N, H, W, K), generator=g2)
+        p2f[torch.rand(N, H, W, K, generator=g2) < 0.3] = -1
+        dists = (torch.randn(N, H, W, K, generator=g2) * sigma * 3).requires_grad_(True)
+        colors = torch.rand(N, H, W, K, 3, generator=g2).requires_grad_(True)
+        fa = torch.rand(N * Ff, generator=g2).requires_grad_(True) if use_alpha else None
+        fr = Frag()
+        fr.pix_to_face, fr.dists = p2f, dists
+        bp = BP()
+        bp.sigma, bp.background_color = sigma, (0.2, 0.3, 0.4) if use_alpha else (0, 0, 0)
+        res = ren.layered_rgb_blend(colors, fr, bp, clip_inside=False, faces_alpha=fa)
+        w = torch.rand(res.shape, generator=g2)
+        (res * w).sum().backward()
+        out.update({f'{tag}/p2f': _np(p2f), f'{tag}/dists': _np(dists), f'{tag}/colors': _np(colors),
+                    f'{tag}/sigma': np.float64(sigma), f'{tag}/bg': np.array(bp.background_color, dtype=np.float32),
+                    f'{tag}/out': _np(res), f'{tag}/w': _np(w), f'{tag}/g_colors': _np(colors.grad), f'{tag}/g_dists': _np(dists.grad)})
+        if use_alpha:
+            out[f'{tag}/faces_alpha'] = _np(fa)
+            out[f'{tag}/g_faces_alpha'] = _np(fa.grad)
+    np.savez_compressed(os.path.join(HERE, 'blend_sigmoid.npz'), **out)
+
     # ---- 2. parametric_sq on icosphere-1 angles, eps grid incl. grads ----------------------------------
     v1, _ = O.get_icosphere(1)
     eta, omega = torch.asin(v1[:, 1]), torch.atan2(v1[:, 0], v1[:, 2])

@@ -61,7 +61,8 @@ int host_blend(const long long *p2f, const float *dists, const float *colors, co
                     const bool valid = p2f[o] >= 0;
                     const float wgt = T[k] * a[k];
                     for (int ch = 0; ch < 3; ++ch) g_colors[o * 3 + ch] = wgt * g[ch];
-                    g_dists[o] = (valid && sigma != 0.f && dists[o] >= 0.f) ? ga * a[k] * (-1.f / sigma) : 0.f;
+                    // (sigma < 0: the sigmoid opacity of clip_inside = False, d e / d d = -e (1 - e) / |sigma| at every d -- as the kernels have it)
+                    g_dists[o] = !valid ? 0.f : (sigma > 0.f ? (dists[o] >= 0.f ? ga * a[k] * (-1.f / sigma) : 0.f) : (sigma < 0.f ? ga * a[k] * (1.f - e[k]) * (1.f / sigma) : 0.f));
                     if (valid && faces_alpha) g_fa[p2f[o]] += ga * e[k];
                 }
             }

@@ -352,14 +352,14 @@ def _packed(scene, pads=None):
                        scene['face_map'].to(torch.int32).to(DEV), desc, flat)
 
 
-def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_clip=0.001, bg=(0., 0., 0.), seed=0, lds=False):
+def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_clip=0.001, bg=(0., 0., 0.), seed=0, lds=False, clip_inside=True):
     """-> dict of (hip, oracle) pairs: image, grad verts, grad maps, grad alpha."""
     verts_o = scene['verts'].detach().clone().requires_grad_(True)
     maps_o = [m.detach().clone().requires_grad_(True) for m in scene['maps']]
     fa_o = None if faces_alpha is None else faces_alpha.detach().clone().requires_grad_(True)
     sc = dict(scene, verts=verts_o, maps=maps_o)
     fa_rep = None if fa_o is None else fa_o.repeat(R.shape[0])          # the reference passes alpha.repeat(B) (dbw.py:219)
-    img_o = O.render(sc, R, T, Kmat, (H, W), sigma, K, detach_bary, fa_rep, z_clip, bg, n_threads=8)
+    img_o = O.render(sc, R, T, Kmat, (H, W), sigma, K, detach_bary, fa_rep, z_clip, bg, n_threads=8, clip_inside=clip_inside)
     w = torch.rand(img_o.shape, generator=torch.Generator().manual_seed(seed))
     (img_o * w).sum().backward()
 
@@ -367,7 +367,7 @@ def _render_both(scene, R, T, Kmat, H, W, sigma, K, detach_bary, faces_alpha, z_
     ps.verts.requires_grad_(True)
     ps.maps.requires_grad_(True)
     fa_h = None if faces_alpha is None else faces_alpha.detach().to(DEV).requires_grad_(True)
-    cfg = ops.RenderCfg(H, W, K, sigma, z_clip, True, detach_bary, scene['faces'].shape[0], lds_aggregate=lds)
+    cfg = ops.RenderCfg(H, W, K, sigma, z_clip, True, detach_bary, scene['faces'].shape[0], lds_aggregate=lds, clip_inside=clip_inside)
     img_h = ops.render_scene(ps.verts, ps.maps, fa_h, ps.faces, R.to(DEV), T.to(DEV), Kmat.to(DEV), ps.face_uvs, ps.face_map,
                              ps.map_desc, ops.make_bg(bg), cfg)
     (img_h * w.to(DEV)).sum().backward()
@@ -383,6 +383,32 @@ def _model(seed=3, n_blocks=4, ts=32, hw=(48, 64), fpp=6):
     m = O.OracleDBW(hw, n_blocks=n_blocks, txt_size=ts, faces_per_pixel=fpp, seed=seed)
     R, T, Km = O.synthetic_cameras(3, R_world=m.R_world[0], dist=2.8)
     return m, R, T, Km
+
+
+@pytest.mark.parametrize('detach_bary,lds,fused', [(True, True, True), (True, False, True), (False, False, False)])
+def test_render_with_the_sigmoid_opacity_of_clip_inside_false_matches_oracle(detach_bary, lds, fused, monkeypatch):
+    """`clip_inside=False` of the reference's Renderer (renderer.py:41,257-258; no shipped config): the blend opacity is
+    sigmoid(-d / sigma) -- a fragment keeps a gradient to its distance INSIDE its face too.  Image and every gradient (vertices through the
+    distances, and through the barycentrics when they are attached; maps; opacities) against the oracle's render with the same switch;
+    uv-fragments and plain fragments, LDS tables and atomics.
+    Attached barycentrics only through the operator-level kernels, whose arithmetic is the oracle's operation by operation: a soft pass has
+    fragments in the blur band OUTSIDE their face, and where such a pixel falls on the line on which the perspective-correct denominator
+    vanishes (barycentrics of 1e10 before clipping) the gradient through the barycentrics is rounding noise amplified by 1e6 -- the
+    fused backward (v_exp_f32 opacities, 1e-7 off) then differs from ANY other evaluation order on that one fragment.  No pass of the
+    reference attaches the barycentrics of a soft pass (every shipped config sets detach_bary: True for the blocks; dbw.py:137 attaches them for
+    the environment's hard K = 1 pass only, whose fragments all lie inside their face)."""
+    monkeypatch.setattr(ops, 'FUSED_FORWARD', fused)
+    monkeypatch.setattr(ops, 'FUSED_BACKWARD', fused)
+    m, R, T, Km = _model(fpp=6)
+    with torch.no_grad():
+        scene = m.build_blocks(True, True, False, None, kill_blocks=False)
+    fa = (torch.rand(scene['faces'].shape[0] // m.BNF, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1).repeat_interleave(m.BNF)
+    res = _render_both(scene, R, T, Km[0], 48, 64, 1e-4, 6, detach_bary, fa, bg=(0.1, 0.2, 0.3), lds=lds, clip_inside=False)
+    ref = _render_both(scene, R, T, Km[0], 48, 64, 1e-4, 6, detach_bary, fa, bg=(0.1, 0.2, 0.3), lds=lds)
+    for k, (a, b) in res.items():
+        assert rel_err(a, b) < REL, f'{k}: rel err {rel_err(a, b)}'
+    assert res['g_verts'][1].abs().max() > 0
+    assert rel_err(res['image'][1], ref['image'][1]) > 1e-2          # (the two opacities do differ on this scene)
 
 
 @pytest.mark.parametrize('fpp', [6, 16, 25])

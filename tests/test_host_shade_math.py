@@ -75,16 +75,17 @@ def test_footprint_matches_grid_sample_on_the_materialised_texture(h, w, pl, pr,
     assert int(inner.sum()) > n // 2
 
 
-@pytest.mark.parametrize('tag', ['s1e-4_a', 's1e-4', 's5e-6_a', 's0', 's0_a'])
+@pytest.mark.parametrize('tag', ['s1e-4_a', 's1e-4', 's5e-6_a', 's0', 's0_a', 'sig1e-4_a', 'sig1e-4', 'sig5e-6_a'])
 def test_blend_recurrences_match_the_reference_golden(golden_dir, tag):
-    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, 'blend.npz')).items()}
+    sigmoid = tag.startswith('sig')                  # the real layered_rgb_blend with clip_inside=False: the library's sigma < 0
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, 'blend_sigmoid.npz' if sigmoid else 'blend.npz')).items()}
     p2f, dists, colors = g[f'{tag}/p2f'].contiguous(), g[f'{tag}/dists'].contiguous(), g[f'{tag}/colors'].contiguous()
     fa = g[f'{tag}/faces_alpha'].contiguous() if f'{tag}/faces_alpha' in g else None
     sigma, bg, w = float(g[f'{tag}/sigma']), g[f'{tag}/bg'].contiguous(), g[f'{tag}/w'].contiguous()
     N, H, W, K = p2f.shape
     out, g_colors, g_dists = torch.empty(N, 4, H, W), torch.empty_like(colors), torch.empty_like(dists)
     g_fa = None if fa is None else torch.zeros_like(fa)
-    assert lib().host_blend(_p(p2f), _p(dists), _p(colors), _p(fa), N, H, W, K, ctypes.c_float(sigma), _p(bg), _p(w), _p(out), _p(g_colors),
+    assert lib().host_blend(_p(p2f), _p(dists), _p(colors), _p(fa), N, H, W, K, ctypes.c_float(-sigma if sigmoid else sigma), _p(bg), _p(w), _p(out), _p(g_colors),
                             _p(g_dists), _p(g_fa)) == 0
     torch.testing.assert_close(out, g[f'{tag}/out'], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(g_colors, g[f'{tag}/g_colors'], rtol=1e-5, atol=1e-6)

@@ -14,14 +14,15 @@ def _load(golden_dir, name):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, name)).items()}
 
 
-@pytest.mark.parametrize('tag', ['s1e-4_a', 's1e-4', 's5e-6_a', 's0', 's0_a'])
+@pytest.mark.parametrize('tag', ['s1e-4_a', 's1e-4', 's5e-6_a', 's0', 's0_a', 'sig1e-4_a', 'sig1e-4', 'sig5e-6_a'])
 def test_layered_rgb_blend_matches_reference(golden_dir, tag):
-    g = _load(golden_dir, 'blend.npz')
+    clip_inside = not tag.startswith('sig')          # sig*: the real function with clip_inside=False (sigmoid opacity), blend_sigmoid.npz
+    g = _load(golden_dir, 'blend.npz' if clip_inside else 'blend_sigmoid.npz')
     colors = g[f'{tag}/colors'].clone().requires_grad_(True)
     dists = g[f'{tag}/dists'].clone().requires_grad_(True)
     fa = g[f'{tag}/faces_alpha'].clone().requires_grad_(True) if f'{tag}/faces_alpha' in g else None
     sigma = float(g[f'{tag}/sigma'])
-    out = O.layered_rgb_blend(colors, g[f'{tag}/p2f'], dists, sigma, tuple(g[f'{tag}/bg'].tolist()), fa)
+    out = O.layered_rgb_blend(colors, g[f'{tag}/p2f'], dists, sigma, tuple(g[f'{tag}/bg'].tolist()), fa, clip_inside)
     assert torch.equal(out, g[f'{tag}/out'])                       # same torch ops -> bit-identical
     (out * g[f'{tag}/w']).sum().backward()
     torch.testing.assert_close(colors.grad, g[f'{tag}/g_colors'], rtol=1e-6, atol=1e-7)
