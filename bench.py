@@ -176,9 +176,24 @@ def measure_perceptual(dev, views=4, steps=30, warmup=5):
         torch.autograd.grad(net(inp['imgs'], rec), rec)
     torch.cuda.synchronize()
     net_ms = (time.perf_counter() - t0) / 10 * 1e3
+    # ... and as dbw_amd.trainer.Trainer runs it: the targets' features are constants of the training views (frozen network, fixed images) --
+    # computed once, gathered by view id (lpips_vgg.LPIPSVGG.cache_targets).  Same values.
+    net.cache_targets(inp['imgs'])
+    inp_ids = dict(inp, view_ids=torch.arange(views, device=dev))
+    for _ in range(warmup):
+        step(inp_ids).host()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vals_c = step(inp_ids).host()
+    torch.cuda.synchronize()
+    ms_c = (time.perf_counter() - t0) / steps * 1e3
     return {'what': f'batch_size {views} with perceptual_weight 0.1: LPIPS-VGG16 (seeded weights, torch / MIOpen, outside the library) between the two '
                     'phases of the C step; loss values read every step', 'ms_per_step': ms, 'lpips_fwd_bwd_alone_ms': net_ms,
-            'render_path_ms': ms - net_ms, 'losses': {k: round(v, 6) for k, v in vals.items()}}
+            'render_path_ms': ms - net_ms, 'losses': {k: round(v, 6) for k, v in vals.items()},
+            'ms_per_step_cached_targets': ms_c, 'cached_targets': 'the Trainer\'s default: target features computed once per training view and gathered by view id '
+                                                                  '(lpips_vgg.py); losses after the same number of steps: '
+                                                                  + str({k: round(v, 6) for k, v in vals_c.items()})}
 
 
 def kernel_breakdown(model, inp, reps=5):

@@ -398,7 +398,7 @@ class CStep:
                     caller.wait_stream(own)
                 with torch.enable_grad():
                     leaf = rec.requires_grad_(True)
-                    perceptual = m._perceptual_term(inp['imgs'], leaf, m.is_live('coarse_learning'))
+                    perceptual = m._perceptual_term(inp['imgs'], leaf, m.is_live('coarse_learning'), inp.get('view_ids'))
                     g_rec, = torch.autograd.grad(perceptual, leaf)
                 perceptual, g_rec = perceptual.detach(), g_rec.contiguous()
                 a.phase, a.rec_out, a.grad_rec = 2, 0, g_rec.data_ptr()

@@ -486,6 +486,13 @@ class DifferentiableBlocksWorld(nn.Module):
         return torch.cat(rows, dim=1)[None]
 
     def forward(self, inp, labels=None):
+        self._view_ids = inp.get('view_ids')          # (for a perceptual criterion with cached targets: _perceptual_term)
+        try:
+            return self._forward(inp)
+        finally:
+            self._view_ids = None
+
+    def _forward(self, inp):
         if inp['imgs'].shape[0] == 0:
             # a data-parallel rank whose shard is exhausted (parallel.py / trainer.py: uneven shards): nothing to render, the step
             # only carries this rank's share of the view-independent regularisers
@@ -563,7 +570,9 @@ class DifferentiableBlocksWorld(nn.Module):
                            + [(f'alpha{k}', a.item()) for k, a in enumerate(opacities)])
 
     # ------------------------------------------------------------------------------------------------ losses (dbw.py:361-408)
-    def _perceptual_term(self, imgs, rec, coarse):
+    def _perceptual_term(self, imgs, rec, coarse, view_ids=None):
+        """view_ids: the batch's `view_ids` entry, if the caller's loader provides one (trainer.py does) -- handed to a criterion that keeps
+        the constant half of its work per training view (lpips_vgg.LPIPSVGG.cache_targets); never needed for the value."""
         if self.perceptual_fn is None:
             raise RuntimeError('perceptual_weight > 0 needs model.set_perceptual(fn): lpips is a third-party network '
                                'outside the HIP path (SURVEY.md 8a A10)')
@@ -573,7 +582,11 @@ class DifferentiableBlocksWorld(nn.Module):
         share = 1.0
         if self.world_size > 1 and getattr(self, '_global_count', None):
             share = imgs.numel() / float(self._global_count)
-        return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * share * self.perceptual_fn(imgs, rec)
+        if view_ids is not None and getattr(self.perceptual_fn, 'target_cache', None) is not None:
+            value = self.perceptual_fn(imgs, rec, view_ids=view_ids)
+        else:
+            value = self.perceptual_fn(imgs, rec)
+        return self.loss_weights['perceptual'] * (1 if coarse else 0.1) * share * value
 
     def compute_losses(self, imgs, rec, layers=None, rgb_value=None):
         w = self.loss_weights
@@ -611,7 +624,7 @@ class DifferentiableBlocksWorld(nn.Module):
                 losses['rgb'] = rgb_value
                 total = total + rgb_value
             if 'perceptual' in w:
-                losses['perceptual'] = self._perceptual_term(imgs, ops.composite(*layers), coarse)
+                losses['perceptual'] = self._perceptual_term(imgs, ops.composite(*layers), coarse, getattr(self, '_view_ids', None))
                 total = total + losses['perceptual']
             losses = {k: losses[k] for k in w}
             losses['total'] = total
@@ -623,7 +636,7 @@ class DifferentiableBlocksWorld(nn.Module):
             share = imgs.numel() / float(self._global_count) if (ws > 1 and getattr(self, '_global_count', None)) else 1.0
             losses['rgb'] = w['rgb'] * share * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
         if 'perceptual' in losses and not empty:
-            losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse)
+            losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse, getattr(self, '_view_ids', None))
         if 'parsimony' in losses:
             factor = 1 if coarse else 0
             alpha = self._alpha_full if coarse else (self._alpha_full > 0.5).float()

@@ -12,7 +12,14 @@ weights (tests/test_lpips.py); the model's perceptual term is checked against th
     and lpips' linear heads ('lin0.model.1.weight' ... 'lin4.model.1.weight', each (1, C, 1, 1), non-negative);
   * without weights the forward refuses to run unless `allow_random_init=True` (shape / throughput checks only).
 
-Usage: `model.set_perceptual(LPIPSVGG().load_weights(vgg_sd, lin_sd).to(device))`."""
+Usage: `model.set_perceptual(LPIPSVGG().load_weights(vgg_sd, lin_sd).to(device))`.
+
+One option changes the cost, not the value (measured on MI355X at 4 + 4 images of 400x300: 12.5 ms forward + backward as the reference
+runs it -- 878 GFLOP of fp32 convolutions; 9.0 ms with it): `cache_targets(imgs_all)`.  The training images never change and the network is
+frozen, so their normalised features are constants -- computed once for every view (58 MB per 400x300 view) and gathered by
+`forward(imgs, rec, view_ids=...)`: a third of the FLOPs gone (the target branch's forward; it never had a backward).  The Trainer does this
+when the features fit (trainer.py).  (channels_last weights and activations were measured too: 11.8 ms where MIOpen had searched its
+kernels in the same process, 20.5 ms where it had not -- not offered.)"""
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -34,6 +41,7 @@ class LPIPSVGG(nn.Module):
         self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
         self.loaded = False
         self.allow_random_init = allow_random_init
+        self.target_cache = None          # per tap: (V, C, h, w) normalised features of the V training images (cache_targets)
         if allow_random_init:
             with torch.no_grad():
                 for lin in self.lins:
@@ -52,6 +60,35 @@ class LPIPSVGG(nn.Module):
         self.loaded = True
         return self
 
+    @staticmethod
+    def _unit(f):
+        return f / (f.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+
+    def target_bytes(self, H, W, n_views=1):
+        """Bytes cache_targets needs for n_views images of H x W."""
+        total, h, w = 0, H, W
+        for k, c in enumerate(_CHANNELS):
+            if k:
+                h, w = h // 2, w // 2
+            total += c * h * w * 4
+        return total * n_views
+
+    @torch.no_grad()
+    def cache_targets(self, imgs_all, chunk=8):
+        """imgs_all (V,3,H,W) in [0, 1]: the training images, in the order the `view_ids` of forward() index them.  Valid as long as the
+        images and the (frozen) weights stay what they are; `cache_targets(None)` drops the cache."""
+        if imgs_all is None:
+            self.target_cache = None
+            return self
+        if not (self.loaded or self.allow_random_init):
+            raise RuntimeError('LPIPSVGG has no weights: bring torchvision vgg16 features + lpips linear heads (load_weights)')
+        parts = [[] for _ in _CHANNELS]
+        for a in range(0, imgs_all.shape[0], chunk):
+            for k, f in enumerate(self.features(imgs_all[a:a + chunk] * 2 - 1)):
+                parts[k].append(self._unit(f))
+        self.target_cache = [torch.cat(p) for p in parts] if imgs_all.shape[0] else None
+        return self
+
     def features(self, x):
         x = (x - self.shift) / self.scale
         taps = []
@@ -63,15 +100,19 @@ class LPIPSVGG(nn.Module):
                 taps.append(x)
         return taps
 
-    def forward(self, imgs, rec):
+    def forward(self, imgs, rec, view_ids=None):
         """imgs, rec (B,3,H,W) in [0, 1] -> scalar: mean over the batch of sum_l mean_hw lin_l((n(f_l(a)) - n(f_l(b)))^2), n = unit
-        normalisation along channels."""
+        normalisation along channels.  view_ids (B,) integer tensor on the device of `rec` + a cache (cache_targets): the targets' features
+        are gathered from the cache instead of being recomputed from `imgs` (which is then not read)."""
         if not (self.loaded or self.allow_random_init):
             raise RuntimeError('LPIPSVGG has no weights: bring torchvision vgg16 features + lpips linear heads (load_weights)')
-        a, b = self.features(imgs * 2 - 1), self.features(rec * 2 - 1)          # normalize=True
+        if view_ids is not None and self.target_cache is not None:
+            if view_ids.shape[0] != rec.shape[0]:
+                raise ValueError(f'{view_ids.shape[0]} view ids for {rec.shape[0]} images')
+            na_all = [c.index_select(0, view_ids) for c in self.target_cache]
+        else:
+            na_all = [self._unit(fa) for fa in self.features(imgs * 2 - 1)]          # normalize=True
         total = 0
-        for fa, fb, lin in zip(a, b, self.lins):
-            na = fa / (fa.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            nb = fb / (fb.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            total = total + lin((na - nb) ** 2).mean((2, 3), keepdim=True)
+        for na, fb, lin in zip(na_all, self.features(rec * 2 - 1), self.lins):
+            total = total + lin((na - self._unit(fb)) ** 2).mean((2, 3), keepdim=True)
         return total.mean()

@@ -67,7 +67,7 @@ class Trainer:
     views: dict of tensors {'imgs' (V,3,H,W), 'R' (V,3,3), 'T' (V,3), 'K' (V,4,4)} resident on the device (the reference's
     DataLoader yields the same dict batch by batch, trainer.py:118,141)."""
 
-    def __init__(self, cfg, model, views, process_group=None, sync_free=True):
+    def __init__(self, cfg, model, views, process_group=None, sync_free=True, cache_perceptual_targets=True):
         tr = cfg['training']
         opt = dict(tr.get('optimizer') or {})
         if opt.pop('name', 'adam') != 'adam':
@@ -96,6 +96,17 @@ class Trainer:
         self.n_batches = -(-max(self.shard_sizes) // self.batch_size)          # every rank runs this many steps per epoch
         self.per_view = views['imgs'][0].numel() if V else 0
         self._perm_gen = torch.Generator().manual_seed(int(tr.get('seed') or 0))
+        # The perceptual criterion's target half is a constant per training view (frozen network, fixed images): a criterion that can keep
+        # it (lpips_vgg.LPIPSVGG.cache_targets) computes it once for this rank's views, if that fits in a quarter of the free memory, and
+        # every batch then carries the local indices of its views.  A third of the criterion's FLOPs; the values do not change.
+        self.view_ids = False
+        fn = getattr(model, 'perceptual_fn', None)
+        if (cache_perceptual_targets and 'perceptual' in getattr(model, 'loss_weights', {}) and hasattr(fn, 'cache_targets') and self.local['imgs'].is_cuda
+                and self.local['imgs'].shape[0] > 0):
+            need = fn.target_bytes(*self.local['imgs'].shape[2:], n_views=self.local['imgs'].shape[0])
+            if need <= torch.cuda.mem_get_info(self.local['imgs'].device)[0] // 4:
+                fn.cache_targets(self.local['imgs'])
+                self.view_ids = True
 
     # trainer.py:137-147
     def run_single_batch_train(self, inp, global_count=None):
@@ -122,7 +133,10 @@ class Trainer:
         # sequence of collectives is the same everywhere, and the MSE normalisation of a step is the size of its global batch
         for b in range(self.n_batches):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size].to(self.local['imgs'].device)
-            last, _ = self.run_single_batch_train({k: v[idx] for k, v in self.local.items()}, self.global_count(b))
+            batch = {k: v[idx] for k, v in self.local.items()}
+            if self.view_ids:
+                batch['view_ids'] = idx
+            last, _ = self.run_single_batch_train(batch, self.global_count(b))
             n_img += idx.numel()
         if self.local['imgs'].is_cuda:
             torch.cuda.synchronize()

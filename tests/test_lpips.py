@@ -94,3 +94,72 @@ def test_model_perceptual_term_is_weight_times_phase_factor_times_batch_share_ti
             got = float(out['perceptual'])
             assert abs(got - 0.1 * factor * share * ref) <= 1e-4 * 0.1 * factor * share * ref, (epoch, world, got, ref)
     model.world_size, model._global_count = 1, None
+
+
+def test_cached_targets_do_not_change_value_or_gradient(golden_dir):
+    """LPIPSVGG.cache_targets: the normalised features of the (fixed) training images, computed once, gathered by view id -- the value and
+    the gradient to `rec` are those of the plain call, whatever the order and repetition of the ids; target_bytes is what the cache holds."""
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    g, vgg, lin = _fixture(golden_dir)
+    net = LPIPSVGG().load_weights(vgg, lin)
+    imgs_all = g['imgs']
+    V, _, H, W = imgs_all.shape
+    ids = torch.tensor([2, 0, 0, 1][:max(V, 1) + 1]) % V
+    rec = g['rec'][ids].clone().requires_grad_(True)
+    ref = net(imgs_all[ids], rec)
+    g_ref, = torch.autograd.grad(ref, rec)
+    net.cache_targets(imgs_all, chunk=2)
+    assert sum(c.numel() * 4 for c in net.target_cache) == net.target_bytes(H, W, V)
+    got = net(torch.full_like(imgs_all[ids], float('nan')), rec, view_ids=ids)          # (the images are not read any more)
+    g_got, = torch.autograd.grad(got, rec)
+    assert abs(float(got) - float(ref)) <= 1e-6 * float(ref) and float((g_got - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
+    with pytest.raises(ValueError):
+        net(imgs_all[ids], rec, view_ids=ids[:1])
+    net.cache_targets(None)
+    assert net.target_cache is None
+
+
+@pytest.mark.gpu
+def test_trainer_with_cached_perceptual_targets_takes_the_same_steps(golden_dir):
+    """Trainer(cache_perceptual_targets=True), the default: the criterion's target features are computed once for the rank's views and every
+    batch carries its view ids through the C step's two phases (c_step.py) -- losses and parameters after two epochs equal those of a
+    trainer that recomputes the targets' features every step, as the reference does."""
+    import dbw_amd
+    import oracle as O
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    from dbw_amd.trainer import Trainer
+    from test_gpu_model import _dtu_like_cfg
+    DEV = 'cuda'
+    g, vgg, lin = _fixture(golden_dir)
+    H, W, V = 48, 64, 6
+    cfg = _dtu_like_cfg(4, 32, 6)
+    cfg['model']['loss']['perceptual_weight'] = 0.1
+    cfg['training'] = {'batch_size': 4, 'n_epoches': 2, 'seed': 11, 'optimizer': {'name': 'adam', 'lr': 5.0e-3, 'texture': {'lr': 5.0e-2}},
+                       'scheduler': {'name': 'multi_step', 'gamma': [0.1], 'milestones': [100]}}
+    R, T, Km = O.synthetic_cameras(V, R_world=O.world_rotation(115, 0, 0))
+    views = {k: v.to(DEV) for k, v in dict(imgs=torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(2)), R=R, T=T, K=Km).items()}
+    results = []
+    for cached in (False, True):
+        torch.manual_seed(227391)
+        model = dbw_amd.create_model(cfg, (H, W)).to(DEV)
+        net = LPIPSVGG().load_weights(vgg, lin).to(DEV)
+        calls = []
+        orig = net.forward
+        net.forward = lambda imgs, rec, view_ids=None, _o=orig: (calls.append(view_ids is not None), _o(imgs, rec, view_ids=view_ids))[1]
+        model.set_perceptual(net)
+        tr = Trainer(cfg, model, views, cache_perceptual_targets=cached)
+        assert tr.view_ids == cached and (net.target_cache is not None) == cached
+        assert tr.step_fn.cstep is not None
+        vals = []
+        for _ in range(2):
+            last = tr.run_epoch()
+            vals.append({k: float(v) for k, v in last.items()})
+        assert calls and all(c == cached for c in calls)          # (the ragged second batch of an epoch too)
+        results.append((vals, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (va, pa), (vb, pb) = results
+    for a, b in zip(va, vb):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
+    for k in pa:
+        if pa[k].is_floating_point():
+            assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * max(float(pa[k].abs().max()), 1e-6), k
