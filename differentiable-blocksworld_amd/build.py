@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['util.hip', 'raster.hip', 'project_clip.hip', 'shade_blend.hip', 'render_fused.hip', 'texture.hip', 'model_ops.hip', 'train_step.hip']
+SOURCES = ['util.hip', 'raster.hip', 'project_clip.hip', 'shade_blend.hip', 'render_fused.hip', 'texture.hip', 'model_ops.hip', 'train_step.hip', 'lpips_head.hip']
 OUT = os.path.join(HERE, 'dbw_amd', 'libdbw_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
          '-fno-gpu-flush-denormals-to-zero', '-Wall', '-Wno-unused-function']

@@ -108,6 +108,8 @@ SIGNATURES = {
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p, c_p],
+    'dbw_lpips_head_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    'dbw_lpips_head_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_finish': [c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],
@@ -125,6 +127,7 @@ OTHER_SIGNATURES = {
     'dbw_train_step_offset': (c_i64, [c_p, c_i]),
     'dbw_train_step_void_flag_offset': (c_i64, [c_p]),
     'dbw_train_step_voided_runs': (c_i, [c_p]),
+    'dbw_lpips_head_blocks': (c_i, [c_i, c_i]),
 }
 
 

@@ -32,6 +32,37 @@ _TAPS = {2: 0, 7: 1, 14: 2, 21: 3, 28: 4}      # relu1_2, relu2_2, relu3_3, relu
 _CHANNELS = [64, 128, 256, 512, 512]
 
 
+class _FusedHead(torch.autograd.Function):
+    """One tap's head on the device in one pass each way (csrc/lpips_head.hip, include/dbw_hip.h: dbw_lpips_head_*): per-image values (N,)
+    from the reconstruction's tap f (N,C,h,w), the targets' unit-normalised tap (rows `ids` of it when given) and the 1x1 head's weights."""
+
+    @staticmethod
+    def forward(ctx, f, target_unit, ids, w):
+        from . import _lib
+        f = f.contiguous()
+        N, C, h, wd = f.shape
+        nb = _lib.load().dbw_lpips_head_blocks(N, h * wd)
+        partial = torch.empty(N, nb, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.call('dbw_lpips_head_fwd', f.data_ptr(), target_unit.data_ptr(), ids.data_ptr() if ids is not None else 0, w.data_ptr(), N, target_unit.shape[0], C, h * wd,
+                      partial.data_ptr(), torch.cuda.current_stream(f.device).cuda_stream)
+        ctx.save_for_backward(f, target_unit, w, *([ids] if ids is not None else []))
+        return partial.sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        f, target_unit, w = ctx.saved_tensors[:3]
+        ids = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        N, C, h, wd = f.shape
+        g = g.contiguous().float()
+        gf = torch.empty_like(f)
+        with torch.cuda.device(f.device):
+            _lib.call('dbw_lpips_head_bwd', f.data_ptr(), target_unit.data_ptr(), ids.data_ptr() if ids is not None else 0, w.data_ptr(), N, target_unit.shape[0], C, h * wd,
+                      g.data_ptr(), gf.data_ptr(), torch.cuda.current_stream(f.device).cuda_stream)
+        return gf, None, None, None
+
+
 class LPIPSVGG(nn.Module):
     def __init__(self, allow_random_init=False):
         super().__init__()
@@ -41,6 +72,7 @@ class LPIPSVGG(nn.Module):
         self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
         self.loaded = False
         self.allow_random_init = allow_random_init
+        self.fused_head = True            # CUDA tensors: the head (normalise, difference, 1x1 head, spatial mean) as one HIP pass per tap
         self.target_cache = None          # per tap: (V, C, h, w) normalised features of the V training images (cache_targets)
         if allow_random_init:
             with torch.no_grad():
@@ -106,13 +138,21 @@ class LPIPSVGG(nn.Module):
         are gathered from the cache instead of being recomputed from `imgs` (which is then not read)."""
         if not (self.loaded or self.allow_random_init):
             raise RuntimeError('LPIPSVGG has no weights: bring torchvision vgg16 features + lpips linear heads (load_weights)')
-        if view_ids is not None and self.target_cache is not None:
-            if view_ids.shape[0] != rec.shape[0]:
-                raise ValueError(f'{view_ids.shape[0]} view ids for {rec.shape[0]} images')
-            na_all = [c.index_select(0, view_ids) for c in self.target_cache]
-        else:
+        cached = view_ids is not None and self.target_cache is not None
+        if cached and view_ids.shape[0] != rec.shape[0]:
+            raise ValueError(f'{view_ids.shape[0]} view ids for {rec.shape[0]} images')
+        if not cached:
             na_all = [self._unit(fa) for fa in self.features(imgs * 2 - 1)]          # normalize=True
+        fb_all = self.features(rec * 2 - 1)
+        if rec.is_cuda and self.fused_head and not any(t.requires_grad for t in (na_all if not cached else [])):
+            # the head of every tap in one pass each way on the device (csrc/lpips_head.hip); the targets' rows are read in place
+            ids = view_ids.to(torch.int64).contiguous() if cached else None
+            per = sum(_FusedHead.apply(fb, (self.target_cache[k] if cached else na_all[k]).contiguous(), ids, lin.weight.detach().reshape(-1).contiguous())
+                      for k, (fb, lin) in enumerate(zip(fb_all, self.lins)))
+            return per.mean()
+        if cached:
+            na_all = [c.index_select(0, view_ids) for c in self.target_cache]
         total = 0
-        for na, fb, lin in zip(na_all, self.features(rec * 2 - 1), self.lins):
+        for na, fb, lin in zip(na_all, fb_all, self.lins):
             total = total + lin((na - self._unit(fb)) ** 2).mean((2, 3), keepdim=True)
         return total.mean()

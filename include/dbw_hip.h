@@ -28,8 +28,9 @@
 /* ABI revision of this header (dbw_abi_version() returns the value the library was built with).  2: image_layout argument of the fused
  * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry); 5: dbw_step_inputs.rng_step
  * (the random-number counter is the caller's step count, not the plan's), skip_flag of dbw_adam_step_groups, a cross-stream wait that
- * gives up voids its step and moves the plan to events instead of failing the next run (dbw_train_step_voided_runs) */
-#define DBW_ABI_VERSION 5
+ * gives up voids its step and moves the plan to events instead of failing the next run (dbw_train_step_voided_runs); 6: dbw_lpips_head_*
+ * (the head of the perceptual criterion) */
+#define DBW_ABI_VERSION 6
 
 #ifdef __cplusplus
 extern "C" {
@@ -531,6 +532,22 @@ int dbw_debug_train_step_force_timeout(dbw_step_plan *plan);
  * and returns out4_ms = env pass, fg pass (+ composite + MSE), fg backward, env backward. */
 int dbw_train_step_profile(dbw_step_plan *plan, int on);
 int dbw_train_step_kernel_times(dbw_step_plan *plan, float *out4_ms);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Head of the perceptual criterion (src/model/loss.py:32-40 -> lpips 0.1.4 `LPIPS(net='vgg')(.., normalize=True)`),
+ * for ONE feature tap of the frozen VGG16.  The convolutions stay with the caller (MIOpen); this replaces what follows them:
+ *   value[n] = mean over the HW pixels of sum_c lin_w[c] * (t[c] - f[c] / (sqrt(sum_c f[c]^2) + 1e-10))^2
+ * feat (N, C, HW): the tap of the reconstruction.  target_unit (V, C, HW): the UNIT-NORMALISED tap of the target images -- row n, or row
+ * view_ids[n] when view_ids is given (the features of the training views are constants, kept by the caller; an id outside [0, V) turns
+ * that image's value and gradient into NaN).  lin_w (C).
+ *   fwd: partial (N, dbw_lpips_head_blocks(N, HW)), fully written: value[n] = the sum of row n (summed by the caller: a fixed order)
+ *   bwd: grad_value (N) -> grad_feat (N, C, HW), fully written; target and weights are constants (the network is frozen, loss.py:36-37)
+ */
+int dbw_lpips_head_blocks(int N, int HW);
+int dbw_lpips_head_fwd(const float *feat, const float *target_unit, const int64_t *view_ids, const float *lin_w, int N, int V, int C, int HW,
+                       float *partial, dbw_stream_t stream);
+int dbw_lpips_head_bwd(const float *feat, const float *target_unit, const int64_t *view_ids, const float *lin_w, int N, int V, int C, int HW,
+                       const float *grad_value, float *grad_feat, dbw_stream_t stream);
 
 #ifdef __cplusplus
 }

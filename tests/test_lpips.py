@@ -163,3 +163,33 @@ def test_trainer_with_cached_perceptual_targets_takes_the_same_steps(golden_dir)
     for k in pa:
         if pa[k].is_floating_point():
             assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * max(float(pa[k].abs().max()), 1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cached', [False, True])
+def test_fused_head_on_the_device_equals_the_torch_formulation(golden_dir, cached):
+    """csrc/lpips_head.hip (dbw_lpips_head_fwd / _bwd through the C-ABI) against the same module with the head written in torch ops: value and
+    gradient to `rec` at 1e-5, with the targets' features computed in the call and gathered from the cache (ids out of order and repeated),
+    at an image size whose taps are no multiple of the workgroup; a view id outside the cache poisons the value instead of reading out of bounds."""
+    from dbw_amd.lpips_vgg import LPIPSVGG
+    g, vgg, lin = _fixture(golden_dir)
+    net = LPIPSVGG().load_weights(vgg, lin).to('cuda')
+    gen = torch.Generator().manual_seed(3)
+    imgs_all = torch.rand(3, 3, 52, 76, generator=gen).cuda()
+    ids = torch.tensor([2, 0, 2, 1], device='cuda')
+    rec = (imgs_all[ids] * 0.7 + 0.3 * torch.rand(4, 3, 52, 76, generator=gen).cuda()).requires_grad_(True)
+    if cached:
+        net.cache_targets(imgs_all)
+    kw = dict(view_ids=ids) if cached else {}
+    out = {}
+    for fused in (False, True):
+        net.fused_head = fused
+        v = net(imgs_all[ids], rec, **kw)
+        gr, = torch.autograd.grad(v * 3.0, rec)
+        out[fused] = (float(v), gr)
+    (v0, g0), (v1, g1) = out[False], out[True]
+    assert v0 > 1e-3 and abs(v1 - v0) <= 1e-5 * v0, (v0, v1)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    if cached:
+        bad = net(imgs_all[ids], rec, view_ids=torch.tensor([0, 1, 3, 1], device='cuda'))
+        assert torch.isnan(bad)
