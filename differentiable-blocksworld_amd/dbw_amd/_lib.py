@@ -110,6 +110,8 @@ SIGNATURES = {
     'dbw_adam_step_groups': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p, c_i64, c_p, c_p],
     'dbw_lpips_head_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     'dbw_lpips_head_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    'dbw_debug_train_step_last_timeout': [c_p, c_p],
+    'dbw_debug_train_step_counters': [c_p, c_p, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_finish': [c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],

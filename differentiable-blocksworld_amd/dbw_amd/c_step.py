@@ -259,13 +259,26 @@ class CStep:
         """Runs of the current plan that voided themselves (host-side counter, no synchronisation); > 0: the plan now runs on events."""
         return int(_lib.load().dbw_train_step_voided_runs(self._cur[0]))
 
+    _WAITS = ('prologue', 'tile order', 'fg forward', 'regularisers', 'bin layout', 'fg backward kernel', "blocks' textures", 'env chain', 'texture preparation')
+
+    def last_timeout(self):
+        """(name of the cross-stream counter the first poll that gave up was waiting on, value wanted, value last seen), or None.  Synchronises."""
+        out = (ctypes.c_int * 3)()
+        _lib.call('dbw_debug_train_step_last_timeout', self._cur[0], out)
+        if out[0] < 0:
+            return None
+        seen, asked = (ctypes.c_uint * 12)(), (ctypes.c_uint * 12)()
+        _lib.call('dbw_debug_train_step_counters', self._cur[0], seen, asked)
+        return (self._WAITS[out[0]] if out[0] < len(self._WAITS) else str(out[0]), out[1], out[2],
+                {n: (int(seen[i]), int(asked[i])) for i, n in enumerate(self._WAITS)})          # counter: (seen then, enqueued so far)
+
     def _report_voided(self):
         h = self._cur[0]
         n = self.voided_runs()
         if n > self._voided_seen.get(h, 0):
             self._voided_seen[h] = n
-            warnings.warn(f'dbw C step: a cross-stream wait gave up ({n} run(s) so far): the step voided itself -- no parameter was updated -- '
-                          'and the plan orders its streams through HIP events from now on', RuntimeWarning)
+            warnings.warn(f'dbw C step: a cross-stream wait gave up ({n} run(s) so far; first: {self.last_timeout()}): the step voided itself -- no '
+                          'parameter was updated -- and the plan orders its streams through HIP events from now on', RuntimeWarning)
 
     def kernel_times(self, inp, global_count=None, reps=5, alone=False):
         """ms of the four big kernels INSIDE a step (env pass, fg pass, fg backward, env backward), everything that shares the GPU with them

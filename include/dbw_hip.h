@@ -439,13 +439,16 @@ typedef struct dbw_step_desc {
     int sync_events;                            /* how the plan's streams wait for each other.  0 (default): through words in device memory -- the
                                                  * producing stream runs a one-thread kernel that stores a counter, the waiting stream a one-thread
                                                  * kernel that polls it (every wait is enqueued after its producer, so no ordering of the hardware
-                                                 * queues can deadlock it; a poll that still gives up -- after 1 s: the process's queues were
-                                                 * descheduled that long -- VOIDS its step on the device: the step's Adam launch (and, through the
+                                                 * queues can deadlock it; a poll that still gives up -- after 1 s of wall clock of which it has
+                                                 * itself been running a good part: the producer's queue was held up that long -- VOIDS its
+                                                 * step on the device: the step's Adam launch (and, through the
                                                  * summed flag, every data-parallel rank's) skips the update, and the plan's next run -- which sees
                                                  * a word in mapped host memory -- switches the plan to events for good and goes on:
                                                  * dbw_train_step_voided_runs, dbw_train_step_sync_timeouts).  Measured: an
                                                  * event costs the stream that records or waits for it 7-11 us before its next kernel and the
-                                                 * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.
+                                                 * waiting stream starts 12-26 us late; the two tiny kernels cost ~2 us and ~1 us.  The FIRST run
+                                                 * of a plan always goes through events: it pays for everything lazy -- at BASELINE config 5 its
+                                                 * first kernel starts 0.96 s late, behind the driver's clearing of the 40 GB just allocated).
                                                  * != 0: HIP events (hipEventRecord / hipStreamWaitEvent) */
     float tv_value_scale;                       /* 0 (= 1): factor on the REPORTED total-variation value only.  Data parallel with deferred texture
                                                  * gradients (dbw_step_inputs.defer_textures): the TV gradient is added on every rank AFTER the
@@ -525,6 +528,13 @@ int dbw_train_step_voided_runs(const dbw_step_plan *plan);
 int64_t dbw_train_step_void_flag_offset(const dbw_step_plan *plan);
 /* tests: the join of the plan's NEXT run polls for a value that never comes and gives up after 0.05 s */
 int dbw_debug_train_step_force_timeout(dbw_step_plan *plan);
+/* diagnostics: out3 = {which of the plan's cross-stream counters the FIRST poll that gave up was waiting on (0 prologue, 1 tile order, 2 fg
+ * forward, 3 regularisers, 4 bin layout, 5 fg backward kernel, 6 blocks' textures, 7 env chain, 8 texture preparation; -1: no poll gave up),
+ * the value it wanted, the value it last saw}.  Synchronises the device. */
+int dbw_debug_train_step_last_timeout(dbw_step_plan *plan, int *out3);
+/* ... and all twelve counters: seen12 as that poll saw them when it gave up (as they are now, if none did), asked12 the values the host has
+ * enqueued stores for so far. */
+int dbw_debug_train_step_counters(dbw_step_plan *plan, unsigned *seen12, unsigned *asked12);
 
 /* Measurement aid (bench.py): on != 0 makes every following run record HIP timing events around its four big kernels, on the streams they
  * run on and with everything that shares the GPU with them in a real step running next to them (the events themselves cost each

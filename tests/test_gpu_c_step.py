@@ -16,6 +16,7 @@ import oracle as O                                              # noqa: E402  (c
 import dbw_amd                                                  # noqa: E402
 from dbw_amd import _lib, ops                                   # noqa: E402
 from dbw_amd.parallel import ShardedTrainStep                   # noqa: E402
+from trajectory import assert_same_trajectory                   # noqa: E402
 
 DEV = 'cuda:0'
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -68,10 +69,7 @@ def _compare(a, b, names):
     for n, off, k in names:
         x, y = ga[off:off + k], gb[off:off + k]
         assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-12, (n, float((x - y).abs().max()), float(y.abs().max()))
-    diff = (pa - pb).abs()
-    # (Adam divides by sqrt(v): an element whose gradient is at the rounding noise of the float atomics moves by +-lr whatever the noise
-    # was; see test_gpu_model.py::test_native_step_equals_autograd_step)
-    assert float((diff > 1e-4).float().mean()) < 1e-2 and float(diff.max()) < 0.02, (float((diff > 1e-4).float().mean()), float(diff.max()))
+    assert_same_trajectory(pa, pb)          # (later steps: tests/trajectory.py)
 
 
 @pytest.mark.parametrize('epoch', [0, 800, 1600])
@@ -426,6 +424,11 @@ def test_c_step_voids_a_step_whose_wait_gave_up_and_goes_on_through_events():
     step(inp)
     torch.cuda.synchronize()
     assert step.cstep.sync_timeouts() == 0 and step.cstep.voided_runs() == 0
+    # (a plan's FIRST run goes through events whatever sync_events says -- it is the run that waits for the driver to clear freshly allocated
+    # memory, a second at BASELINE config 5 -- so no counter has been asked for yet; the polls start with the second run)
+    seen, asked = (ctypes.c_uint * 12)(), (ctypes.c_uint * 12)()
+    _lib.call('dbw_debug_train_step_counters', step.cstep._cur[0], seen, asked)
+    assert not any(asked) and step.cstep.last_timeout() is None
     before = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone())
     _lib.call('dbw_debug_train_step_force_timeout', step.cstep._cur[0])
     with warnings.catch_warnings(record=True) as w:
@@ -433,6 +436,8 @@ def test_c_step_voids_a_step_whose_wait_gave_up_and_goes_on_through_events():
         step(inp)                          # voided: its join gives up
         torch.cuda.synchronize()
         assert step.cstep.sync_timeouts() == 1 and step.cstep.voided_runs() == 1
+        which = step.cstep.last_timeout()
+        assert which[0] == 'env chain' and which[3]['prologue'] == (1, 1)          # the join's poll, and what the counters stood at then
         for a, b in zip(before, (step.params.flat, step.exp_avg, step.exp_avg_sq)):
             assert torch.equal(a, b)       # nothing moved
         step.n_steps -= 1                  # (test only: line the Adam step count up with the reference's two applied steps)
@@ -441,8 +446,7 @@ def test_c_step_voids_a_step_whose_wait_gave_up_and_goes_on_through_events():
     assert any('gave up' in str(x.message) for x in w)
     assert step.cstep.sync_timeouts() == 1 and step.cstep.voided_runs() == 1
     assert all(torch.isfinite(v).all() for v in out.values())
-    diff = (step.params.flat - ref.params.flat).abs()
-    assert float((diff > 1e-4).float().mean()) < 1e-2 and float(diff.max()) < 0.02, (float((diff > 1e-4).float().mean()), float(diff.max()))
+    assert_same_trajectory(step.params.flat, ref.params.flat)
 
 
 def test_arena_cleaned_by_the_caller_counts_for_the_plan_it_cleaned_only():
