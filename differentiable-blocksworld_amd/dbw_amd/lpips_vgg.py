@@ -139,14 +139,16 @@ class LPIPSVGG(nn.Module):
         if not (self.loaded or self.allow_random_init):
             raise RuntimeError('LPIPSVGG has no weights: bring torchvision vgg16 features + lpips linear heads (load_weights)')
         cached = view_ids is not None and self.target_cache is not None
-        if cached and view_ids.shape[0] != rec.shape[0]:
-            raise ValueError(f'{view_ids.shape[0]} view ids for {rec.shape[0]} images')
+        if cached:
+            if view_ids.shape[0] != rec.shape[0]:
+                raise ValueError(f'{view_ids.shape[0]} view ids for {rec.shape[0]} images')
+            view_ids = view_ids.to(device=rec.device, dtype=torch.int64).contiguous()          # (a loader may hand them over on the host)
         if not cached:
             na_all = [self._unit(fa) for fa in self.features(imgs * 2 - 1)]          # normalize=True
         fb_all = self.features(rec * 2 - 1)
         if rec.is_cuda and self.fused_head and not any(t.requires_grad for t in (na_all if not cached else [])):
             # the head of every tap in one pass each way on the device (csrc/lpips_head.hip); the targets' rows are read in place
-            ids = view_ids.to(torch.int64).contiguous() if cached else None
+            ids = view_ids if cached else None
             per = sum(_FusedHead.apply(fb, (self.target_cache[k] if cached else na_all[k]).contiguous(), ids, lin.weight.detach().reshape(-1).contiguous())
                       for k, (fb, lin) in enumerate(zip(fb_all, self.lins)))
             return per.mean()

@@ -192,3 +192,5 @@ def test_fused_head_on_the_device_equals_the_torch_formulation(golden_dir, cache
     if cached:
         bad = net(imgs_all[ids], rec, view_ids=torch.tensor([0, 1, 3, 1], device='cuda'))
         assert torch.isnan(bad)
+        host_ids = net(imgs_all[ids], rec, view_ids=ids.cpu().int())          # ids on the host, 32-bit: moved and widened by the module
+        assert abs(float(host_ids) - v1) <= 1e-6 * v1
