@@ -14,6 +14,9 @@ if os.environ.get('DBW_DEBUG_FLAGS'):
     _lib.load().dbw_debug_set_flags(int(os.environ['DBW_DEBUG_FLAGS']))
 if os.environ.get('DBW_RENDER_VARIANT'):
     _lib.load().dbw_debug_set_render_variant(int(os.environ['DBW_RENDER_VARIANT']))
+if os.environ.get('DBW_PMC_EMPTY'):          # every block far outside every view: all tiles of the fg pass are empty (env layer + epilogue only)
+    with torch.no_grad():
+        model.T.add_(100.0)
 model.sync_free = True
 model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
 step = ShardedTrainStep(model, seed=1)
