@@ -144,7 +144,85 @@ int launch(const float *feat, const float *target_unit, const int64_t *view_ids,
     return dbw_check_launch(BWD ? "lpips_head_kernel<bwd>" : "lpips_head_kernel<fwd>");
 }
 
+// ---- the two element-wise layers between the frozen network's convolutions (torch runs each as several kernels) ------------------------
+// bias + ReLU behind a convolution that was run WITHOUT its bias: y = max(x + b[c], 0) in one pass (torch: the convolution's bias add, then
+// clamp -- two passes over the largest tensors of the network).  x == y allowed.
+__global__ __launch_bounds__(NT) void bias_relu_kernel(const float *__restrict__ x, const float *__restrict__ b, int C, int HW, float *__restrict__ y, int vec) {
+    const long long plane = (long long)blockIdx.y;                      // n * C + c
+    const float bc = b[(int)(plane % C)];
+    const long long o = plane * HW;
+    if (vec) {
+        const int i = (blockIdx.x * NT + threadIdx.x) * 4;
+        if (i >= HW) return;
+        const v4f t = *reinterpret_cast<const v4f *>(x + o + i);
+        const v4f r = {fmaxf(t.x + bc, 0.f), fmaxf(t.y + bc, 0.f), fmaxf(t.z + bc, 0.f), fmaxf(t.w + bc, 0.f)};
+        *reinterpret_cast<v4f *>(y + o + i) = r;
+    } else {
+        const int i = blockIdx.x * NT + threadIdx.x;
+        if (i < HW) y[o + i] = fmaxf(x[o + i] + bc, 0.f);
+    }
+}
+
+// 2x2 / stride 2 max pooling (floor mode: an odd last row / column is dropped), and its backward WITHOUT stored indices: the window's
+// maximum is found again from the input -- the FIRST one in row-major window order, `>` comparisons, as torch's forward picks it (behind a
+// ReLU most windows are ties of zeros) -- and a thread per INPUT pixel writes its own gradient (zeros included: gx is fully written).
+__global__ __launch_bounds__(NT) void maxpool2_fwd_kernel(const float *__restrict__ x, int H, int W, int Ho, int Wo, float *__restrict__ y) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const int ho = i / Wo, wo = i - ho * Wo;
+    const float *p = x + (long long)blockIdx.y * H * W + (long long)(2 * ho) * W + 2 * wo;
+    float m = p[0];
+    if (p[1] > m || p[1] != p[1]) m = p[1];
+    if (p[W] > m || p[W] != p[W]) m = p[W];
+    if (p[W + 1] > m || p[W + 1] != p[W + 1]) m = p[W + 1];
+    y[(long long)blockIdx.y * Ho * Wo + i] = m;
+}
+__global__ __launch_bounds__(NT) void maxpool2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy, int H, int W, int Ho, int Wo, float *__restrict__ gx) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W) return;
+    const int h = i / W, w = i - h * W, ho = h >> 1, wo = w >> 1;
+    float g = 0.f;
+    if (ho < Ho && wo < Wo) {
+        const float *p = x + (long long)blockIdx.y * H * W + (long long)(2 * ho) * W + 2 * wo;
+        float m = p[0];
+        int arg = 0;
+        if (p[1] > m || p[1] != p[1]) { m = p[1]; arg = 1; }
+        if (p[W] > m || p[W] != p[W]) { m = p[W]; arg = 2; }
+        if (p[W + 1] > m || p[W + 1] != p[W + 1]) { m = p[W + 1]; arg = 3; }
+        if (arg == ((h & 1) << 1 | (w & 1))) g = gy[(long long)blockIdx.y * Ho * Wo + (long long)ho * Wo + wo];
+    }
+    gx[(long long)blockIdx.y * H * W + i] = g;
+}
+
 }  // namespace
+
+extern "C" int dbw_bias_relu(const float *x, const float *bias, int N, int C, int HW, float *y, dbw_stream_t stream) {
+    DBW_REQUIRE(x && bias && y, "null pointer");
+    DBW_REQUIRE(N >= 0 && C > 0 && HW > 0 && (long long)N * C < 65536, "bad sizes");
+    if (N == 0) return 0;
+    const int vec = HW % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+    const int per = vec ? NT * 4 : NT;
+    hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)((HW + per - 1) / per), (unsigned)(N * C)), dim3(NT), 0, (hipStream_t)stream, x, bias, C, HW, y, vec);
+    return dbw_check_launch("bias_relu_kernel");
+}
+
+extern "C" int dbw_maxpool2_fwd(const float *x, int planes, int H, int W, float *y, dbw_stream_t stream) {
+    DBW_REQUIRE(x && y, "null pointer");
+    DBW_REQUIRE(planes >= 0 && planes < 65536 && H >= 2 && W >= 2, "bad sizes");
+    if (planes == 0) return 0;
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((Ho * Wo + NT - 1) / NT), (unsigned)planes), dim3(NT), 0, (hipStream_t)stream, x, H, W, Ho, Wo, y);
+    return dbw_check_launch("maxpool2_fwd_kernel");
+}
+
+extern "C" int dbw_maxpool2_bwd(const float *x, const float *grad_y, int planes, int H, int W, float *grad_x, dbw_stream_t stream) {
+    DBW_REQUIRE(x && grad_y && grad_x, "null pointer");
+    DBW_REQUIRE(planes >= 0 && planes < 65536 && H >= 2 && W >= 2, "bad sizes");
+    if (planes == 0) return 0;
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((H * W + NT - 1) / NT), (unsigned)planes), dim3(NT), 0, (hipStream_t)stream, x, grad_y, H, W, Ho, Wo, grad_x);
+    return dbw_check_launch("maxpool2_bwd_kernel");
+}
 
 extern "C" int dbw_lpips_head_blocks(int N, int HW) { return blocks_of(N, HW); }
 

@@ -112,6 +112,9 @@ SIGNATURES = {
     'dbw_lpips_head_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     'dbw_debug_train_step_last_timeout': [c_p, c_p],
     'dbw_debug_train_step_counters': [c_p, c_p, c_p],
+    'dbw_bias_relu': [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    'dbw_maxpool2_fwd': [c_p, c_i, c_i, c_i, c_p, c_p],
+    'dbw_maxpool2_bwd': [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     'dbw_train_step_run': [c_p, c_p, c_p, c_p],
     'dbw_train_step_finish': [c_p, c_p, c_p],
     'dbw_train_step_losses': [c_p, c_p],

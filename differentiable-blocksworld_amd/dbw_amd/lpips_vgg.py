@@ -63,6 +63,52 @@ class _FusedHead(torch.autograd.Function):
         return gf, None, None, None
 
 
+class _BiasReLU(torch.autograd.Function):
+    """max(x + bias[c], 0) in place on the output of a convolution that was run without its bias: one pass (dbw_bias_relu) where torch
+    runs the bias add and the clamp as two; the bias is frozen (loss.py:36-37): gradient to x only."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        from . import _lib
+        N, C, h, w = x.shape
+        with torch.cuda.device(x.device):
+            _lib.call('dbw_bias_relu', x.data_ptr(), bias.data_ptr(), N, C, h * w, x.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        return torch.ops.aten.threshold_backward(g.contiguous(), y, 0), None
+
+
+class _MaxPool2(torch.autograd.Function):
+    """F.max_pool2d(x, 2, 2) without an index tensor: the backward finds each window's maximum again (dbw_maxpool2_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        x = x.contiguous()
+        N, C, h, w = x.shape
+        y = torch.empty(N, C, h // 2, w // 2, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call('dbw_maxpool2_fwd', x.data_ptr(), N * C, h, w, y.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, = ctx.saved_tensors
+        N, C, h, w = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call('dbw_maxpool2_bwd', x.data_ptr(), g.data_ptr(), N * C, h, w, gx.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        return gx
+
+
 class LPIPSVGG(nn.Module):
     def __init__(self, allow_random_init=False):
         super().__init__()
@@ -72,7 +118,8 @@ class LPIPSVGG(nn.Module):
         self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
         self.loaded = False
         self.allow_random_init = allow_random_init
-        self.fused_head = True            # CUDA tensors: the head (normalise, difference, 1x1 head, spatial mean) as one HIP pass per tap
+        self.fused_head = True            # CUDA tensors: the head (normalise, difference, 1x1 head, spatial mean) as one HIP pass per tap and
+                                          # direction, bias + ReLU and the 2x2 max-pools as one pass each (csrc/lpips_head.hip)
         self.target_cache = None          # per tap: (V, C, h, w) normalised features of the V training images (cache_targets)
         if allow_random_init:
             with torch.no_grad():
@@ -124,10 +171,15 @@ class LPIPSVGG(nn.Module):
     def features(self, x):
         x = (x - self.shift) / self.scale
         taps = []
+        fused = x.is_cuda and self.fused_head and x.dtype == torch.float32      # the layers between the convolutions as single HIP passes
         for i, _, _ in _VGG16_CONVS:
+            conv = self.convs[str(i)]
             if i in _POOL_BEFORE:
-                x = F.max_pool2d(x, 2, 2)
-            x = F.relu(self.convs[str(i)](x))
+                x = _MaxPool2.apply(x) if fused else F.max_pool2d(x, 2, 2)
+            if fused:
+                x = _BiasReLU.apply(F.conv2d(x, conv.weight, None, padding=1), conv.bias)
+            else:
+                x = F.relu(conv(x))
             if i in _TAPS:
                 taps.append(x)
         return taps

@@ -559,6 +559,14 @@ int dbw_lpips_head_fwd(const float *feat, const float *target_unit, const int64_
 int dbw_lpips_head_bwd(const float *feat, const float *target_unit, const int64_t *view_ids, const float *lin_w, int N, int V, int C, int HW,
                        const float *grad_value, float *grad_feat, dbw_stream_t stream);
 
+/* The two element-wise layers between the frozen network's convolutions, each one pass (torch: several kernels over the largest tensors):
+ * dbw_bias_relu: y = max(x + bias[c], 0) for x (N, C, HW) behind a convolution run WITHOUT its bias (y == x allowed);
+ * dbw_maxpool2_fwd / _bwd: 2x2, stride 2, floor mode over `planes` = N * C planes of (H, W) -> (H/2, W/2); the backward finds the window's
+ * maximum again from x (the first one in row-major window order, as torch's forward picks it) and fully writes grad_x (N, C, H, W). */
+int dbw_bias_relu(const float *x, const float *bias, int N, int C, int HW, float *y, dbw_stream_t stream);
+int dbw_maxpool2_fwd(const float *x, int planes, int H, int W, float *y, dbw_stream_t stream);
+int dbw_maxpool2_bwd(const float *x, const float *grad_y, int planes, int H, int W, float *grad_x, dbw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

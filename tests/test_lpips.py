@@ -194,3 +194,32 @@ def test_fused_head_on_the_device_equals_the_torch_formulation(golden_dir, cache
         assert torch.isnan(bad)
         host_ids = net(imgs_all[ids], rec, view_ids=ids.cpu().int())          # ids on the host, 32-bit: moved and widened by the module
         assert abs(float(host_ids) - v1) <= 1e-6 * v1
+
+
+@pytest.mark.gpu
+def test_bias_relu_and_maxpool_kernels_equal_torch_bit_for_bit():
+    """dbw_bias_relu / dbw_maxpool2_fwd / dbw_maxpool2_bwd (the layers between the frozen network's convolutions) against torch's own ops on
+    the device: same bits forward and backward, at odd sizes (floor mode drops the last row / column), with windows that are ties -- zeros
+    behind a ReLU: the gradient goes to the FIRST maximum of the window, as torch's forward picks it."""
+    import torch.nn.functional as F
+    from dbw_amd.lpips_vgg import _BiasReLU, _MaxPool2
+    g = torch.Generator().manual_seed(7)
+    for shape in ((2, 5, 13, 19), (3, 4, 8, 12), (1, 3, 37, 50)):
+        x = torch.randn(*shape, generator=g).cuda()
+        b = torch.randn(shape[1], generator=g).cuda()
+        x0 = x.clone().requires_grad_(True)
+        ref = F.relu(x0 + b.view(1, -1, 1, 1))
+        x1 = x.clone().requires_grad_(True)
+        got = _BiasReLU.apply(x1 * 1.0, b)                       # (in place on the product, a non-leaf like a convolution's output)
+        w = torch.randn(*shape, generator=g).cuda()
+        (ref * w).sum().backward()
+        (got * w).sum().backward()
+        assert torch.equal(ref, got) and torch.equal(x0.grad, x1.grad)
+        y0 = ref.detach().clone().requires_grad_(True)             # behind a ReLU: many all-zero windows
+        y1 = ref.detach().clone().requires_grad_(True)
+        p0, p1 = F.max_pool2d(y0, 2, 2), _MaxPool2.apply(y1)
+        wp = torch.randn(*p0.shape, generator=g).cuda()
+        (p0 * wp).sum().backward()
+        (p1 * wp).sum().backward()
+        assert torch.equal(p0, p1) and torch.equal(y0.grad, y1.grad)
+        assert (y0.grad != 0).sum() > 0 and float((ref == 0).float().mean()) > 0.2
