@@ -74,7 +74,6 @@ class CStep:
         self.backward_order = None          # None: by configuration (see _plan_for), 0 / 1 force
         self.binned_concurrent = None
         self.use_side_stream = True         # False: everything in order on the caller's stream
-        self.own_main_stream = False        # (experiment) True: the two-phase iteration's launches on a stream of the step's own
         self.own_side_stream = False        # True: the env chain on a (high-priority) torch stream of the caller instead of the plan's own
         self.serial_setup_max_views = 12    # include/dbw_hip.h: up to that many views the blocks' set-up stays on the main stream
         # how the step's streams wait for each other: polled words in device memory (include/dbw_hip.h: sync_events), or HIP events
@@ -336,16 +335,6 @@ class CStep:
         with torch.cuda.device(self.params.flat.device):
             _lib.call('dbw_train_step_wait_blocks_ready', self._cur[0], stream.cuda_stream)
 
-    def _own_main_stream(self, dev):
-        """With a network of the caller's between the two phases of the step (the perceptual term: MIOpen / rocBLAS kernels on the caller's
-        stream), the step's own launches go to a stream -- a hardware queue -- of their own, fenced against the caller's stream by events."""
-        if not self.own_main_stream:
-            return None
-        key = (dev.index, 'main')
-        if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-        return _SIDE_STREAMS[key]
-
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------
     def __call__(self, inp, global_count=None, adam=None, tiled_target=True, defer_textures=False, rng_step=None):
         """Enqueue forward + backward (+ Adam when `adam` = (step, (lr, lr_texture), (beta1, beta2), eps)) of one iteration on this rank's
@@ -389,10 +378,6 @@ class CStep:
         a.rng_step = int(self._calls if rng_step is None else rng_step) & 0xffffffffffffffff
         self._calls += 1
         cur = torch.cuda.current_stream(dev)
-        own = self._own_main_stream(dev) if 'perceptual' in m.loss_weights else None
-        if own is not None:          # (see _own_main_stream: the step's launches on a queue of their own, fenced against the caller's stream)
-            own.wait_stream(cur)
-            caller, cur = cur, own
         # the env chain and the regularisers: streams of the plan (NULL), a torch stream of this process, or the caller's own stream
         side = side_stream(dev, self.side_priority).cuda_stream if (self.use_side_stream and self.own_side_stream) else 0
         a.single_stream = int(not self.use_side_stream)
@@ -407,8 +392,6 @@ class CStep:
                 rec = torch.empty(B, 3, m.img_size[0], m.img_size[1], device=dev)       # (a fresh leaf every step: autograd owns it)
                 a.phase, a.rec_out = 1, rec.data_ptr()
                 _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
-                if own is not None:
-                    caller.wait_stream(own)
                 with torch.enable_grad():
                     leaf = rec.requires_grad_(True)
                     perceptual = m._perceptual_term(inp['imgs'], leaf, m.is_live('coarse_learning'), inp.get('view_ids'))
@@ -416,11 +399,7 @@ class CStep:
                 perceptual, g_rec = perceptual.detach(), g_rec.contiguous()
                 a.phase, a.rec_out, a.grad_rec = 2, 0, g_rec.data_ptr()
                 self._keep_rec = (rec, g_rec)
-                if own is not None:
-                    own.wait_stream(caller)
             _lib.call('dbw_train_step_run', handle, ctypes.byref(a), cur.cuda_stream, side)
-            if own is not None:
-                caller.wait_stream(own)
         self._keep = (imgs, R, T, nz, u)            # inputs stay referenced until the next call has been enqueued behind this one
         self._report_voided()
         nb = m.n_blocks
