@@ -133,3 +133,31 @@ def test_train_step_rejects_a_bad_descriptor_without_a_gpu():
     assert lib.dbw_train_step_workspace_bytes(ctypes.byref(d)) == 0 and b'dbw' not in lib.dbw_last_error()[:0]
     assert not lib.dbw_train_step_create(ctypes.byref(d), 0, 0)
     assert lib.dbw_train_step_offset(None, 0) == -1
+
+
+def test_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/dbw_hip.h compiles as C99 with warnings as errors (no C++ in it outside the extern "C" guard), and a
+    host written in C links against libdbw_hip.so and calls it -- here the two entry points that need no GPU, plus the address of every
+    function the header declares (an undefined symbol fails the link)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    _lib.load()
+    names = sorted(parse_header())
+    src = tmp_path / 'host.c'
+    src.write_text('#include <stdio.h>\n#include "dbw_hip.h"\n'
+                   'int main(void) {\n'
+                   'typedef void (*fn_t)(void);\n'
+                   '    fn_t fns[] = {\n' + ',\n'.join(f'        (fn_t){n}' for n in names) + '};\n'
+                   '    unsigned long k = 0; for (unsigned i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) k += fns[i] != 0;\n'
+                   '    printf("%d %lu %s\\n", dbw_abi_version(), k, dbw_last_error() ? "ok" : "null");\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / 'host'
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe),
+                        '-L', libdir, '-ldbw_hip', f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) == _lib.ABI_VERSION and int(out[1]) == len(names) and out[2] == 'ok'
