@@ -30,9 +30,10 @@ DBW_HD float tv_l2sq_texel(const float *r, int x, int y, int w, int h, int wrap,
 // premultiplied AND multiplied by the mask again).  Returns the pixel's sum of squared differences to `target`;
 // with two_scale = 2 * (weight / count): gf = d loss / d fg_rgb, ge = d loss / d env_rgb, gmask = d loss / d mask.
 // extra (optional): d(another loss term) / d rec of this pixel -- the perceptual term, which a network outside this path differentiates --
-// added to the MSE's before the chain rule through the composite.
+// added to the MSE's before the chain rule through the composite (has_extra: a flag next to the three values, not a nullable pointer --
+// a run-time-selected pointer to a local array keeps that array in scratch memory).
 DBW_HD float composite_mse_pixel(const float fc[3], float mask, const float ec[3], const float target[3], bool has_target, float two_scale,
-                                 float rec[3], float gf[3], float ge[3], float &gmask, const float *extra = nullptr) {
+                                 float rec[3], float gf[3], float ge[3], float &gmask, const float extra[3], bool has_extra) {
     float part = 0.f;
     gmask = 0.f;
 #pragma unroll
@@ -40,12 +41,18 @@ DBW_HD float composite_mse_pixel(const float fc[3], float mask, const float ec[3
         rec[c] = fc[c] * mask + (1.f - mask) * ec[c];
         const float d = has_target ? rec[c] - target[c] : 0.f;
         part += d * d;
-        const float gr = extra ? two_scale * d + extra[c] : two_scale * d;
+        const float gr = has_extra ? two_scale * d + extra[c] : two_scale * d;
         gf[c] = gr * mask;
         ge[c] = gr * (1.f - mask);
         gmask += gr * (fc[c] - ec[c]);
     }
     return part;
+}
+
+DBW_HD float composite_mse_pixel(const float fc[3], float mask, const float ec[3], const float target[3], bool has_target, float two_scale,
+                                 float rec[3], float gf[3], float ge[3], float &gmask) {
+    const float none[3] = {0.f, 0.f, 0.f};
+    return composite_mse_pixel(fc, mask, ec, target, has_target, two_scale, rec, gf, ge, gmask, none, false);
 }
 
 // torch.optim.Adam (no weight decay, no amsgrad; optimizer.py:6-18) for one element: step_size = lr / (1 - beta1^t),

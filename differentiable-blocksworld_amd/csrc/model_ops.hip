@@ -330,7 +330,6 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P
         load_pose(nullptr, nullptr, P.R6g, P.Tg, 0, 0.f, p);
         for (int v = tid; v < P.ngv; v += blockDim.x) pose_fwd(p, P.ground_base + (long long)v * 3, P.S_world, P.Rw, P.Tw, P.ground_verts + (long long)v * 3);
         for (int i = tid; i < P.nzero0; i += blockDim.x) P.zero0[i] = 0.f;
-        if (tid == 0 && P.void_flag) *P.void_flag = 0.f;
     }
 }
 
@@ -338,6 +337,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueArgs P
 __global__ __launch_bounds__(64) void blocks_tail_kernel(const BlocksTailArgs A) {
     const int k = blockIdx.x, lane = threadIdx.x;
     const bool alive = !A.keep || A.keep[k];
+    if (k == 0 && lane == 0 && A.void_flag) *A.void_flag = *A.void_raised;       // (train_step.hip: the run's latch of the plan's sticky word)
     if (lane == 0) {          // block_alpha_bwd_kernel
         const float a = A.alpha[k];
         float g = 0.f;

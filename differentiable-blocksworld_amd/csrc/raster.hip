@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void coarse_bin_kernel(const float4 *__restric
 }
 
 __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restrict__ cell, const int *__restrict__ rank, const int *__restrict__ hdr,
-                                                           long long total, int *__restrict__ work, unsigned *sync_flag, unsigned sync_val) {
+                                                           long long total, int tiles_x, int per_view, int2 *__restrict__ work, unsigned *sync_flag,
+                                                           unsigned sync_val) {
     if (sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sync_flag, sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
         if (small) p = ((unsigned)e * (unsigned)len) / (unsigned)E;
         else p = (unsigned)(((unsigned long long)e * (unsigned long long)len) / (unsigned long long)E);
     }
-    work[seg0 + p] = (int)L;
+    const int n = (int)(L / per_view), t = (int)(L - (long long)n * per_view), ty = t / tiles_x;
+    work[seg0 + p] = make_int2(n, (ty << 16) | (t - ty * tiles_x));
 }
 
 __global__ __launch_bounds__(256) void cell_bin_kernel(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx,
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void scene_bins_kernel(const SceneBinsArgs A) 
     const int cnt = coarse_bin_block(G.bbox, G.first_idx, G.num_faces, A.H, A.W, A.nx, A.ny, G.list, G.count, G.mask, n, bin, S);
     if (!G.cells) return;
     // (coarse_bin_block ends its last round with a barrier: S.ent is complete)
-    cell_bin_block<true>((const FaceRec *)G.recs, G.first_idx, A.B, A.H, A.W, A.nx, A.ny, nullptr, cnt, G.cell, G.pool, G.pool_cap, G.hdr, G.rank, n, bin, S);
+    cell_bin_block<true>((const FaceRec *)G.recs, G.first_idx, A.B, A.H, A.W, A.nx, A.ny, nullptr, cnt, G.cell, G.pool, G.pool_cap, G.hdr, G.rank, n, bin, S, G.dom);
 }
 
 template <int KMAX, int TW, int TH>
@@ -238,7 +240,7 @@ extern "C" size_t dbw_rasterize_workspace_bytes(int64_t F_total) {
 }
 
 // ... [coarse-bin lists][cell-list header: pool cursor, 8 x 16 class cursors][cell table (N, tiles) int2][work list (N * tiles)]
-//     [tile ranks (N * tiles)][cell-list pool]
+//     [tile ranks (N * tiles)][dominant faces (N * tiles)][cell-list pool]     (a work-list entry is an int2)
 static size_t coarse_bytes(int64_t F_total, int N, int H, int W) {
     const size_t nb = (size_t)((W + COARSE - 1) / COARSE) * ((H + COARSE - 1) / COARSE);
     return align256((size_t)(N > 0 ? N : 1) * nb * 3 * sizeof(int)) + align256((size_t)(F_total > 0 ? F_total : 1) * nb * sizeof(int));
@@ -253,7 +255,7 @@ static size_t cell_pool_entries(int64_t F_total, int N, int H, int W) {
 extern "C" size_t dbw_rasterize_workspace_bytes_binned(int64_t F_total, int N, int H, int W) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
     return dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W) + align256(CELL_HDR_INTS * sizeof(int)) +
-           align256(n * t * sizeof(int2)) + 2 * align256(n * t * sizeof(int)) + align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
+           2 * align256(n * t * sizeof(int2)) + 2 * align256(n * t * sizeof(int)) + align256(cell_pool_entries(F_total, N, H, W) * sizeof(int));
 }
 
 const FaceRec *dbw_workspace_recs(const void *workspace, long long F_total) {
@@ -293,9 +295,10 @@ int dbw_raster_workspace_layout(void *workspace, size_t workspace_bytes, long lo
         if (L.cells) {
             const size_t t = cell_tiles(H, W);
             L.cell = (int2 *)((char *)L.hdr + align256(CELL_HDR_INTS * sizeof(int)));
-            L.work = (int *)((char *)L.cell + align256((size_t)N * t * sizeof(int2)));
-            L.rank = (int *)((char *)L.work + align256((size_t)N * t * sizeof(int)));
-            L.pool = (int *)((char *)L.rank + align256((size_t)N * t * sizeof(int)));
+            L.work = (int2 *)((char *)L.cell + align256((size_t)N * t * sizeof(int2)));
+            L.rank = (int *)((char *)L.work + align256((size_t)N * t * sizeof(int2)));
+            L.dom = (int *)((char *)L.rank + align256((size_t)N * t * sizeof(int)));
+            L.pool = (int *)((char *)L.dom + align256((size_t)N * t * sizeof(int)));
             L.pool_cap = (int)cell_pool_entries(F_total, N, H, W);
         }
     }
@@ -310,6 +313,12 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
     // kernels of the training step); only `cb` is rebuilt
     cb.list = nullptr; cb.count = nullptr; cb.mask = nullptr; cb.nx = cb.ny = 0;
     cb.cell = nullptr; cb.pool = nullptr; cb.work = nullptr;
+    {       // pixel -> NDC constants (SURVEY A.1 NonSquarePixToNdc): IEEE single divisions, the same bits as the device's
+        float rx = 2.0f, ry = 2.0f;
+        if (W > H) rx = ((float)W * rx) / (float)H;
+        if (H > W) ry = ((float)H * ry) / (float)W;
+        cb.ndc[0] = rx; cb.ndc[1] = rx / 2.0f; cb.ndc[2] = ry; cb.ndc[3] = ry / 2.0f;
+    }
     if (F_total <= 0) return DBW_OK;
     dbw::RasterWorkspace L;
     int rc = dbw_raster_workspace_layout(workspace, workspace_bytes, F_total, max_faces_per_view, N, H, W, want_cells, L);
@@ -335,8 +344,8 @@ int dbw_prepare_raster(const float *face_verts, const int *first_idx, const int 
                 rc = dbw_check_launch("cell_bin_kernel");
                 if (rc) return rc;
                 const long long total = (long long)N * (long long)cell_tiles(H, W);
-                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work,
-                                   (unsigned *)nullptr, 0u);
+                hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, (W + 7) / 8,
+                                   (int)cell_tiles(H, W), L.work, (unsigned *)nullptr, 0u);
                 rc = dbw_check_launch("work_scatter_kernel");
                 if (rc) return rc;
             }
@@ -367,7 +376,8 @@ int dbw::launch_scene_bins(const SceneBinsArgs &A, hipStream_t s) {
 // the launch-order kernel alone (the training step's fused set-up fills cell / rank / hdr itself)
 int dbw::dbw_launch_work_scatter(const dbw::RasterWorkspace &L, int N, int H, int W, hipStream_t s, unsigned *sync_flag, unsigned sync_val) {
     const long long total = (long long)N * (long long)cell_tiles(H, W);
-    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, L.work, sync_flag, sync_val);
+    hipLaunchKernelGGL(work_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L.cell, L.rank, L.hdr, total, (W + 7) / 8, (int)cell_tiles(H, W),
+                       L.work, sync_flag, sync_val);
     return dbw_check_launch("work_scatter_kernel");
 }
 
@@ -425,8 +435,8 @@ extern "C" void dbw_debug_cell_layout(int64_t F_total, int N, int H, int W, unsi
     size_t o = dbw_rasterize_workspace_bytes(F_total) + coarse_bytes(F_total, N, H, W);
     out6[0] = o; o += align256(CELL_HDR_INTS * sizeof(int));
     out6[1] = o; o += align256(n * t * sizeof(int2));
-    out6[2] = o; o += align256(n * t * sizeof(int));
-    out6[3] = o; o += align256(n * t * sizeof(int));
+    out6[2] = o; o += align256(n * t * sizeof(int2));       // (work-list entries are int2 {view, tile row << 16 | tile column})
+    out6[3] = o; o += 2 * align256(n * t * sizeof(int));      // (ranks, then the dominant faces)
     out6[4] = o;
     out6[5] = cell_pool_entries(F_total, N, H, W);
 }

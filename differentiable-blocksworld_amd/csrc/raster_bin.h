@@ -13,7 +13,7 @@ namespace dbw {
 // heaviest first, and the empty tiles -- whose composite + loss epilogue is pure memory traffic -- are spread evenly between the
 // occupied ones, so that the streaming work hides behind the arithmetic instead of piling up at the end.
 //   cell_bin_block: class + rank inside (segment, class) of every tile (returning atomics on hdr[1 + segment * 16 + class])
-//   work_scatter_kernel (raster.hip): thread = tile: work[position] = view * tiles + tile
+//   work_scatter_kernel (raster.hip): thread = tile: work[position] = {view, tile row << 16 | tile column}
 constexpr int WORK_CLASSES = 10, WORK_RANK_BITS = 27;      // (rank < tiles of the pass < 2^27: checked where the workspace is laid out)
 __device__ __forceinline__ int work_class(int c) {
     return c < 0 ? 0 : c == 0 ? 9 : c >= 64 ? 0 : c >= 48 ? 1 : c >= 32 ? 2 : c >= 24 ? 3 : c >= 16 ? 4 : c >= 12 ? 5 : c >= 8 ? 6 : c >= 4 ? 7 : 8;
@@ -154,7 +154,8 @@ __device__ __forceinline__ int coarse_bin_block(const float4 *__restrict__ bbox,
 template <bool STASHED>
 __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs, const int *__restrict__ first_idx, int N, int H, int W, int nx, int ny,
                                                const int *__restrict__ lst, int cnt_all, int2 *__restrict__ cell, int *__restrict__ pool,
-                                               int pool_cap, int *__restrict__ hdr, int *__restrict__ rank, int n, int bin, BinShared &S) {
+                                               int pool_cap, int *__restrict__ hdr, int *__restrict__ rank, int n, int bin, BinShared &S,
+                                               int *__restrict__ dom = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = (bin % nx) * COARSE, y0 = (bin / nx) * COARSE;
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3, tiles = tiles_x * tiles_y;
@@ -245,6 +246,38 @@ __device__ __forceinline__ void cell_bin_block(const FaceRec *__restrict__ recs,
         if (in_img) rank[L] = r | ((key - seg16) << WORK_RANK_BITS);
     }
     __syncthreads();
+    // dom (the env scene of the training step: a hard pass of a few huge faces): the face of a cell's list that is IN FRONT OF all the
+    // others over its whole extent -- its farthest vertex nearer than every other listed face's nearest (depths are convex combinations of
+    // the vertex depths, so it wins at every pixel it covers) -- and is no half of a split quad and inside the guarded range of the
+    // shared-reciprocal divisions; -1 where there is none (or the list has more than four entries).  The ground in front of the sky dome, a
+    // sky face alone: the fg pass's folded env layer then evaluates ONLY that face for the tile (render_fused.hip: env_fold_pixel) -- decided
+    // here once per tile by one lane, next to the fill, instead of by every render wave through a chain of dependent scalar loads.
+    if (dom && wv == 1) {
+        int jb = -1, all = 0;
+        for (int ch = 0; ch < chunks; ++ch) all += __popcll(S.col[ch][lane]);
+        if (S.base == 0 && all >= 1 && all <= 4) {
+            int jbest = 0;
+            float near_b = 0.f, far_b = INFINITY, near_others = INFINITY;
+            for (int ch = 0; ch < chunks; ++ch) {
+                unsigned long long bits = S.col[ch][lane];
+                while (bits) {
+                    const int i = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1ull;
+                    const int j = S.ent[ch * 64 + i] & 0xfffff;
+                    const float *zp = (const float *)(recs + f_begin + j) + 6;          // FaceRec::z0, z1, z2
+                    const float z0 = zp[0], z1 = zp[1], z2 = zp[2];
+                    const float zn = fminf(z0, fminf(z1, z2)), zf = fmaxf(z0, fmaxf(z1, z2));
+                    if (zf < far_b) { near_others = fminf(near_others, near_b > 0.f ? near_b : INFINITY); jbest = j; near_b = zn; far_b = zf; }
+                    else near_others = fminf(near_others, zn);
+                }
+            }
+            if (far_b * 1.00001f < near_others) {
+                const FaceRec *rb = recs + f_begin + jbest;
+                if ((rb->flags & REC_FAST) && rb->nb == -1) jb = jbest;
+            }
+        }
+        if (in_img) dom[(long long)n * tiles + tile] = jb;
+    }
     if (S.base < 0) return;
     for (int ch = wv; ch < chunks; ch += 4) {
         unsigned long long bits = S.col[ch][lane];
@@ -266,7 +299,8 @@ struct RasterWorkspace {
     bool binned, cells;
     int nx, ny;
     int *count; unsigned *mask; int *list;       // coarse level
-    int *hdr; int2 *cell; int *work; int *rank; int *pool; int pool_cap;      // fine level
+    int *hdr; int2 *cell; int2 *work; int *rank; int *pool; int pool_cap;      // fine level
+    int *dom;                          // (N * tiles) dominant face of every cell or -1 (cell_bin_block; filled for the env scene of the training step only)
 };
 
 }  // namespace dbw

@@ -31,7 +31,9 @@ struct CoarseBins {
     // fine level (cell_bin_kernel, raster.hip): the ordered face list of every cell = 8x8-pixel tile.  nullptr: coarse level only
     const int2 *cell;   // (N, tiles): {first entry in `pool`, count}; count < 0: the pool was full, the tile walks its coarse bin
     const int *pool;    // view-local face indices
-    const int *work;    // (N * tiles): launch order of the tiles (work_order_kernel): position in the XCD-aware grid -> view * tiles + tile
+    const int2 *work;   // (N * tiles): launch order of the tiles (work_scatter_kernel): position in the XCD-aware grid -> {view, tile row << 16 |
+                        // tile column} -- resolved once per tile by the thread that places it, not by two integer divisions in every render wave
+    float ndc[4];       // pixel -> NDC constants of the pass, computed on the host (ndc_axis_given): range and offset of x, of y
 };
 #ifndef DBW_CELL_LISTS
 #define DBW_CELL_LISTS 1
@@ -175,16 +177,20 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     bool cell_mode = false, empty_tile = false;
     int coff = 0, ccnt = 0;
     unsigned lt = lg;
+    int ty, tx;
     if (CELLS && cb.cell) {
         // the tile this position of the grid was given (heavy tiles first, the empty ones spread between them) and its face list
-        lt = (unsigned)cb.work[lg];
+        const int2 w = cb.work[lg];
+        n = w.x; ty = (int)((unsigned)w.y >> 16); tx = w.y & 0xffff;
+        lt = (unsigned)n * per_view + (unsigned)(ty * tiles_x + tx);
         const int2 c = cb.cell[lt];
         if (c.y == 0) empty_tile = true;
         else if (c.y > 0) { cell_mode = true; coff = c.x; ccnt = c.y; }
+    } else {
+        n = (int)(lt / per_view);
+        const int t = (int)(lt - (unsigned)n * per_view);
+        ty = t / tiles_x; tx = t - ty * tiles_x;
     }
-    n = (int)(lt / per_view);
-    const int t = (int)(lt - (unsigned)n * per_view);
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // a wave always owns an 8-aligned compact footprint: lanes 0..63 -> 8x8 (TW == 8) or 16x4 (TW == 16) pixels
     xi = tx * TW + (tid % TW);
@@ -227,7 +233,7 @@ __device__ __forceinline__ bool raster_tile(const FaceRec *__restrict__ recs, co
     f2 p{0.f, 0.f};
     float txmax = 0.f, txmin = 0.f, tymax = 0.f, tymin = 0.f;
     if (nf > 0 || ccnt > 0) {
-        const NdcAxis ax = ndc_axis(W, H), ay = ndc_axis(H, W);
+        const NdcAxis ax = ndc_axis_given(W, cb.ndc[0], cb.ndc[1]), ay = ndc_axis_given(H, cb.ndc[2], cb.ndc[3]);
         p.x = pix_to_ndc_fast(W - 1 - xi, ax);
         p.y = pix_to_ndc_fast(H - 1 - yi, ay);
         txmax = pix_to_ndc_fast(W - 1 - x0, ax); txmin = pix_to_ndc_fast(W - 1 - x1, ax);

@@ -136,6 +136,15 @@ DBW_HD NdcAxis ndc_axis(int S1, int S2) {
     a.r = rcp_refined(a.s1);
     return a;
 }
+// the same axis from its host-computed range and offset (IEEE divisions: the same bits on either side; CoarseBins::ndc): a tile then pays
+// no division for them -- only the refined reciprocal of S1, which stays a device value (v_rcp_f32 seed)
+DBW_HD NdcAxis ndc_axis_given(int S1, float range, float offset) {
+    NdcAxis a;
+    a.range = range; a.offset = offset;
+    a.s1 = (float)S1;
+    a.r = rcp_refined(a.s1);
+    return a;
+}
 DBW_HD float pix_to_ndc_fast(int i, const NdcAxis &a) { return -a.offset + div_fast(a.range * (float)i + a.offset, a.s1, a.r); }
 
 // ---- per-face record -----------------------------------------------------------------------------------------------------------

@@ -46,6 +46,9 @@ extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out16, int reset)
 #ifndef DBW_NT_STORES
 #define DBW_NT_STORES 1
 #endif
+#ifndef DBW_FWD_KEXACT
+#define DBW_FWD_KEXACT 1
+#endif
 #ifndef DBW_FWD_FAST_EXP
 #define DBW_FWD_FAST_EXP 1
 #endif
@@ -209,6 +212,7 @@ struct EnvFold {
     const FaceRec *recs;            // nullptr: not folded (the epilogue reads env_img)
     const int *first_idx;
     const int2 *cell; const int *pool;                  // per-tile face lists of the env scene (cell_bin_block)
+    const int *dom;                                     // ... and the face that is in front of all others of a tile's list, or -1
     const int *clist, *ccount; int nx, ny;              // its coarse bins: what a tile whose list did not fit the pool walks
     const int *num_faces;
     const ShadeRec *srec;
@@ -216,6 +220,7 @@ struct EnvFold {
     float bg[3];
     int *p2f; float *uvj;                               // hard uv-fragments out: [tile][64], [tile][3][64]
     int persp, dbg;
+    float ndc[4];                                       // CoarseBins::ndc of the pass
 };
 
 __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, int n_, int xi, int yi, bool in_img, float (&rgb)[3]) {
@@ -223,14 +228,53 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
     const int n = __builtin_amdgcn_readfirstlane(n_);          // (the tile's view: wave-uniform, and the record loads below need to know)
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int L = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
-    const NdcAxis ax = ndc_axis(W, H), ay = ndc_axis(H, W);
+    const NdcAxis ax = ndc_axis_given(W, E.ndc[0], E.ndc[1]), ay = ndc_axis_given(H, E.ndc[2], E.ndc[3]);
     f2 p;
     p.x = pix_to_ndc_fast(W - 1 - xi, ax);
     p.y = pix_to_ndc_fast(H - 1 - yi, ay);
-    TopK<1, false> q;
-    q.init();
     const bool fastdiv = DBW_RASTER_FASTDIV && !(E.dbg & 1);
     const int fb = __builtin_amdgcn_readfirstlane(E.first_idx[n]);
+    // Most tiles of the env layer lie INSIDE one large face that is in front of everything else on their list -- the ground in front of
+    // the sky dome, a sky face alone: the binning has looked (raster_bin.h: `dom`, the listed face whose farthest vertex is nearer than
+    // every other listed face's nearest, no half of a split quad, inside the guarded range of the shared-reciprocal divisions).  Uniform
+    // fast path: ONLY that face is evaluated -- the same eval_pair, the same barycentrics, bit for bit -- and if every pixel of the tile
+    // passes its box and inside tests the tile is done: no list, no top-1 list, no evaluation of the faces behind, shading record through
+    // scalar loads, no validity masks.  Anything else -- a pixel outside the face, overlapping depth ranges, an operand outside the guarded
+    // range -- takes the general path below.
+    const int jb = __builtin_amdgcn_readfirstlane(E.dom[L]);
+    if (jb >= 0 && fastdiv && !(E.dbg & 4096)) {          // (dbw_debug_set_flags 1 << 20: the general path everywhere)
+        const FaceRec r = load_rec_nowait(E.recs + fb + jb);          // (uniform address: scalar loads)
+        float pz1 = 0.f, sd1 = 0.f;
+        f3 bc1{0.f, 0.f, 0.f};
+        bool unsafe = false;
+        const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
+        const bool keep = inbox && eval_pair<true>(r, p, 0.f, E.persp, 1, pz1, sd1, bc1, unsafe, true);
+        if (__ballot(in_img && (!keep || unsafe)) == 0ull) {
+            const ShadeRec sr = load_srec_uniform(E.srec + fb + jb);
+            const float bc[3] = {bc1.x, bc1.y, bc1.z};
+            float bo[3], u, vv;
+            convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
+            interp_uv(bo, sr.uv, u, vv);
+            Sample s;
+            footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+            fetch(E.maps, s, rgb);
+            if (in_img) {
+                const long long o = ((long long)L << 6) + lane;
+                float *bp = E.uvj + ((long long)L * 3 << 6) + lane;
+#if DBW_NT_STORES
+                __builtin_nontemporal_store(fb + jb, E.p2f + o);
+                __builtin_nontemporal_store(u, bp); __builtin_nontemporal_store(vv, bp + 64);
+                __builtin_nontemporal_store(__int_as_float(sr.j | (sr.map << 20)), bp + 128);
+#else
+                E.p2f[o] = fb + jb;
+                bp[0] = u; bp[64] = vv; bp[128] = __int_as_float(sr.j | (sr.map << 20));
+#endif
+            }
+            return;
+        }
+    }
+    TopK<1, false> q;
+    q.init();
     const int2 c_ = E.cell[L];
     const int2 c = make_int2(__builtin_amdgcn_readfirstlane(c_.x), __builtin_amdgcn_readfirstlane(c_.y));
     // the tile's own list; or, where the bin's lists did not fit the pool (count < 0), the bin's coarse list: its entries in order, those
@@ -245,62 +289,6 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
         total = __builtin_amdgcn_readfirstlane(E.ccount[n * nb + bin]);
         lst = E.clist + (long long)fb * nb + (long long)bin * __builtin_amdgcn_readfirstlane(E.num_faces[n]);
         cx = (x0 & (COARSE - 1)) >> 3; cy = (y0 & (COARSE - 1)) >> 3;
-    }
-    // Most tiles of the env layer lie INSIDE one large face that is in front of everything else on their list -- the ground in front of
-    // the sky dome, a sky face alone.  Uniform fast path: the depth ranges of the (at most four) listed faces are compared as scalars; if
-    // one face's farthest vertex is nearer than every other face's nearest (depths are convex combinations of the vertex depths, so it
-    // wins at every pixel it covers) and it is no half of a split quad, ONLY that face is evaluated -- the same eval_pair, the same
-    // barycentrics, bit for bit -- and if every pixel of the tile passes its box and inside tests the tile is done: no list walk, no top-1
-    // list, no evaluation of the faces behind, shading record through scalar loads, no validity masks.  Anything else -- a pixel outside
-    // the face, overlapping depth ranges, an operand outside the guarded range of the shared-reciprocal divisions -- takes the general path.
-    if (!walk && total >= 1 && total <= 4 && fastdiv && !(E.dbg & 4096)) {          // (dbw_debug_set_flags 1 << 20: the general path everywhere)
-        const int mine = lane < total ? lst[lane] : 0;
-        int jb = 0;
-        float near_b = 0.f, far_b = INFINITY, near_others = INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < total) {
-                const int j = __builtin_amdgcn_readlane(mine, i);
-                const float *zp = (const float *)(E.recs + fb + j) + 6;          // FaceRec::z0, z1, z2 (scalar loads)
-                const float z0 = zp[0], z1 = zp[1], z2 = zp[2];
-                const float zn = fminf(z0, fminf(z1, z2)), zf = fmaxf(z0, fmaxf(z1, z2));
-                if (zf < far_b) { near_others = fminf(near_others, near_b > 0.f ? near_b : INFINITY); jb = j; near_b = zn; far_b = zf; }
-                else near_others = fminf(near_others, zn);
-            }
-        }
-        if (far_b * 1.00001f < near_others) {
-            const FaceRec r = load_rec_nowait(E.recs + fb + jb);          // (uniform address: scalar loads)
-            if ((r.flags & REC_FAST) && r.nb == -1) {
-                float pz1 = 0.f, sd1 = 0.f;
-                f3 bc1{0.f, 0.f, 0.f};
-                bool unsafe = false;
-                const bool inbox = in_img && !(p.x < r.xlo || p.x > r.xhi || p.y < r.ylo || p.y > r.yhi);
-                const bool keep = inbox && eval_pair<true>(r, p, 0.f, E.persp, 1, pz1, sd1, bc1, unsafe, true);
-                if (__ballot(in_img && (!keep || unsafe)) == 0ull) {
-                    const ShadeRec sr = load_srec_uniform(E.srec + fb + jb);
-                    const float bc[3] = {bc1.x, bc1.y, bc1.z};
-                    float bo[3], u, vv;
-                    convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
-                    interp_uv(bo, sr.uv, u, vv);
-                    Sample s;
-                    footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
-                    fetch(E.maps, s, rgb);
-                    if (in_img) {
-                        const long long o = ((long long)L << 6) + lane;
-                        float *bp = E.uvj + ((long long)L * 3 << 6) + lane;
-#if DBW_NT_STORES
-                        __builtin_nontemporal_store(fb + jb, E.p2f + o);
-                        __builtin_nontemporal_store(u, bp); __builtin_nontemporal_store(vv, bp + 64);
-                        __builtin_nontemporal_store(__int_as_float(sr.j | (sr.map << 20)), bp + 128);
-#else
-                        E.p2f[o] = fb + jb;
-                        bp[0] = u; bp[64] = vv; bp[128] = __int_as_float(sr.j | (sr.map << 20));
-#endif
-                    }
-                    return;
-                }
-            }
-        }
     }
 #pragma unroll 1
     for (int cb0 = 0; cb0 < total; cb0 += DBW_WAVE) {
@@ -347,9 +335,11 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
 }
 
 // the pixel's blended colour -> the image, or (training) the composite + MSE partials and the two image gradients
-// (env_rgb: the env layer's colour of this pixel when the env pass is folded into this one, else nullptr: read from A.env_img)
+// (env_rgb: the env layer's colour of this pixel when the env pass is folded into this one (`fold`), else read from A.env_img; three values
+// and a flag instead of a nullable pointer: selecting between a local array and nullptr at run time kept the array in scratch memory --
+// 44 B per lane, a scratch store behind the env layer and a scratch load in the epilogue of every tile)
 __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
-                                             float *__restrict__ image, const float *env_rgb = nullptr, bool no_fragments = false) {
+                                             float *__restrict__ image, const float (&env_rgb)[3], bool fold, bool no_fragments = false) {
     const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
     const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
     if (A.target) {
@@ -360,13 +350,13 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
         if (in_img) {
             const float *tg = A.target + i3.base;
             float ec3[3];
-            if (env_rgb) { ec3[0] = env_rgb[0]; ec3[1] = env_rgb[1]; ec3[2] = env_rgb[2]; }
+            if (fold) { ec3[0] = env_rgb[0]; ec3[1] = env_rgb[1]; ec3[2] = env_rgb[2]; }
             else { const float *ev = A.env_img + i4.base; ec3[0] = ev[0]; ec3[1] = ev[i4.cstride]; ec3[2] = ev[2 * i4.cstride]; }
             const float fc3[3] = {f0, f1, f2}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
             float rec3[3], gf3[3], ge3[3], gmask, gp3[3] = {0.f, 0.f, 0.f};
             const long long plane = (long long)A.H * A.W, po = (long long)n * 3 * plane + (long long)yi * A.W + xi;
             if (A.grad_rec) { gp3[0] = A.grad_rec[po]; gp3[1] = A.grad_rec[po + plane]; gp3[2] = A.grad_rec[po + 2 * plane]; }
-            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask, A.grad_rec ? gp3 : nullptr);      // loss_math.h
+            sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask, gp3, A.grad_rec != nullptr);      // loss_math.h
             if (A.rec_out) { A.rec_out[po] = rec3[0]; A.rec_out[po + plane] = rec3[1]; A.rec_out[po + 2 * plane] = rec3[2]; }
             float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
             const long long cs = i4.cstride;
@@ -396,30 +386,30 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
 
 // a tile no face reaches (cell list of length 0): every pixel is the background; the fragment record is the count 0
 template <int KMAX>
-__device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image,
-                                                const float *env_rgb = nullptr) {
+__device__ __forceinline__ void shade_uv8_empty(const ShadeArgs &A, int K, int n, int xi, int yi, int *__restrict__ p2f, float *__restrict__ image,
+                                                const float (&env_rgb)[3], bool fold) {
     const int lane = threadIdx.x;
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
-    if (in_img) p2f[(((long long)tile * A.K) << 6) + lane] = -1;
+    if (in_img) p2f[(((long long)tile * K) << 6) + lane] = -1;
     BlendFront bl;
     blend_front_init(bl);
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, true);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, fold, true);
 }
 
 template <int KMAX>
-__device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
+__device__ __forceinline__ void shade_uv8(const ShadeArgs &A, int K, const ShadeRec *__restrict__ srec, const TopK<KMAX, true> &q, const pay4 *home, int n,
                                           int xi, int yi, int *__restrict__ p2f, float *__restrict__ bary, float *__restrict__ dists,
-                                          float *__restrict__ image, int dbg, const float *env_rgb = nullptr) {
+                                          float *__restrict__ image, int dbg, const float (&env_rgb)[3], bool fold) {
     // dbg (tools/diag ablations, dbw_debug_set_flags): 32 = no fragment stores (flags 8192), 64 = no layer loop at all (16384)
     const int lane = threadIdx.x;            // == ((yi & 7) << 3) | (xi & 7): the fragment lane of the 8x8-tile planar layout
     const bool in_img = xi < A.W && yi < A.H;
     const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
     const int tile = __builtin_amdgcn_readfirstlane((n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3));
-    const long long tb = ((long long)tile * A.K) << 6;
+    const long long tb = ((long long)tile * K) << 6;
     int *__restrict__ p2f_t = p2f + tb;
     float *__restrict__ dists_t = dists + tb;
     float *__restrict__ bary_t = bary + tb * 8;
@@ -428,7 +418,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
 #else
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) cnt += (in_img && k < A.K && q.valid(k)) ? 1 : 0;
+    for (int k = 0; k < KMAX; ++k) cnt += (in_img && k < K && q.valid(k)) ? 1 : 0;
 #endif
     if (in_img && cnt == 0) p2f_t[lane] = -1;         // an empty pixel still tells the backward its fragment count (0)
     BlendFront bl;
@@ -440,7 +430,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     UvSlot nxt = cur;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        more = more && k < A.K && __ballot(cnt > k) != 0ull;               // wave-uniform: lists are filled front to back
+        more = more && k < K && __ballot(cnt > k) != 0ull;               // wave-uniform: lists are filled front to back
         if (!more) continue;
         if (k + 1 < KMAX) nxt = uv_slot(q, home, srec, k + 1, in_img);
         const ShadeRec &sr = cur.sr;
@@ -496,12 +486,14 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, const ShadeRec *__
     }
     float px[4];
     blend_front_finish(bl, A.bg, px);
-    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb);
+    uv8_epilogue(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, fold);
 }
 
 // UV: the specialised shading of uv-fragments on 8x8 tiles (shade_uv8) with 12 B payloads; otherwise the generic form
 #define DBW_RENDER_WAVES(KMAX, UV) ((UV) ? ((KMAX) <= 4 ? 6 : (KMAX) <= 10 ? 5 : (KMAX) <= 16 ? 3 : 2) : DBW_RASTER_WAVES(KMAX))
-template <int KMAX, int TW, int TH, int GROUP, bool UV>
+// KEX: faces_per_pixel == KMAX (every shipped configuration: 4, 10, 16, 25) -- the list length is then a compile-time constant: no run-time
+// selection of the list's last entry per inserted face, no `k < K` tests in the unrolled loops
+template <int KMAX, int TW, int TH, int GROUP, bool UV, bool KEX = false>
 __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fwd_kernel(const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
                                                              const int *__restrict__ first_idx, const int *__restrict__ num_faces,
                                                              float blur, int persp, int dbg,
@@ -525,13 +517,14 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     auto env_layer = [&](int n_, int xi_, int yi_, bool in_img_) {
         if constexpr (UV) { if (fold) env_fold_pixel(E, A.H, A.W, n_, xi_, yi_, in_img_, env_rgb); }
     };
-    if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, A.K, blur, persp, 1, total_blocks, cb,
+    const int K = KEX ? KMAX : A.K;
+    if (!raster_tile<KMAX, TW, TH, GROUP, UV>(recs, bbox, first_idx, num_faces, A.H, A.W, K, blur, persp, 1, total_blocks, cb,
                                               (dbg & (3 | 128)) | ((KMAX == 1 && A.tiled != 0 && !(dbg & 8)) ? 8 : 0), n, xi, yi, q, home,
                                               UV ? &empty : nullptr, env_layer)) return;
     FPROF_T(t_k1);
     if constexpr (UV) {
-        if (empty) shade_uv8_empty<KMAX>(A, n, xi, yi, p2f, image, fold ? env_rgb : nullptr);
-        else shade_uv8<KMAX>(A, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg, fold ? env_rgb : nullptr);
+        if (empty) shade_uv8_empty<KMAX>(A, K, n, xi, yi, p2f, image, env_rgb, fold);
+        else shade_uv8<KMAX>(A, K, srec, q, home, n, xi, yi, p2f, bary, dists, image, dbg, env_rgb, fold);
     }
     else {
         if (xi >= A.W || yi >= A.H) return;
@@ -543,13 +536,13 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     FPROF_ADD(14, wall_clock64());
 }
 
-template <int KMAX, int TW, int TH, int GROUP, bool UV>
+template <int KMAX, int TW, int TH, int GROUP, bool UV, bool KEX = false>
 int launch_v(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces, float blur,
              int persp, ShadeArgs &A, const CoarseBins &cb, const ShadeRec *srec, int *p2f, float *bary, float *dists, float *image, const EnvFold &E,
              hipStream_t s) {
     const long long total = (long long)A.N * ((A.W + TW - 1) / TW) * ((A.H + TH - 1) / TH);
     DBW_REQUIRE(total < (1LL << 31) - 8, "more than 2^31 tiles in one pass");
-    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP, UV>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
+    hipLaunchKernelGGL((render_fwd_kernel<KMAX, TW, TH, GROUP, UV, KEX>), dim3(dbw_xcd_grid(total)), dim3(TW * TH), 0, s, recs, bbox, first_idx,
                        num_faces, blur, persp, g_render_dbg, total, A, cb, srec, p2f, bary, dists, image, E);
     return dbw_check_launch("render_fwd_kernel");
 }
@@ -569,7 +562,12 @@ int launch(const FaceRec *recs, const float4 *bbox, const int *first_idx, const 
 #ifndef DBW_FWD_GROUP
 #define DBW_FWD_GROUP 2
 #endif
-        if (A.tiled == 2 && (A.target || !(g_render_dbg & 4)) && A.sigma >= 0.f) return DBW_V(8, 8, DBW_FWD_GROUP, true);      // (sigma < 0, the sigmoid opacity: generic shading)
+        if (A.tiled == 2 && (A.target || !(g_render_dbg & 4)) && A.sigma >= 0.f) {      // (sigma < 0, the sigmoid opacity: generic shading)
+#if DBW_FWD_KEXACT
+            if (A.K == KMAX) return launch_v<KMAX, 8, 8, DBW_FWD_GROUP, true, true>(recs, bbox, first_idx, num_faces, blur, persp, A, cb, srec, p2f, bary, dists, image, E, s);
+#endif
+            return DBW_V(8, 8, DBW_FWD_GROUP, true);
+        }
         return DBW_V(8, 8, DBW_FWD_GROUP, false);
     }
 #undef DBW_V
@@ -637,12 +635,13 @@ static int render_fwd_impl(const float *face_verts_c, const int32_t *first_idx, 
     memset(&E, 0, sizeof(E));
     if (fold) {
         DBW_REQUIRE(mse && frag_layout == 2 && K > 1, "the env layer folds into the soft pass with the loss epilogue");
-        DBW_REQUIRE(fold->ws && fold->ws->cells && fold->ws->shade_recs && fold->first_idx && fold->num_faces && fold->maps && fold->p2f && fold->uvj, "null pointer (env fold)");
+        DBW_REQUIRE(fold->ws && fold->ws->cells && fold->ws->dom && fold->ws->shade_recs && fold->first_idx && fold->num_faces && fold->maps && fold->p2f && fold->uvj, "null pointer (env fold)");
         const dbw::RasterWorkspace &w = *fold->ws;
-        E.recs = w.recs; E.first_idx = fold->first_idx; E.cell = w.cell; E.pool = w.pool; E.clist = w.list; E.ccount = w.count; E.nx = w.nx; E.ny = w.ny;
+        E.recs = w.recs; E.first_idx = fold->first_idx; E.cell = w.cell; E.pool = w.pool; E.dom = w.dom; E.clist = w.list; E.ccount = w.count; E.nx = w.nx; E.ny = w.ny;
         E.num_faces = fold->num_faces; E.srec = (const ShadeRec *)w.shade_recs; E.maps = fold->maps;
         for (int i = 0; i < 3; ++i) E.bg[i] = fold->bg[i];
         E.p2f = fold->p2f; E.uvj = fold->uvj; E.persp = perspective_correct; E.dbg = g_render_dbg;
+        for (int i = 0; i < 4; ++i) E.ndc[i] = cb.ndc[i];
         A.lean_grads = 1;          // (the training step: its two backward kernels are the only readers of the gradient images)
     }
 #define DBW_RF(KM) launch<KM>(recs, bbox, first_idx, num_faces, blur_radius, perspective_correct, A, cb, srec, pix_to_face, bary, dists, image, E, s)

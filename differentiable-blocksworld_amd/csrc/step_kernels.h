@@ -51,7 +51,6 @@ struct PrologueArgs {
     float *ground_verts;
     // floats cleared by the launch (the accumulated pose / shape / opacity gradients)
     float *zero0; int nzero0;
-    float *void_flag;                               // the step's void flag (train_step.hip: sync_wait_kernel), cleared with them
 };
 int launch_step_prologue(const PrologueArgs &P, hipStream_t s);
 
@@ -77,6 +76,7 @@ struct SceneBinsArgs {
         const float4 *bbox; const void *recs; const int *first_idx, *num_faces;
         int *list, *count; unsigned *mask;
         int cells; int2 *cell; int *pool; int pool_cap; int *hdr; int *rank;
+        int *dom;                                   // per-tile dominant face out (raster_bin.h), or NULL
     } sc[2];
     int B, H, W, nx, ny;
     int scene0, nscenes;
@@ -111,6 +111,7 @@ struct BlocksTailArgs {
     const float *g_verts;
     float *g_sq_eps, *g_S, *g_R6, *g_T;
     const float *alpha, *g_alpha_parts, *g_alpha_full; int alpha_parts; float *g_logit;      // g_alpha_parts may be NULL (fine phase)
+    const float *void_raised; float *void_flag;     // *void_flag = *void_raised by the launch's first thread (train_step.hip: sync_wait_kernel); or NULL
 };
 int launch_blocks_tail(const BlocksTailArgs &A, hipStream_t s);
 

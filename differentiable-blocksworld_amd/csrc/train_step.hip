@@ -275,15 +275,23 @@ int step_streams(hipStream_t &r, hipStream_t &e) {
 // consumer's stream polls it in front of its own.  Kernel boundaries do the rest: the producer's kernels have released their writes before
 // the store kernel starts, and the kernel behind the poll acquires at its start like any kernel behind an event wait.
 constexpr int SYNC_FLAGS = 12, SYNC_TIMEOUT_SLOT = 15, SYNC_WORDS = 32;      // (words 16 .. 27: the counters as the first poll that gave up saw them)
+constexpr int SYNC_VOID_SLOT = 28;       // the plan's "a poll gave up" word (float 1.0), see sync_wait_kernel
 enum { F_PROLOGUE, F_SCATTER, F_FG_FWD, F_REG, F_LAYOUT, F_KERNEL_DONE, F_BLOCKS_READY, F_ENV_DONE, F_TEX };
 __global__ void sync_set_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 // (timeouts: a counter in device memory; host_timeouts: the same in mapped host memory -- the next dbw_train_step_run sees it without a
 // transfer and fails loudly: a poll that gave up let its stream run ahead of what it was waiting for)
 // A poll that gives up (`limit` ticks of the 100 MHz wall clock: 1 s; the order of the enqueues rules a deadlock out, so this only ever
-// fires when the process's queues were descheduled that long) VOIDS the step instead of letting it update anything: it raises `void_flag`
-// (device float, what the step's Adam launch -- and, summed over the ranks, every rank's -- reads: != 0 -> the update is skipped, the arena
-// still cleared), counts itself in device memory, and leaves a nonzero word in mapped host memory (a plain system-scope store: no PCIe
+// fires when the process's queues were descheduled that long) VOIDS the step instead of letting it update anything: it raises the plan's
+// `void_raised` word, counts itself in device memory, and leaves a nonzero word in mapped host memory (a plain system-scope store: no PCIe
 // atomics needed) that the next dbw_train_step_run sees without a transfer: from then on the plan orders its streams through events.
+// `void_raised` is STICKY: nothing on the device ever clears it -- a clear at the head of a run, ordered on the main stream, is exactly
+// what a main stream that was stalled for a second behind the caller's earlier work would execute AFTER its side streams' polls had
+// given up, wiping the flag in front of an Adam launch that then applies gradients of stale inputs.  Every run latches the word into the
+// step's `void_flag` behind its join (void_latch: the tail kernel's first thread) -- the float the run's Adam launch, and summed over
+// the ranks every rank's, reads: != 0 -> no parameter, no moment moves, the arena is still cleared -- so every run enqueued between the
+// poll that gave up and the host noticing is voided too; the host clears the word once it has synchronised the device (the head of the
+// next dbw_train_step_run) and the plan goes on through events.
+__global__ void void_latch_kernel(const float *void_raised, float *void_flag) { *void_flag = *void_raised; }
 __global__ void sync_wait_kernel(const unsigned *flag, unsigned v, unsigned *timeouts, unsigned *host_timeouts, float *void_flag, unsigned long long limit) {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
     // (a poll only gives up after it has itself been RUNNING for a good part of the limit -- `spins`, about a microsecond each: wall-clock
@@ -456,6 +464,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         // its streams through events -- the form that cannot give up -- and the caller simply goes on: one optimisation step was lost.
         HIP_OK(hipDeviceSynchronize());
         *(volatile unsigned *)p->host_timeouts = 0u;
+        HIP_OK(hipMemset(p->sync_words + SYNC_VOID_SLOT, 0, sizeof(unsigned)));       // (the sticky word: cleared by nobody but the host, here)
         p->d.sync_events = 1;
         p->voided_runs += 1;
         p->arena_clean = false;          // (whatever the voided run left in the arena: this run opens with a fill)
@@ -489,14 +498,16 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         return dbw_check_launch("sync_set_kernel");
     };
     char *ws = p->ws;
-    float *void_flag = (float *)(ws + L.losses) + 7;          // raised by a poll that gave up; cleared by the head of every run; read by Adam
+    float *void_flag = (float *)(ws + L.losses) + 7;          // this run's copy of void_raised, latched behind the join; read by Adam
+    float *void_raised = (float *)(p->sync_words + SYNC_VOID_SLOT);      // raised by a poll that gave up; sticky until the host has seen it
     const int force_timeout = p->force_timeout;
     p->force_timeout = 0;
     auto await = [&](hipStream_t st, int idx, hipEvent_t ev) -> int {
         if (!flags) { HIP_OK(hipStreamWaitEvent(st, ev, 0)); return DBW_OK; }
-        const bool forced = force_timeout && idx == F_ENV_DONE;       // (tests: a value that never comes, a 0.05 s limit)
+        const bool forced = force_timeout == 1 && idx == F_ENV_DONE;       // (tests: a value that never comes, a 0.05 s limit)
+        const bool hasty = force_timeout == 2 && idx == F_PROLOGUE;        // (tests: the real value, a 0.02 s limit -- in front of a stalled main stream)
         hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(p->sync_words + idx), p->sync_val[idx] + (forced ? 0x10000000u : 0u),
-                           p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, void_flag, forced ? 5000000ull : SYNC_LIMIT_TICKS);
+                           p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, void_raised, forced ? 5000000ull : hasty ? 2000000ull : SYNC_LIMIT_TICKS);
         return dbw_check_launch("sync_wait_kernel");
     };
 #define FP(off) ((float *)(ws + (off)))
@@ -518,7 +529,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
     // Adam itself without clearing it) by a fill
     if (head && !p->arena_clean && !(in->arena_is_clean && p->runs > 0)) HIP_OK(hipMemsetAsync(ws + L.arena_begin, 0, L.arena_end - L.arena_begin, M));
     p->arena_clean = false;
-    if (head && !(d.fuse & 1)) HIP_OK(hipMemsetAsync(void_flag, 0, sizeof(float), M));       // (the fused prologue clears it itself)
 
     // ---- texture sets: sky, blocks, ground (dbw.py:273-293,306,331-334) ----
     dbw_texture_set sets[3];
@@ -565,7 +575,6 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         P.noise_scale = noise_on ? d.opacity_noise : 0.f; P.thresh = thresh; P.nb = nb;
         P.alpha = FP(L.alpha); P.alpha_full = FP(L.alpha_full); P.keep = IP(L.keep);
         P.seed = d.seed; P.rng_step = in->rng_step;
-        P.void_flag = void_flag;
         P.sq_eps = d.sq_eps; P.S = d.S; P.R6 = d.R6; P.T = d.T; P.trig = d.trig; P.nv = nv;
         P.ratio = d.ratio_block_scene; P.scale_min = d.scale_min; P.S_world = d.S_world; P.Rw = d.R_world; P.Tw = d.T_world;
         P.blk_verts = FP(L.blk_verts);
@@ -681,6 +690,7 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
             e.hdr = we.hdr; e.nhdr = CELL_HDR_INTS;
             e.srec = we.shade_recs; e.face_uvs = d.env_face_uvs; e.face_map = d.env_face_map; e.map_desc = d.env_map_desc; e.map_alpha = nullptr;
             Bn.sc[0].cells = 1; Bn.sc[0].cell = we.cell; Bn.sc[0].pool = we.pool; Bn.sc[0].pool_cap = we.pool_cap; Bn.sc[0].hdr = we.hdr; Bn.sc[0].rank = we.rank;
+            Bn.sc[0].dom = we.dom;       // ... and the dominant face of every tile (env_fold_pixel's fast path)
         }
         if (setup_aside) {
             RC(await(E, F_PROLOGUE, p->ev_prologue));
@@ -867,11 +877,14 @@ extern "C" int dbw_train_step_run(dbw_step_plan *p, const dbw_step_inputs *in, d
         A.scale_min = d.scale_min; A.S_world = d.S_world; A.Rw = d.R_world; A.g_verts = FP(L.g_blk_verts);
         A.g_sq_eps = d.g_sq_eps; A.g_S = d.g_S; A.g_R6 = d.g_R6; A.g_T = d.g_T;
         A.alpha = FP(L.alpha); A.g_alpha_parts = coarse ? FP(L.g_fa) : nullptr; A.alpha_parts = 64; A.g_alpha_full = FP(L.g_alpha_full); A.g_logit = d.g_alpha_logit;
+        A.void_raised = void_raised; A.void_flag = void_flag;          // (the run's latch: behind the join, in front of Adam)
         RC(launch_blocks_tail(A, M));
     } else {
         RC(dbw_sq_blocks_bwd(d.sq_eps, d.S, d.R6, d.T, d.trig, IP(L.keep), 0, nb, nv, d.ratio_block_scene, d.scale_min, d.S_world, d.R_world, FP(L.g_blk_verts),
                              d.g_sq_eps, d.g_S, d.g_R6, d.g_T, M));
         RC(dbw_block_alpha_bwd(FP(L.alpha), IP(L.keep), coarse ? FP(L.g_fa) : nullptr, 64, FP(L.g_alpha_full), nb, d.g_alpha_logit, M));
+        hipLaunchKernelGGL(void_latch_kernel, dim3(1), dim3(1), 0, M, (const float *)void_raised, void_flag);
+        RC(dbw_check_launch("void_latch_kernel"));
     }
 
     // ---- M: Adam on both learning-rate groups, which also clears the zero arena for the next run ----
@@ -911,7 +924,7 @@ extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t s
     DBW_REQUIRE(p, "null pointer");
     if (!p->cur_flags) { HIP_OK(hipStreamWaitEvent((hipStream_t)stream, p->ev_blocks_ready, 0)); return DBW_OK; }
     hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned *)(p->sync_words + F_BLOCKS_READY), p->sync_val[F_BLOCKS_READY],
-                       p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, (float *)(p->ws + p->L.losses) + 7, SYNC_LIMIT_TICKS);
+                       p->sync_words + SYNC_TIMEOUT_SLOT, p->host_timeouts_dev, (float *)(p->sync_words + SYNC_VOID_SLOT), SYNC_LIMIT_TICKS);
     return dbw_check_launch("sync_wait_kernel");
 }
 
@@ -919,6 +932,13 @@ extern "C" int dbw_train_step_wait_blocks_ready(dbw_step_plan *p, dbw_stream_t s
 extern "C" int dbw_debug_train_step_force_timeout(dbw_step_plan *p) {
     if (!p) return DBW_ERR_INVALID;
     p->force_timeout = 1;
+    return DBW_OK;
+}
+// (tests: the side streams' polls for the prologue of the NEXT run give up after 0.02 s -- with their real value: behind a main stream that
+// the caller has stalled for longer than that, the side streams then do run ahead of the prologue)
+extern "C" int dbw_debug_train_step_hasty_prologue_wait(dbw_step_plan *p) {
+    if (!p) return DBW_ERR_INVALID;
+    p->force_timeout = 2;
     return DBW_OK;
 }
 

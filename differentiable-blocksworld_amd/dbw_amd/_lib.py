@@ -121,6 +121,7 @@ SIGNATURES = {
     'dbw_train_step_wait_blocks_ready': [c_p, c_p],
     'dbw_train_step_sync_timeouts': [c_p],
     'dbw_debug_train_step_force_timeout': [c_p],
+    'dbw_debug_train_step_hasty_prologue_wait': [c_p],
     'dbw_train_step_profile': [c_p, c_i],
     'dbw_train_step_kernel_times': [c_p, c_p],
 }

@@ -519,15 +519,23 @@ int64_t dbw_train_step_offset(const dbw_step_plan *plan, int which);
 int dbw_train_step_wait_blocks_ready(dbw_step_plan *plan, dbw_stream_t stream);
 /* Number of cross-stream waits of this plan that gave up (sync_events == 0; never in a healthy process) -- synchronises the device; < 0 on error */
 int dbw_train_step_sync_timeouts(dbw_step_plan *plan);
-/* Runs of this plan that voided themselves because one of their waits gave up (host-side, no synchronisation: a run counts once the NEXT
- * run -- or this call -- has seen its word in mapped host memory).  > 0: the plan runs on events (as if created with sync_events = 1). */
+/* Times this plan had a wait give up and voided the runs in flight (host-side, no synchronisation: counted once the NEXT run -- or this
+ * call -- has seen the word in mapped host memory; the runs enqueued between the poll giving up and that moment are all voided and count as
+ * one).  > 0: the plan runs on events (as if created with sync_events = 1). */
 int dbw_train_step_voided_runs(const dbw_step_plan *plan);
-/* Byte offset inside the workspace of the step's void flag: one float, != 0 behind a run whose wait gave up, cleared by the head of the
- * next run.  A data-parallel caller sums it over the ranks next to the gradients and hands it to dbw_adam_step_groups as skip_flag (the
- * plan's own Adam launches -- dbw_train_step_run with_adam, dbw_train_step_finish -- read it themselves), so that all ranks skip together. */
+/* Byte offset inside the workspace of the step's void flag: one float that every run WRITES behind the join of its streams (in front of its
+ * Adam launch): != 0 when a wait of this plan has given up and the host has not handled it yet -- the plan's "a poll gave up" word is
+ * sticky on the device (no launch clears it: a clear ordered on a stalled main stream would run after the polls that raised it), the head
+ * of the dbw_train_step_run that sees the word in mapped host memory synchronises the device and clears it; every run enqueued in between
+ * is voided.  A data-parallel caller sums the float over the ranks next to the gradients and hands it to dbw_adam_step_groups as skip_flag
+ * (the plan's own Adam launches -- dbw_train_step_run with_adam, dbw_train_step_finish -- read it themselves), so that all ranks skip
+ * together; the sum may be taken in place, the next run overwrites it. */
 int64_t dbw_train_step_void_flag_offset(const dbw_step_plan *plan);
 /* tests: the join of the plan's NEXT run polls for a value that never comes and gives up after 0.05 s */
 int dbw_debug_train_step_force_timeout(dbw_step_plan *plan);
+/* tests: the side streams' polls for the prologue of the plan's NEXT run give up after 0.02 s (with their real value: they only do give up
+ * behind a main stream that is stalled for longer than that -- the case a void flag cleared at the head of the run used to lose) */
+int dbw_debug_train_step_hasty_prologue_wait(dbw_step_plan *plan);
 /* diagnostics: out3 = {which of the plan's cross-stream counters the FIRST poll that gave up was waiting on (0 prologue, 1 tile order, 2 fg
  * forward, 3 regularisers, 4 bin layout, 5 fg backward kernel, 6 blocks' textures, 7 env chain, 8 texture preparation; -1: no poll gave up),
  * the value it wanted, the value it last saw}.  Synchronises the device. */

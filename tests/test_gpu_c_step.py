@@ -449,6 +449,54 @@ def test_c_step_voids_a_step_whose_wait_gave_up_and_goes_on_through_events():
     assert_same_trajectory(step.params.flat, ref.params.flat)
 
 
+def test_c_step_side_polls_that_give_up_in_front_of_a_stalled_main_stream_void_the_step():
+    """The descheduling case the void flag exists for: the caller's stream is stalled (here: 0.25 s of spinning enqueued in front of the
+    step) while the plan's side streams -- which wait for the step's prologue through polled words -- give up (limit forced down to 0.02 s,
+    their real value) and run ahead on stale inputs.  When the main stream finally runs, nothing it executes may wipe the flag those polls
+    raised (a clear at the head of the run, ordered on the main stream, did exactly that): the step's Adam launch moves no parameter and
+    no moment, the next run notices, goes on through events, and equals the reference from there."""
+    import warnings
+    inp = _inputs(2, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def mk(events):
+        model = _model(0)
+        model._noise_override, model._overlap_u_override = noise, u
+        step = ShardedTrainStep(model, lr=5e-3, lr_texture=5e-2, seed=99)
+        step.cstep.sync_events = events
+        return step
+    ref = mk(True)
+    ref(inp)
+    ref(inp)                               # reference: two applied steps on events
+    step = mk(False)
+    step(inp)                              # (a plan's first run goes through events; the polls start with the second)
+    torch.cuda.synchronize()
+    assert step.cstep.sync_timeouts() == 0 and step.cstep.voided_runs() == 0
+    # how many spin cycles are 0.25 s on this GPU
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+    cycles = int(20_000_000 * 250.0 / max(e0.elapsed_time(e1), 1e-3))
+    before = (step.params.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone())
+    _lib.call('dbw_debug_train_step_hasty_prologue_wait', step.cstep._cur[0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        torch.cuda._sleep(cycles)          # the main stream is busy for 0.25 s; the side streams are not
+        step(inp)                          # voided: the side streams' polls for the prologue give up after 0.02 s
+        torch.cuda.synchronize()
+        assert step.cstep.sync_timeouts() >= 1 and step.cstep.voided_runs() == 1
+        assert step.cstep.last_timeout()[0] == 'prologue'
+        for a, b in zip(before, (step.params.flat, step.exp_avg, step.exp_avg_sq)):
+            assert torch.equal(a, b)       # nothing moved, although the main stream ran its whole chain AFTER the polls had given up
+        step.n_steps -= 1                  # (test only: line the Adam step count up with the reference's two applied steps)
+        out = step(inp)                    # goes on: through events from here
+        torch.cuda.synchronize()
+    assert any('gave up' in str(x.message) for x in w)
+    assert step.cstep.voided_runs() == 1
+    assert all(torch.isfinite(v).all() for v in out.values())
+    assert_same_trajectory(step.params.flat, ref.params.flat)
+
+
 def test_arena_cleaned_by_the_caller_counts_for_the_plan_it_cleaned_only():
     """A caller that runs Adam itself (data parallel, whole-buffer flow) clears the CURRENT plan's zero arena; a run of ANOTHER plan --
     the next phase -- must still open with its own fill: the mark is per plan."""

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One gpurun session of round 5 (everything lands under gpurun_out/r05/<tag>): usage: tools/gpu_call.sh <tag> <stage>...
+# One gpurun session of round 6 (everything lands under gpurun_out/r06/<tag>): usage: tools/gpu_call.sh <tag> <stage>...
 # stages: cstep_tests | tests '<pytest args>' | all_tests | times [epoch] | trace <views> <epoch> | ablate '<epoch flags...>' | profiles | bench
-O=gpurun_out/r05/$1; shift; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/r06/$1; shift; mkdir -p $O; export TMPDIR=/tmp
 while [ $# -gt 0 ]; do
   case $1 in
     cstep_tests) timeout 1500 python -m pytest tests/test_gpu_c_step.py -x -q > $O/cstep_tests.log 2>&1; tail -15 $O/cstep_tests.log;;
@@ -15,7 +15,7 @@ while [ $# -gt 0 ]; do
       python tools/rocprof_csv_summary.py $csv $O/kernel_stats_B${v}_epoch$e.txt "14 training steps, $v views of 400x300, 10 blocks, faces_per_pixel 10, 256^2 textures, epoch $e (tools/diag/trace_cfg.py; rocprofv3 --kernel-trace)" > /dev/null
       rm -rf $O/t; cat $O/step_sequence_B${v}_epoch$e.txt;;
     ablate) timeout 900 python tools/ablate.py $2 > $O/ablate.log 2>&1; cat $O/ablate.log; shift;;
-    profiles)   # the evidence kept under profiles/ (copied from gpurun_out/r05/<tag>/ by hand): kernel stats + step sequences of the three phases,
+    profiles)   # the evidence kept under profiles/ (copied from gpurun_out/r06/<tag>/ by hand): kernel stats + step sequences of the three phases,
                 # every kernel alone (--no-overlap), batch 4, PMC counters with the byte-counter calibration, the bench line
       for e in 0 800 1600; do
         timeout 900 rocprofv3 --kernel-trace -d $O/t -o p --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --epoch $e > $O/trace_$e.log 2>&1
