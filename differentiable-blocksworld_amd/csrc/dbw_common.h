@@ -249,10 +249,13 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_<0x111, 0xf, 0xf>(t);           // row_shr:1
     v += dpp_<0x112, 0xf, 0xf>(t);           // row_shr:2
     v += dpp_<0x113, 0xf, 0xf>(t);           // row_shr:3   -> every lane: itself + the 3 lanes below it in its row
-    v += dpp_<0x114, 0xf, 0xe>(v);           // row_shr:4
-    v += dpp_<0x118, 0xf, 0xc>(v);           // row_shr:8   -> lane 15 of every row: the row's sum
-    v += dpp_<0x142, 0xa, 0xf>(v);           // row_bcast:15
-    v += dpp_<0x143, 0xc, 0xf>(v);           // row_bcast:31 -> lane 63: the wave's sum
+    // (all lanes take part in every step: the row / bank masks of the textbook form only keep lanes that nobody reads from adding what
+    // they do not need -- lane 15 of a row, lane 31, lane 63 get the same operands either way -- and a masked DPP operand cannot be folded
+    // into the add: v_mov 0, v_mov_dpp, v_add per step instead of one v_add_f32_dpp)
+    v += dpp_<0x114, 0xf, 0xf>(v);           // row_shr:4
+    v += dpp_<0x118, 0xf, 0xf>(v);           // row_shr:8   -> lane 15 of every row: the row's sum
+    v += dpp_<0x142, 0xf, 0xf>(v);           // row_bcast:15 -> lane 31: rows 0 + 1, lane 63: rows 2 + 3
+    v += dpp_<0x143, 0xf, 0xf>(v);           // row_bcast:31 -> lane 63: the wave's sum
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 

@@ -255,9 +255,9 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
             float bo[3], u, vv;
             convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
             interp_uv(bo, sr.uv, u, vv);
-            Sample s;
-            footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
-            fetch(E.maps, s, rgb);
+            SampleFwd s;
+            footprint_fwd(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+            fetch_fwd(E.maps, s, rgb);
             if (in_img) {
                 const long long o = ((long long)L << 6) + lane;
                 float *bp = E.uvj + ((long long)L * 3 << 6) + lane;
@@ -309,10 +309,10 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
     float bo[3], u, vv;
     convert_bary(sr.cd, sr.w2, sr.w3, bc, bo);
     interp_uv(bo, sr.uv, u, vv);
-    Sample s;
-    footprint_desc(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+    SampleFwd s;
+    footprint_fwd(u, vv, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
     float col[3];
-    fetch(E.maps, s, col);
+    fetch_fwd(E.maps, s, col);
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = valid ? col[k] : E.bg[k];
     if (in_img) {
@@ -338,9 +338,17 @@ __device__ __forceinline__ void env_fold_pixel(const EnvFold &E, int H, int W, i
 // (env_rgb: the env layer's colour of this pixel when the env pass is folded into this one (`fold`), else read from A.env_img; three values
 // and a flag instead of a nullable pointer: selecting between a local array and nullptr at run time kept the array in scratch memory --
 // 44 B per lane, a scratch store behind the env layer and a scratch load in the epilogue of every tile)
-__device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
-                                             float *__restrict__ image, const float (&env_rgb)[3], bool fold, bool no_fragments = false) {
-    const ImgAddr i4 = img_addr(A, n, yi, xi, 4), i3 = img_addr(A, n, yi, xi, 3);
+template <bool TILED>
+__device__ __forceinline__ void uv8_epilogue_t(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
+                                               float *__restrict__ image, const float (&env_rgb)[3], bool fold, bool no_fragments) {
+    // image-shaped buffers of this pixel: in the 8x8-tile planar layout (TILED: the training step) every plane of the tile is a wave-uniform
+    // base + the lane -- scalar address arithmetic, one store instruction per plane with the plane as its immediate offset; otherwise
+    // (N, C, H, W)
+    const long long plane = (long long)A.H * A.W, pix = (long long)yi * A.W + xi;
+    const long long cs = TILED ? 64 : plane;
+    const long long o4 = TILED ? (long long)tile * 256 : (long long)n * 4 * plane, o3 = TILED ? (long long)tile * 192 : (long long)n * 3 * plane;      // (wave-uniform)
+    const unsigned ul = (unsigned)lane;
+    const long long ol = TILED ? (long long)ul : pix;
     const float f0 = px[0], f1 = px[1], f2 = px[2], m = px[3];
     if (A.target) {
         // decoupled composite + MSE on registers (dbw.py:223,366-367): rec = fg_rgb * mask + (1 - mask) * env_rgb (the fg colour is
@@ -348,18 +356,17 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
         // d loss / d fg and d loss / d env straight to the two backward passes and never stores its image
         float sq = 0.f;
         if (in_img) {
-            const float *tg = A.target + i3.base;
+            const float *tg = A.target + o3 + ol;
             float ec3[3];
             if (fold) { ec3[0] = env_rgb[0]; ec3[1] = env_rgb[1]; ec3[2] = env_rgb[2]; }
-            else { const float *ev = A.env_img + i4.base; ec3[0] = ev[0]; ec3[1] = ev[i4.cstride]; ec3[2] = ev[2 * i4.cstride]; }
-            const float fc3[3] = {f0, f1, f2}, t3[3] = {tg[0], tg[i3.cstride], tg[2 * i3.cstride]};
+            else { const float *ev = A.env_img + o4 + ol; ec3[0] = ev[0]; ec3[1] = ev[cs]; ec3[2] = ev[2 * cs]; }
+            const float fc3[3] = {f0, f1, f2}, t3[3] = {tg[0], tg[cs], tg[2 * cs]};
             float rec3[3], gf3[3], ge3[3], gmask, gp3[3] = {0.f, 0.f, 0.f};
-            const long long plane = (long long)A.H * A.W, po = (long long)n * 3 * plane + (long long)yi * A.W + xi;
-            if (A.grad_rec) { gp3[0] = A.grad_rec[po]; gp3[1] = A.grad_rec[po + plane]; gp3[2] = A.grad_rec[po + 2 * plane]; }
+            // rec_out / grad_rec (the perceptual term's two phases): always (N, 3, H, W)
+            if (A.grad_rec) { const long long po = (long long)n * 3 * plane + pix; gp3[0] = A.grad_rec[po]; gp3[1] = A.grad_rec[po + plane]; gp3[2] = A.grad_rec[po + 2 * plane]; }
             sq = composite_mse_pixel(fc3, m, ec3, t3, true, 2.f * A.mse_scale, rec3, gf3, ge3, gmask, gp3, A.grad_rec != nullptr);      // loss_math.h
-            if (A.rec_out) { A.rec_out[po] = rec3[0]; A.rec_out[po + plane] = rec3[1]; A.rec_out[po + 2 * plane] = rec3[2]; }
-            float *gf = A.g_fg + i4.base, *ge = A.g_env + i4.base;
-            const long long cs = i4.cstride;
+            if (A.rec_out) { const long long po = (long long)n * 3 * plane + pix; A.rec_out[po] = rec3[0]; A.rec_out[po + plane] = rec3[1]; A.rec_out[po + 2 * plane] = rec3[2]; }
+            float *gf = A.g_fg + o4 + ol, *ge = A.g_env + o4 + ol;
 #if DBW_NT_STORES
             if (!(A.lean_grads && no_fragments)) {
                 __builtin_nontemporal_store(gf3[0], gf); __builtin_nontemporal_store(gf3[1], gf + cs); __builtin_nontemporal_store(gf3[2], gf + 2 * cs);
@@ -376,12 +383,17 @@ __device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, 
         const float tot = wave_sum_dpp(sq);
         if (lane == 0) A.loss_part[tile] = tot;
     } else if (in_img) {
-        float *out = image + i4.base;
+        float *out = image + o4 + ol;
         out[0] = f0;
-        out[i4.cstride] = f1;
-        out[2 * i4.cstride] = f2;
-        out[3 * i4.cstride] = m;
+        out[cs] = f1;
+        out[2 * cs] = f2;
+        out[3 * cs] = m;
     }
+}
+__device__ __forceinline__ void uv8_epilogue(const ShadeArgs &A, int n, int xi, int yi, bool in_img, int tile, int lane, const float (&px)[4],
+                                             float *__restrict__ image, const float (&env_rgb)[3], bool fold, bool no_fragments = false) {
+    if (A.img_tiled) uv8_epilogue_t<true>(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, fold, no_fragments);
+    else uv8_epilogue_t<false>(A, n, xi, yi, in_img, tile, lane, px, image, env_rgb, fold, no_fragments);
 }
 
 // a tile no face reaches (cell list of length 0): every pixel is the background; the fragment record is the count 0
@@ -431,7 +443,7 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, int K, const Shade
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         more = more && k < K && __ballot(cnt > k) != 0ull;               // wave-uniform: lists are filled front to back
-        if (!more) continue;
+        if (!more) break;          // (break, not continue: nothing of the pipeline's state flows back into the skipped iterations)
         if (k + 1 < KMAX) nxt = uv_slot(q, home, srec, k + 1, in_img);
         const ShadeRec &sr = cur.sr;
         const float bc[3] = {cur.v.y, cur.v.z, cur.v.w};
@@ -451,10 +463,10 @@ __device__ __forceinline__ void shade_uv8(const ShadeArgs &A, int K, const Shade
         else e = expf(-(d > 0.f ? d : 0.f) / A.sigma);
 #endif
         const float a = cur.valid ? e * sr.fa : 0.f;
-        Sample s;
-        footprint_desc(u, v, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
+        SampleFwd s;
+        footprint_fwd(u, v, sr.off, sr.hw >> 16, sr.hw & 0xffff, sr.pads >> 16, sr.pads & 0xffff, sr.sh, s);
         float c[3];
-        fetch(A.maps, s, c);
+        fetch_fwd(A.maps, s, c);
         if (!(a != 0.f)) c[0] = c[1] = c[2] = 0.f;
         const float T = bl.T;                  // transmittance in front of this layer
         blend_front_step(bl, a, c);

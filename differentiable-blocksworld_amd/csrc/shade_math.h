@@ -103,6 +103,36 @@ DBW_HD void fetch(const float *maps, const Sample &s, float c[3]) {
         c[ch] = maps[s.a00 + ch] * s.w00 + maps[s.a01 + ch] * s.w01 + maps[s.a10 + ch] * s.w10 + maps[s.a11 + ch] * s.w11;
 }
 
+// The same footprint for consumers that only SAMPLE (the fused forward: no gradient to (u, v) here, the backward rebuilds its own): no
+// border-gradient bookkeeping, the border clamp as max / min (same value for every input, NaN included: !(ix > 0) -> 0), and the four
+// texels as 32-bit BYTE offsets from `maps` -- a wave-uniform base plus a 32-bit per-lane offset is one load instruction with no 64-bit
+// address arithmetic in front of it (contract of the uv-fragment passes, include/dbw_hip.h: the maps buffer is smaller than 2^30 floats).
+struct SampleFwd { unsigned b00, b01, b10, b11; float w00, w01, w10, w11; };
+DBW_HD void footprint_fwd(float u, float v, int off, int h, int w, int pl, int pr, int sh, SampleFwd &s) {
+    const int wp = w + pl + pr;
+    float ix = ((u * 2.f - 1.f) + 1.f) / 2.f * (float)(wp - 1);
+    float iy = ((v * 2.f - 1.f) + 1.f) / 2.f * (float)(h - 1);
+    ix = __builtin_fminf(__builtin_fmaxf(ix, 0.f), (float)(wp - 1));
+    iy = __builtin_fminf(__builtin_fmaxf(iy, 0.f), (float)(h - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const int x1 = x0 + 1 < wp - 1 ? x0 + 1 : wp - 1, y1 = y0 + 1 < h - 1 ? y0 + 1 : h - 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    int c0 = wrap_col(x0 - pl, w), c1 = wrap_col(x1 - pl, w);
+    const int r0 = (h - 1 - y0) >> sh, r1 = (h - 1 - y1) >> sh, ws = w >> sh;
+    c0 >>= sh; c1 >>= sh;
+    s.b00 = ((unsigned)off + (unsigned)(r0 * ws + c0) * 3u) * 4u; s.b01 = ((unsigned)off + (unsigned)(r0 * ws + c1) * 3u) * 4u;
+    s.b10 = ((unsigned)off + (unsigned)(r1 * ws + c0) * 3u) * 4u; s.b11 = ((unsigned)off + (unsigned)(r1 * ws + c1) * 3u) * 4u;
+    s.w00 = wx0 * wy0; s.w01 = wx1 * wy0; s.w10 = wx0 * wy1; s.w11 = wx1 * wy1;
+}
+DBW_HD void fetch_fwd(const float *maps, const SampleFwd &s, float c[3]) {
+    DBW_FMA_SCOPE
+    const char *m = (const char *)maps;
+    const float *t00 = (const float *)(m + s.b00), *t01 = (const float *)(m + s.b01), *t10 = (const float *)(m + s.b10), *t11 = (const float *)(m + s.b11);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) c[ch] = t00[ch] * s.w00 + t01[ch] * s.w01 + t10[ch] * s.w10 + t11[ch] * s.w11;
+}
+
 
 // d (sum_ch gc[ch] * colour[ch]) / d (u, v) of the bilinear sample (grid_sampler_2d_backward's gradient to the grid, times the
 // align_corners scale; zero where the coordinate was clamped at the border)
