@@ -630,7 +630,7 @@ def main():
                          'limiter': 'instruction issue and latency, not HBM: see `counters` (share of the SIMD time the VALU is busy, lane '
                                     f'utilisation, HBM traffic per launch; profiles/{PMC_FILE}) and DESIGN.md section 4; frac is the '
                                     'share of the HBM roofline the ALGORITHMIC bytes reach, traffic_frac the share the measured bytes reach'},
-            'phases': phases, 'allreduce_ms': allreduce_ms, 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms, 'ms_per_step_flat_allreduce': flat_ms, 'allreduce_bytes': allreduce_bytes,
+            'phases': phases, 'allreduce_ms': allreduce_ms, 'allreduce_path': getattr(step, 'allreduce_path', None), 'other_scaling': other_scaling, 'ms_per_step_overlap_allreduce_off': overlap_off_ms, 'ms_per_step_flat_allreduce': flat_ms, 'allreduce_bytes': allreduce_bytes,
             'final_loss': total_loss,
             # polls between the step's streams that gave up (dbw_train_step_sync_timeouts): anything but 0 voids the run
             'sync_timeouts': step.cstep.sync_timeouts() if step.cstep is not None and step.cstep._cur is not None else None,

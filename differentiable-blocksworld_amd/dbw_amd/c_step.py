@@ -95,7 +95,9 @@ class CStep:
         r = m.renderer
         # (the perceptual term: a network of the caller's evaluated between two phases of the step -- needs the env layer inside the fg pass)
         perceptual_ok = 'perceptual' not in w or (m.perceptual_fn is not None and (self.fuse & 18) == 18)
+        # (clip_inside = False, the sigmoid opacity, travels as a negative sigma that dbw_train_step_create refuses: the autograd path has it)
         ok = (m.decouple_rendering and m.sync_free and 'rgb' in w and perceptual_ok and r.detach_bary and r.faces_per_pixel > 1
+              and r.clip_inside and getattr(m.renderer_fine, 'clip_inside', True)
               and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11) and m.n_blocks <= 64
               and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS and ops.HARD_UV_FRAGMENTS
               and ops.COARSE_BINS and ops.TEXTURE_BINS)

@@ -32,6 +32,12 @@ _TAPS = {2: 0, 7: 1, 14: 2, 21: 3, 28: 4}      # relu1_2, relu2_2, relu3_3, relu
 _CHANNELS = [64, 128, 256, 512, 512]
 
 
+def _f32_nchw(t):
+    """Whether the HIP passes below may be handed this tensor's data_ptr(): they index float32 in (N, C, h, w) order -- a half-precision
+    output of a convolution under torch.autocast, or a channels_last one, must go through torch's own ops instead."""
+    return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
+
 class _FusedHead(torch.autograd.Function):
     """One tap's head on the device in one pass each way (csrc/lpips_head.hip, include/dbw_hip.h: dbw_lpips_head_*): per-image values (N,)
     from the reconstruction's tap f (N,C,h,w), the targets' unit-normalised tap (rows `ids` of it when given) and the 1x1 head's weights."""
@@ -137,6 +143,8 @@ class LPIPSVGG(nn.Module):
             for k, lin in enumerate(self.lins):
                 lin.weight.copy_(lin_state[f'lin{k}.model.1.weight'])
         self.loaded = True
+        self.target_cache = None          # (features of the previous weights)
+        self._cache_key = None
         return self
 
     @staticmethod
@@ -157,16 +165,26 @@ class LPIPSVGG(nn.Module):
         """imgs_all (V,3,H,W) in [0, 1]: the training images, in the order the `view_ids` of forward() index them.  Valid as long as the
         images and the (frozen) weights stay what they are; `cache_targets(None)` drops the cache."""
         if imgs_all is None:
-            self.target_cache = None
+            self.target_cache, self._cache_key = None, None
             return self
         if not (self.loaded or self.allow_random_init):
             raise RuntimeError('LPIPSVGG has no weights: bring torchvision vgg16 features + lpips linear heads (load_weights)')
-        parts = [[] for _ in _CHANNELS]
-        for a in range(0, imgs_all.shape[0], chunk):
-            for k, f in enumerate(self.features(imgs_all[a:a + chunk] * 2 - 1)):
-                parts[k].append(self._unit(f))
-        self.target_cache = [torch.cat(p) for p in parts] if imgs_all.shape[0] else None
+        # (each tap's (V, C, h, w) buffer is allocated once and filled chunk by chunk: a list of parts + torch.cat holds the cache twice at its peak)
+        V, cache = imgs_all.shape[0], None
+        for a in range(0, V, chunk):
+            feats = self.features(imgs_all[a:a + chunk] * 2 - 1)
+            if cache is None:
+                cache = [torch.empty((V,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in feats]
+            for k, f in enumerate(feats):
+                cache[k][a:a + f.shape[0]] = self._unit(f)
+        self.target_cache = cache
+        # whose features these are: forward(view_ids=...) refuses a cache built on other images (a second Trainer on other views)
+        self._cache_key = (imgs_all.data_ptr(), tuple(imgs_all.shape), imgs_all._version) if V else None
         return self
+
+    def cache_matches(self, imgs_all):
+        """Whether the cache was built from exactly this tensor (address, shape, version counter)."""
+        return self.target_cache is not None and getattr(self, '_cache_key', None) == (imgs_all.data_ptr(), tuple(imgs_all.shape), imgs_all._version)
 
     def features(self, x):
         x = (x - self.shift) / self.scale
@@ -175,9 +193,14 @@ class LPIPSVGG(nn.Module):
         for i, _, _ in _VGG16_CONVS:
             conv = self.convs[str(i)]
             if i in _POOL_BEFORE:
-                x = _MaxPool2.apply(x) if fused else F.max_pool2d(x, 2, 2)
-            if fused:
-                x = _BiasReLU.apply(F.conv2d(x, conv.weight, None, padding=1), conv.bias)
+                x = _MaxPool2.apply(x) if (fused and _f32_nchw(x)) else F.max_pool2d(x, 2, 2)
+            # (decided on the tensor each kernel is actually handed: under torch.autocast the convolution returns half precision whatever
+            # its input was, and an in-place float32 pass over that buffer would write twice its size)
+            y = F.conv2d(x, conv.weight, None, padding=1) if fused else None
+            if y is not None and _f32_nchw(y) and conv.bias.dtype == torch.float32:
+                x = _BiasReLU.apply(y, conv.bias)
+            elif y is not None:
+                x = F.relu(y + conv.bias.to(y.dtype).view(1, -1, 1, 1))
             else:
                 x = F.relu(conv(x))
             if i in _TAPS:
@@ -198,7 +221,9 @@ class LPIPSVGG(nn.Module):
         if not cached:
             na_all = [self._unit(fa) for fa in self.features(imgs * 2 - 1)]          # normalize=True
         fb_all = self.features(rec * 2 - 1)
-        if rec.is_cuda and self.fused_head and not any(t.requires_grad for t in (na_all if not cached else [])):
+        heads_ok = all(fb.is_cuda and fb.dtype == torch.float32 for fb in fb_all) and \
+            all(t.dtype == torch.float32 for t in (self.target_cache if cached else na_all))
+        if rec.is_cuda and self.fused_head and heads_ok and not any(t.requires_grad for t in (na_all if not cached else [])):
             # the head of every tap in one pass each way on the device (csrc/lpips_head.hip); the targets' rows are read in place
             ids = view_ids if cached else None
             per = sum(_FusedHead.apply(fb, (self.target_cache[k] if cached else na_all[k]).contiguous(), ids, lin.weight.detach().reshape(-1).contiguous())

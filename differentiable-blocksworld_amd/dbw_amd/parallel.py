@@ -87,7 +87,9 @@ class ShardedTrainStep:
             overlap_allreduce = dist.is_initialized() and dist.get_backend(process_group) == 'nccl' and self.world_size > 1
         self.overlap_allreduce = bool(overlap_allreduce) and dist.is_initialized() and self._early_range is not None
         self._early_work, self._early_done = None, False
-        self._coalesce = True
+        self._coalesce, self._coalesce_verified, self._coalesce_error = True, False, None
+        self._coalesce_backends = ('nccl',)        # (tests add 'gloo' to run the trial logic on CPU tensors)
+        self.allreduce_path = None
         self.defer_textures = True        # data parallel through the C step: sum the prepared maps' gradient, not the textures' (_c_iteration)
         if dist.is_initialized() or seed is not None:
             # identical noise / overlap samples on every rank: same seed for the default generator everywhere
@@ -119,7 +121,11 @@ class ShardedTrainStep:
 
     def __call__(self, inp, labels=None, global_count=None):
         """One optimisation step on this rank's shard of views (possibly EMPTY: the rank then only contributes its share of the
-        view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors)."""
+        view-independent regularisers and still takes part in the all-reduce); returns the (local) loss dict (device tensors).
+        `n_steps` -- Adam's bias-correction count, the counter of the step's random numbers, part of a checkpoint -- advances with every
+        CALL: a step the C plan voided (a cross-stream wait gave up, c_step.py: RuntimeWarning; never in a healthy process) moved no
+        parameter and no moment but still counts, on every rank alike -- the host learns of it a run later and cannot know how many runs
+        it had enqueued in between, and a bias correction that is one step ahead is harmless where replicas that disagree are not."""
         self.model._global_count = self._global_count(inp['imgs'], global_count)
         dirty = None
         if self.cstep is not None and self.model.training and inp['imgs'].shape[0] > 0 and self._fused_adam() and self.cstep.supported():
@@ -216,21 +222,47 @@ class ShardedTrainStep:
         return per_view > 0 and self.model._global_count / per_view >= self.world_size
 
     def _allreduce_all(self, tensors):
-        """Sum all-reduce of several small buffers: one coalesced collective where the backend has it (RCCL: one launch), else one each."""
-        if self._coalesce and dist.get_backend(self.pg) == 'nccl' and all(t.is_cuda for t in tensors) and hasattr(dist, '_coalescing_manager'):
-            # (torch's coalescing context is not public API: if this build of torch refuses it, one collective per tensor from then on --
-            # decided before any collective of the call is issued, so every rank decides the same)
-            try:
-                cm = dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False)
-            except (TypeError, RuntimeError):
-                self._coalesce = False
+        """Sum all-reduce of several small buffers: one coalesced collective where the backend has it (RCCL: one launch), else one each.
+        torch's coalescing context is NOT public API, so its first use is a trial: the buffers (0.15 MB at config 2) are copied first, and
+        whatever goes wrong -- building the context, a collective inside it, the launch at its exit -- puts the copies back and reduces
+        them one by one; the ranks then agree through one PUBLIC all-reduce of a flag that the trial held everywhere, and if it did not
+        on any rank, all of them drop the coalesced form for the rest of the run.  Only a trial that every rank passed switches the
+        copies off.  `allreduce_path` says which form the last call took ('coalesced' / 'per-tensor'; bench.py prints it)."""
+        usable = (self._coalesce and dist.get_backend(self.pg) in self._coalesce_backends and all(t.is_cuda or 'gloo' in self._coalesce_backends for t in tensors)
+                  and hasattr(dist, '_coalescing_manager'))
+        if not usable:
+            for t in tensors:
+                self._allreduce(t)
+            self.allreduce_path = 'per-tensor'
+            return
+        trial = not self._coalesce_verified
+        backup = [t.clone() for t in tensors] if trial else None
+        ok = True
+        try:
+            with dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False):
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        except Exception as e:          # noqa: BLE001  (private API: anything may come out of it)
+            if not trial:
+                raise                   # (it has worked on every rank before: this is a failure of the collective itself, not of the API)
+            ok, self._coalesce_error = False, repr(e)
+        if trial:
+            flag = torch.tensor([1.0 if ok else 0.0], device=tensors[0].device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            if float(flag.item()) == 1.0:
+                self._coalesce_verified = True
             else:
-                with cm:
-                    for t in tensors:
-                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+                self._coalesce = False
+                if ok:
+                    # this rank's trial went through but another's did not: what it summed is not what the others will sum now
+                    pass
+                for t, c in zip(tensors, backup):
+                    t.copy_(c)
+                for t in tensors:
+                    self._allreduce(t)
+                self.allreduce_path = 'per-tensor'
                 return
-        for t in tensors:
-            self._allreduce(t)
+        self.allreduce_path = 'coalesced'
 
     def _fused_adam(self):
         return self.adam_fn is ops.adam_step_ and self.params.flat.is_cuda

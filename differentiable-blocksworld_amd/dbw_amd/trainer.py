@@ -126,6 +126,12 @@ class Trainer:
         scheduler / model step (trainer.py:127,163-169)."""
         V = self.local['imgs'].shape[0]
         order = torch.randperm(V, generator=self._perm_gen) if shuffle else torch.arange(V)
+        if self.view_ids:
+            # the criterion is shared by whoever holds the model: if its cache is not (or no longer) the one of THESE views -- new weights,
+            # another Trainer on other views -- the ids would index foreign features; built again (a forward pass over the views, once)
+            fn = self.model.perceptual_fn
+            if not (hasattr(fn, 'cache_matches') and fn.cache_matches(self.local['imgs'])):
+                fn.cache_targets(self.local['imgs'])
         last = None
         t_start, n_img = time.time(), 0
         # Uneven shards (49 views over 8 ranks: 7,6,...,6; batch 4 -> two steps everywhere, the second of sizes 3,2,...,2): all ranks

@@ -281,6 +281,63 @@ def test_c_step_at_a_config_4_like_geometry_equals_the_native_step():
         _compare(got, ref, ref[0].params.names)
 
 
+@pytest.mark.parametrize('epoch', [0, 800])
+def test_c_step_at_config_5_geometry_equals_the_native_step(epoch):
+    """BASELINE config 5 at FULL size -- 1080 x 1920, 50 blocks (4 000 faces: sixteen chunks of faces per view in the set-up kernel), faces_per_pixel
+    16, 512^2 textures (texture bins at epoch 800; int32 texel offsets of 52 maps), 2 of the 25 views a GPU holds -- through `dbw_train_step_run`,
+    the entry point bench.py's `configs.c5` leg measures, INCLUDING the plan's first run (the one that starts behind the driver's clearing of
+    the freshly allocated workspace and goes through events; it met a real voided step in round 5): loss values, the whole flat gradient and
+    the parameters after two Adam steps against the launch-by-launch native step.  (The oracle at this scene is held by
+    test_gpu_configs.py: one full view of indices / depths / distances bit-exact, and -- at a size the CPU finishes -- the C step at 50
+    blocks, 25 faces per pixel against OracleDBW.)"""
+    H, W, nb = 1080, 1920, 50
+    inp = _inputs(2, H, W)
+    noise = torch.randn(nb, generator=torch.Generator().manual_seed(3)).to(DEV)
+    u = torch.rand(nb, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    mk = lambda: _model(epoch, nb=nb, ts=512, fpp=16, H=H, W=W, kill=False)
+    got = _run(mk(), inp, 2, noise, u, use_c_step=True)          # (first: its plan's first run is then the first thing to touch new memory)
+    assert got[0].cstep is not None and got[0].cstep.fuse == 127 and got[0].cstep.sync_timeouts() == 0 and got[0].cstep.voided_runs() == 0
+    torch.cuda.empty_cache()
+    ref = _run(mk(), inp, 2, noise, u, use_c_step=False)
+    assert ref[0].cstep is None and ref[0].native is not None
+    _compare(got, ref, ref[0].params.names)
+    del got, ref
+    torch.cuda.empty_cache()
+
+
+def test_sharded_step_with_the_sigmoid_opacity_takes_the_autograd_path():
+    """`clip_inside=False` (renderer.py:41,257-258) is implemented by the generic kernels of the autograd path only: a ShardedTrainStep
+    on such a model must say so (neither the C step nor the launch-by-launch native step claims it) and run the iteration through
+    autograd -- not hand a negative sigma to dbw_train_step_create and raise."""
+    inp = _inputs(2, 48, 64)
+    noise = torch.zeros(4, device=DEV)
+    u = torch.rand(4, 1000, 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def mk():
+        torch.manual_seed(227391)
+        cfg = _cfg()
+        cfg['model']['renderer']['clip_inside'] = False
+        model = dbw_amd.create_model(cfg, (48, 64)).to(DEV).train()
+        model.set_cur_epoch(0)
+        model.sync_free = True
+        model._noise_override, model._overlap_u_override = noise, u
+        return model
+    model = mk()
+    assert not model.renderer.clip_inside
+    step = ShardedTrainStep(model, lr=0.0, lr_texture=0.0, seed=99)
+    assert step.cstep is None or not step.cstep.supported()
+    assert step.native is None or not step.native.supported()
+    out = step(inp)
+    torch.cuda.synchronize()
+    ref_model = mk()
+    ref = ref_model(inp, None)
+    ref['total'].backward()
+    assert abs(float(out['total']) - float(ref['total'])) <= 1e-6 * abs(float(ref['total']))
+    for n, off, k in step.params.names:
+        g = getattr(ref_model, n).grad.reshape(-1)
+        assert float((step.params.grad[off:off + k] - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-12, n
+
+
 def test_c_step_one_stream_equals_side_streams_and_every_launch_is_there():
     """dbw_step_inputs.single_stream: everything in order on the caller's stream (what a per-kernel profile wants) gives the same step as
     the three-stream schedule."""

@@ -59,7 +59,7 @@ def _run_nccl_single(rank, port, out):
         res.append(step.params.flat.detach().cpu().clone())
     # (the deferred flow went through ONE coalesced RCCL call for the map gradients + the small gradients + the void flag: torch's
     # coalescing context was accepted, not replaced by the per-tensor fallback)
-    out[1] = bool(step._coalesce) and dist.get_backend() == 'nccl'
+    out[1] = bool(step._coalesce and step._coalesce_verified and step.allreduce_path == 'coalesced') and dist.get_backend() == 'nccl'
     dist.destroy_process_group()
     out[0] = max(float((res[0] - res[1]).abs().max()), float((res[0] - res[2]).abs().max()))
 

@@ -165,3 +165,43 @@ def test_perceptual_term_is_weighted_by_the_rank_share_of_the_global_batch():
     m.world_size, m._global_count = 2, float(5 * 3 * 8 * 8)          # this rank holds 3 of the 5 views of the step
     assert torch.allclose(m._perceptual_term(imgs, rec, True), single * 3 / 5)
     assert torch.allclose(m._perceptual_term(imgs, rec, False), single * 0.1 * 3 / 5)
+
+
+def _coalesce_worker(rank, world, port, out, fails):
+    """_allreduce_all with torch's private coalescing context replaced by one that runs the collectives of its block and then (fails)
+    raises at its exit -- the worst case for the caller: the buffers ARE summed when the error surfaces."""
+    import contextlib
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    @contextlib.contextmanager
+    def fake_manager(group=None, device=None, async_ops=False):
+        yield
+        if fails:
+            raise RuntimeError('coalescing is not what it used to be')
+    dist._coalescing_manager = fake_manager
+    step = ShardedTrainStep(ToyModel(), adam_fn=torch_adam)
+    step._coalesce_backends = ('nccl', 'gloo')
+    res = []
+    for call in range(2):
+        a, b = torch.full((5,), float(rank + 1 + call)), torch.full((3,), 10.0 * (rank + 1))
+        step._allreduce_all([a, b])
+        res.append((a.clone(), b.clone(), step.allreduce_path, step._coalesce, step._coalesce_verified))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fails', [True, False])
+def test_coalesced_allreduce_survives_a_private_api_that_raises_inside_its_block(fails):
+    """The first coalesced all-reduce is a trial: if torch's private coalescing context raises -- here at its exit, AFTER the collectives
+    of the block ran -- the buffers are put back, reduced one by one, every rank learns of it through a public all-reduce of a flag and
+    drops the coalesced form for good; the sums are the plain sums either way (nothing is reduced twice), on every rank alike."""
+    world, port = 2, 29500 + (os.getpid() * 7 + int(fails)) % 1000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_coalesce_worker, args=(world, port, out, fails), nprocs=world, join=True)
+    for rank in range(world):
+        for call, (a, b, path, coalesce, verified) in enumerate(out[rank]):
+            assert torch.equal(a, torch.full((5,), float(1 + call) + float(2 + call))) and torch.equal(b, torch.full((3,), 30.0))
+            assert path == ('per-tensor' if fails else 'coalesced')
+            assert coalesce == (not fails) and verified == (not fails)
