@@ -48,5 +48,20 @@ def build(force=False, verbose=False, extra_flags=()):
     return OUT
 
 
+def build_device_checks(force=False):
+    """tests/_build/libdbw_device_checks.so from tests/device_checks.hip: the DEVICE build of the shared host+device headers as a
+    checker-side library (same flags as the product), for the GPU tests that hold that arithmetic to the reference's golden vectors."""
+    src = os.path.join(HERE, '..', 'tests', 'device_checks.hip')
+    out_dir = os.path.join(HERE, '..', 'tests', '_build')
+    out = os.path.join(out_dir, 'libdbw_device_checks.so')
+    deps = [src] + [os.path.join(CSRC, f) for f in ('dbw_common.h', 'raster_math.h', 'model_math.h', 'rng_math.h')]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):
+        return out
+    os.makedirs(out_dir, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    subprocess.check_call([hipcc] + FLAGS + ['-shared', src, '-o', out])
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True, extra_flags=[a for a in sys.argv[1:] if a.startswith('-D')]))

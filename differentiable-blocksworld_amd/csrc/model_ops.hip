@@ -485,49 +485,3 @@ extern "C" int dbw_overlap_loss(const float *u, int npts, const float *sq_eps, c
                        g_sq_eps, g_S, g_R6, g_T, g_alpha);
     return dbw_check_launch("overlap_finish_kernel");
 }
-
-
-// ---- test hook: the model-side arithmetic of this file, evaluated ON THE DEVICE (device powf / logf / expf) on caller-supplied
-// operands, so that the GPU tests can hold it to the golden vectors of the reference's own parametric_sq / implicit_sq / safe_pow /
-// signed_pow (tests/golden/*.npz) directly instead of through the host build of model_math.h --------------------------------------------
-namespace {
-__global__ void model_math_kernel(int what, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c, int n,
-                                  float ratio, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (what == 0) {
-        // parametric_sq_point: a = (cos eta, sin eta, cos omega, sin omega) x n, b = (e1, e2) -> out (n, 9) = loc, d loc / d e1, d loc / d e2
-        float loc[3], d1[3], d2[3];
-        parametric_sq_point(a[i * 4], a[i * 4 + 1], a[i * 4 + 2], a[i * 4 + 3], b[0], b[1], ratio, loc, d1, d2);
-        for (int k = 0; k < 3; ++k) { out[i * 9 + k] = loc[k]; out[i * 9 + 3 + k] = d1[k]; out[i * 9 + 6 + k] = d2[k]; }
-    } else if (what == 1) {
-        // implicit superquadric distance as overlap_kernel applies it: a = points (n, 3) in the block frame, b = (e1, e2) x n,
-        // c = d loss / d sdf (n) -> out (n, 6) = sdf, d / d e1, d / d e2, d / d point (clamped coordinates carry no gradient)
-        float pc[3];
-        bool inr[3];
-        for (int k = 0; k < 3; ++k) { const float v = a[i * 3 + k]; inr[k] = v >= -5.f && v <= 5.f; pc[k] = v < -5.f ? -5.f : (v > 5.f ? 5.f : v); }
-        ImplicitSq im;
-        const float sdf = implicit_sq_sdf2(pc, b[i * 2], b[i * 2 + 1], im);
-        float ge1, ge2, gpc[3];
-        implicit_sq_sdf2_bwd(pc, b[i * 2], b[i * 2 + 1], im, c[i], ge1, ge2, gpc);
-        out[i * 6] = sdf; out[i * 6 + 1] = ge1; out[i * 6 + 2] = ge2;
-        for (int k = 0; k < 3; ++k) out[i * 6 + 3 + k] = inr[k] ? gpc[k] : 0.f;
-    } else if (what == 2) {
-        // safe_pow: a = t (n), b[0] = exponent -> out (n, 2) = value, d / d t
-        float dt, de;
-        out[i * 2] = safe_pow_f(a[i], b[0], dt, de);
-        out[i * 2 + 1] = dt;
-    } else {
-        // signed_pow: a = t (n), b[0] = exponent -> out (n)
-        float dde;
-        out[i] = spow(a[i], b[0], dde);
-    }
-}
-}  // namespace
-
-extern "C" int dbw_debug_model_math(int what, const float *a, const float *b, const float *c, int n, float ratio, float *out, dbw_stream_t stream) {
-    DBW_REQUIRE(what >= 0 && what <= 3 && a && b && out && n >= 0 && (what != 1 || c), "bad argument");
-    if (n == 0) return DBW_OK;
-    hipLaunchKernelGGL(model_math_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, what, a, b, c, n, ratio, out);
-    return dbw_check_launch("model_math_kernel");
-}

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void raster_bwd_kernel(
     }
 }
 
-int g_raster_dbg = 0;
+thread_local int g_raster_dbg = 0;      // (dbw_debug_set_flags: per host thread)
 
 template <int KMAX, int TW, int TH>
 int launch_fwd_t(const FaceRec *recs, const float4 *bbox, const int *first_idx, const int *num_faces,
@@ -426,9 +426,10 @@ extern "C" int dbw_rasterize_bwd(const float *face_verts, const int32_t *pix_to_
     return dbw_check_launch("raster_bwd_kernel");
 }
 
-extern "C" void dbw_debug_set_raster_flags(int flags) { g_raster_dbg = flags; }
+void dbw_set_raster_dbg(int flags) { g_raster_dbg = flags; }
 
-// tools/diag only: byte offsets, inside a binned workspace, of {cell-list header, cell table, work list, tile ranks, pool} and the
+#ifdef DBW_DIAG
+// tools/diag only (builds with -DDBW_DIAG, tools/variants.sh): byte offsets, inside a binned workspace, of {cell-list header, cell table, work list, tile ranks, pool} and the
 // pool capacity in entries -- lets a script read the per-tile face counts of a pass and try launch orders of its own
 extern "C" void dbw_debug_cell_layout(int64_t F_total, int N, int H, int W, unsigned long long *out6) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = cell_tiles(H, W);
@@ -440,18 +441,4 @@ extern "C" void dbw_debug_cell_layout(int64_t F_total, int N, int H, int W, unsi
     out6[4] = o;
     out6[5] = cell_pool_entries(F_total, N, H, W);
 }
-
-// Test hook: div_fast (shared-reciprocal division of the rasteriser, raster_math.h) against the IEEE quotient on the real v_rcp_f32,
-// for caller-supplied operands; *mismatches (device, zeroed by the caller) counts the lanes whose bits differ (NaN == NaN).
-__global__ void divcheck_kernel(const float *__restrict__ n, const float *__restrict__ d, long long count, unsigned long long *__restrict__ bad) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float q = div_fast(n[i], d[i], rcp_refined(d[i])), e = n[i] / d[i];
-    if (__float_as_uint(q) != __float_as_uint(e) && !(q != q && e != e)) atomicAdd(bad, 1ull);
-}
-extern "C" int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream) {
-    DBW_REQUIRE(n && d && mismatches && count >= 0, "bad argument");
-    if (count == 0) return DBW_OK;
-    hipLaunchKernelGGL(divcheck_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d, (long long)count, mismatches);
-    return dbw_check_launch("divcheck_kernel");
-}
+#endif

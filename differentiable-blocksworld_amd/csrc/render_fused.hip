@@ -65,10 +65,12 @@ extern "C" void dbw_debug_read_fwd_profile_raw(unsigned long long *out, int nblo
     }
 }
 #endif
-int g_render_variant = 0;
-int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
+thread_local int g_render_variant = 0;
+thread_local int g_render_dbg = 0;       // bit 0: plain IEEE divisions in the rasteriser, bit 1: no tile culling, bit 2: generic shading, bit 3: hard passes
                             // compute their (unused) distances too (dbw_debug_set_flags >> 8)
-extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }
+#ifdef DBW_DIAG
+extern "C" void dbw_debug_set_render_variant(int v) { g_render_variant = v; }      // (tile shapes of the hard pass: tools/ builds only)
+#endif
 void dbw_set_render_dbg(int v) { g_render_dbg = v; }
 
 namespace {

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
 }
 
 
-int g_dbg_flags = 0;
+thread_local int g_dbg_flags = 0;      // (per host thread, like the error text: dbw_debug_set_flags)
 #ifdef DBW_PROFILE_BWD
 extern "C" void dbw_debug_read_profile(unsigned long long *out8, int reset) {
     static unsigned long long *host = nullptr;
@@ -1508,34 +1508,12 @@ extern "C" int dbw_bin_layout(const int32_t *asked, int64_t n, double total_reco
     return dbw_check_launch("bin_layout_kernel");
 }
 
-// test hook: lane_merge on caller-supplied keys / values (tests/test_gpu_parity.py)
-template <int STEPS>
-__global__ __launch_bounds__(64) void lane_merge_test_kernel(const int *__restrict__ keys, const int *__restrict__ active,
-                                                             const float *__restrict__ values, int *__restrict__ active_out,
-                                                             float *__restrict__ values_out) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    bool on = active[i] != 0;
-    float v[3] = {values[i * 3], values[i * 3 + 1], values[i * 3 + 2]};
-    lane_merge<3, STEPS>(keys[i], on, v);
-    active_out[i] = on ? 1 : 0;
-    values_out[i * 3] = v[0]; values_out[i * 3 + 1] = v[1]; values_out[i * 3 + 2] = v[2];
-}
-extern "C" int dbw_debug_lane_merge(const int32_t *keys, const int32_t *active, const float *values, int waves, int steps,
-                                    int32_t *active_out, float *values_out, dbw_stream_t stream) {
-    DBW_REQUIRE(keys && active && values && active_out && values_out, "null pointer");
-    DBW_REQUIRE(waves >= 0 && steps >= 1 && steps <= 4, "bad size / steps must be 1..4");
-    if (waves == 0) return DBW_OK;
-    hipStream_t s = (hipStream_t)stream;
-#define DBW_LM(S) hipLaunchKernelGGL(lane_merge_test_kernel<S>, dim3(waves), dim3(64), 0, s, keys, active, values, active_out, values_out)
-    if (steps == 1) DBW_LM(1); else if (steps == 2) DBW_LM(2); else if (steps == 3) DBW_LM(3); else DBW_LM(4);
-#undef DBW_LM
-    return dbw_check_launch("lane_merge_test_kernel");
-}
-
-// Ablation hook for profiling scripts (tools/): not part of the rendering contract.
-extern "C" void dbw_debug_set_raster_flags(int flags);
+// Ablation hook for profiling scripts (tools/) and for the parity tests, which run the product kernels' alternative code paths against the
+// oracle too: not part of the rendering contract.  The switches belong to the CALLING HOST THREAD (thread_local, read when a launch is
+// enqueued): two threads with different settings do not see each other's.
+void dbw_set_raster_dbg(int flags);
 void dbw_set_render_dbg(int v);
 // bits 0-7: shading/blend ablations (ShadeArgs::dbg) and rasteriser ablations (16, 128); bit 8: plain IEEE divisions in the
 // rasteriser, bit 9: no tile culling in the binning (the parity tests run these variants against the oracle too)
 extern "C" void dbw_debug_set_flags(int flags) { g_dbg_flags = (flags & 0xff) | (flags & ~0xffff);   // bits 16+: backward experiments (ShadeArgs::dbg)
-    dbw_debug_set_raster_flags(flags); dbw_set_render_dbg(flags >> 8); }
+    dbw_set_raster_dbg(flags); dbw_set_render_dbg(flags >> 8); }

@@ -101,9 +101,6 @@ SIGNATURES = {
     'dbw_block_alpha_bwd': [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     'dbw_sqrt_mean': [c_p, c_i, c_f, c_f, c_p, c_p, c_p],
     'dbw_adam_step': [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i, c_p],
-    'dbw_debug_divcheck': [c_p, c_p, c_i64, c_p, c_p],
-    'dbw_debug_model_math': [c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],
-    'dbw_debug_lane_merge': [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     'dbw_texture_prep_fwd_sets': [c_p, c_i, c_p],
     'dbw_texture_prep_bwd_sets': [c_p, c_i, c_p],
     'dbw_tv_l2sq_sets': [c_p, c_i, c_p, c_p],

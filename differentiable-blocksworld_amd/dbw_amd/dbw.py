@@ -521,6 +521,8 @@ class DifferentiableBlocksWorld(nn.Module):
         renderer = self.renderer_fine if fine else self.renderer
         if not renderer.detach_bary or renderer.faces_per_pixel < 2 or renderer.cam_name != 'perspective' or renderer.cameras.K is None:
             return None
+        if not renderer.clip_inside:          # the sigmoid opacity (renderer.py:257-258): generic shading kernels only, the loss epilogue is exp-only
+            return None
         blocks = self.build_blocks_scene(filter_transparent=fine)
         if blocks is None or blocks.faces.shape[0] >= (1 << 20) or blocks.map_desc.shape[0] >= (1 << 11):
             return None

@@ -47,27 +47,16 @@ typedef void *dbw_stream_t;
 int dbw_abi_version(void);
 int dbw_bin_subcursors(void);      /* DBW_BIN_SUBCURSORS of this build: callers size bin_cursor and round bin_cap with it */
 const char *dbw_last_error(void);
-/* profiling/ablation switches used by tools/ and by the parity tests (0 = product behaviour); bits 0-7: shading ablations,
- * 16: no fragment stores, 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal
- * div_fast, which is bit-identical inside its guards), 512: no conservative tile-vs-edge culling in the binning, 4096: no per-tile
- * face lists (every tile walks its coarse bin); bits 16 and up: wall-clock ablations of the fused kernels for tools/diag (results
- * are wrong by construction): 1 << 17 no record stores, 1 << 18 no cursor atomics, 1 << 19 no record path in the binned backward */
+/* Ablation switches of the product kernels' alternative code paths, used by the parity tests (which run those paths against the oracle
+ * too) and by tools/ (0 = product behaviour).  They belong to the CALLING HOST THREAD (thread-local, read when a launch is enqueued), like
+ * the text of dbw_last_error: the library keeps no other state between calls.  bits 0-7: shading ablations, 16: no fragment stores,
+ * 128: no coarse bins, 256: plain IEEE divisions in the rasteriser (instead of the shared-reciprocal div_fast, which is bit-identical
+ * inside its guards), 512: no conservative tile-vs-edge culling in the binning, 4096: no per-tile face lists (every tile walks its coarse
+ * bin); bits 16 and up: wall-clock ablations of the fused kernels for tools/diag (results are wrong by construction): 1 << 17 no record
+ * stores, 1 << 18 no cursor atomics, 1 << 19 no record path in the binned backward.
+ * (The device-side test hooks of earlier ABI versions -- dbw_debug_divcheck, dbw_debug_model_math, dbw_debug_lane_merge -- are no longer
+ * part of this library: the same inline arithmetic is built into a checker-side library, tests/device_checks.hip.) */
 void dbw_debug_set_flags(int flags);
-/* test hook: counts in *mismatches (device, zeroed by the caller) the operand pairs for which the rasteriser's shared-reciprocal
- * division differs from the IEEE quotient n / d on this GPU (must stay 0 inside the guarded operand range, raster_math.h) */
-int dbw_debug_divcheck(const float *n, const float *d, int64_t count, unsigned long long *mismatches, dbw_stream_t stream);
-/* test hook: the model-side arithmetic of the kernels evaluated on the device (its powf / logf / expf), for the tests that hold it to
- * the golden vectors of the reference's own functions.  what = 0: superquadric surface point (superquadric.py:10-14) from
- * a = (cos eta, sin eta, cos omega, sin omega) x n and b = (eps1, eps2) -> out (n, 9) = point * ratio, d / d eps1, d / d eps2;
- * 1: implicit superquadric distance (superquadric.py:17-38, as_sdf = 2, as the overlap term applies it: clamp to [-5, 5]) of
- * a = points (n, 3) with b = (eps1, eps2) x n and upstream gradient c (n) -> out (n, 6) = sdf, d / d eps1, d / d eps2, d / d point;
- * 2: safe_pow (pytorch.py:35-36) of a = t (n) to the power b[0] -> out (n, 2) = value, d / d t;  3: signed_pow (pytorch.py:31-32) */
-int dbw_debug_model_math(int what, const float *a, const float *b, const float *c, int n, float ratio, float *out, dbw_stream_t stream);
-/* test hook: lane_merge (csrc/dbw_common.h), the in-register merge of neighbouring lanes that update the same key in front of the LDS
- * tables of the backward kernels, applied to waves * 64 lanes with `steps` (1..4) merging steps: keys (>= 0), active (0 / 1) and
- * values (lane, 3) in; active and values out (a lane that handed its values over comes back inactive) */
-int dbw_debug_lane_merge(const int32_t *keys, const int32_t *active, const float *values, int waves, int steps, int32_t *active_out,
-                         float *values_out, dbw_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Camera transform + z-clipping of one scene seen from B cameras.

@@ -62,7 +62,8 @@ def test_shared_reciprocal_division_equals_ieee_division_on_this_gpu():
     n2 = torch.nextafter(n2, torch.where(torch.rand(1 << 22, device=DEV, generator=g) < 0.5, n2 * 2, n2 * 0))
     num, den = torch.cat([num, n2]).contiguous(), torch.cat([den, d2]).contiguous()
     bad = torch.zeros(1, dtype=torch.int64, device=DEV)
-    _lib.call('dbw_debug_divcheck', num.data_ptr(), den.data_ptr(), num.numel(), bad.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    import device_checks
+    device_checks.call('dbwt_divcheck', num.data_ptr(), den.data_ptr(), num.numel(), bad.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert int(bad.item()) == 0
 
 
@@ -773,8 +774,8 @@ def test_lane_merge_preserves_the_per_key_sums(steps):
     vals = torch.randint(-8, 9, (n, 3), generator=g).float()
     k_d, a_d, v_d = keys.int().to(DEV), active.to(DEV), vals.to(DEV)
     a_out, v_out = torch.zeros_like(a_d), torch.zeros_like(v_d)
-    rc = lib.dbw_debug_lane_merge(k_d.data_ptr(), a_d.data_ptr(), v_d.data_ptr(), waves, steps, a_out.data_ptr(), v_out.data_ptr(), 0)
-    assert rc == 0, lib.dbw_last_error()
+    import device_checks
+    device_checks.call('dbwt_lane_merge', k_d.data_ptr(), a_d.data_ptr(), v_d.data_ptr(), waves, steps, a_out.data_ptr(), v_out.data_ptr(), 0)
     torch.cuda.synchronize()
     a_out, v_out = a_out.cpu(), v_out.cpu()
     assert bool(((a_out == 1) <= (active == 1)).all())                  # nobody wakes up

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/variants
 CS=differentiable-blocksworld_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-gpu-flush-denormals-to-zero -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-gpu-flush-denormals-to-zero -Wno-unused-function -DDBW_DIAG"   # (DBW_DIAG: the tools-only exports -- hard-pass tile shapes, the cell-table layout)
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   ( objs=""; for f in util raster project_clip shade_blend render_fused texture model_ops train_step lpips_head; do
