@@ -14,6 +14,7 @@
 // and scatters: texel gradients (wave-aggregated atomics: under magnification -- sky dome, ground -- most lanes of a
 // wave share one bilinear footprint), per-face opacity gradients, d/d dists, and optionally d/d barycentrics.
 #include "shade_common.h"
+#include "env_bwd.h"
 #include "../../include/dbw_hip.h"
 #include "step_kernels.h"
 
@@ -999,20 +1000,33 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
 // One workgroup per (texture bin, BIN_SUB_PER_WG of its record sub-ranges): accumulate the records into a (32+1)x(32+1) texel LDS tile
 // (1-texel halo: row -1, column +32), then add the tile to the gradient map.  bin_info (nbins,4) = {offset of the map in floats,
 // stored width ws, stored height hs, tile_y << 16 | tile_x}.
-// The tile is accumulated in fp64: on gfx950 ds_add_f32 retires ~1 lane per 3 clk whatever the addresses (193 clk for a full
-// wave), while ds_add_f64 is pipelined (~10 clk per wave) as long as the lanes hit distinct addresses
-// (profiles/r01_lds_atomic_ubench.txt).  Records arrive in runs of up to 64 written by one wave of the backward (an 8x8 pixel
-// patch of one layer, ~10 lanes per texel), so each batch of BIN_STAGE records is staged in LDS with coalesced loads and re-read
-// transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
+// The tile is accumulated in 32-bit FIXED POINT with a block exponent (round 6; fp64 before).  What the LDS atomic unit of gfx950 does
+// (profiles/r01_lds_atomic_ubench.txt, clk per wave-instruction): ds_add_f32 193 whatever the addresses (one lane per ~3 clk), ds_add_f64
+// 8 with distinct addresses but 20 / 44 with two / four lanes per address, ds_add_u32 4 / 6 / 14 -- and the records of a bin arrive as
+// 8x8 pixel patches whose neighbours share texels: measured 34 clk per fp64 atomic here, 61 % of this kernel (218 -> 91 us without them;
+// tools/diag/r06_trace.sh).  Integer adds are native to the LDS banks.  Exactness: the tile holds value * 2^(SH - e) as int32, e = the
+// block exponent: |g| < 2^e for every record accumulated so far -- taken per staged batch (a wave maximum next to the staging loads), and
+// when a batch raises it the tile is shifted down first.  Bilinear weights sum to one, so a texel gains less than 2^SH units per record
+// whatever the records hold: the workgroup keeps a BUDGET of records it may still add blindly -- (2^31 - 1 - B) >> SH with B a bound on
+// |tile|, 2047 records for an empty tile -- and when the budget is used up it looks (one pass over the tile: B = its largest entry, in
+// practice a few dozen addends' worth) and goes on, or -- never seen -- flushes and clears first.  No overflow, ever; every addend is
+// rounded to 2^(e - SH - 1) = 2^-21 of the bin's largest pixel gradient (measured against the fp64 tile: 2e-6 of a texture gradient's
+// largest entry; SH = 17 with a fixed 8192-record budget read 1.4e-5).  A non-finite gradient poisons the bin's first texel instead of
+// being quantised away.  Integer addition is associative: between two rescalings the tile does not depend on the order of the records.
+// Records arrive in runs of up to 64 written by one wave of the backward, so each batch of BIN_STAGE records is staged in LDS with
+// coalesced loads and re-read transposed: the 64 lanes of an instruction then hold records BIN_STAGE/64 apart.
 #ifndef DBW_BIN_STAGE
-#define DBW_BIN_STAGE 512       // (round 3: 1024 -> 512 records per batch and 4 -> 2 sub-ranges per workgroup: 43 instead of 60 KB of LDS, three
-#endif                          // workgroups per CU instead of two, eight per bin: 0.268 -> 0.236 ms at config 2; 256 records: 0.234)
+#define DBW_BIN_STAGE 512       // (round 3: 1024 -> 512 records per batch and 4 -> 2 sub-ranges per workgroup: three workgroups per CU instead of
+#endif                          // two, eight per bin: 0.268 -> 0.236 ms at config 2; 256 records: 0.234.  Round 6: 30 KB of LDS with the int32 tile)
 constexpr int BIN_STAGE = DBW_BIN_STAGE, BIN_PER_THREAD = BIN_STAGE / 256, BIN_LANE_STRIDE = BIN_STAGE / 64;
+typedef int bin_fix_t;          // (a 64-bit tile -- ds_add_u64, no budget needed -- measured 196 us against this one's 138 and fp64's 233)
+constexpr int BIN_FIX_SH = 20, BIN_FIX_EMIN = -100;
 __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restrict__ bin_info, const int *__restrict__ cursor,
                                                             const int4 *__restrict__ records, int cap, const unsigned *__restrict__ layout,
                                                             float *__restrict__ gmaps) {
-    __shared__ double tile[33 * 33 * 3];
+    __shared__ bin_fix_t tile[33 * 33 * 3];
     __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
+    __shared__ float s_wmax[4];
     const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG;
     int n_sub[BIN_SUB_PER_WG], total = 0;
     unsigned first[BIN_SUB_PER_WG];
@@ -1024,9 +1038,30 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
         total += n_sub[g];
     }
     if (total == 0) return;
-    for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0.0;
+    for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) tile[i] = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long off = bin_info[bin * 4];
+    const int ws = bin_info[bin * 4 + 1], hs = bin_info[bin * 4 + 2];
+    const int ty = bin_info[bin * 4 + 3] >> 16, tx = bin_info[bin * 4 + 3] & 0xffff;
+    int e_tile = -1000;            // block exponent of the tile (none yet); every thread holds the same value
+    int budget = (int)(0x7fffffffu >> BIN_FIX_SH);          // records that may still be added without looking at the tile (see above)
+    // tile -> gradient map (+ clear): at the end, and whenever CHUNK records have gone in
+    auto flush = [&](bool clear) {
+        const float unit = __int_as_float((unsigned)(e_tile - BIN_FIX_SH + 127) << 23);      // 2^(e - SH): e >= EMIN keeps it a normal float
+        for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) {
+            const bin_fix_t q = tile[i];
+            if (clear) tile[i] = 0;
+            if (q == 0) continue;
+            const float v = (float)q * unit;
+            const int ch = i % 3, lc = (i / 3) % 33, lr = i / 99;
+            const int r = ty * 32 - 1 + lr, c = tx * 32 + lc;
+#ifndef DBW_REDUCE_NOFLUSH
+            if (r >= 0 && r < hs && c < ws) unsafeAtomicAdd(gmaps + off + ((long long)r * ws + c) * 3 + ch, v);
+#endif
+        }
+    };
     auto accumulate = [&](int m) {
+        const float scale = __int_as_float((unsigned)(BIN_FIX_SH - e_tile + 127) << 23);     // 2^(SH - e)
 #pragma unroll 2
         for (int j = 0; j < BIN_PER_THREAD; ++j) {
             const int r = lane * BIN_LANE_STRIDE + wv * BIN_PER_THREAD + j;
@@ -1039,14 +1074,20 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
             const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
             const int idx[4] = {(lr0 * 33 + lc0) * 3, (lr0 * 33 + lc0 + dc) * 3, ((lr0 - dr) * 33 + lc0) * 3, ((lr0 - dr) * 33 + lc0 + dc) * 3};
+#ifndef DBW_REDUCE_NOATOMIC
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                atomicAdd(&tile[idx[q]], (double)(g0 * w[q]));
-                atomicAdd(&tile[idx[q] + 1], (double)(g1 * w[q]));
-                atomicAdd(&tile[idx[q] + 2], (double)(g2 * w[q]));
+                const int q0 = __float2int_rn(g0 * w[q] * scale), q1 = __float2int_rn(g1 * w[q] * scale), q2 = __float2int_rn(g2 * w[q] * scale);
+                if (q0) atomicAdd(&tile[idx[q]], q0);
+                if (q1) atomicAdd(&tile[idx[q] + 1], q1);
+                if (q2) atomicAdd(&tile[idx[q] + 2], q2);
             }
+#else
+            if (w[0] * g0 + w[1] * g1 + w[2] * g2 + w[3] == 123.456f) tile[idx[0]] = 1;        // (ablation build: the arithmetic stays, the LDS atomics go)
+#endif
         }
     };
+    bool poisoned = false;
 #pragma unroll 1
     for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
     const int n = n_sub[g];
@@ -1054,6 +1095,25 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
     for (int sb = 0; sb < n; sb += BIN_STAGE) {
         const int m = min(n - sb, BIN_STAGE);
         __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
+        if (m > budget) {
+            // the blind budget is used up: B = the tile's largest |entry| (wave maxima through s_wmax, which the batch below rewrites
+            // behind a barrier of its own)
+            int bmax = 0;
+            for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) { const int q = (int)tile[i]; bmax = max(bmax, q < 0 ? -q : q); }
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x111, 0xf, 0xf, false));
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x112, 0xf, 0xf, false));
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x114, 0xf, 0xf, false));
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x118, 0xf, 0xf, false));
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x142, 0xf, 0xf, false));
+            bmax = max(bmax, __builtin_amdgcn_update_dpp(0, bmax, 0x143, 0xf, 0xf, false));
+            if (lane == 63) s_wmax[wv] = __int_as_float(bmax);
+            __syncthreads();
+            const unsigned B = (unsigned)max(max(__float_as_int(s_wmax[0]), __float_as_int(s_wmax[1])), max(__float_as_int(s_wmax[2]), __float_as_int(s_wmax[3])));
+            budget = (int)((0x7fffffffu - B) >> BIN_FIX_SH);
+            __syncthreads();
+            if (m > budget) { flush(true); budget = (int)(0x7fffffffu >> BIN_FIX_SH); __syncthreads(); }
+        }
+        float gm = 0.f;
 #pragma unroll
         for (int it = 0; it < BIN_PER_THREAD; ++it) {
             const int r = it * 256 + threadIdx.x;
@@ -1061,25 +1121,39 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                 const int4 a = rec[(sb + r) * 2], b = rec[(sb + r) * 2 + 1];
                 stage[r * 2 + r / BIN_LANE_STRIDE] = a;
                 stage[r * 2 + r / BIN_LANE_STRIDE + 1] = b;
+                // (as unsigned bit patterns: a NaN or an infinity is then the largest of all and ends up in the batch's exponent)
+                gm = __uint_as_float(max(__float_as_uint(gm), max((unsigned)a.w & 0x7fffffffu, max((unsigned)b.x & 0x7fffffffu, (unsigned)b.y & 0x7fffffffu))));
             }
         }
+        {   // wave maximum of the bit patterns (non-negative ints order like the floats they encode)
+            int x = (int)__float_as_uint(gm);
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xf, 0xf, false));
+            if (lane == 63) s_wmax[wv] = __int_as_float(x);
+        }
         __syncthreads();
-        accumulate(m);
+        const unsigned mb = max(max(__float_as_uint(s_wmax[0]), __float_as_uint(s_wmax[1])), max(__float_as_uint(s_wmax[2]), __float_as_uint(s_wmax[3])));
+        const int E = (int)(mb >> 23);                         // biased exponent of the batch's largest |g|: |g| < 2^(E - 126)
+        if (E == 255) poisoned = true;                         // infinity / NaN among the gradients
+        const int e_b = max(min(E, 254) - 126, BIN_FIX_EMIN);
+        if (e_b > e_tile) {                                    // (uniform: every thread read the same four words)
+            if (e_tile > -1000) {
+                const int sh = min(e_b - e_tile, (int)sizeof(bin_fix_t) * 8 - 1);
+                for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) { const bin_fix_t q = tile[i]; if (q) tile[i] = (q + ((bin_fix_t)1 << (sh - 1))) >> sh; }
+                __syncthreads();
+            }
+            e_tile = e_b;
+        }
+        if (mb != 0u) { accumulate(m); budget -= m; }          // (a batch of zero gradients adds nothing)
     }
     }
     __syncthreads();
-    const long long off = bin_info[bin * 4];
-    const int ws = bin_info[bin * 4 + 1], hs = bin_info[bin * 4 + 2];
-    const int ty = bin_info[bin * 4 + 3] >> 16, tx = bin_info[bin * 4 + 3] & 0xffff;
-    for (int i = threadIdx.x; i < 33 * 33 * 3; i += 256) {
-        const float v = (float)tile[i];
-        if (v == 0.f) continue;
-        const int ch = i % 3, lc = (i / 3) % 33, lr = i / 99;
-        const int r = ty * 32 - 1 + lr, c = tx * 32 + lc;
-#ifndef DBW_REDUCE_NOFLUSH
-        if (r >= 0 && r < hs && c < ws) unsafeAtomicAdd(gmaps + off + ((long long)r * ws + c) * 3 + ch, v);
-#endif
-    }
+    if (e_tile > -1000) flush(false);
+    if (poisoned && threadIdx.x == 0) unsafeAtomicAdd(gmaps + off, __int_as_float(0x7fc00000));
 }
 
 
@@ -1152,30 +1226,13 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
 
 
 // ---- the hard single-layer pass (sky + ground), specialised: hard uv-fragments (layout 3) ---------------------------------------------
-// K = 1, sigma = 0, no learned opacity, texel gradients through the LDS hash (magnified / decimated maps).  A kept pixel lies inside
-// its face, its opacity is 1 and nothing flows through the distance, so the forward leaves (clipped face, u, v, face | map) per pixel
-// and this kernel needs no table chain at all for the texture gradient: four coalesced loads, the footprint, the texel table.  The
-// geometry gradient (through the barycentrics: uv -> clipped barycentrics -> perspective correction -> vertices) is only computed for
-// faces whose vertices are variables (geom_begin: the sky dome is a constant), from the face tables, recomputing the barycentrics
-// from the pixel position as the rasteriser backward does anyway.  Same mathematics as shade_blend_bwd_kernel<true, false, true>.
-// (a 64-slot texel table and a 32-slot face table: a 16x16-pixel tile of the magnified env maps touches a few cells and a handful of
-// large faces; with the soft pass's 512 / 128 slots the clears, the flush scans and the lost residency cost a quarter of this kernel:
-// 0.22 -> 0.16 ms with decimated maps, 0.31 -> 0.26 ms at full resolution; 16 slots and fewer overflow at full resolution (0.9 ms).
-// What does not fit goes straight to memory, as always)
-#ifndef DBW_HARD_TEX_LOG2
-#define DBW_HARD_TEX_LOG2 6
-#endif
-#ifndef DBW_HARD_FACE_LOG2
-#define DBW_HARD_FACE_LOG2 5
-#endif
-typedef LdsAgg<3, DBW_HARD_TEX_LOG2> HardTexAgg;
-typedef LdsAgg<9, DBW_HARD_FACE_LOG2> HardFaceAgg;      // a 16x16-pixel tile of the hard pass sees a handful of (large) faces
+// K = 1, sigma = 0, no learned opacity, texel gradients through the LDS hash (magnified / decimated maps).  The forward leaves (clipped
+// face, u, v, face | map) per pixel; this kernel loads them with the pixel's image gradient -- four coalesced loads -- and runs the
+// per-pixel backward of env_bwd.h (the same function the training step's fused forward runs in its epilogue).
 __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                             float *__restrict__ gmaps, const float *__restrict__ fv,
                                                             float *__restrict__ gfv, int want_bary, int persp) {
     extern __shared__ __attribute__((aligned(16))) float s_hard[];
-    constexpr bool SINGLE = true;       // (cycle accounting macros)
-    (void)SINGLE;
     HardTexAgg tex_agg;
     HardFaceAgg face_agg;
     tex_agg.bind(s_hard);
@@ -1186,8 +1243,6 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
     __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
-    const int lane = threadIdx.x & 63;
-    PROF_T(t_begin);
     const FragAddr o = frag_addr(A, n, yi, xi, 0);
     const int fc = in_img ? ld_stream(A.p2f + o.s) : -1;
     const bool valid = fc >= 0;
@@ -1200,112 +1255,14 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
         const float gs = A.gscale ? *A.gscale : 1.f;
         gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs;
     }
-    const int j = jm & 0xfffff, map = jm >> 20;
     const float gc[3] = {gr, gg, gbl};               // blend weight of a hard fragment = 1
-    const bool tex = valid && (gr != 0.f || gg != 0.f || gbl != 0.f);
-    Sample s;
-    s.a00 = s.a01 = s.a10 = s.a11 = 0;
-    s.w00 = s.w01 = s.w10 = s.w11 = 0.f;
-    PROF_T(t_a);
-    PROF_ADD(2, t_begin, t_a);
-    if (__ballot(tex) != 0ull) {
-        const int *md = A.map_desc + (valid ? map : 0) * 8;
-        footprint_desc(u, v, md[0], md[1], md[2], md[3], md[4], md[5], s);
-        // colour -> texels: merge the footprint's texels that fall into the same stored cell
-        float w00 = s.w00, w01 = s.w01, w10 = s.w10, w11 = s.w11;
-        if (s.a01 == s.a00) { w00 += w01; w01 = 0.f; }
-        if (s.a10 == s.a00) { w00 += w10; w10 = 0.f; }
-        if (s.a11 == s.a00) { w00 += w11; w11 = 0.f; }
-        else if (s.a11 == s.a01) { w01 += w11; w11 = 0.f; }
-        else if (s.a11 == s.a10) { w10 += w11; w11 = 0.f; }
-        const int ad[4] = {s.a00, s.a01, s.a10, s.a11};
-        const float wt[4] = {w00, w01, w10, w11};
-        // neighbouring pixels that hit the same texel (magnified maps: most of them) are merged in registers first (lane_merge, up to 16
-        // lanes into one; full-resolution env maps 0.27 -> 0.24 ms, decimated ones unchanged)
-        // (tap 0 and the lane's first other tap with weight as wave-wide passes; the rest -- footprints that cross a cell border in x AND y:
-        // few lanes on magnified / decimated maps, every lane on full-resolution ones -- lane by lane or wave-wide accordingly.  See the uv
-        // backward)
-        const int f = wt[1] != 0.f ? 1 : (wt[2] != 0.f ? 2 : 3);
-        const int a2[2] = {ad[0], f == 1 ? ad[1] : (f == 2 ? ad[2] : ad[3])};
-        const float w2[2] = {wt[0], f == 1 ? wt[1] : (f == 2 ? wt[2] : wt[3])};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float val[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
-            bool on = tex && w2[q] != 0.f;
-            const int key = (int)((unsigned)a2[q] / 3u);
-            if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
-            tex_agg.add_wave(gmaps, key, val, on);
-        }
-        const bool rest = tex && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
-        const unsigned long long rm = __ballot(rest);
-        if (rm != 0ull) {
-            const bool wide = __popcll(rm) > 16;
-#pragma unroll
-            for (int q = 2; q < 4; ++q) {
-                float val[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                bool on = rest && q > f && wt[q] != 0.f;
-                const int key = (int)((unsigned)ad[q] / 3u);
-                if (wide) {
-                    if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
-                    tex_agg.add_wave(gmaps, key, val, on);
-                } else if (on) tex_agg.add(gmaps, key, val);
-            }
-        }
-    }
-    PROF_T(t_b);
-    PROF_ADD(4, t_a, t_b);
-    // colour -> uv -> barycentrics -> vertices, for the faces whose vertices are variables
-    const bool geom = tex && want_bary != 0 && j >= A.geom_begin;
-    float g9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bool has_g9 = false;
-    if (__ballot(geom) != 0ull) {
-        if (geom) {
-            float gu, gv;
-            sample_grad_uv(A.maps, s, gc, gu, gv);
-            const float *uv = A.face_uvs + (long long)j * 6;
-            const float go[3] = {gu * uv[0] + gv * uv[1], gu * uv[2] + gv * uv[3], gu * uv[4] + gv * uv[5]};
-            int cd = -1;
-            float w2 = 0.f, w3 = 0.f;
-            if (A.c2o) {
-                cd = A.code[fc]; w2 = A.cw[(long long)fc * 2]; w3 = A.cw[(long long)fc * 2 + 1];
-            }
-            float gb[3] = {0.f, 0.f, 0.f};
-            convert_bary_bwd(cd, w2, w3, go, gb);
-            if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
-                has_g9 = true;
-                f2 pndc;
-                pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
-                pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
-                const float *q = fv + (long long)fc * 9;
-                const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
-                const float z0 = q[2], z1 = q[5], z2 = q[8];
-                // (gradient-only arithmetic: v_rcp_f32 instead of ~15 IEEE divisions per pixel, as in the soft backward -- held at 1e-4)
-                const f3 bary0 = bary_fwd<true>(pndc, a, b, c);
-                const f3 bp = persp ? persp_fwd<true>(bary0, z0, z1, z2) : bary0;
-                f3 gg3{gb[0], gb[1], gb[2]};
-                gg3 = clip_bwd<true>(bp, gg3);
-                float pz0 = 0.f, pz1 = 0.f, pz2 = 0.f;
-                if (persp) gg3 = persp_bwd<true>(bary0, z0, z1, z2, gg3, pz0, pz1, pz2);
-                f2 e0, e1, e2;
-                bary_bwd<true>(pndc, a, b, c, gg3, e0, e1, e2);
-                g9[0] = e0.x; g9[1] = e0.y; g9[2] = pz0;
-                g9[3] = e1.x; g9[4] = e1.y; g9[5] = pz1;
-                g9[6] = e2.x; g9[7] = e2.y; g9[8] = pz2;
-            }
-        }
-        PROF_T(t_c);
-        PROF_ADD(5, t_b, t_c);
-        face_agg.add_wave(gfv, valid ? fc : 0, g9, has_g9);
-        PROF_T(t_d);
-        PROF_ADD(6, t_c, t_d);
-    }
-    PROF_T(t_e);
+    EnvBwdArgs E;
+    E.map_desc = A.map_desc; E.maps = A.maps; E.face_uvs = A.face_uvs; E.code = A.c2o ? A.code : nullptr; E.cw = A.cw; E.fv = fv; E.gmaps = gmaps; E.gfv = gfv;
+    E.H = A.H; E.W = A.W; E.geom_begin = A.geom_begin; E.want_bary = want_bary; E.persp = persp;
+    env_bwd_pixel(E, tex_agg, face_agg, valid, fc, u, v, jm, gc, xi, yi);
     __syncthreads();
     tex_agg.flush(gmaps, threadIdx.x, NT);
     face_agg.flush(gfv, threadIdx.x, NT);
-    PROF_T(t_end);
-    PROF_ADD(3, t_e, t_end);
-    PROF_ADD(7, t_begin, t_end);
 }
 
 __global__ void flag_store_kernel(unsigned *flag, unsigned v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
