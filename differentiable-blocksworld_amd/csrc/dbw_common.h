@@ -351,6 +351,25 @@ struct LdsAgg {
             add(gbase, key, v);
         }
     }
+    // add_wave with the merge of neighbouring lanes (lane_merge, STEPS steps) in front of the table -- but only where it is needed: a wave whose
+    // active lanes all carry ONE key (magnified / decimated maps: most waves; a wave inside one large face) goes straight to the wave sum,
+    // where the merge steps -- a dozen instructions each -- would only have halved what the sum adds up anyway
+    template <int STEPS>
+    __device__ __forceinline__ void add_wave_merged(float *__restrict__ gbase, int key, float (&v)[NV], bool active) {
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) return;
+        const int leader = __ffsll((long long)am) - 1;
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
+        if (__popcll(am) >= 8 && __ballot(active && key == k0) == am) {
+            float s[NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) s[c] = wave_sum_dpp(active ? v[c] : 0.f);
+            if ((int)(threadIdx.x & 63) == leader) add(gbase, k0, s);
+            return;
+        }
+        lane_merge<NV, STEPS>(key, active, v);
+        if (active) add(gbase, key, v);
+    }
     __device__ __forceinline__ void flush(float *__restrict__ gbase, int tid, int nthreads) {
         for (int i = tid; i < NSLOT; i += nthreads) {
             const int k = keys[i];

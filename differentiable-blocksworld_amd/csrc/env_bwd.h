@@ -35,6 +35,7 @@ struct EnvBwdArgs {
     const float *fv;                                                    // clipped face vertices (F_total, 3, 3)
     float *gmaps, *gfv;                                                 // out: d loss / d maps, d loss / d clipped face vertices
     int H, W, geom_begin, want_bary, persp;
+    float ndc[4];                                                       // pixel -> NDC constants from the host (CoarseBins::ndc)
 };
 
 // valid: the pixel holds a fragment -- clipped face fc, texture coordinates (u, v), jm = original face | map << 20 -- with colour gradient gc
@@ -68,10 +69,8 @@ __device__ __forceinline__ void env_bwd_pixel(const EnvBwdArgs &A, HardTexAgg &t
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float val[3] = {gc[0] * w2[q], gc[1] * w2[q], gc[2] * w2[q]};
-            bool on = tex && w2[q] != 0.f;
-            const int key = (int)((unsigned)a2[q] / 3u);
-            if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
-            tex_agg.add_wave(A.gmaps, key, val, on);
+            const bool on = tex && w2[q] != 0.f;
+            tex_agg.template add_wave_merged<4>(A.gmaps, (int)((unsigned)a2[q] / 3u), val, on);
         }
         const bool rest = tex && ((f == 1 && (wt[2] != 0.f || wt[3] != 0.f)) || (f == 2 && wt[3] != 0.f));
         const unsigned long long rm = __ballot(rest);
@@ -80,12 +79,10 @@ __device__ __forceinline__ void env_bwd_pixel(const EnvBwdArgs &A, HardTexAgg &t
 #pragma unroll
             for (int q = 2; q < 4; ++q) {
                 float val[3] = {gc[0] * wt[q], gc[1] * wt[q], gc[2] * wt[q]};
-                bool on = rest && q > f && wt[q] != 0.f;
+                const bool on = rest && q > f && wt[q] != 0.f;
                 const int key = (int)((unsigned)ad[q] / 3u);
-                if (wide) {
-                    if (__ballot(on) != 0ull) lane_merge<3, 4>(key, on, val);
-                    tex_agg.add_wave(A.gmaps, key, val, on);
-                } else if (on) tex_agg.add(A.gmaps, key, val);
+                if (wide) tex_agg.template add_wave_merged<4>(A.gmaps, key, val, on);
+                else if (on) tex_agg.add(A.gmaps, key, val);
             }
         }
     }
@@ -108,9 +105,9 @@ __device__ __forceinline__ void env_bwd_pixel(const EnvBwdArgs &A, HardTexAgg &t
             convert_bary_bwd(cd, w2, w3, go, gb);
             if (gb[0] != 0.f || gb[1] != 0.f || gb[2] != 0.f) {
                 has_g9 = true;
-                f2 pndc;
-                pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
-                pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
+                f2 pndc;          // (same bits as pix_to_ndc: the shared-reciprocal division is exact for these operands, raster_math.h)
+                pndc.x = pix_to_ndc_fast(A.W - 1 - xi, ndc_axis_given(A.W, A.ndc[0], A.ndc[1]));
+                pndc.y = pix_to_ndc_fast(A.H - 1 - yi, ndc_axis_given(A.H, A.ndc[2], A.ndc[3]));
                 const float *q = A.fv + (long long)fc * 9;
                 const f2 a{q[0], q[1]}, b{q[3], q[4]}, c{q[6], q[7]};
                 const float z0 = q[2], z1 = q[5], z2 = q[8];

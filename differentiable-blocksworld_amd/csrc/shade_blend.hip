@@ -1185,6 +1185,12 @@ int fill_args(ShadeArgs &A, const int32_t *pix_to_face, const float *bary, const
     A.Fc_stride = Fc_stride; A.face_uvs = face_uvs; A.face_map = face_map; A.map_desc = map_desc; A.maps = maps;
     A.faces_alpha = faces_alpha; A.alpha_len = alpha_len; A.N = N; A.H = H; A.W = W; A.K = K; A.F = F; A.sigma = sigma; A.inv_sigma = sigma != 0.f ? 1.f / fabsf(sigma) : 0.f;
     for (int i = 0; i < 3; ++i) A.bg[i] = background3 ? background3[i] : 0.f;
+    {       // pixel -> NDC constants (SURVEY A.1 NonSquarePixToNdc): IEEE single divisions, the same bits as the device's
+        float rx = 2.0f, ry = 2.0f;
+        if (W > H) rx = ((float)W * rx) / (float)H;
+        if (H > W) ry = ((float)H * ry) / (float)W;
+        A.ndc[0] = rx; A.ndc[1] = rx / 2.0f; A.ndc[2] = ry; A.ndc[3] = ry / 2.0f;
+    }
     A.dbg = g_dbg_flags;
     A.agg = 0;
     A.tiled = 0;
@@ -1243,22 +1249,39 @@ __global__ __launch_bounds__(NT) void render_bwd_hard_kernel(ShadeArgs A, long l
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
     __syncthreads();
     const bool in_img = xi < A.W && yi < A.H;
-    const FragAddr o = frag_addr(A, n, yi, xi, 0);
-    const int fc = in_img ? ld_stream(A.p2f + o.s) : -1;
-    const bool valid = fc >= 0;
+    int fc = -1, jm = 0;
     float u = 0.f, v = 0.f, gr = 0.f, gg = 0.f, gbl = 0.f;
-    int jm = 0;
-    if (valid) {
-        u = ld_stream(A.bary + o.b); v = ld_stream(A.bary + o.b + o.bstride); jm = __float_as_int(ld_stream(A.bary + o.b + 2 * o.bstride));
-        const ImgAddr ia = img_addr(A, n, yi, xi, 4);
-        const float *gi = gimg + ia.base;
-        const float gs = A.gscale ? *A.gscale : 1.f;
-        gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs;
+    const float gs = A.gscale ? *A.gscale : 1.f;
+    if (A.tiled && A.img_tiled) {
+        // 8x8-tile planar fragments and images (the training step): a wave's quadrant is ONE tile -- scalar base + lane, immediate plane offsets
+        const int tiles_x = (A.W + 7) >> 3, tiles_y = (A.H + 7) >> 3;
+        const int lane = threadIdx.x & 63;
+        const bool real = (yi >> 3) < tiles_y && (xi >> 3) < tiles_x;       // (a 16x16 workgroup at the border can hold quadrants outside the tile grid)
+        const int tile = __builtin_amdgcn_readfirstlane(real ? (n * tiles_y + (yi >> 3)) * tiles_x + (xi >> 3) : n * tiles_y * tiles_x);
+        if (in_img && real) {
+            fc = ld_stream(A.p2f + ((long long)tile << 6) + lane);
+            if (fc >= 0) {
+                const float *b = A.bary + ((long long)tile * 3 << 6) + lane, *gi = gimg + ((long long)tile * 4 << 6) + lane;
+                u = ld_stream(b); v = ld_stream(b + 64); jm = __float_as_int(ld_stream(b + 128));
+                gr = ld_stream(gi) * gs; gg = ld_stream(gi + 64) * gs; gbl = ld_stream(gi + 128) * gs;
+            }
+        }
+    } else {
+        const FragAddr o = frag_addr(A, n, yi, xi, 0);
+        fc = in_img ? ld_stream(A.p2f + o.s) : -1;
+        if (fc >= 0) {
+            u = ld_stream(A.bary + o.b); v = ld_stream(A.bary + o.b + o.bstride); jm = __float_as_int(ld_stream(A.bary + o.b + 2 * o.bstride));
+            const ImgAddr ia = img_addr(A, n, yi, xi, 4);
+            const float *gi = gimg + ia.base;
+            gr = ld_stream(gi) * gs; gg = ld_stream(gi + ia.cstride) * gs; gbl = ld_stream(gi + 2 * ia.cstride) * gs;
+        }
     }
+    const bool valid = fc >= 0;
     const float gc[3] = {gr, gg, gbl};               // blend weight of a hard fragment = 1
     EnvBwdArgs E;
     E.map_desc = A.map_desc; E.maps = A.maps; E.face_uvs = A.face_uvs; E.code = A.c2o ? A.code : nullptr; E.cw = A.cw; E.fv = fv; E.gmaps = gmaps; E.gfv = gfv;
     E.H = A.H; E.W = A.W; E.geom_begin = A.geom_begin; E.want_bary = want_bary; E.persp = persp;
+    for (int i = 0; i < 4; ++i) E.ndc[i] = A.ndc[i];
     env_bwd_pixel(E, tex_agg, face_agg, valid, fc, u, v, jm, gc, xi, yi);
     __syncthreads();
     tex_agg.flush(gmaps, threadIdx.x, NT);

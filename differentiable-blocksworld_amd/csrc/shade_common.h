@@ -27,6 +27,7 @@ struct ShadeArgs {
     // texture-space binning of texel gradients (backward, agg == 0): fragments are appended as 32 B records to the bin of the
     // 32x32-texel tile their bilinear footprint starts in; dbw_texbin_reduce then accumulates every bin in LDS.  NULL = off.
     const int *bin_base;   // (M) first bin of each map
+    float ndc[4];          // pixel -> NDC constants computed on the host: range and offset of x, of y (raster_math.h: ndc_axis_given)
     int *bin_cursor;       // (nbins) append cursors
     int4 *bin_records;     // (nbins, bin_cap, 2)
     int bin_cap;

@@ -97,7 +97,7 @@ class CStep:
         perceptual_ok = 'perceptual' not in w or (m.perceptual_fn is not None and (self.fuse & 18) == 18)
         # (clip_inside = False, the sigmoid opacity, travels as a negative sigma that dbw_train_step_create refuses: the autograd path has it)
         ok = (m.decouple_rendering and m.sync_free and 'rgb' in w and perceptual_ok and r.detach_bary and r.faces_per_pixel > 1
-              and r.clip_inside and getattr(m.renderer_fine, 'clip_inside', True)
+              and r.clip_inside and getattr(m.renderer_fine, 'clip_inside', True) and getattr(m, 'default_criteria', True)
               and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11) and m.n_blocks <= 64
               and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS and ops.HARD_UV_FRAGMENTS
               and ops.COARSE_BINS and ops.TEXTURE_BINS)

@@ -37,6 +37,12 @@ def safe_pow(t, exponent, eps=1e-6):      # utils/pytorch.py:35-36
     return t.clamp(eps).pow(exponent)
 
 
+# loss.py:11-24: the registry's criteria on an image pair, called as criterion(imgs, rec) with their default (mean) reduction
+_CRITERIA = {'mse': F.mse_loss, 'l2': F.mse_loss, 'l1': F.l1_loss, 'huber': F.smooth_l1_loss}
+# loss.py:43-47 (tv_norm_funcs): norm of a difference tensor over its channel axis
+_TV_NORMS = {'l1': lambda t: t.abs().sum(-1), 'l2': lambda t: safe_pow(t.pow(2).sum(-1), 0.5), 'l2sq': lambda t: t.pow(2).sum(-1)}
+
+
 class DifferentiableBlocksWorld(nn.Module):
     name = 'dbw'
 
@@ -189,10 +195,17 @@ class DifferentiableBlocksWorld(nn.Module):
         kwargs.pop('perceptual_name', 'lpips')
         tv_type = kwargs.pop('tv_type', 'l2sq')
         assert len(kwargs) == 0, kwargs
-        if name not in ('mse', 'l2'):
-            raise NotImplementedError(f"loss '{name}': the HIP path implements the MSE criterion (default.yml)")
-        if tv_type != 'l2sq':
-            raise NotImplementedError(f"tv_type '{tv_type}': only 'l2sq' (default) is implemented")
+        # loss.py:11-24,43-47: the image criteria of the registry that are criteria on an RGB image pair (mse / l2, l1, huber = SmoothL1)
+        # and the three total-variation norms.  The defaults of every shipped config (mse, l2sq) run inside the HIP kernels (loss epilogue of
+        # the fg pass, tv_l2sq_sets); the others through torch on the rendered image / the prepared maps -- autograd then reaches the HIP
+        # backward the same way (general path of compute_losses; the one-call C step and the fused loss epilogue stand aside)
+        if name not in _CRITERIA:
+            raise NotImplementedError(f"loss '{name}': an image criterion out of {sorted(_CRITERIA)} (loss.py:11-24; bce / cosine / ssim / "
+                                      'chamfer / tv / lpips are not reconstruction criteria on an RGB image pair)')
+        if tv_type not in _TV_NORMS:
+            raise NotImplementedError(f"tv_type '{tv_type}': one of {sorted(_TV_NORMS)} (loss.py:43-47)")
+        self.criterion_name, self.tv_type = name, tv_type
+        self.default_criteria = name in ('mse', 'l2') and tv_type == 'l2sq'
         self.loss_weights = {k: v for k, v in weights.items() if v > 0}
         self.loss_names = [f'loss_{n}' for n in list(self.loss_weights.keys()) + ['total']]
 
@@ -513,7 +526,7 @@ class DifferentiableBlocksWorld(nn.Module):
         trips.  Returns None when the configuration needs the general path (non-decoupled, perceptual term, no block left, layered
         fallbacks switched off)."""
         w = self.loss_weights
-        if (not self.decouple_rendering or 'rgb' not in w or 'perceptual' in w
+        if (not self.decouple_rendering or 'rgb' not in w or 'perceptual' in w or not self.default_criteria
                 or not (ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS)):
             return None
         self._ensure_cameras(inp)
@@ -598,7 +611,7 @@ class DifferentiableBlocksWorld(nn.Module):
         # view-independent regularisers: every rank computes them identically; scaled by 1/world_size so that the
         # sum all-reduce of gradients counts them once
         rs = 1.0 / ws
-        if (layers is not None or rgb_value is not None) and 'rgb' in w:
+        if (layers is not None or rgb_value is not None) and 'rgb' in w and self.default_criteria:
             # training path: composite + MSE and the regularisers as ONE autograd node (ops.fused_losses); factors of
             # dbw.py:373-405: parsimony and overlap only act in the coarse phase, tv is scaled by 0.1 afterwards (and the
             # ground map once more)
@@ -636,7 +649,7 @@ class DifferentiableBlocksWorld(nn.Module):
         if 'rgb' in losses and not empty:
             # a mean over the GLOBAL batch under view-sharded data parallelism (the ranks' gradients are summed)
             share = imgs.numel() / float(self._global_count) if (ws > 1 and getattr(self, '_global_count', None)) else 1.0
-            losses['rgb'] = w['rgb'] * share * F.mse_loss(imgs, rec if rec is not None else ops.composite(*layers))
+            losses['rgb'] = w['rgb'] * share * _CRITERIA[self.criterion_name](imgs, rec if rec is not None else ops.composite(*layers))
         if 'perceptual' in losses and not empty:
             losses['perceptual'] = self._perceptual_term(imgs, rec if rec is not None else ops.composite(*layers), coarse, getattr(self, '_view_ids', None))
         if 'parsimony' in losses:
@@ -645,7 +658,13 @@ class DifferentiableBlocksWorld(nn.Module):
             losses['parsimony'] = w['parsimony'] * factor * rs * safe_pow(alpha, 0.5).mean()
         if 'tv' in losses:
             factor = 1 if coarse else 0.1
-            tv = ops.tv_l2sq(self._bkg_maps) + ops.tv_l2sq(self._blocks_maps, wrap_x=True) + ops.tv_l2sq(self._ground_maps) * factor
+            if self.tv_type == 'l2sq':
+                tv = ops.tv_l2sq(self._bkg_maps) + ops.tv_l2sq(self._blocks_maps, wrap_x=True) + ops.tv_l2sq(self._ground_maps) * factor
+            else:       # dbw.py:378-387 with tv_norm_funcs['l1' | 'l2'], in torch on the prepared maps
+                norm, bm = _TV_NORMS[self.tv_type], self._blocks_maps
+                tv = sum(norm(torch.diff(self._bkg_maps, dim=k)).mean() for k in (1, 2))
+                tv = tv + norm(torch.diff(bm, dim=2, append=bm[:, :, 0:1])).sum(0).mean() + norm(torch.diff(bm, dim=1)).sum(0).mean()
+                tv = tv + sum(norm(torch.diff(self._ground_maps, dim=k)).mean() for k in (1, 2)) * factor
             losses['tv'] = w['tv'] * factor * rs * tv
         if 'overlap' in losses and coarse:
             # (the term is switched off after the coarse phase, dbw.py:390: no samples are drawn then -- the fused and the native path

@@ -55,7 +55,7 @@ class NativeStep:
         # (clip_inside = False -- the sigmoid opacity -- is implemented by the generic shading / backward kernels of the autograd path only: the
         # specialised uv kernels and the loss epilogue are exp-only, sigma >= 0)
         return (m.decouple_rendering and m.sync_free and 'rgb' in w and 'perceptual' not in w and r.detach_bary and r.faces_per_pixel > 1
-                and r.clip_inside and getattr(m.renderer_fine, 'clip_inside', True)
+                and r.clip_inside and getattr(m.renderer_fine, 'clip_inside', True) and getattr(m, 'default_criteria', True)
                 and r.cam_name == 'perspective' and m.blocks_n_faces < (1 << 20) and m.n_blocks + 2 < (1 << 11)
                 and ops.FUSED_FORWARD and ops.FUSED_BACKWARD and ops.TILED_FRAGMENTS and ops.UV_FRAGMENTS)
 

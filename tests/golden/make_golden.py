@@ -11,7 +11,7 @@ SURVEY.md 8c):
   model/renderer.py:241-273   layered_rgb_blend
   utils/superquadric.py:10-14 parametric_sq          utils/superquadric.py:17-38 implicit_sq(as_sdf=2)
   utils/pytorch.py:31-36      signed_pow / safe_pow
-  model/loss.py:43-47         tv_norm_funcs['l2sq']
+  model/loss.py:43-47         tv_norm_funcs['l2sq'] (implicit_misc.npz); all three norms + the criteria of loss.py:11-24 (criteria.npz)
   model/tools.py:173-207      elev/azim/roll_to_rotation_matrix (R_world, dbw.py:59)
   model/loss.py:28-29,124-156 mse2psnr, SSIMLoss (evaluation metrics)
   utils/mesh.py:78-89,127-169 point_to_uv_sphericalmap, get_icosphere_uvs post-processing
@@ -247,6 +247,37 @@ def main():
     out['mse'] = _np(mse)
     out['psnr'] = _np(loss.mse2psnr(mse))
     np.savez_compressed(os.path.join(HERE, 'ssim.npz'), **out)
+
+    # ---- 8. the non-default keys of the loss registry the model's config accepts (loss.py:11-24: l1, huber next to mse / l2; loss.py:43-47:
+    #         tv_norm_funcs l1 / l2 next to l2sq): the criteria on an image pair as dbw.py:367 calls them, the TV term as dbw.py:378-387
+    #         assembles it from the norms (sky map, wrapped block maps, ground map x factor), values and gradients.  Its own generator: the
+    #         sections above keep their draws
+    g = torch.Generator().manual_seed(8)
+    out = {}
+    imgs = torch.rand(2, 3, 9, 11, generator=g)
+    rec0 = (imgs + 0.3 * torch.randn(2, 3, 9, 11, generator=g)).clamp(0, 1)
+    rec0[0, :, :2] += 1.7                           # (differences above 1: the quadratic / linear switch of the Huber criterion)
+    out['crit_imgs'], out['crit_rec'] = _np(imgs), _np(rec0)
+    for name in ('mse', 'l2', 'l1', 'huber'):
+        rec = rec0.clone().requires_grad_(True)
+        val = loss.get_loss(name)()(imgs, rec)
+        val.backward()
+        out[f'crit_{name}'], out[f'crit_{name}_grad'] = _np(val), _np(rec.grad)
+    bkg, blocks, ground = (torch.rand(1, 6, 7, 3, generator=g), torch.rand(3, 5, 8, 3, generator=g), torch.rand(1, 4, 6, 3, generator=g))
+    blocks[0, 2, 3] = blocks[0, 2, 4]               # a zero difference: where safe_pow's clamp decides the l2 norm's gradient
+    out['tv_bkg'], out['tv_blocks'], out['tv_ground'] = _np(bkg), _np(blocks), _np(ground)
+    for name in ('l1', 'l2', 'l2sq'):
+        norm = loss.tv_norm_funcs[name]
+        b_, m_, g_ = (t.clone().requires_grad_(True) for t in (bkg, blocks, ground))
+        tv = sum([norm(torch.diff(b_, dim=k)).mean() for k in [1, 2]])
+        dx = norm(torch.diff(m_, dim=2, append=m_[:, :, 0:1]))
+        dy = norm(torch.diff(m_, dim=1))
+        tv = tv + (dx.sum(0).mean() + dy.sum(0).mean())
+        tv = tv + sum([norm(torch.diff(g_, dim=k)).mean() for k in [1, 2]]) * 0.1
+        tv.backward()
+        out[f'tv_{name}'] = _np(tv)
+        out[f'tv_{name}_g_bkg'], out[f'tv_{name}_g_blocks'], out[f'tv_{name}_g_ground'] = _np(b_.grad), _np(m_.grad), _np(g_.grad)
+    np.savez_compressed(os.path.join(HERE, 'criteria.npz'), **out)
     print('golden fixtures written to', HERE)
 
 

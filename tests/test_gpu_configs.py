@@ -45,12 +45,13 @@ def _packed(scene, pads=None):
                        scene['face_map'].to(torch.int32).to(DEV), desc, flat)
 
 
-def _cfg(nb, ts, fpp, bkg_upscale=1):
+def _cfg(nb, ts, fpp, bkg_upscale=1, criterion='mse', tv_type='l2sq'):
     return {'model': {'name': 'dbw', 'mesh': {'n_blocks': nb, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts, 'txt_bkg_upscale': bkg_upscale},
                       'renderer': {'faces_per_pixel': fpp, 'cameras': {'name': 'perspective'}, 'detach_bary': True, 'z_clip': 0.001},
                       'rend_optim': {'coarse_learning': 1500, 'decimate_txt': 750, 'decimate_factor': 8, 'kill_blocks': True,
                                      'decouple_rendering': True, 'opacity_noise': True},
-                      'loss': {'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1, 'overlap_weight': 1}}}
+                      'loss': {'name': criterion, 'tv_type': tv_type, 'rgb_weight': 1, 'perceptual_weight': 0, 'parsimony_weight': 0.01, 'tv_weight': 0.1,
+                               'overlap_weight': 1}}}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -91,11 +92,12 @@ def _oracle_in_double(orc):
     return d
 
 
-def _iteration(shape, seed, epoch, decimate, c_step=False, bkg_upscale=1, device_vertices=False):
+def _iteration(shape, seed, epoch, decimate, c_step=False, bkg_upscale=1, device_vertices=False, criterion='mse', tv_type='l2sq'):
     H, W, nb, ts, fpp, V = shape
     torch.manual_seed(227391)
-    model = dbw_amd.create_model(_cfg(nb, ts, fpp, bkg_upscale), (H, W))
-    orc = O.OracleDBW((H, W), n_blocks=nb, txt_size=ts, txt_bkg_upscale=bkg_upscale, faces_per_pixel=fpp, seed=227391)
+    model = dbw_amd.create_model(_cfg(nb, ts, fpp, bkg_upscale, criterion, tv_type), (H, W))
+    orc = O.OracleDBW((H, W), n_blocks=nb, txt_size=ts, txt_bkg_upscale=bkg_upscale, faces_per_pixel=fpp, seed=227391, criterion=criterion,
+                      tv_type=tv_type)
     for k, v in orc.p.items():                                       # same seed, same draw order -> identical init
         assert torch.equal(v.detach(), getattr(model, k).detach()), k
     with torch.no_grad():
@@ -245,6 +247,17 @@ def test_config1_c_step_matches_oracle(epoch, decimate, record_property):
         assert flips > 0, f'seed {seed}: {worst} off by {errs[worst]:.2e} although the fragment lists are identical'
         tried.append((seed, worst, errs[worst], flips))
     pytest.fail(f'no parameter draw without a borderline fragment flip: {tried}')
+
+
+@pytest.mark.parametrize('criterion,tv_type,epoch,decimate', [('l1', 'l2', 0, True), ('huber', 'l1', 800, False)])
+def test_config1_with_the_registrys_other_criteria_matches_oracle(criterion, tv_type, epoch, decimate):
+    """The config keys loss.name / loss.tv_type beyond the defaults (loss.py:11-24: l1, huber; loss.py:43-47: l1, l2 -- no shipped config sets
+    them): the rendered image comes from the HIP kernels, the criterion and the TV norm run in torch on it and on the prepared maps, autograd
+    hands their gradients to the HIP backward.  BASELINE configs[0] at the oracle's vertices (the l1 criterion's gradient is a sign: a
+    pixel an ulp on the other side of its target flips it, so nothing upstream may differ): every loss term and every gradient at 1e-4."""
+    errs, _ = _iteration(C1, 12, epoch, decimate, device_vertices=True, criterion=criterion, tv_type=tv_type)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < REL, (worst, errs[worst], {k: v for k, v in errs.items() if v >= REL})
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -70,6 +70,36 @@ def test_implicit_sq_safe_pow_tv_match_reference(golden_dir):
     torch.testing.assert_close(m.grad, g['tv_grad'])
 
 
+@pytest.mark.parametrize('side', ['oracle', 'product'])
+def test_registry_criteria_and_tv_norms_match_reference(golden_dir, side):
+    """The non-default keys of the loss registry the config schema accepts (loss.py:11-24: l1, huber next to mse / l2; loss.py:43-47:
+    tv_norm_funcs l1 / l2 next to l2sq), as dbw.py:367 and dbw.py:378-387 use them: the oracle's restatement and the product's own host-side
+    tables (dbw_amd/dbw.py runs these keys through torch on the rendered image / the prepared maps) against vectors of the REAL functions
+    (tests/golden/criteria.npz): values and gradients, incl. Huber's quadratic / linear switch and the l2 norm's clamp at a zero difference."""
+    g = _load(golden_dir, 'criteria.npz')
+    if side == 'oracle':
+        crit, norms = O.CRITERIA, O.TV_NORMS
+    else:
+        from dbw_amd import dbw as D
+        crit, norms = D._CRITERIA, D._TV_NORMS
+    for name in ('mse', 'l2', 'l1', 'huber'):
+        rec = g['crit_rec'].clone().requires_grad_(True)
+        val = crit[name](g['crit_imgs'], rec)
+        val.backward()
+        torch.testing.assert_close(val.detach(), g[f'crit_{name}'], rtol=1e-6, atol=0)
+        torch.testing.assert_close(rec.grad, g[f'crit_{name}_grad'], rtol=1e-6, atol=1e-9)
+    for name in ('l1', 'l2', 'l2sq'):
+        norm = norms[name]
+        b_, m_, g_ = (g[k].clone().requires_grad_(True) for k in ('tv_bkg', 'tv_blocks', 'tv_ground'))
+        tv = sum(norm(torch.diff(b_, dim=k)).mean() for k in (1, 2))
+        tv = tv + norm(torch.diff(m_, dim=2, append=m_[:, :, 0:1])).sum(0).mean() + norm(torch.diff(m_, dim=1)).sum(0).mean()
+        tv = tv + sum(norm(torch.diff(g_, dim=k)).mean() for k in (1, 2)) * 0.1
+        tv.backward()
+        torch.testing.assert_close(tv.detach(), g[f'tv_{name}'], rtol=1e-6, atol=0)
+        for t, k in ((b_, 'bkg'), (m_, 'blocks'), (g_, 'ground')):
+            torch.testing.assert_close(t.grad, g[f'tv_{name}_g_{k}'], rtol=1e-5, atol=1e-8)
+
+
 def test_world_rotation_matches_reference(golden_dir):
     g = _load(golden_dir, 'world_rotation.npz')
     for tag in ['dtu', 'bmvs', 'mix']:
