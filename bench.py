@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, 'differentiable-blocksworld_amd'))
 import torch                                                            # noqa: E402
 import torch.distributed as dist                                        # noqa: E402
 
-PMC_FILE = 'r05_pmc_counters.json'
+PMC_FILE = 'r06_pmc_counters.json'
 
 
 def csrc_sha16():

@@ -667,7 +667,11 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     }
     fa_agg.bind((char *)s_uvbwd + (BINNED ? 0 : TexAgg::BYTES));
     fa_agg.clear(threadIdx.x, NT);
-    __shared__ __attribute__((aligned(16))) int s_md[BINNED ? MD_CACHE_MAPS * 8 : 8];
+#ifndef DBW_MD_LDS_UNBINNED
+#define DBW_MD_LDS_UNBINNED 0
+#endif
+    constexpr bool MD_LDS = BINNED || DBW_MD_LDS_UNBINNED;
+    __shared__ __attribute__((aligned(16))) int s_md[MD_LDS ? MD_CACHE_MAPS * 8 : 8];
 #ifndef DBW_LAST_WAVE_FLUSH
 #define DBW_LAST_WAVE_FLUSH 1
 #endif
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     __shared__ int s_done;                     // waves of the workgroup that have finished their layers
     if (threadIdx.x == 0) s_done = 0;
     MapDescCache mdc;
-    mdc.load(A, s_md, BINNED ? A.bin_base : nullptr, threadIdx.x, NT, BINNED);
+    mdc.load(A, s_md, BINNED ? A.bin_base : nullptr, threadIdx.x, NT, MD_LDS);
     // one opacity per texture map (the training path: one per block, alpha_len = -M) with few maps: the opacity gradient goes to a small
     // DIRECT-mapped fp64 array, map * 8 + a lane-derived spread -- a fire-and-forget ds_add_f64 per fragment, no slot look-up.  The
     // face table then only sees the fragments whose distance carries a gradient (outside their face, inside the blur band): the

@@ -243,6 +243,9 @@ int check_desc(const dbw_step_desc *d) {
     DBW_REQUIRE(d->w_overlap == 0.f || (d->overlap_points > 0 && d->overlap_temperature > 0.f), "bad overlap constants");
     DBW_REQUIRE(((size_t)(d->n_sky_verts + d->n_ground_verts) * 12 <= 48 * 1024 && (size_t)d->n_blocks * d->block_nv * 12 <= 48 * 1024) || !(d->fuse & 8),
                 "fused tails keep a scene's vertex gradients in 48 KB of LDS");
+    // (the fused forward addresses its texels with 32-bit byte offsets from the first prepared map of a scene: include/dbw_hip.h, frag_layout 2)
+    DBW_REQUIRE((size_t)d->n_blocks * d->txt_size * d->txt_size * 3 < ((size_t)1 << 30) &&
+                    (size_t)2 * d->env_txt_size * d->env_txt_size * 3 < ((size_t)1 << 30), "a scene's prepared maps must hold fewer than 2^30 floats");
     return DBW_OK;
 }
 

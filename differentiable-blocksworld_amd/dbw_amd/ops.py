@@ -342,6 +342,8 @@ def _render_fwd_fused(fvc, cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, b
         img = tiled_image_empty(B, 4, cfg.H, cfg.W, dev) if img_tiled else torch.empty(B, 4, cfg.H, cfg.W, dtype=torch.float32, device=dev)
         out = (p2f, bary, dists, img)
     p2f, bary, dists, img = out
+    if int(TILED_FRAGMENTS) == 2 and maps.numel() >= (1 << 30):
+        raise RuntimeError(f'uv-fragment passes address their texels with 32-bit byte offsets: the maps buffer ({maps.numel()} floats) must hold fewer than 2^30')
     _lib.call('dbw_render_fwd_fused', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),
@@ -533,6 +535,8 @@ def render_fwd_fused_mse(cl, B, cfg, face_uvs, face_map, map_desc, maps, fa, bg,
         g_env = torch.empty_like(g_fg)
         out = (p2f, bary, dists, part, g_fg, g_env)
     p2f, bary, dists, part, g_fg, g_env = out
+    if maps.numel() >= (1 << 30):
+        raise RuntimeError(f'uv-fragment passes address their texels with 32-bit byte offsets: the maps buffer ({maps.numel()} floats) must hold fewer than 2^30')
     _lib.call('dbw_render_fwd_fused_mse', _ptr(fvc), _ptr(cl['first_idx']), _ptr(cl['num_faces']), _ptr(cl['neighbor']), _ptr(cl['c2o']),
               _ptr(cl['clip_code']), _ptr(cl['clip_w']), 2 * cfg.F, _ptr(face_uvs), _ptr(face_map), _ptr(map_desc), _ptr(maps), _ptr(fa),
               _alpha_len(fa, map_desc, cfg.F), B, Ft, cfg.H, cfg.W, cfg.K, cfg.F, float(cfg.sigma), float(cfg.blur), int(cfg.persp),

@@ -29,8 +29,10 @@
  * render entry points; 3: bin_layout; 4: dbw_train_step_* (the whole optimisation iteration behind one entry); 5: dbw_step_inputs.rng_step
  * (the random-number counter is the caller's step count, not the plan's), skip_flag of dbw_adam_step_groups, a cross-stream wait that
  * gives up voids its step and moves the plan to events instead of failing the next run (dbw_train_step_voided_runs); 6: dbw_lpips_head_*
- * (the head of the perceptual criterion) */
-#define DBW_ABI_VERSION 6
+ * (the head of the perceptual criterion); 7: the device-side test hooks (dbw_debug_divcheck / _model_math / _lane_merge) left the library,
+ * dbw_debug_set_flags is per host thread, the void flag is written by every run from a word that only the host clears
+ * (dbw_train_step_void_flag_offset), uv-fragment passes address their maps with 32-bit byte offsets (maps buffer < 2^30 floats) */
+#define DBW_ABI_VERSION 7
 
 #ifdef __cplusplus
 extern "C" {
@@ -164,7 +166,8 @@ int dbw_shade_blend_bwd(const int32_t *pix_to_face, const float *bary, const flo
  * the sampled texture colour, transmittance in front of the fragment) -- everything the blend needs already resolved --,
  * and the pix_to_face entry of a pixel's first layer = id | fragment count << 26; for passes whose barycentrics carry no
  * gradient (detach_bary): the backward then needs no per-face table gathers, no texel fetch and no front-to-back pass
- * (F < 2^20, F_total < 2^26, maps < 2^11); 3 = layout 1 whose three `bary` planes hold (u, v, bitcast(face | map << 20)) and whose
+ * (F < 2^20, F_total < 2^26, maps < 2^11, and the `maps` buffer holds fewer than 2^30 floats: the pass addresses its texels with 32-bit byte
+ * offsets from `maps`); 3 = layout 1 whose three `bary` planes hold (u, v, bitcast(face | map << 20)) and whose
  * `dists` are not written, for the HARD single-layer pass (K == 1, sigma == 0, no faces_alpha; F < 2^20, maps < 2^11): a kept pixel
  * lies inside its face and its opacity is 1, so that is all the backward needs for the texture gradient, and it rebuilds the
  * barycentrics from the pixel position for the geometry gradient (dbw_render_bwd_fused then requires lds_aggregate != 0).

@@ -20,24 +20,24 @@ while [ $# -gt 0 ]; do
       for e in 0 800 1600; do
         timeout 900 rocprofv3 --kernel-trace -d $O/t -o p --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --epoch $e > $O/trace_$e.log 2>&1
         csv=$(find $O/t -name "*kernel_trace.csv" | head -1)
-        python tools/rocprof_csv_summary.py $csv $O/r05_kernel_stats_epoch$e.txt "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --epoch $e (rocprofv3 --kernel-trace)" > /dev/null
-        python tools/step_sequence.py $csv > $O/r05_step_sequence_epoch$e.txt 2>&1
+        python tools/rocprof_csv_summary.py $csv $O/r06_kernel_stats_epoch$e.txt "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --epoch $e (rocprofv3 --kernel-trace)" > /dev/null
+        python tools/step_sequence.py $csv > $O/r06_step_sequence_epoch$e.txt 2>&1
         rm -rf $O/t
       done
       timeout 900 rocprofv3 --kernel-trace -d $O/t -o p --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --no-overlap > $O/trace_alone.log 2>&1
       csv=$(find $O/t -name "*kernel_trace.csv" | head -1)
-      python tools/rocprof_csv_summary.py $csv $O/r05_kernel_stats_epoch0_alone.txt "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --no-overlap: everything in order on ONE stream, every kernel alone on the GPU (rocprofv3 --kernel-trace)" > /dev/null
-      python tools/step_sequence.py $csv > $O/r05_step_sequence_epoch0_alone.txt 2>&1
+      python tools/rocprof_csv_summary.py $csv $O/r06_kernel_stats_epoch0_alone.txt "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-phases --no-extras --no-overlap: everything in order on ONE stream, every kernel alone on the GPU (rocprofv3 --kernel-trace)" > /dev/null
+      python tools/step_sequence.py $csv > $O/r06_step_sequence_epoch0_alone.txt 2>&1
       rm -rf $O/t
       DBW_EPOCH=0 timeout 600 rocprofv3 --kernel-trace -d $O/t -o p --output-format csv -- python tools/diag/trace_cfg.py 4 300 400 10 10 256 14 > $O/trace_b4.log 2>&1
       csv=$(find $O/t -name "*kernel_trace.csv" | head -1)
-      python tools/step_sequence.py $csv > $O/r05_step_sequence_batch4.txt 2>&1
-      python tools/rocprof_csv_summary.py $csv $O/r05_kernel_stats_batch4.txt "14 training steps of 4 views (configs/dtu/default.yml:28) of 400x300, 10 blocks, faces_per_pixel 10 (tools/diag/trace_cfg.py; rocprofv3 --kernel-trace)" > /dev/null
+      python tools/step_sequence.py $csv > $O/r06_step_sequence_batch4.txt 2>&1
+      python tools/rocprof_csv_summary.py $csv $O/r06_kernel_stats_batch4.txt "14 training steps of 4 views (configs/dtu/default.yml:28) of 400x300, 10 blocks, faces_per_pixel 10 (tools/diag/trace_cfg.py; rocprofv3 --kernel-trace)" > /dev/null
       rm -rf $O/t
-      bash tools/pmc_sq.sh $O/pmc 0 > $O/r05_pmc_sq_counters.txt 2>&1
-      cp $O/pmc/bench_counters.json $O/r05_pmc_counters.json
+      bash tools/pmc_sq.sh $O/pmc 0 > $O/r06_pmc_sq_counters.txt 2>&1
+      cp $O/pmc/bench_counters.json $O/r06_pmc_counters.json
       rm -rf $O/pmc/g1 $O/pmc/g2 $O/pmc/g3 $O/pmc/g4 $O/pmc/calib_FETCH_SIZE $O/pmc/calib_WRITE_SIZE
-      tail -5 $O/r05_pmc_sq_counters.txt; head -24 $O/r05_step_sequence_epoch0.txt;;
+      tail -5 $O/r06_pmc_sq_counters.txt; head -24 $O/r06_step_sequence_epoch0.txt;;
     bench) timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; cut -c1-1500 $O/bench.json;;
   esac
   shift
