@@ -57,7 +57,8 @@ for n, row in res.items():
             row['waves_per_simd'] = round(row['SQ_WAVE_CYCLES'] * 1e6 * 4 / (d * CLK * SIMDS), 2)
 json.dump(res, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 # the file bench.py reads: keyed by its kernel labels
-LABEL = {'render_fwd_kernel<10, 8, 8, 2, true>': 'render_fwd_fused K=10 (fg pass)', 'render_bwd_uv_kernel<false>': 'render_bwd_fused K=10 (fg pass)',
+LABEL = {'render_fwd_kernel<10, 8, 8, 2, true>': 'render_fwd_fused K=10 (fg pass)', 'render_fwd_kernel<10, 8, 8, 2, true, true>': 'render_fwd_fused K=10 (fg pass)',
+         'render_fwd_kernel<10, 8, 8, 2, true, false>': 'render_fwd_fused K=10 (fg pass)', 'render_bwd_uv_kernel<false>': 'render_bwd_fused K=10 (fg pass)',
          'render_bwd_uv_kernel<true>': 'render_bwd_fused K=10 (fg pass)', 'render_bwd_uv_kernel': 'render_bwd_fused K=10 (fg pass)',
          'render_fwd_kernel<1, 16, 16, 2, false>': 'render_fwd_fused K=1 (env pass)', 'render_fwd_kernel<1, 16, 16, 1, false>': 'render_fwd_fused K=1 (env pass)',
          'render_bwd_hard_kernel': 'render_bwd_fused K=1 (env pass)',
