@@ -646,6 +646,44 @@ def test_texture_space_binning_equals_atomic_scatter(monkeypatch):
     assert rel_err(grads[2], grads[0]) < 1e-5
 
 
+def test_bin_reduction_in_fixed_point_holds_long_record_runs_and_wide_dynamic_range(monkeypatch):
+    """`texbin_reduce_kernel` accumulates a bin in int32 fixed point with a block exponent and an overflow BUDGET (shade_blend.hip): a
+    workgroup may add 2047 records blindly, then has to look at its tile.  Here ONE 32x32 bin per map takes every record of a 300x400
+    render -- tens of thousands per workgroup, dozens of budget checks -- and the image gradient spans nine decades (a few pixels weigh
+    1e6, most 1e-3: batches of small gradients arrive before and after the large ones, so the tile's exponent is raised on the way and
+    small addends meet a coarse grid): against the atomic scatter, which adds the same fp32 products in fp32, to 1e-5 of the largest
+    entry, and texel by texel for the texels only small pixels touch (their sums must not drown in the large pixels' quantum)."""
+    m, R, T, Km = _model(seed=31, ts=32, hw=(300, 400), fpp=8)
+    with torch.no_grad():
+        scene = m.build_blocks(False, True, False, None, kill_blocks=False)
+    pl, pr = m.txt_padding
+    unpadded = [mp[:, pl:mp.shape[1] - pr] for mp in scene['maps']]
+    args = (R.to(DEV), T.to(DEV), Km[0].to(DEV))
+    g = torch.Generator().manual_seed(6)
+    w = torch.rand(3, 4, 300, 400, generator=g) * 1e-3
+    w[:, :, 140:150, 190:200] *= 1e9                       # a 10x10 patch of heavy pixels in the middle of the blocks
+    w = w.to(DEV)
+    grads = []
+    for binned in (False, True):
+        monkeypatch.setattr(ops, 'TEXTURE_BINS', binned)
+        ps = _packed(dict(scene, maps=unpadded), pads=[(pl, pr)] * len(unpadded))
+        ps.maps.requires_grad_(True)
+        bins = PackedScene.describe_bins([(32, 32)] * len(unpadded), DEV)
+        cfg = ops.RenderCfg(300, 400, 8, 1e-4, 0.001, True, True, scene['faces'].shape[0], lds_aggregate=False, texbins=bins)
+        img = ops.render_scene(ps.verts, ps.maps, None, ps.faces, *args, ps.face_uvs, ps.face_map, ps.map_desc, None, cfg)
+        (img * w).sum().backward()
+        grads.append(ps.maps.grad.clone())
+    assert bins[2] == len(unpadded)
+    ref, got = grads
+    assert float(ref.abs().max()) > 1e3 and rel_err(got, ref) < 1e-5
+    # every bin holds heavy and light texels: a light texel's sum is held to the quantum of ITS bin's largest pixel gradient (2^-21 of it per
+    # addend), i.e. here to an absolute error far below the heavy entries' 1e-5 -- and bins the heavy patch does not reach keep full precision
+    per_map = ref.numel() // len(unpadded)
+    for k in range(len(unpadded)):
+        a, b = got[k * per_map:(k + 1) * per_map], ref[k * per_map:(k + 1) * per_map]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
+
+
 def test_lds_aggregation_is_equivalent_on_magnified_env_pass():
     m, R, T, Km = _model(seed=17, ts=16)
     with torch.no_grad():
