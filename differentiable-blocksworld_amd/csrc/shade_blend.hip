@@ -47,6 +47,20 @@ __device__ __forceinline__ void st_stream4(int4 *p, int4 v) {
 #endif
 }
 
+// One texel-gradient record of the texture bins: 24 B = three 8 B words {packed footprint, wx1} {wy1, g0} {g1, g2} at index `idx` of the
+// record array (round 6: 32 B before, two of its eight words padding -- the bin reduction runs at the rate its records stream in)
+__device__ __forceinline__ void st_record(int4 *records, unsigned long long idx, int packed, float wx1, float wy1, float g0, float g1, float g2) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i *q = (v2i *)records + idx * 3ull;
+    v2i a, b, c;
+    a.x = packed; a.y = __float_as_int(wx1); b.x = __float_as_int(wy1); b.y = __float_as_int(g0); c.x = __float_as_int(g1); c.y = __float_as_int(g2);
+#if DBW_NT_LOADS
+    __builtin_nontemporal_store(a, q); __builtin_nontemporal_store(b, q + 1); __builtin_nontemporal_store(c, q + 2);
+#else
+    q[0] = a; q[1] = b; q[2] = c;
+#endif
+}
+
 namespace {
 
 #ifndef DBW_BWD_UNROLL
@@ -401,9 +415,7 @@ __global__ __launch_bounds__(NT, (SINGLE || !FUSED ? 1 : 4)) void shade_blend_bw
                     if (rank < s_room[h]) {
                         const unsigned packed = (unsigned)(s.r0 & 31) | ((unsigned)(s.c0 & 31) << 5) | ((unsigned)(s.r0 - s.r1) << 10) |
                                                 ((unsigned)(s.c1 - s.c0) << 11);
-                        int4 *dst = A.bin_records + (long long)((unsigned)s_base[h] + (unsigned)rank) * 2;
-                        dst[0] = make_int4((int)packed, __float_as_int(s.wx1), __float_as_int(s.wy1), __float_as_int(gc[0]));
-                        dst[1] = make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0);
+                        st_record(A.bin_records, (unsigned long long)((unsigned)s_base[h] + (unsigned)rank), (int)packed, s.wx1, s.wy1, gc[0], gc[1], gc[2]);
                         pending = false;
                     }
                 }
@@ -849,11 +861,8 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
                 bool pending = tex;
                 if (tex && cres.bin >= 0) {
                     if (cres.rank < room) {
-                        int4 *dst = A.bin_records + (long long)(start + (unsigned)cres.rank) * 2;
-                        if (!(A.dbg & (1 << 17))) {                    // (1 << 17: ablation of the record stores, tools/diag)
-                            st_stream4(dst, make_int4(cres.packed, __float_as_int(cres.wx1), __float_as_int(cres.wy1), __float_as_int(gc[0])));
-                            st_stream4(dst + 1, make_int4(__float_as_int(gc[1]), __float_as_int(gc[2]), 0, 0));
-                        }
+                        if (!(A.dbg & (1 << 17)))                      // (1 << 17: ablation of the record stores, tools/diag)
+                            st_record(A.bin_records, (unsigned long long)(start + (unsigned)cres.rank), cres.packed, cres.wx1, cres.wy1, gc[0], gc[1], gc[2]);
                         pending = false;
                     }
                 }
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
                                                             const int4 *__restrict__ records, int cap, const unsigned *__restrict__ layout,
                                                             float *__restrict__ gmaps) {
     __shared__ bin_fix_t tile[33 * 33 * 3];
-    __shared__ int4 stage[BIN_STAGE * 2 + BIN_STAGE / BIN_LANE_STRIDE];   // one int4 of padding per lane stride: conflict-free reads
+    __shared__ int2 stage[BIN_STAGE * 3 + BIN_STAGE / BIN_LANE_STRIDE];   // 24 B records; one int2 of padding per lane stride: conflict-free reads
     __shared__ float s_wmax[4];
     const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG;
     int n_sub[BIN_SUB_PER_WG], total = 0;
@@ -1070,11 +1079,12 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
         for (int j = 0; j < BIN_PER_THREAD; ++j) {
             const int r = lane * BIN_LANE_STRIDE + wv * BIN_PER_THREAD + j;
             if (r >= m) continue;
-            const int4 a = stage[r * 2 + r / BIN_LANE_STRIDE], b = stage[r * 2 + r / BIN_LANE_STRIDE + 1];
+            const int so = r * 3 + r / BIN_LANE_STRIDE;
+            const int2 a = stage[so], b = stage[so + 1], c = stage[so + 2];
             const unsigned p = (unsigned)a.x;
             const int lr0 = (int)(p & 31) + 1, lc0 = (int)((p >> 5) & 31), dr = (int)((p >> 10) & 1), dc = (int)((p >> 11) & 1);
-            const float wx1 = __int_as_float(a.y), wy1 = __int_as_float(a.z);
-            const float g0 = __int_as_float(a.w), g1 = __int_as_float(b.x), g2 = __int_as_float(b.y);
+            const float wx1 = __int_as_float(a.y), wy1 = __int_as_float(b.x);
+            const float g0 = __int_as_float(b.y), g1 = __int_as_float(c.x), g2 = __int_as_float(c.y);
             const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
             const int idx[4] = {(lr0 * 33 + lc0) * 3, (lr0 * 33 + lc0 + dc) * 3, ((lr0 - dr) * 33 + lc0) * 3, ((lr0 - dr) * 33 + lc0 + dc) * 3};
@@ -1095,7 +1105,7 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
 #pragma unroll 1
     for (int g = 0; g < BIN_SUB_PER_WG; ++g) {
     const int n = n_sub[g];
-    const int4 *rec = records + (long long)first[g] * 2;
+    const int2 *rec = (const int2 *)records + (long long)first[g] * 3;
     for (int sb = 0; sb < n; sb += BIN_STAGE) {
         const int m = min(n - sb, BIN_STAGE);
         __syncthreads();                                       // previous batch consumed (first pass: tile cleared)
@@ -1122,11 +1132,11 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
         for (int it = 0; it < BIN_PER_THREAD; ++it) {
             const int r = it * 256 + threadIdx.x;
             if (r < m) {
-                const int4 a = rec[(sb + r) * 2], b = rec[(sb + r) * 2 + 1];
-                stage[r * 2 + r / BIN_LANE_STRIDE] = a;
-                stage[r * 2 + r / BIN_LANE_STRIDE + 1] = b;
+                const int2 a = rec[(sb + r) * 3], b = rec[(sb + r) * 3 + 1], c = rec[(sb + r) * 3 + 2];
+                const int so = r * 3 + r / BIN_LANE_STRIDE;
+                stage[so] = a; stage[so + 1] = b; stage[so + 2] = c;
                 // (as unsigned bit patterns: a NaN or an infinity is then the largest of all and ends up in the batch's exponent)
-                gm = __uint_as_float(max(__float_as_uint(gm), max((unsigned)a.w & 0x7fffffffu, max((unsigned)b.x & 0x7fffffffu, (unsigned)b.y & 0x7fffffffu))));
+                gm = __uint_as_float(max(__float_as_uint(gm), max((unsigned)b.y & 0x7fffffffu, max((unsigned)c.x & 0x7fffffffu, (unsigned)c.y & 0x7fffffffu))));
             }
         }
         {   // wave maximum of the bit patterns (non-negative ints order like the floats they encode)

@@ -209,7 +209,7 @@ int dbw_render_fwd_fused_mse(const float *face_verts_c, const int32_t *first_idx
  * dists only).  grad_face_verts_c (B*2F,3,3): accumulate.
  * Texture-space binning (optional; used when lds_aggregate == 0, i.e. full-resolution maps under minification, where a
  * 16x16-pixel tile shares no texels but the whole batch hits every texel ~70 times): instead of 12 scattered atomics per
- * fragment, each fragment appends one 32 B record to the bin of the 32x32-texel tile its footprint starts in
+ * fragment, each fragment appends one 24 B record (32 B until ABI 6; the buffer is sized as before, 32 B per record) to the bin of the 32x32-texel tile its footprint starts in
  * (bin = bin_base[map] + tile_y * ceil(ws/32) + tile_x; bin_cursor (nbins * DBW_BIN_SUBCURSORS) zeroed by the caller: a bin's
  * record range is split into DBW_BIN_SUBCURSORS sub-ranges of bin_cap / DBW_BIN_SUBCURSORS records with one cursor each, because
  * returning atomics on one hot address serialise; bin_records
