@@ -47,6 +47,57 @@ def csrc_sha16():
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def live_traffic(dom_label, calib, steps=5, limit_s=240):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two child processes of this bench run -- `rocprofv3 --kernel-trace
+    --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE`, one counter per pass as MI355X_MICROARCH.md prescribes, no other trace domain -- each over
+    `steps` training steps of the headline workload (tools/pmc_target.py: the same build_workload, the same one-call step; its streams wait
+    through events there, a counter pass runs one kernel at a time).  Median over the kernel's dispatches of the sum over the counter's
+    instances, x the byte-counter factors `calib` ({fetch, write}: known bytes / reported bytes for 4 B-per-lane plane traffic, measured with
+    tools/ubench/plane_rw.hip next to the committed counters; 2.0 / 1.0 = the guide's gfx950 correction).  Returns (bytes or None, note)."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    rp = shutil.which('rocprofv3') or next((p for p in ('/opt/rocm/bin/rocprofv3',) if os.path.exists(p)), None)
+    if rp is None:
+        return None, 'rocprofv3 not found'
+    want = next((v for k, v in (('render_fwd_fused K=1 ', 'render_fwd_kernel<1,'), ('render_fwd_fused', 'render_fwd_kernel<'), ('render_bwd_fused K=1 ', 'render_bwd_hard_kernel'),
+                                ('render_bwd_fused', 'render_bwd_uv_kernel')) if dom_label.startswith(k)), None)
+    if want is None:
+        return None, f'no kernel name known for {dom_label}'
+    kb = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='dbw_pmc_', dir='/tmp')
+        env = dict(os.environ, DBW_STEP_EVENTS='1', DBW_EPOCH='0', DBW_STEPS=str(steps), TMPDIR='/tmp')
+        for k in ('DBW_DEBUG_FLAGS', 'DBW_RENDER_VARIANT', 'DBW_PMC_EMPTY', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k, None)
+        try:
+            proc = subprocess.Popen([rp, '--kernel-trace', '--pmc', ctr, '-d', d, '-o', 'p', '--output-format', 'csv', '--', sys.executable,
+                                     os.path.join(ROOT, 'tools', 'pmc_target.py')], env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # (the process group this call started, nothing else)
+                proc.wait()
+                return None, f'the {ctr} pass did not finish within {limit_s} s'
+            if rc != 0:
+                return None, f'the {ctr} pass exited with {rc}'
+            per = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f, encoding='utf-8', errors='replace')):
+                    if want in r['Kernel_Name'] and r['Counter_Name'] == ctr:
+                        per[r['Dispatch_Id']] = per.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+            if not per:
+                return None, f'the {ctr} pass reported no dispatch of {want}'
+            kb[ctr] = sorted(per.values())[len(per) // 2]
+        except (OSError, ValueError, KeyError) as e:
+            return None, f'the {ctr} pass failed: {e!r}'
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = int((calib['fetch'] * kb['FETCH_SIZE'] + calib['write'] * kb['WRITE_SIZE']) * 1024)          # (the counters are in KB)
+    return nbytes, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over {steps} steps of this workload in child '
+                    f'processes, median per launch of {want}...; FETCH_SIZE {kb["FETCH_SIZE"] / 1024:.1f} MB x {calib["fetch"]:.3f} + WRITE_SIZE '
+                    f'{kb["WRITE_SIZE"] / 1024:.1f} MB x {calib["write"]:.3f}')
+
+
 def make_cfg(n_blocks, fpp, ts):
     return {'model': {'name': 'dbw',
                       'mesh': {'n_blocks': n_blocks, 'S_world': 0.5, 'R_world': [115, 0, 0], 'txt_size': ts},
@@ -361,6 +412,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the measurements reported next to the headline at N = 1: the reference\'s own '
                     'operating point (batch 4, loss values read every step), BASELINE configs 4 and 5 (per-GPU share) and the sustained run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live-counters', action='store_true', help='do not collect roofline.traffic in this run (two rocprofv3 --pmc child processes, '
+                    '~1 min at N = 1 on the headline workload): report the committed counters only')
     ap.add_argument('--backward-order', choices=['auto', 'sequential', 'concurrent'], default='auto', help='debug: the two backward kernels')
     ap.add_argument('--no-side-priority', action='store_true', help='debug: the side stream of the native step at normal priority')
     ap.add_argument('--no-overlap', action='store_true', help='everything in order on ONE stream: every kernel alone on the GPU (per-kernel averages of a '
@@ -585,7 +638,21 @@ def main():
                 else:       # counters of another build of the kernels say nothing about this one
                     counters_note = f'profiles/{PMC_FILE} was collected on csrc {pmc.get("_csrc_sha16")}, this library is built from {sha}: not reported'
         except (OSError, ValueError, KeyError):
-            pass
+            pmc = {}
+        # ... and the HBM bytes measured live, in child processes of this run (N = 1, headline workload; --no-live-counters: the committed value only)
+        traffic_source = None if traffic is None else f'profiles/{PMC_FILE} (committed; keyed on csrc_sha16)'
+        default_workload = inp['R'].shape[0] == 49 and (args.H, args.W, args.fpp, args.blocks, args.txt, args.epoch) == (300, 400, 10, 10, 256, 0)
+        profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)       # (no profiler inside a profiler)
+        if world == 1 and default_workload and not (args.no_live_counters or args.no_extras or profiled) and step.cstep is not None:
+            cal = pmc.get('_calibration') if isinstance(pmc, dict) else None
+            cal = {'fetch': float(cal['fetch']), 'write': float(cal['write'])} if cal and 'fetch' in cal and 'write' in cal else {'fetch': 2.0, 'write': 1.0}
+            torch.cuda.synchronize()
+            live, note = live_traffic(dom, cal)
+            if live is not None:
+                committed = traffic
+                traffic, traffic_source = live, note + ('' if committed is None else f'; the committed passes (profiles/{PMC_FILE}) read {committed} B')
+            else:
+                traffic_source = (traffic_source or 'none') + f' (live collection: {note})'
         local_views = inp['R'].shape[0]
         out = {
             'metric': 'rendered views/sec (fwd+bwd) per node, DTU 400x300 K=10 blocks', 'value': views_per_s, 'unit': 'views/s',
@@ -612,6 +679,7 @@ def main():
                        'nranks': dist.get_world_size() if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_frac': None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'traffic_source': traffic_source,
                          'avg_ms_per_launch': ms, 'algorithmic_bytes_per_launch': nbytes,
                          # frac: the kernel alone on the GPU, launched by the step itself in order on one stream (HIP events recorded by the
                          # step); frac_in_step: the same launch where it really runs, sharing the GPU with the env backward chain and the

@@ -26,6 +26,17 @@ int dbw_fill_shade_args(ShadeArgs &A, const int32_t *pix_to_face, const float *b
                         const int32_t *face_map, const int32_t *map_desc, const float *maps, const float *faces_alpha,
                         int alpha_len, int N, int H, int W, int K, int F, float sigma, const float *background3);
 
+#ifdef DBW_TILE_CLOCK
+// tools-only (tools/diag/r06_spike4.py): when every workgroup of the fused forward finished, and on which tile -- {view, tile row << 16 |
+// tile column, low 32 bits of the 100 MHz wall clock at its end, the same at its start} per workgroup of the last launch (the start stamp
+// goes to memory at once: kept in registers across the kernel it costs the scalar registers the env layer's record loads need, and the
+// backend fails on them)
+namespace dbw { __device__ unsigned g_tile_clock[1 << 18][4]; }
+extern "C" void dbw_debug_read_tile_clock(unsigned *out, int nblocks) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dbw::g_tile_clock), (size_t)(nblocks < (1 << 18) ? nblocks : (1 << 18)) * 16);
+}
+#endif
 #ifdef DBW_PROFILE_FWD
 // sums the per-workgroup records into out16 (host) and optionally clears them
 extern "C" void dbw_debug_read_fwd_profile(unsigned long long *out16, int reset) {
@@ -520,9 +531,12 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     pay4 *home;
     FPROF_T(t_k0);
     FPROF_ADD(13, wall_clock64());            // (100 MHz, common to the XCDs: the wave's place on the kernel's time line)
+#ifdef DBW_TILE_CLOCK
+    if (KMAX > 1 && blockIdx.x < (1u << 18)) g_tile_clock[blockIdx.x][3] = (unsigned)wall_clock64();       // (start stamp: to memory at once, by every lane -- no divergent branch in front of the record loads)
+#endif
     bool empty = false;
     float env_rgb[3] = {0.f, 0.f, 0.f};
-#ifdef DBW_PROFILE_FWD
+#if defined(DBW_PROFILE_FWD) || defined(DBW_TILE_CLOCK)
     constexpr bool fold = false;        // (the cycle-accounting build measures the pass without the folded env layer: with the counters'
     (void)E;                            // extra control flow around the record loads the backend fails on the second evaluation site)
 #else
@@ -548,6 +562,12 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
     FPROF_ADD(2, t_k2 - t_k1);
     FPROF_ADD(3, t_k2 - t_k0);
     FPROF_ADD(14, wall_clock64());
+#ifdef DBW_TILE_CLOCK
+    if (KMAX > 1 && threadIdx.x == 0 && blockIdx.x < (1u << 18)) {
+        unsigned *o = g_tile_clock[blockIdx.x];
+        o[0] = (unsigned)n; o[1] = ((unsigned)(yi >> 3) << 16) | (unsigned)(xi >> 3); o[2] = (unsigned)wall_clock64();
+    }
+#endif
 }
 
 template <int KMAX, int TW, int TH, int GROUP, bool UV, bool KEX = false>

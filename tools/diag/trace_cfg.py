@@ -10,7 +10,7 @@ dev = torch.device('cuda', 0)
 model, inp = bench.build_workload(args, dev)
 model.sync_free = True
 model.set_cur_epoch(int(os.environ.get("DBW_EPOCH", "0")))
-step = ShardedTrainStep(model, seed=1)
+step = ShardedTrainStep(model, seed=int(os.environ.get('DBW_SEED', '1')))          # (bench.py: 227391)
 reads = os.environ.get("DBW_READS", "0") != "0"          # the host reads the loss values of every step (src/trainer.py:143)
 if step.cstep is not None:
     step.cstep.read_losses = reads
