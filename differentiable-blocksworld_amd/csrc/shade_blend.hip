@@ -640,6 +640,14 @@ constexpr int TEX_MERGE = DBW_TEX_MERGE, FACE_MERGE = DBW_FACE_MERGE;
 #define DBW_UVB_WAVES 4      // (the binned instantiation keeps two layers of fragments + one of vertices in flight: 4 waves of 128 VGPRs, no spills --
                              // a spill reload in the layer loop is a vmcnt(0); 4 / 5 / 6 waves per SIMD measured alike before)
 #endif
+#ifdef DBW_TILE_CLOCK
+// tools-only (tools/diag/r06_bwd_clock.py): {view, layers of the workgroup's first wave (-1: left at the first barrier), end stamp, start
+// stamp (low 32 bits of the 100 MHz wall clock)} per workgroup of the last launch of the uv backward
+__device__ unsigned g_bwd_clock[1 << 16][4];
+#define BWD_CLOCK_END(n_, layers_) { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { unsigned *o_ = g_bwd_clock[blockIdx.x]; o_[0] = (unsigned)(n_); o_[1] = (unsigned)(layers_); o_[2] = (unsigned)wall_clock64(); } }
+#else
+#define BWD_CLOCK_END(n_, layers_)
+#endif
 template <bool BINNED>
 __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_uv_kernel(ShadeArgs A, long long total_blocks, const float *__restrict__ gimg,
                                                               float *__restrict__ gmaps, float *__restrict__ galpha,
@@ -650,6 +658,9 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     TexAgg tex_agg;
     FaceAlphaAgg fa_agg;
     if (A.sync_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.sync_flag, A.sync_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DBW_TILE_CLOCK
+    if (blockIdx.x < (1u << 16)) { g_bwd_clock[blockIdx.x][3] = (unsigned)wall_clock64(); g_bwd_clock[blockIdx.x][2] = 0u; }
+#endif
     int n, xi, yi;
     if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
     const bool in_img = xi < A.W && yi < A.H;
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     const bool alpha_direct = galpha && A.faces_alpha && A.alpha_len < 0 && n_maps <= ALPHA_DIRECT_MAPS;
     if (alpha_direct)
         for (int i = threadIdx.x; i < n_maps * ALPHA_DIRECT_SPREAD; i += NT) alpha_dir[i] = 0.0;
-    if (!__syncthreads_or(cnt > 0)) return;
+    if (!__syncthreads_or(cnt > 0)) { BWD_CLOCK_END(n, -1); return; }
     f2 pndc;
     pndc.x = pix_to_ndc(A.W - 1 - xi, A.W, A.H);
     pndc.y = pix_to_ndc(A.H - 1 - yi, A.H, A.W);
@@ -1008,6 +1019,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     PROF_T(t_fl);
     PROF_ADD(1, t_sync, t_fl);                 // (flushes)
     PROF_ADD(7, t_begin, t_fl);
+    BWD_CLOCK_END(n, kmax);
 }
 
 // One workgroup per (texture bin, BIN_SUB_PER_WG of its record sub-ranges): accumulate the records into a (32+1)x(32+1) texel LDS tile
@@ -1446,6 +1458,13 @@ extern "C" int dbw_render_bwd_fused(const int32_t *pix_to_face, const float *bar
                                         grad_face_verts_c, lds_aggregate, frag_layout, bin_base, bin_cursor, bin_records, bin_cap, bin_layout, const_geometry_faces,
                                         grad_scale, image_layout, stream, nullptr, 0);
 }
+
+#ifdef DBW_TILE_CLOCK
+extern "C" void dbw_debug_read_bwd_clock(unsigned *out, int nblocks) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_clock), (size_t)(nblocks < (1 << 16) ? nblocks : (1 << 16)) * 16);
+}
+#endif
 
 extern "C" int dbw_texbin_reduce(const int32_t *bin_info, const int32_t *bin_cursor, const void *bin_records, int bin_cap,
                                  const uint32_t *bin_layout, int nbins, float *grad_maps, dbw_stream_t stream) {

@@ -95,6 +95,16 @@ for name, i in (('fast', fast_i), ('slow', slow_i)):
         print('   segment %d end stamps: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f us; finishing after 300 us: %d workgroups, list lengths mean %.1f max %d; '
               'completions per 50 us: %s' % (x, *(np.percentile(e_, q) for q in (10, 50, 90, 99)), e_.max(), int(late.sum()), c_[late].mean() if late.any() else 0,
                                              c_[late].max() if late.any() else 0, ' '.join(str(int(((e_ >= a0) & (e_ < a0 + 50)).sum())) for a0 in range(0, 800, 50))))
+    m0 = (tid >= 0) & (tid < per)
+    st0, en0, c0 = (t[m0, 3].astype(np.int64) - t0) / 100.0, end[m0] / 100.0, cell[tid[m0], 1]
+    print('   segment 0, workgroups in flight every 10 us:', ' '.join(str(int(((st0 <= a0) & (en0 > a0)).sum())) for a0 in range(0, int(en0.max()) + 10, 10)))
+    lastw = en0 > en0.max() - 30
+    print('   segment 0, workgroups finishing in its last 30 us: %d, list lengths: %s; their run times p50 %.1f p90 %.1f max %.1f us' %
+          (int(lastw.sum()), np.bincount(np.clip(c0[lastw], 0, 40)).tolist(), *(np.percentile((en0 - st0)[lastw], q) for q in (50, 90, 100))))
+    for lo_, hi_ in ((0, 0), (1, 3), (4, 7), (8, 15), (16, 31), (32, 63), (64, 999)):
+        mm = (c0 >= lo_) & (c0 <= hi_)
+        if mm.any(): print('      lists of %d-%d faces: %d tiles, run time p50 %.1f p90 %.1f us, started p50 %.1f p90 %.1f us' %
+                           (lo_, hi_, int(mm.sum()), *(np.percentile((en0 - st0)[mm], q) for q in (50, 90)), *(np.percentile(st0[mm], q) for q in (50, 90))))
     for j in order[-8:][::-1]:
         n, rc = int(t[j, 0]), int(t[j, 1])
         row, col = rc >> 16, rc & 0xffff
