@@ -71,28 +71,9 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
     int r = kr & ((1 << WORK_RANK_BITS) - 1), O = 0;
 #pragma unroll
     for (int c = 0; c < WORK_CLASSES - 1; ++c) { const int h = hdr[1 + x * 16 + c]; if (c < k) r += h; O += h; }
-    const int E = len - O;
-    unsigned p;
-    const bool small = (unsigned long long)len * (unsigned long long)(len + 1) < (1ull << 32);
-    if (k < WORK_CLASSES - 1) {        // the r-th of O slots spread evenly over the segment
-        if (small) p = ((unsigned)(r + 1) * (unsigned)len + (unsigned)O - 1u) / (unsigned)O - 1u;
-        else p = (unsigned)((((unsigned long long)(r + 1)) * (unsigned long long)len + (unsigned long long)O - 1ull) / (unsigned long long)O - 1ull);
-    } else {                           // the rank-th position that is not a slot (rank among the empty tiles: r - O)
-        const int e = r - O;
-        if (small) p = ((unsigned)e * (unsigned)len) / (unsigned)E;
-        else p = (unsigned)(((unsigned long long)e * (unsigned long long)len) / (unsigned long long)E);
-    }
-    // ... and the positions of every window of 64 bit-reversed inside the window.  Evenly spaced slots are PERIODIC, and the hardware hands
-    // the workgroups of an XCD to its SIMDs in launch order, round robin: with one tile in four occupied -- config 2 -- the slots of a
-    // segment sit at positions 4 r + 3, every occupied tile of the segment lands on the same SIMD of its CU, that SIMD fills up (five waves),
-    // the in-order dispatcher waits for it and the other three SIMDs idle: measured (tools/diag/r06_spike4.py) 144 workgroups in flight on
-    // that XCD instead of 550, the pass 0.78 instead of 0.27 ms in the scene states where len / O of a segment came within 1e-3 of 4, and
-    // 15-20 % on the slowest segment whenever it was within a few percent.  The bit reversal maps a stride-2^k comb onto a run of
-    // consecutive positions (which round robin spreads over the SIMDs) and leaves the mix of light and heavy tiles what it was at the
-    // scale of the ~550 workgroups an XCD holds at a time
-    // -- and XORed with a hash of the window's number, so that the runs do not sit at the same offset of every window either (a period of 64
-    // or 128 positions would line up with 32 CUs x 4 SIMDs the same way)
-    if (p < ((unsigned)len & ~63u)) p = (p & ~63u) | ((__brev(p & 63u) >> 26) ^ (((p >> 6) * 2654435761u) >> 26));
+    // (raster_math.h: work_position -- the occupied tiles spread evenly between the empty ones, then scrambled inside windows of 64: an even
+    // comb lines up with the hardware's round robin over the SIMDs)
+    const unsigned p = k < WORK_CLASSES - 1 ? work_position(true, r, O, len) : work_position(false, r - O, O, len);
     const int n = (int)(L / per_view), t = (int)(L - (long long)n * per_view), ty = t / tiles_x;
     work[seg0 + p] = make_int2(n, (ty << 16) | (t - ty * tiles_x));
 }

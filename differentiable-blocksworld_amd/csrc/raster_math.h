@@ -310,6 +310,49 @@ DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, 
     return true;
 }
 
+// ---- launch order of a pass's tiles ------------------------------------------------------------------------------------------------
+// Position, inside its XCD segment of `len` tiles, of the tile with rank r among the segment's O OCCUPIED tiles (ordered by face-count
+// class, heaviest first) or, occupied == false, among its len - O EMPTY ones (raster_bin.h: the ranks; raster.hip: work_scatter_kernel).
+//   1. The occupied tiles are spread evenly -- slot r at ceil((r + 1) len / O) - 1 -- and the empty ones fill what is left, the e-th at
+//      floor(e len / (len - O)): the two sets partition [0, len) (the empty tiles' loss epilogue is pure memory traffic, which hides
+//      behind the arithmetic of the occupied ones instead of piling up at the end).
+//   2. The positions inside every window of 64 are then bit-reversed and XORed with a hash of the window's number.  Evenly spaced slots are
+//      PERIODIC, and the hardware hands the workgroups of an XCD to its SIMDs in launch order, round robin: with one tile in four
+//      occupied -- config 2 -- the slots sit at positions 4 r + 3, every occupied tile of the segment lands on the same SIMD of its CU,
+//      that SIMD fills up (five waves), the in-order dispatcher waits for it and the other three SIMDs idle.  Measured
+//      (profiles/r06_experiments.md): 144 workgroups in flight on that XCD instead of 550, the pass 0.78 instead of 0.27 ms in the
+//      scene states where len / O came within 1e-3 of 4, 15-20 % on the slowest segment within a few percent of it.  The bit reversal
+//      maps a stride-2^k comb onto a run of consecutive positions (which round robin spreads over the SIMDs), the hash moves the run
+//      from window to window, and the mix of light and heavy tiles stays what it was at the scale of the ~550 workgroups an XCD holds.
+//      A bijection of every full window; the last, partial window keeps step 1's positions.
+constexpr unsigned WORK_WINDOW_LOG2 = 6;
+DBW_HD unsigned bit_reverse32(unsigned x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+#endif
+}
+DBW_HD unsigned work_position(bool occupied, int r, int O, int len) {
+    unsigned p;
+    const bool small = (unsigned long long)len * (unsigned long long)(len + 1) < (1ull << 32);
+    if (occupied) {
+        if (small) p = ((unsigned)(r + 1) * (unsigned)len + (unsigned)O - 1u) / (unsigned)O - 1u;
+        else p = (unsigned)((((unsigned long long)(r + 1)) * (unsigned long long)len + (unsigned long long)O - 1ull) / (unsigned long long)O - 1ull);
+    } else {
+        const int E = len - O;
+        if (small) p = ((unsigned)r * (unsigned)len) / (unsigned)E;
+        else p = (unsigned)(((unsigned long long)r * (unsigned long long)len) / (unsigned long long)E);
+    }
+    constexpr unsigned WL = WORK_WINDOW_LOG2, WM = (1u << WL) - 1u;
+    if (p < ((unsigned)len & ~WM)) p = (p & ~WM) | ((bit_reverse32(p & WM) >> (32 - WL)) ^ (((p >> WL) * 2654435761u) >> (32 - WL)));
+    return p;
+}
+
 // ---- per-pixel top-K list --------------------------------------------------------------------------------------------------------
 // key = depth bits (32) | packed face id (27) | payload slot (5): unsigned 64-bit order == the oracle's (pz, face id) tuple order
 // for pz >= +0 (pz < 0 is rejected; -0 is canonicalised to +0).  Empty entries are sentinels (all ones above the slot field) that

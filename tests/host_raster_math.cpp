@@ -117,3 +117,10 @@ extern "C" long long host_divcheck(const float *n, const float *d, long long cou
     }
     return bad;
 }
+
+// the launch positions of an XCD segment of `len` tiles of which O are occupied (work_position, what work_scatter_kernel computes per tile):
+// pos[0 .. O) = the occupied tiles by rank, pos[O .. len) = the empty ones by rank
+extern "C" void host_work_positions(int len, int O, int32_t *pos) {
+    for (int r = 0; r < O; ++r) pos[r] = (int32_t)work_position(true, r, O, len);
+    for (int e = 0; e < len - O; ++e) pos[O + e] = (int32_t)work_position(false, e, O, len);
+}

@@ -208,3 +208,35 @@ def test_host_build_reproduces_the_frozen_tiny_scenes(golden_dir, name):
         (p2f, zbuf, bary, dists), _ = host_rasterize(fv, first, num, nbr, size, blur, K, fastdiv=fastdiv)
         for got, key in ((p2f, 'p2f'), (zbuf, 'zbuf'), (bary, 'bary'), (dists, 'dists')):
             assert torch.equal(got, g[f'{name}/{key}']), (key, fastdiv)
+
+
+def _work_positions(length, occupied):
+    pos = np.empty(length, dtype=np.int32)
+    lib().host_work_positions(int(length), int(occupied), ctypes.c_void_p(pos.ctypes.data))
+    return pos
+
+
+def test_launch_order_is_a_permutation_of_every_segment():
+    """work_position (raster_math.h, what work_scatter_kernel evaluates per tile): the occupied and the empty tiles of a segment take every
+    position exactly once -- whole windows of 64, a partial last window, segments shorter than a window, all or none occupied."""
+    rng = np.random.default_rng(3)
+    cases = [(1, 0), (1, 1), (5, 2), (63, 20), (64, 16), (65, 1), (200, 199), (11638, 2909), (11638, 2902), (11634, 2693), (101250, 30000)]
+    cases += [(int(n), int(rng.integers(0, n + 1))) for n in rng.integers(1, 5000, size=40)]
+    for length, occ in cases:
+        pos = _work_positions(length, occ)
+        assert np.array_equal(np.sort(pos), np.arange(length)), (length, occ)
+
+
+def test_launch_order_keeps_heavy_tiles_first_and_has_no_comb():
+    """Heaviest first at the scale of the scramble's windows; and the reason for the scramble: with one tile in 2, 3, 4, 8 or 16 occupied --
+    exactly, or to within one tile -- the occupied tiles' positions fall evenly into the residues modulo 2 ... 128 (an even comb put all
+    of them into ONE residue modulo 4: every occupied tile on the same SIMD of its CU, profiles/r06_experiments.md)."""
+    for length in (11638, 11634, 32400, 4096):
+        for ratio in (2, 3, 4, 8, 16):
+            for occ in (length // ratio - 1, length // ratio, length // ratio + 1):
+                pos = _work_positions(length, occ)[:occ]
+                assert np.all(np.diff(pos // 64) >= 0), 'the windows follow the ranks'
+                for m in (2, 4, 8, 16, 32, 128):
+                    share = np.bincount(pos % m, minlength=m) / occ
+                    slack = max(0.5 / m, 4.0 * math.sqrt(1.0 / (m * occ)))       # (half the even share, or four sigma of a random draw)
+                    assert np.abs(share - 1.0 / m).max() <= slack, (length, occ, m, share)
