@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void work_scatter_kernel(const int2 *__restric
 #pragma unroll
     for (int c = 0; c < WORK_CLASSES - 1; ++c) { const int h = hdr[1 + x * 16 + c]; if (c < k) r += h; O += h; }
     // (raster_math.h: work_position -- the occupied tiles spread evenly between the empty ones, then scrambled inside windows of 64: an even
-    // comb lines up with the hardware's round robin over the SIMDs)
+    // comb lines up with the hardware's round robin over the shader engines)
     const unsigned p = k < WORK_CLASSES - 1 ? work_position(true, r, O, len) : work_position(false, r - O, O, len);
     const int n = (int)(L / per_view), t = (int)(L - (long long)n * per_view), ty = t / tiles_x;
     work[seg0 + p] = make_int2(n, (ty << 16) | (t - ty * tiles_x));

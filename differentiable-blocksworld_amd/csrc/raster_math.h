@@ -317,12 +317,12 @@ DBW_HD bool eval_pair(const FaceRec &r, f2 p, float blur, int persp, int clipb, 
 //      floor(e len / (len - O)): the two sets partition [0, len) (the empty tiles' loss epilogue is pure memory traffic, which hides
 //      behind the arithmetic of the occupied ones instead of piling up at the end).
 //   2. The positions inside every window of 64 are then bit-reversed and XORed with a hash of the window's number.  Evenly spaced slots are
-//      PERIODIC, and the hardware hands the workgroups of an XCD to its SIMDs in launch order, round robin: with one tile in four
-//      occupied -- config 2 -- the slots sit at positions 4 r + 3, every occupied tile of the segment lands on the same SIMD of its CU,
-//      that SIMD fills up (five waves), the in-order dispatcher waits for it and the other three SIMDs idle.  Measured
+//      PERIODIC, and the hardware deals the workgroups of an XCD to its four shader engines in launch order, round robin: with one tile in four
+//      occupied -- config 2 -- the slots sit at positions 4 r + 3, every occupied tile of the segment lands on the same shader engine,
+//      that engine's 8 CUs fill up (five waves per SIMD), the in-order dispatcher waits for them and the other three engines idle.  Measured
 //      (profiles/r06_experiments.md): 144 workgroups in flight on that XCD instead of 550, the pass 0.78 instead of 0.27 ms in the
 //      scene states where len / O came within 1e-3 of 4, 15-20 % on the slowest segment within a few percent of it.  The bit reversal
-//      maps a stride-2^k comb onto a run of consecutive positions (which round robin spreads over the SIMDs), the hash moves the run
+//      maps a stride-2^k comb onto a run of consecutive positions (which round robin spreads over the engines), the hash moves the run
 //      from window to window, and the mix of light and heavy tiles stays what it was at the scale of the ~550 workgroups an XCD holds.
 //      A bijection of every full window; the last, partial window keeps step 1's positions.
 constexpr unsigned WORK_WINDOW_LOG2 = 6;
@@ -349,7 +349,9 @@ DBW_HD unsigned work_position(bool occupied, int r, int O, int len) {
         else p = (unsigned)(((unsigned long long)r * (unsigned long long)len) / (unsigned long long)E);
     }
     constexpr unsigned WL = WORK_WINDOW_LOG2, WM = (1u << WL) - 1u;
+#ifndef DBW_WORK_NO_SCRAMBLE      // (tools/diag/r06_spike4.py: the comb itself, to see where the hardware puts it)
     if (p < ((unsigned)len & ~WM)) p = (p & ~WM) | ((bit_reverse32(p & WM) >> (32 - WL)) ^ (((p >> WL) * 2654435761u) >> (32 - WL)));
+#endif
     return p;
 }
 

@@ -565,7 +565,8 @@ __global__ __launch_bounds__(TW * TH, DBW_RENDER_WAVES(KMAX, UV)) void render_fw
 #ifdef DBW_TILE_CLOCK
     if (KMAX > 1 && threadIdx.x == 0 && blockIdx.x < (1u << 18)) {
         unsigned *o = g_tile_clock[blockIdx.x];
-        o[0] = (unsigned)n; o[1] = ((unsigned)(yi >> 3) << 16) | (unsigned)(xi >> 3); o[2] = (unsigned)wall_clock64();
+        // (HW_REG_HW_ID of gfx9: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], shader array [12], shader engine [15:13])
+        o[0] = (unsigned)n | ((__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffffu) << 16); o[1] = ((unsigned)(yi >> 3) << 16) | (unsigned)(xi >> 3); o[2] = (unsigned)wall_clock64();
     }
 #endif
 }

@@ -1052,7 +1052,13 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
     __shared__ bin_fix_t tile[33 * 33 * 3];
     __shared__ int2 stage[BIN_STAGE * 3 + BIN_STAGE / BIN_LANE_STRIDE];   // 24 B records; one int2 of padding per lane stride: conflict-free reads
     __shared__ float s_wmax[4];
+#ifdef DBW_REDUCE_SCRAMBLE        // (experiment: consecutive workgroups are dealt round robin to the shader engines -- do the hot bins form a comb?)
+    const unsigned bx = blockIdx.x, nb_ = gridDim.x;
+    const int bin = bx < (nb_ & ~63u) ? (int)((bx & ~63u) | ((__brev(bx & 63u) >> 26) ^ (((bx >> 6) * 2654435761u) >> 26))) : (int)bx;
+    const int sub0 = blockIdx.y * BIN_SUB_PER_WG;
+#else
     const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG;
+#endif
     int n_sub[BIN_SUB_PER_WG], total = 0;
     unsigned first[BIN_SUB_PER_WG];
 #pragma unroll

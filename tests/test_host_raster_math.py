@@ -230,7 +230,7 @@ def test_launch_order_is_a_permutation_of_every_segment():
 def test_launch_order_keeps_heavy_tiles_first_and_has_no_comb():
     """Heaviest first at the scale of the scramble's windows; and the reason for the scramble: with one tile in 2, 3, 4, 8 or 16 occupied --
     exactly, or to within one tile -- the occupied tiles' positions fall evenly into the residues modulo 2 ... 128 (an even comb put all
-    of them into ONE residue modulo 4: every occupied tile on the same SIMD of its CU, profiles/r06_experiments.md)."""
+    of them into ONE residue modulo 4 at a time: every occupied tile on the same shader engine of its XCD, profiles/r06_experiments.md)."""
     for length in (11638, 11634, 32400, 4096):
         for ratio in (2, 3, 4, 8, 16):
             for occ in (length // ratio - 1, length // ratio, length // ratio + 1):

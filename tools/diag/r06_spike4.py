@@ -50,8 +50,10 @@ for name, i in (('fast', fast_i), ('slow', slow_i)):
     buf = (ctypes.c_uint * (NB * 4))()
     lib.dbw_debug_read_tile_clock(buf, NB)
     t = np.frombuffer(buf, dtype=np.uint32).reshape(NB, 4)
-    t = t[:dbw_blocks]
+    t = t[:dbw_blocks].copy()
     t = t[t[:, 2] != 0]
+    hwid = t[:, 0] >> 16          # HW_REG_HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], shader array [12], shader engine [15:13]
+    t[:, 0] &= 0xffff
     t0 = int(t[:, 3].astype(np.int64).min())
     end = t[:, 2].astype(np.int64) - t0
     dur = (t[:, 2].astype(np.int64) - t[:, 3].astype(np.int64))
@@ -105,6 +107,13 @@ for name, i in (('fast', fast_i), ('slow', slow_i)):
         mm = (c0 >= lo_) & (c0 <= hi_)
         if mm.any(): print('      lists of %d-%d faces: %d tiles, run time p50 %.1f p90 %.1f us, started p50 %.1f p90 %.1f us' %
                            (lo_, hi_, int(mm.sum()), *(np.percentile((en0 - st0)[mm], q) for q in (50, 90)), *(np.percentile(st0[mm], q) for q in (50, 90))))
+    for x in range(8):          # where the hardware put the occupied and the empty tiles of a segment
+        m = (tid >= x * per) & (tid < (x + 1) * per)
+        oc = m & (cell[tid, 1] > 0)
+        em = m & (cell[tid, 1] == 0)
+        f = lambda sel, sh, bits: np.bincount((hwid[sel] >> sh) & ((1 << bits) - 1), minlength=1 << bits).tolist()
+        print('   segment %d: occupied tiles by SIMD %s, by shader engine %s, by CU %s | empty tiles by SIMD %s, by shader engine %s' %
+              (x, f(oc, 4, 2), f(oc, 13, 3), f(oc, 8, 4), f(em, 4, 2), f(em, 13, 3)))
     for j in order[-8:][::-1]:
         n, rc = int(t[j, 0]), int(t[j, 1])
         row, col = rc >> 16, rc & 0xffff
