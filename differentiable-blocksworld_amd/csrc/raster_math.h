@@ -337,6 +337,16 @@ DBW_HD unsigned bit_reverse32(unsigned x) {
     return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
 #endif
 }
+// step 2 on its own: position p of a list of `len` -> its place after the scramble (a bijection of [0, len)).  Also the order in which
+// texbin_reduce_kernel takes the texture bins: neighbouring bins differ by orders of magnitude in records, and hot bins at a regular
+// stride are the same comb (shade_blend.hip)
+DBW_HD unsigned window_scramble(unsigned p, unsigned len) {
+    constexpr unsigned WL = WORK_WINDOW_LOG2, WM = (1u << WL) - 1u;
+#ifndef DBW_WORK_NO_SCRAMBLE      // (tools/diag/r06_spike4.py: the comb itself, to see where the hardware puts it)
+    if (p < (len & ~WM)) p = (p & ~WM) | ((bit_reverse32(p & WM) >> (32 - WL)) ^ (((p >> WL) * 2654435761u) >> (32 - WL)));
+#endif
+    return p;
+}
 DBW_HD unsigned work_position(bool occupied, int r, int O, int len) {
     unsigned p;
     const bool small = (unsigned long long)len * (unsigned long long)(len + 1) < (1ull << 32);
@@ -348,11 +358,7 @@ DBW_HD unsigned work_position(bool occupied, int r, int O, int len) {
         if (small) p = ((unsigned)r * (unsigned)len) / (unsigned)E;
         else p = (unsigned)(((unsigned long long)r * (unsigned long long)len) / (unsigned long long)E);
     }
-    constexpr unsigned WL = WORK_WINDOW_LOG2, WM = (1u << WL) - 1u;
-#ifndef DBW_WORK_NO_SCRAMBLE      // (tools/diag/r06_spike4.py: the comb itself, to see where the hardware puts it)
-    if (p < ((unsigned)len & ~WM)) p = (p & ~WM) | ((bit_reverse32(p & WM) >> (32 - WL)) ^ (((p >> WL) * 2654435761u) >> (32 - WL)));
-#endif
-    return p;
+    return window_scramble(p, (unsigned)len);
 }
 
 // ---- per-pixel top-K list --------------------------------------------------------------------------------------------------------

@@ -1057,7 +1057,10 @@ __global__ __launch_bounds__(256) void texbin_reduce_kernel(const int *__restric
     const int bin = bx < (nb_ & ~63u) ? (int)((bx & ~63u) | ((__brev(bx & 63u) >> 26) ^ (((bx >> 6) * 2654435761u) >> 26))) : (int)bx;
     const int sub0 = blockIdx.y * BIN_SUB_PER_WG;
 #else
-    const int bin = blockIdx.x, sub0 = blockIdx.y * BIN_SUB_PER_WG;
+    // (the bins in scrambled order, raster_math.h: window_scramble -- consecutive workgroups are dealt to the XCD's shader engines round robin,
+    // a bin holds anything between no record and tens of thousands, and hot bins at a regular stride of the bin table piled up on one
+    // engine: 128 -> 114 us at config 2, config 5's full-resolution step 22.05 -> 20.75 ms; profiles/r06_experiments.md)
+    const int bin = (int)window_scramble(blockIdx.x, gridDim.x), sub0 = blockIdx.y * BIN_SUB_PER_WG;
 #endif
     int n_sub[BIN_SUB_PER_WG], total = 0;
     unsigned first[BIN_SUB_PER_WG];
