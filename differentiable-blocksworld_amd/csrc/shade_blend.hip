@@ -69,9 +69,32 @@ namespace {
 constexpr int NT = 256;
 constexpr int TILE = 16;
 
+// The uv backward of the training step takes its blocks INTERLEAVED over the XCDs in chunks of BWD_CHUNK (every XCD works on a share of
+// every view) instead of one contiguous range of views per XCD: a backward workgroup streams its own fragments, nothing in an XCD's L2 is
+// worth keeping between workgroups, and with contiguous ranges the XCDs finished 10 % apart (the views differ in coverage; the kernel
+// ends with its slowest XCD).  Measured, alternating on one box: the kernel next to the env backward 0.431 -> 0.421 ms, the step 0.878-0.883
+// -> 0.865-0.866 ms at epoch 0 (chunks of 1, 4, 8, 32 alike, 128 no gain); nothing either way at epoch 800 or for the env backward, whose
+// blocks all cost the same.  Grid: bwd_interleave_grid(total) workgroups (the padding ones leave at once)
+#ifndef DBW_BWD_CHUNK
+#define DBW_BWD_CHUNK 8
+#endif
+constexpr int BWD_CHUNK = DBW_BWD_CHUNK;
+static inline unsigned bwd_interleave_grid(long long total) {
+    if (BWD_CHUNK <= 0) return dbw_xcd_grid(total);
+    const long long g = 8LL * BWD_CHUNK;
+    return (unsigned)(g * ((total + g - 1) / g));
+}
+template <bool INTERLEAVED = false>
 __device__ __forceinline__ bool pixel_of_block(const ShadeArgs &A, long long total_blocks, int &n, int &xi, int &yi) {
-    const long long logical = xcd_remap(blockIdx.x, total_blocks);
-    if (logical < 0) return false;
+    long long logical;
+    if (INTERLEAVED && BWD_CHUNK > 0) {
+        const long long j = blockIdx.x >> 3;
+        logical = ((j / BWD_CHUNK) * 8 + (blockIdx.x & 7)) * BWD_CHUNK + j % BWD_CHUNK;
+        if (logical >= total_blocks) return false;
+    } else {
+        logical = xcd_remap(blockIdx.x, total_blocks);
+        if (logical < 0) return false;
+    }
     const int tiles_x = (A.W + TILE - 1) / TILE, tiles_y = (A.H + TILE - 1) / TILE;
     n = (int)(logical / (tiles_x * tiles_y));
     const int t = (int)(logical % (tiles_x * tiles_y));
@@ -662,7 +685,7 @@ __global__ __launch_bounds__(NT, (BINNED ? DBW_UVB_WAVES : 5)) void render_bwd_u
     if (blockIdx.x < (1u << 16)) { g_bwd_clock[blockIdx.x][3] = (unsigned)wall_clock64(); g_bwd_clock[blockIdx.x][2] = 0u; }
 #endif
     int n, xi, yi;
-    if (!pixel_of_block(A, total_blocks, n, xi, yi)) return;
+    if (!pixel_of_block<true>(A, total_blocks, n, xi, yi)) return;
     const bool in_img = xi < A.W && yi < A.H;
     const int lane = threadIdx.x & 63;
     // wave-uniform tile of the 8x8-tile planar fragment layout
@@ -1371,10 +1394,10 @@ static int launch_bwd(ShadeArgs &A, int N, int H, int W, int K, const float *gra
             raised_uv = true;
         }
         if (A.bin_records)
-            hipLaunchKernelGGL(render_bwd_uv_kernel<true>, dim3(dbw_xcd_grid(total)), dim3(NT), FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total, grad_image, grad_maps,
+            hipLaunchKernelGGL(render_bwd_uv_kernel<true>, dim3(bwd_interleave_grid(total)), dim3(NT), FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total, grad_image, grad_maps,
                                grad_faces_alpha, fv, gfv);
         else
-            hipLaunchKernelGGL(render_bwd_uv_kernel<false>, dim3(dbw_xcd_grid(total)), dim3(NT), TexAgg::BYTES + FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total,
+            hipLaunchKernelGGL(render_bwd_uv_kernel<false>, dim3(bwd_interleave_grid(total)), dim3(NT), TexAgg::BYTES + FaceAlphaAgg::BYTES + ALPHA_DIRECT_BYTES, s, A, total,
                                grad_image, grad_maps, grad_faces_alpha, fv, gfv);
         return dbw_check_launch("render_bwd_uv_kernel");
     }
